@@ -1,0 +1,184 @@
+"""Golden-vector generator -- runs ONLY in the build container (needs /root/reference).
+
+    python tests/golden/make_golden.py
+
+1. imports the real reference on CPU under oracle/ref_shim.py,
+2. checks the oracle restatement (oracle/model_ref.py, oracle/loss_ref.py) against it stage by stage
+   and loss term by loss term on seeded inputs (asserts), key/shape-checks oracle/synth.spec() against
+   the reference's real state_dict for both configs,
+3. writes small fixtures (reference OUTPUTS only; inputs and weights are regenerated from seeds by
+   oracle/synth.py) into tests/golden/*.npz for tests/test_oracle_golden.py.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import ref_shim, synth, model_ref, loss_ref  # noqa: E402
+
+
+def digest(t, n=512, seed=123):
+    """Small fingerprint of a big tensor: stats + a fixed pseudo-random sample."""
+    if t is None:
+        return np.zeros(4 + n)
+    t = t.detach().double().flatten()
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, t.numel(), (n,), generator=g)
+    return np.concatenate([[t.mean().item(), t.std().item(), t.abs().sum().item(), float(t.numel())], t[idx].numpy()])
+
+
+def maxrel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12)).item()
+
+
+def main():
+    torch.manual_seed(0)
+    np.random.seed(0)
+    torch.set_num_threads(8)
+    for cname in ("PlaneRecNet_50_config", "PlaneRecNet_101_config"):
+        ref = ref_shim.load_reference(cname)
+        net = ref["planerecnet"].PlaneRecNet(ref["config"].cfg)
+        rsd = net.state_dict()
+        sp = synth.spec(cname)
+        assert sorted(k for k, _, _ in sp) == sorted(rsd.keys()), "state-dict key naming mismatch"
+        for k, shape, _ in sp:
+            assert tuple(rsd[k].shape) == tuple(shape), (k, rsd[k].shape, shape)
+        print(cname, "state_dict layout OK:", len(sp), "keys", sum(v.numel() for v in rsd.values() if v.dtype.is_floating_point), "floats")
+        del net
+
+    # ---------------------------------------------------------------- model, R50, small image
+    cname = "PlaneRecNet_50_config"
+    ref = ref_shim.load_reference(cname)
+    cfg = ref["config"].cfg
+    arch = model_ref.ARCH[cname]
+    net = ref["planerecnet"].PlaneRecNet(cfg)
+    sd = synth.make_state_dict(cname, seed=1)
+    net.load_state_dict(sd)
+    x, _, _ = synth.make_batch(2, 64, 96, seed=2)
+    fix = {}
+    for mode in ("train", "eval"):
+        net.train()
+        for m in net.modules():                      # BN mode without touching train-mode return path
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.train(mode == "train")
+        with torch.no_grad():
+            r_mask, r_cate, r_kern, r_depth = net(x)
+        net.load_state_dict(sd)                       # undo running-stat updates
+        with torch.no_grad():
+            o = model_ref.forward(sd, x, arch, training=(mode == "train"), return_stages=True)
+        errs = {"mask": maxrel(o["mask"], r_mask), "depth": maxrel(o["depth"], r_depth)}
+        for i in range(4):
+            errs[f"cate{i}"] = maxrel(o["cate"][i], r_cate[i])
+            errs[f"kern{i}"] = maxrel(o["kernel"][i], r_kern[i])
+        print(mode, "oracle vs reference max-rel (fp32):", {k: f"{v:.1e}" for k, v in errs.items()})
+        # fp32: both sides are deterministic but differ by 1-ulp kernel-selection noise (in-place vs
+        # out-of-place ops) that small-batch BN amplifies; semantics are pinned by the fp64 pass below.
+        assert max(errs.values()) < 2e-4, errs
+        net.double()
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        with torch.no_grad():
+            r64 = net(x.double())
+            net.load_state_dict(sd64)
+            o64 = model_ref.forward(sd64, x.double(), arch, training=(mode == "train"))
+        e64 = max([maxrel(o64[0], r64[0]), maxrel(o64[3], r64[3])] + [maxrel(a, b) for a, b in zip(o64[1] + o64[2], r64[1] + r64[2])])
+        print(mode, "oracle vs reference max-rel (fp64):", f"{e64:.1e}")
+        assert e64 < 1e-10, e64
+        net.float()
+        net.load_state_dict(sd)
+        fix[f"{mode}_mask"] = r_mask.numpy()
+        fix[f"{mode}_depth"] = r_depth.numpy()
+        for i in range(4):
+            fix[f"{mode}_cate{i}"] = r_cate[i].numpy()
+            fix[f"{mode}_kern{i}_digest"] = digest(r_kern[i])
+    # eval-mode post-process (list[dict]) on a larger image so that detections exist
+    net.eval()
+    x2, _, _ = synth.make_batch(1, 128, 160, seed=3)
+    sd_inf = dict(sd)
+    sd_inf["inst_head.cate_pred.bias"] = sd["inst_head.cate_pred.bias"] + 1.0   # push scores over score_thr
+    net.load_state_dict(sd_inf)
+    with torch.no_grad():
+        r_res = net(x2)
+        o_res = model_ref.inference(sd_inf, x2, arch)
+    n_det = 0 if r_res[0]["pred_scores"] is None else len(r_res[0]["pred_scores"])
+    print("inference detections (reference):", n_det)
+    assert n_det > 0
+    for k in ("pred_scores", "pred_classes", "pred_boxes", "pred_depth"):
+        assert torch.allclose(o_res[0][k].double(), r_res[0][k].double(), rtol=1e-4, atol=1e-5), k
+    assert (o_res[0]["pred_masks"] != r_res[0]["pred_masks"]).float().mean() < 1e-4
+    fix["inf_scores"] = r_res[0]["pred_scores"].numpy()
+    fix["inf_classes"] = r_res[0]["pred_classes"].numpy()
+    fix["inf_boxes"] = r_res[0]["pred_boxes"].numpy()
+    fix["inf_depth_digest"] = digest(r_res[0]["pred_depth"])
+    fix["inf_mask_area"] = r_res[0]["pred_masks"].sum((1, 2)).numpy()
+    np.savez_compressed(os.path.join(HERE, "model_r50_small.npz"), **fix)
+
+    # ---------------------------------------------------------------- loss on synthetic predictions
+    crit = ref["losses"].PlaneRecNetLoss()
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    _, inst, gtd = synth.make_batch(B, 480, 640, seed=4)
+    mask_pred = torch.randn(B, 128, 120, 160, generator=g).relu_()
+    cate = [torch.randn(B, 2, s, s, generator=g) - 2.0 for s in arch.num_grids]
+    kern = [torch.randn(B, 128, s, s, generator=g) * 0.1 for s in arch.num_grids]
+    depth = torch.rand(B, 1, 240, 320, generator=g) * 4 + 0.3
+    leaves = [mask_pred] + cate + kern + [depth]
+    for t in leaves:
+        t.requires_grad_(True)
+    np.random.seed(7)
+    rl = crit(None, mask_pred, cate, kern, depth, inst, gtd)
+    rtot = sum(rl.values())
+    rg = torch.autograd.grad(rtot.sum(), leaves, allow_unused=True)
+    np.random.seed(7)
+    ol = loss_ref.joint_loss(mask_pred, cate, kern, depth, inst, gtd)
+    og = torch.autograd.grad(sum(ol.values()).sum(), leaves, allow_unused=True)
+    print("loss reference:", {k: float(v) for k, v in rl.items()})
+    print("loss oracle   :", {k: float(v) for k, v in ol.items()})
+    for k in rl:
+        assert abs(float(rl[k]) - float(ol[k])) <= 1e-6 * max(1.0, abs(float(rl[k]))), k
+        assert rl[k].dtype == ol[k].dtype and rl[k].shape == ol[k].shape, (k, rl[k].dtype, ol[k].dtype)
+    for a, b in zip(rg, og):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert maxrel(b, a) < 1e-5
+    lfix = {k: np.asarray(v.detach().double()) for k, v in rl.items()}
+    lfix["grad_mask_digest"] = digest(rg[0])
+    lfix["grad_depth_digest"] = digest(rg[-1])
+    for i in range(4):
+        lfix[f"grad_cate{i}_digest"] = digest(rg[1 + i])
+        lfix[f"grad_kern{i}_digest"] = digest(rg[5 + i])
+    # GT assignment fixture (integer work: bit exact)
+    tg = crit.prepare_ground_truth(inst[0], mask_feat_size=(120, 160))
+    for lv in range(4):
+        lfix[f"tg_cate{lv}"] = tg[1][lv].numpy()
+        lfix[f"tg_order{lv}"] = np.asarray(tg[3][lv], dtype=np.int64)
+        lfix[f"tg_ins_area{lv}"] = tg[0][lv].sum((1, 2)).numpy()
+    np.savez_compressed(os.path.join(HERE, "loss_synth.npz"), **lfix)
+
+    # ---------------------------------------------------------------- end to end R50 480x640 B=1
+    net.load_state_dict(sd)
+    net.train()
+    x3, inst3, gtd3 = synth.make_batch(1, 480, 640, seed=6)
+    np.random.seed(11)
+    out = net(x3)
+    rl = crit(net, *out, inst3, gtd3)
+    net.load_state_dict(sd)
+    np.random.seed(11)
+    oo = model_ref.forward(sd, x3, arch, training=True)
+    ol = loss_ref.joint_loss(*oo, inst3, gtd3)
+    print("e2e reference:", {k: float(v) for k, v in rl.items()})
+    print("e2e oracle   :", {k: float(v) for k, v in ol.items()})
+    for k in rl:
+        assert abs(float(rl[k]) - float(ol[k])) <= 1e-4 * max(1.0, abs(float(rl[k]))), k
+    np.savez_compressed(os.path.join(HERE, "e2e_r50_480x640.npz"),
+                        **{k: np.asarray(v.detach().double()) for k, v in rl.items()},
+                        mask_digest=digest(out[0]), depth_digest=digest(out[3]))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
