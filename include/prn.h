@@ -1,0 +1,117 @@
+/* prn.h -- C ABI of libprn_hip.so: the MI355X (gfx950) kernels behind PlaneRecNet's forward/backward hot path.
+ *
+ * The reference (EryiXie/PlaneRecNet) has no FFI of its own: its native boundary is the set of PyTorch /
+ * torchvision operators its modules call.  Each entry point below replaces one such operator family and
+ * cites the reference call sites it serves (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - tensors are fp32, NCHW, contiguous, device pointers; the caller owns every buffer (outputs and
+ *     workspaces come from the host framework's allocator -- nothing is allocated inside);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - the return value is 0 on success, non-zero on error (message: prn_last_error()); nothing throws;
+ *   - no global mutable state except the thread-local error string; re-entrant; callable from any host
+ *     thread (PyTorch's autograd worker threads call the backward entry points).
+ */
+#ifndef PRN_H
+#define PRN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int prn_version(void);
+const char* prn_last_error(void);
+
+/* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------------------------------
+ * replaces ATen/cuDNN conv2d fwd / dgrad / wgrad behind every nn.Conv2d + F.conv2d:
+ *   models/backbone.py:22,34-42,45,101,156-164 ; models/dcn.py:25-50 ; models/fpn.py:27,31 ;
+ *   planerecnet.py:337,345-353,414-460,510-584,592 ; models/functions/losses.py:91
+ * Input-side modes fold the reference's padding / resampling modules into the operand gather:
+ *   PRN_IN_ZERO     zero padding `pad`                            (nn.Conv2d(padding=p))
+ *   PRN_IN_REFLECT  ReflectionPad2d(1) then conv                  (planerecnet.py:516,522,528,534,579,570)
+ *   PRN_IN_UP2_REFLECT  Upsample(x2, nearest) -> ReflectionPad2d(1) -> conv   (planerecnet.py:540-566)
+ *   PRN_IN_DILATED  input holds every `dil`-th sample of a zero-dilated tensor (dgrad of a strided conv)
+ */
+enum { PRN_IN_ZERO = 0, PRN_IN_REFLECT = 1, PRN_IN_UP2_REFLECT = 2, PRN_IN_DILATED = 3 };
+enum { PRN_EPI_NONE = 0, PRN_EPI_RELU = 1, PRN_EPI_SIGMOID = 2 };
+
+typedef struct prn_conv_desc {
+  int32_t B, C, H, W;      /* input tensor [B,C,H,W] as stored                                        */
+  int32_t M;               /* output channels                                                          */
+  int32_t KH, KW;          /* 1x1, 3x3 or 7x7                                                          */
+  int32_t stride, pad;     /* pad is ignored (==1) for the reflect modes                               */
+  int32_t Ho, Wo;          /* output spatial size                                                      */
+  int32_t in_mode;         /* PRN_IN_*                                                                 */
+  int32_t dil;             /* PRN_IN_DILATED: dilation factor of the virtual input                     */
+  int32_t epilogue;        /* PRN_EPI_* (fwd only)                                                     */
+} prn_conv_desc;
+
+/* y[b,m,oh,ow] = epi( sum_{c,r,s} w[m,c,r,s] * gather(x)[b,c,oh*stride-pad+r, ow*stride-pad+s] + bias[m] + addend[b,m,oh,ow] )
+ * w is [M, C*KH*KW] row-major; bias and addend may be NULL. */
+int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
+                   const float* addend, float* y, void* stream);
+
+/* wt[c][m][KH-1-r][KW-1-s] = w[m][c][r][s]   (operand layout for dgrad-as-forward) */
+int prn_weight_flip_transpose(const float* w, float* wt, int M, int C, int KH, int KW, void* stream);
+
+/* dw[m, c*KH*KW + r*KW + s] = sum_{b,oh,ow} dy[b,m,oh,ow] * gather(x)[b,c,oh*stride-pad+r,ow*stride-pad+s]
+ * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
+int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);
+int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream);
+
+/* adjoint of the PRN_IN_REFLECT / PRN_IN_UP2_REFLECT gather: folds dP [B,C,Hv+2,Wv+2] (gradient w.r.t. the
+ * virtual padded tensor, Hv = H or 2H) back onto dx [B,C,H,W]. */
+int prn_pad_fold(const float* dp, float* dx, int B, int C, int H, int W, int up2, void* stream);
+
+/* out[c] = sum_{b,h,w} x[b,c,h,w]    (bias gradients) */
+int prn_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+
+/* ---- modulated deformable convolution (DCNv2) ------------------------------------------------------------
+ * replaces torchvision.ops.deform_conv2d (models/dcn.py:59-66) together with the clamp / 2*sigmoid the
+ * wrapper applies to the raw offset / modulator conv outputs (models/dcn.py:53-57).
+ * om = raw output of the merged offset(18)+modulator(9) 3x3 conv, [B,27,Ho,Wo].
+ * cols[b, c*9+k, ho, wo] = 2*sigmoid(om[b,18+k]) * bilinear(x[b,c], ho*s-1+i+clamp(om[b,2k]), wo*s-1+j+clamp(om[b,2k+1]))
+ * The contraction with regular_conv.weight is a prn_conv2d_fwd (1x1) over cols.                            */
+int prn_dcn_sample(const float* x, const float* om, float* cols, int B, int C, int H, int W, int Ho, int Wo,
+                   int stride, float max_offset, void* stream);
+/* backward of prn_dcn_sample: dx (+= , caller zero-fills) and d_om from dcols. */
+int prn_dcn_sample_bwd(const float* x, const float* om, const float* dcols, float* dx, float* d_om,
+                       int B, int C, int H, int W, int Ho, int Wo, int stride, float max_offset, void* stream);
+
+/* ---- BatchNorm2d (+ residual add, + ReLU) --------------------------------------------------------------------
+ * replaces ATen batch_norm fwd/bwd: models/backbone.py:24,44,48,102,166 ; planerecnet.py:518..582           */
+/* training statistics: stats[0:C]=mean, stats[C:2C]=invstd; updates running_mean/var (momentum, unbiased var).
+ * ws: 2*C*PRN_BN_SPLITS doubles. */
+#define PRN_BN_SPLITS 32
+int prn_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, double* ws,
+                 int B, int C, int HW, float eps, float momentum, void* stream);
+/* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) ; for eval mode pass stats built from running stats */
+int prn_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
+                 float* y, int B, int C, int HW, int relu, void* stream);
+/* backward (training statistics). g = dy * (y>0 if relu). Outputs dx, dgamma, dbeta and, if dres != NULL, dres = g.
+ * ws: 2*C*PRN_BN_SPLITS doubles. */
+int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+               float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
+               int B, int C, int HW, int relu, int frozen, void* stream);
+
+/* ---- GroupNorm(32) + ReLU ---------------------------------------------------------------------------------------
+ * replaces ATen group_norm fwd/bwd + ReLU: planerecnet.py:340-342,419-421,436-437,450-451,463-464           */
+int prn_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats /*[B*G*2]*/,
+                    int B, int C, int HW, int G, float eps, void* stream);
+int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+                    float* dx, float* dgamma_part /*[B*C]*/, float* dbeta_part /*[B*C]*/,
+                    int B, int C, int HW, int G, void* stream);
+
+/* ---- resampling ---------------------------------------------------------------------------------------------------
+ * bilinear, align_corners=False (F.interpolate / nn.Upsample): models/fpn.py:54 ; planerecnet.py:115,381,439,453,594 ;
+ * losses.py:143,299.  bwd accumulates into dx (caller zero-fills). */
+int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
+int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
+/* MaxPool2d(3, stride 2, pad 1): models/backbone.py:104 */
+int prn_maxpool3s2_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
+int prn_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

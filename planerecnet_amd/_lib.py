@@ -1,0 +1,67 @@
+"""ctypes binding of libprn_hip.so (C ABI declared in include/prn.h).
+
+There is deliberately NO fallback: if the library is missing or a symbol is absent, importing this
+module raises, and every op in planerecnet_amd.ops raises on non-device tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprn_hip.so")
+
+c_int, c_float, c_void_p, c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of prn_conv_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "C", "H", "W", "M", "KH", "KW", "stride", "pad", "Ho", "Wo", "in_mode", "dil", "epilogue")]
+
+
+IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED = 0, 1, 2, 3
+EPI_NONE, EPI_RELU, EPI_SIGMOID = 0, 1, 2
+BN_SPLITS = 32
+
+P = c_void_p
+_DP = ctypes.POINTER(ConvDesc)
+SIGNATURES = {
+    "prn_version": (c_int, []),
+    "prn_last_error": (ctypes.c_char_p, []),
+    "prn_conv2d_fwd": (c_int, [_DP, P, P, P, P, P, P]),
+    "prn_weight_flip_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
+    "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),
+    "prn_pad_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_channel_sum": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "prn_dcn_sample": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
+    "prn_dcn_sample_bwd": (c_int, [P, P, P, P, P] + [c_int] * 7 + [c_float, P]),
+    "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
+    "prn_bn_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_bn_bwd": (c_int, [P] * 10 + [c_int] * 5 + [P]),
+    "prn_gn_relu_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "prn_gn_relu_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),
+    "prn_resize_bilinear_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "prn_resize_bilinear_bwd": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "prn_maxpool3s2_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "prn_maxpool3s2_bwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib.prn_last_error().decode()}")

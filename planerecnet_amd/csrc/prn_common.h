@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels (wave64, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/prn.h"
+
+#define PRN_WAVE 64
+
+void prn_set_error(const char* fmt, ...);
+
+#define PRN_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e_ = hipGetLastError();                                                \
+    if (e_ != hipSuccess) {                                                           \
+      prn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));            \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+#define PRN_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      prn_set_error(__VA_ARGS__);       \
+      return 2;                         \
+    }                                   \
+  } while (0)
+
+// Block b is observed to run on XCD b % 8 (MI355X_MICROARCH.md): give every XCD a contiguous range of
+// logical tile ids so that neighbouring tiles (which share operand rows) hit the same 4 MiB L2.
+// Speed only -- any placement is correct.
+__device__ __forceinline__ int prn_xcd_remap(int bid, int nblocks) {
+  const int per = nblocks >> 3;
+  if (per == 0 || bid >= (per << 3)) return bid;
+  return (bid & 7) * per + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,262 @@
+// BatchNorm2d (+residual +ReLU) and GroupNorm(32)+ReLU, forward and backward. HBM-bound: every pass is a
+// float4-vectorised stream over NCHW planes with wave-level (shuffle) reductions; cross-block combines are
+// done in fp64 from fixed-order partials, so results are deterministic.
+#include "prn_common.h"
+
+namespace {
+
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[8 + w] = b; }
+  __syncthreads();
+  double ra = 0.0, rb = 0.0;
+  for (int i = 0; i < nw; ++i) { ra += sm[i]; rb += sm[8 + i]; }
+  a = ra; b = rb;
+}
+
+// ------------------------------------------------------------------------------------------- BatchNorm
+// grid (C, SPLITS): block (c, s) reduces a fixed slice of the B*HW elements of channel c.
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int B, int C, int HW) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int beg = (int)((int64_t)HW * s / S), end = (int)((int64_t)HW * (s + 1) / S);   // slice of every image plane
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* xp = x + ((size_t)b * C + c) * HW;
+    for (int p = beg + threadIdx.x; p < end; p += 256) {
+      const float v = xp[p];
+      s1 += v; s2 += v * v;
+    }
+  }
+  __shared__ double sm[16];
+  double d1 = s1, d2 = s2;
+  block_sum2(d1, d2, sm);
+  if (threadIdx.x == 0) { ws[((size_t)c * S + s) * 2] = d1; ws[((size_t)c * S + s) * 2 + 1] = d2; }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, int C, int S, double count, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) { s1 += ws[((size_t)c * S + s) * 2]; s2 += ws[((size_t)c * S + s) * 2 + 1]; }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+
+// y = relu?(x*scale + shift + res?) ; one block row per (b,c) plane chunk, float4 when HW % 4 == 0
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, float* __restrict__ y, int C, int HW, int relu) {
+  const int bc = blockIdx.y, c = bc % C;
+  const float sc = stats[C + c] * gamma[c], sh = beta[c] - stats[c] * sc;
+  const size_t base = (size_t)bc * HW;
+  if ((HW & 3) == 0) {
+    const int n4 = HW >> 2;
+    const float4* xp = reinterpret_cast<const float4*>(x + base);
+    const float4* rp = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+    float4* yp = reinterpret_cast<float4*>(y + base);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+      float4 v = xp[i];
+      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      if (rp) { const float4 r = rp[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      yp[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+      float v = x[base + i] * sc + sh;
+      if (res) v += res[base + i];
+      if (relu) v = fmaxf(v, 0.f);
+      y[base + i] = v;
+    }
+  }
+}
+
+// partial sums of g and g*xhat, g = dy * (y > 0 if relu)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ y, const float* __restrict__ stats,
+                                                             double* __restrict__ ws, int B, int C, int HW, int relu) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int beg = (int)((int64_t)HW * s / S), end = (int)((int64_t)HW * (s + 1) / S);
+  const float mean = stats[c], istd = stats[C + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const size_t base = ((size_t)b * C + c) * HW;
+    for (int p = beg + threadIdx.x; p < end; p += 256) {
+      float g = dy[base + p];
+      if (relu && !(y[base + p] > 0.f)) g = 0.f;
+      s1 += g; s2 += g * (x[base + p] - mean) * istd;
+    }
+  }
+  __shared__ double sm[16];
+  double d1 = s1, d2 = s2;
+  block_sum2(d1, d2, sm);
+  if (threadIdx.x == 0) { ws[((size_t)c * S + s) * 2] = d1; ws[((size_t)c * S + s) * 2 + 1] = d2; }
+}
+
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) { s1 += ws[((size_t)c * S + s) * 2]; s2 += ws[((size_t)c * S + s) * 2 + 1]; }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  ws[(size_t)c * S * 2] = s1;       // totals for the apply pass
+  ws[(size_t)c * S * 2 + 1] = s2;
+}
+
+// dx = gamma*istd*(g - sum_g/N - xhat*sum_gx/N)   (training)   |   dx = gamma*istd*g   (frozen / eval stats)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const double* __restrict__ ws,
+                                                           float* __restrict__ dx, float* __restrict__ dres, int C, int HW,
+                                                           int S, float inv_count, int relu, int frozen) {
+  const int bc = blockIdx.y, c = bc % C;
+  const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
+  const float m1 = frozen ? 0.f : (float)ws[(size_t)c * S * 2] * inv_count;
+  const float m2 = frozen ? 0.f : (float)ws[(size_t)c * S * 2 + 1] * inv_count;
+  const size_t base = (size_t)bc * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float g = dy[base + i];
+    if (relu && !(y[base + i] > 0.f)) g = 0.f;
+    if (dres) dres[base + i] = g;
+    const float xh = (x[base + i] - mean) * istd;
+    dx[base + i] = gi * (g - m1 - xh * m2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- GroupNorm
+// one block per (b, group): pass 1 statistics, pass 2 normalise + affine + ReLU (second read is L2-resident)
+__global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ stats, int C, int HW, int G, float eps) {
+  const int bg = blockIdx.x, g = bg % G, cpg = C / G;
+  const int b = bg / G;
+  const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
+  const int n = cpg * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[base + i]; s1 += v; s2 += v * v; }
+  __shared__ double sm[16];
+  double d1 = s1, d2 = s2;
+  block_sum2(d1, d2, sm);
+  const double mean = d1 / n;
+  double var = d2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)mean, istd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) { stats[bg * 2] = mu; stats[bg * 2 + 1] = istd; }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = g * cpg + i / HW;
+    const float v = (x[base + i] - mu) * istd * gamma[c] + beta[c];
+    y[base + i] = fmaxf(v, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ y, const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma, float* __restrict__ dx,
+                                                          float* __restrict__ dgp, float* __restrict__ dbp, int C, int HW, int G) {
+  const int bg = blockIdx.x, g = bg % G, cpg = C / G, b = bg / G;
+  const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
+  const float mu = stats[bg * 2], istd = stats[bg * 2 + 1];
+  __shared__ double sm[16];
+  __shared__ double tot[2];
+  double ds = 0.0, db = 0.0;       // sum_c gamma_c * sum(g*xhat), sum_c gamma_c * sum(g)
+  for (int cc = 0; cc < cpg; ++cc) {
+    const int c = g * cpg + cc;
+    const size_t cb = base + (size_t)cc * HW;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      float gg = dy[cb + i];
+      if (!(y[cb + i] > 0.f)) gg = 0.f;
+      s1 += gg; s2 += gg * (x[cb + i] - mu) * istd;
+    }
+    double d1 = s1, d2 = s2;
+    block_sum2(d1, d2, sm);
+    if (threadIdx.x == 0) { dbp[(size_t)b * C + c] = (float)d1; dgp[(size_t)b * C + c] = (float)d2; }
+    ds += (double)gamma[c] * d2;
+    db += (double)gamma[c] * d1;
+  }
+  const int n = cpg * HW;
+  const float m1 = (float)(db / n), m2 = (float)(ds / n);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = g * cpg + i / HW;
+    float gg = dy[base + i];
+    if (!(y[base + i] > 0.f)) gg = 0.f;
+    const float xh = (x[base + i] - mu) * istd;
+    dx[base + i] = istd * (gamma[c] * gg - m1 - xh * m2);
+  }
+  (void)tot;
+}
+
+}  // namespace
+
+extern "C" int prn_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, double* ws,
+                            int B, int C, int HW, float eps, float momentum, void* stream) {
+  PRN_REQUIRE(x && stats && ws && B > 0 && C > 0 && HW > 0, "prn_bn_stats: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, PRN_BN_SPLITS), dim3(256), 0, st, x, ws, B, C, HW);
+  PRN_CHECK_LAUNCH("prn_bn_stats/partial");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, stats, running_mean, running_var, C,
+                     PRN_BN_SPLITS, (double)B * HW, eps, momentum);
+  PRN_CHECK_LAUNCH("prn_bn_stats/finalize");
+  return 0;
+}
+
+extern "C" int prn_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
+                            float* y, int B, int C, int HW, int relu, void* stream) {
+  PRN_REQUIRE(x && stats && gamma && beta && y && B > 0 && C > 0 && HW > 0, "prn_bn_apply: bad arguments");
+  int gx = cdiv(HW, 256 * 8);
+  if (gx < 1) gx = 1;
+  PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_apply: B*C too large for grid.y");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, residual, y, C, HW, relu);
+  PRN_CHECK_LAUNCH("prn_bn_apply");
+  return 0;
+}
+
+extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+                          float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
+                          int B, int C, int HW, int relu, int frozen, void* stream) {
+  PRN_REQUIRE(dy && x && stats && gamma && dx && ws && B > 0 && C > 0 && HW > 0, "prn_bn_bwd: bad arguments");
+  PRN_REQUIRE(!relu || y, "prn_bn_bwd: relu needs the forward output");
+  PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_bwd: B*C too large for grid.y");
+  hipStream_t st = (hipStream_t)stream;
+  if (!frozen || dgamma || dbeta) {
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, PRN_BN_SPLITS), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu);
+    PRN_CHECK_LAUNCH("prn_bn_bwd/partial");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, dgamma, dbeta, C, PRN_BN_SPLITS);
+    PRN_CHECK_LAUNCH("prn_bn_bwd/finalize");
+  }
+  int gx = cdiv(HW, 256 * 8);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, st, dy, x, y, stats, gamma, (const double*)ws, dx, dres, C, HW,
+                     PRN_BN_SPLITS, 1.f / ((float)B * HW), relu, frozen);
+  PRN_CHECK_LAUNCH("prn_bn_bwd/apply");
+  return 0;
+}
+
+extern "C" int prn_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                               int B, int C, int HW, int G, float eps, void* stream) {
+  PRN_REQUIRE(x && gamma && beta && y && stats && B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "prn_gn_relu_fwd: bad arguments");
+  hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, y, stats, C, HW, G, eps);
+  PRN_CHECK_LAUNCH("prn_gn_relu_fwd");
+  return 0;
+}
+
+extern "C" int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+                               float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int HW, int G, void* stream) {
+  PRN_REQUIRE(dy && x && y && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd: bad arguments");
+  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, y, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G);
+  PRN_CHECK_LAUNCH("prn_gn_relu_bwd");
+  return 0;
+}

@@ -1,0 +1,124 @@
+// Resampling family: bilinear resize (align_corners=False, PyTorch area_pixel source index rule) and
+// MaxPool2d(3, 2, 1). HBM-bound gathers; one thread per output element, consecutive lanes along W.
+#include "prn_common.h"
+
+namespace {
+
+struct Lerp { int i0, i1; float w0, w1; };
+
+// PyTorch upsample_bilinear2d, align_corners=False: src = max(0, scale*(dst+0.5)-0.5), scale = in/out
+__device__ __forceinline__ Lerp lerp_idx(int o, int in, float scale) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lerp l;
+  l.i0 = (int)s;
+  if (l.i0 > in - 1) l.i0 = in - 1;
+  l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+  l.w1 = s - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total,
+                                                         int H, int W, int Ho, int Wo, float sh, float sw) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int wo = i % Wo, ho = (i / Wo) % Ho;
+  const int64_t bc = i / ((int64_t)Wo * Ho);
+  const Lerp a = lerp_idx(ho, H, sh), b = lerp_idx(wo, W, sw);
+  const float* p = x + bc * (int64_t)H * W;
+  y[i] = a.w0 * (b.w0 * p[a.i0 * W + b.i0] + b.w1 * p[a.i0 * W + b.i1]) + a.w1 * (b.w0 * p[a.i1 * W + b.i0] + b.w1 * p[a.i1 * W + b.i1]);
+}
+
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total,
+                                                         int H, int W, int Ho, int Wo, float sh, float sw) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int wo = i % Wo, ho = (i / Wo) % Ho;
+  const int64_t bc = i / ((int64_t)Wo * Ho);
+  const Lerp a = lerp_idx(ho, H, sh), b = lerp_idx(wo, W, sw);
+  float* p = dx + bc * (int64_t)H * W;
+  const float g = dy[i];
+  atomicAdd(p + a.i0 * W + b.i0, g * a.w0 * b.w0);
+  atomicAdd(p + a.i0 * W + b.i1, g * a.w0 * b.w1);
+  atomicAdd(p + a.i1 * W + b.i0, g * a.w1 * b.w0);
+  atomicAdd(p + a.i1 * W + b.i1, g * a.w1 * b.w1);
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total,
+                                                          int H, int W, int Ho, int Wo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int wo = i % Wo, ho = (i / Wo) % Ho;
+  const int64_t bc = i / ((int64_t)Wo * Ho);
+  const float* p = x + bc * (int64_t)H * W;
+  float m = -INFINITY;
+  for (int r = 0; r < 3; ++r) {
+    const int h = ho * 2 - 1 + r;
+    if ((unsigned)h >= (unsigned)H) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int w = wo * 2 - 1 + s;
+      if ((unsigned)w >= (unsigned)W) continue;
+      const float v = p[h * W + w];
+      if (v > m || v != v) m = v;
+    }
+  }
+  y[i] = m;
+}
+
+// gradient goes to the first maximum in scan order (ATen max_pool2d_with_indices rule)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int64_t total, int H, int W, int Ho, int Wo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int wo = i % Wo, ho = (i / Wo) % Ho;
+  const int64_t bc = i / ((int64_t)Wo * Ho);
+  const float* p = x + bc * (int64_t)H * W;
+  float m = -INFINITY;
+  int arg = -1;
+  for (int r = 0; r < 3; ++r) {
+    const int h = ho * 2 - 1 + r;
+    if ((unsigned)h >= (unsigned)H) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int w = wo * 2 - 1 + s;
+      if ((unsigned)w >= (unsigned)W) continue;
+      const float v = p[h * W + w];
+      if (v > m || v != v || arg < 0) { m = v; arg = h * W + w; }
+    }
+  }
+  if (arg >= 0) atomicAdd(dx + bc * (int64_t)H * W + arg, dy[i]);
+}
+
+}  // namespace
+
+extern "C" int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  PRN_REQUIRE(x && y && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_fwd: bad arguments");
+  const int64_t n = (int64_t)BC * Ho * Wo;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
+  PRN_CHECK_LAUNCH("prn_resize_bilinear_fwd");
+  return 0;
+}
+
+extern "C" int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  PRN_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_bwd: bad arguments");
+  const int64_t n = (int64_t)BC * Ho * Wo;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
+  PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd");
+  return 0;
+}
+
+extern "C" int prn_maxpool3s2_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  PRN_REQUIRE(x && y && BC > 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "prn_maxpool3s2_fwd: bad arguments");
+  const int64_t n = (int64_t)BC * Ho * Wo;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, Ho, Wo);
+  PRN_CHECK_LAUNCH("prn_maxpool3s2_fwd");
+  return 0;
+}
+
+extern "C" int prn_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  PRN_REQUIRE(x && dy && dx && BC > 0, "prn_maxpool3s2_bwd: bad arguments");
+  const int64_t n = (int64_t)BC * Ho * Wo;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, H, W, Ho, Wo);
+  PRN_CHECK_LAUNCH("prn_maxpool3s2_bwd");
+  return 0;
+}

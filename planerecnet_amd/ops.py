@@ -1,0 +1,305 @@
+"""Operator layer: torch.autograd.Function wrappers over the HIP C ABI (include/prn.h).
+
+Mirrors the operator surface the reference's modules call (torch.nn.functional conv2d / batch_norm /
+group_norm / interpolate / max_pool2d and torchvision.ops.deform_conv2d) with the fusions the MI355X
+kernels provide (padding / reflection / nearest-x2 inside the conv gather, residual + ReLU inside BN,
+ReLU inside GroupNorm).  PyTorch supplies device memory, the current HIP stream and the autograd
+graph; all arithmetic of these ops runs in libprn_hip.so.  Non-device tensors raise: there is no
+CPU path in the product.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise RuntimeError("planerecnet_amd ops need fp32 tensors resident on the MI355X (got %s %s); "
+                               "there is no CPU fallback" % (t.device, t.dtype))
+
+
+def _c(t):
+    return t if (t is None or t.is_contiguous()) else t.contiguous()
+
+
+def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE):
+    return ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi)
+
+
+def _out_hw(H, W, K, stride, pad, mode):
+    if mode == IN_REFLECT:
+        return H, W
+    if mode == IN_UP2_REFLECT:
+        return 2 * H, 2 * W
+    return (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+
+
+# ------------------------------------------------------------------------------------------ raw launches
+def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE):
+    B, C, H, W = x.shape
+    y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
+    d = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+    check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _stream()), "prn_conv2d_fwd")
+    return y
+
+
+def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
+    B, C, H, W = x.shape
+    Ho, Wo = dy.shape[2:]
+    d = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
+    nbytes = lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d))
+    if nbytes < 0:
+        raise RuntimeError(lib.prn_last_error().decode())
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
+    check(lib.prn_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
+    return dw
+
+
+def flip_transpose(w):
+    M, C, KH, KW = w.shape
+    wt = torch.empty(C, M, KH, KW, device=w.device, dtype=torch.float32)
+    check(lib.prn_weight_flip_transpose(_p(w), _p(wt), M, C, KH, KW, _stream()), "prn_weight_flip_transpose")
+    return wt
+
+
+def channel_sum(g):
+    B, C, H, W = g.shape
+    out = torch.empty(C, device=g.device, dtype=torch.float32)
+    check(lib.prn_channel_sum(_p(g), _p(out), B, C, H * W, _stream()), "prn_channel_sum")
+    return out
+
+
+def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode):
+    """Gradient w.r.t. the conv input: the same implicit-GEMM kernel run over dy with flipped/transposed weights."""
+    B, C, H, W = x_shape
+    M, _, K, _ = w.shape
+    wt = flip_transpose(w)                                  # [C, M, K, K]
+    if mode in (IN_REFLECT, IN_UP2_REFLECT):
+        Hv, Wv = (2 * H, 2 * W) if mode == IN_UP2_REFLECT else (H, W)
+        dp = conv_fwd_raw(dy, wt, None, None, C, K, 1, 2, Hv + 2, Wv + 2)       # grad of the virtual padded tensor
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        check(lib.prn_pad_fold(_p(dp), _p(dx), B, C, H, W, 1 if mode == IN_UP2_REFLECT else 0, _stream()), "prn_pad_fold")
+        return dx
+    if stride == 1:
+        return conv_fwd_raw(dy, wt, None, None, C, K, 1, K - 1 - pad, H, W)
+    if stride != 2:
+        raise RuntimeError("conv dgrad: stride %d not implemented" % stride)
+    return conv_fwd_raw(dy, wt, None, None, C, K, 1, K - 1 - pad, H, W, IN_DILATED, 2)
+
+
+# ------------------------------------------------------------------------------------------ conv2d
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi):
+        _dev(x, w, bias, addend)
+        x, w, bias, addend = _c(x), _c(w), _c(bias), _c(addend)
+        M, C, K, _ = w.shape
+        assert x.shape[1] == C, (x.shape, w.shape)
+        Ho, Wo = _out_hw(x.shape[2], x.shape[3], K, stride, pad, mode)
+        y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
+        ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
+        ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, mode, epi, has_bias, has_add = ctx.cfg
+        dy = _c(dy)
+        if epi == EPI_RELU:
+            dy = dy * (y > 0)
+        elif epi == EPI_SIGMOID:
+            dy = dy * y * (1 - y)
+        M, C, K, _ = w.shape
+        dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode) if ctx.needs_input_grad[1] else None
+        db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[2]) else None
+        da = dy if (has_add and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, da, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
+    """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list)."""
+    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue)
+
+
+# ------------------------------------------------------------------------------------------ DCNv2
+class _DeformConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, om, w, bias, stride, max_offset):
+        _dev(x, om, w, bias)
+        x, om, w, bias = _c(x), _c(om), _c(w), _c(bias)
+        B, C, H, W = x.shape
+        M = w.shape[0]
+        Ho, Wo = om.shape[2:]
+        assert om.shape[1] == 27 and w.shape[2] == 3
+        cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
+        check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
+        y = conv_fwd_raw(cols, w, bias, None, M, 1, 1, 0, Ho, Wo)
+        ctx.save_for_backward(x, om, w, cols)
+        ctx.cfg = (stride, float(max_offset), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, om, w, cols = ctx.saved_tensors
+        stride, max_offset, has_bias = ctx.cfg
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        M = w.shape[0]
+        Ho, Wo = om.shape[2:]
+        w1 = w.view(M, C * 9, 1, 1)
+        dcols = conv_dgrad_raw(dy, w1, cols.shape, 1, 0, IN_ZERO)
+        dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[2] else None
+        db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[3]) else None
+        dx = torch.zeros_like(x)
+        dom = torch.empty_like(om)
+        check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
+              "prn_dcn_sample_bwd")
+        return dx, dom, dw, db, None, None
+
+
+def deform_conv2d(x, om_raw, weight, bias, stride, max_offset):
+    """torchvision.ops.deform_conv2d replacement with the wrapper's clamp / 2*sigmoid folded in
+    (reference models/dcn.py:52-67). om_raw = raw [offset(18) | modulator(9)] conv output."""
+    return _DeformConv.apply(x, om_raw, weight, bias, stride, max_offset)
+
+
+# ------------------------------------------------------------------------------------------ BatchNorm
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, eps, momentum, relu):
+        _dev(x, gamma, beta, rmean, rvar, residual)
+        x, residual = _c(x), _c(residual)
+        B, C, H, W = x.shape
+        HW = H * W
+        if training:
+            stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
+            check(lib.prn_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), _p(ws), B, C, HW, eps, momentum, _stream()), "prn_bn_stats")
+        else:
+            stats = torch.cat([rmean, torch.rsqrt(rvar + eps)])
+        y = torch.empty_like(x)
+        check(lib.prn_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), B, C, HW, int(relu), _stream()), "prn_bn_apply")
+        ctx.save_for_backward(x, y if relu else None, stats, gamma)
+        ctx.cfg = (training, relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, stats, gamma = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        need_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dg = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
+        ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
+        check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
+                             B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
+        return dx, dg, db, None, None, dres, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, residual=None, relu=False):
+    """F.batch_norm (+ residual add + ReLU) replacement. training=True uses batch statistics and updates the
+    running buffers in place (momentum, unbiased variance) like nn.BatchNorm2d."""
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps), float(momentum), bool(relu))
+
+
+# ------------------------------------------------------------------------------------------ GroupNorm + ReLU
+class _GroupNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        _dev(x, gamma, beta)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(B * groups * 2, device=x.device, dtype=torch.float32)
+        check(lib.prn_gn_relu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, C, H * W, groups, eps, _stream()), "prn_gn_relu_fwd")
+        ctx.save_for_backward(x, y, stats, gamma)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, stats, gamma = ctx.saved_tensors
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dgp = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        dbp = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), B, C, H * W, ctx.groups, _stream()),
+              "prn_gn_relu_bwd")
+        return dx, dgp.sum(0), dbp.sum(0), None, None
+
+
+def group_norm_relu(x, gamma, beta, groups=32, eps=1e-5):
+    return _GroupNormReLU.apply(x, gamma, beta, groups, eps)
+
+
+# ------------------------------------------------------------------------------------------ resampling
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        _dev(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        check(lib.prn_resize_bilinear_fwd(_p(x), _p(y), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_fwd")
+        ctx.shape = (B, C, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, Ho, Wo = ctx.shape
+        dy = _c(dy)
+        dx = torch.zeros(B, C, H, W, device=dy.device, dtype=torch.float32)
+        check(lib.prn_resize_bilinear_bwd(_p(dy), _p(dx), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_bwd")
+        return dx, None, None
+
+
+def resize_bilinear(x, size):
+    """F.interpolate(mode='bilinear', align_corners=False) replacement; size = (Ho, Wo)."""
+    return _Resize.apply(x, int(size[0]), int(size[1]))
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        check(lib.prn_maxpool3s2_fwd(_p(x), _p(y), B * C, H, W, Ho, Wo, _stream()), "prn_maxpool3s2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        dx = torch.zeros_like(x)
+        check(lib.prn_maxpool3s2_bwd(_p(x), _p(dy), _p(dx), B * C, H, W, dy.shape[2], dy.shape[3], _stream()), "prn_maxpool3s2_bwd")
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    """nn.MaxPool2d(3, 2, 1) replacement (models/backbone.py:104)."""
+    return _MaxPool.apply(x)

@@ -1,0 +1,233 @@
+"""GPU parity of every HIP operator (called through the C ABI via planerecnet_amd.ops) against the CPU
+restatement of the same operator: torch CPU fp64 for conv / norm / resample (the ATen ops the reference
+calls), oracle/dcn_ref.py for DCNv2.  fp32 tolerance: max-abs error <= 2e-4 * max|ref| (K up to 4608 fp32
+accumulations, different summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def rnd(*s, seed=0, scale=1.0):
+    return torch.randn(*s, generator=torch.Generator().manual_seed(seed), dtype=torch.float64) * scale
+
+
+def close(got, ref, what, rtol=RTOL):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    den = ref.abs().max().item() + 1e-12
+    assert err <= rtol * den, f"{what}: max-abs {err:.3e} vs scale {den:.3e} (rel {err / den:.2e})"
+
+
+def ref_conv(x, w, b, stride, pad, mode, addend=None, epi=0):
+    if mode == 2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if mode in (1, 2):
+        x = F.pad(x, (1, 1, 1, 1), mode="reflect")
+        pad = 0
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if addend is not None:
+        y = y + addend
+    if epi == 1:
+        y = F.relu(y)
+    elif epi == 2:
+        y = torch.sigmoid(y)
+    return y
+
+
+CONV_CASES = [
+    # B, C, H, W, M, K, stride, pad, mode, bias, addend, epi
+    (2, 16, 13, 17, 24, 1, 1, 0, 0, False, False, 0),
+    (2, 64, 30, 40, 256, 1, 1, 0, 0, False, False, 0),
+    (2, 70, 12, 20, 130, 3, 1, 1, 0, True, False, 1),
+    (1, 3, 38, 50, 64, 7, 2, 3, 0, False, False, 0),
+    (2, 32, 15, 21, 48, 3, 2, 1, 0, True, False, 0),
+    (2, 40, 16, 20, 72, 1, 2, 0, 0, False, False, 0),
+    (2, 24, 9, 12, 40, 3, 1, 1, 1, True, False, 0),
+    (2, 24, 7, 10, 40, 3, 1, 1, 2, True, False, 0),
+    (1, 258, 16, 16, 64, 3, 1, 1, 0, False, False, 0),
+    (2, 20, 10, 14, 27, 3, 1, 1, 0, True, True, 0),
+    (1, 128, 12, 16, 300, 1, 1, 0, 0, True, False, 2),
+    (1, 64, 24, 32, 1, 3, 1, 1, 1, True, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case):
+    from planerecnet_amd import ops
+    B, C, H, W, M, K, stride, pad, mode, has_b, has_a, epi = case
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(M, C, K, K, seed=2, scale=(C * K * K) ** -0.5).requires_grad_(True)
+    b = rnd(M, seed=3).requires_grad_(True) if has_b else None
+    yr = ref_conv(x, w, b, stride, pad, mode, None, 0)
+    a = rnd(*yr.shape, seed=4).requires_grad_(True) if has_a else None
+    yr = ref_conv(x, w, b, stride, pad, mode, a, epi)
+    go = rnd(*yr.shape, seed=5)
+    leaves = [t for t in (x, w, b, a) if t is not None]
+    gr = torch.autograd.grad(yr, leaves, go)
+
+    d = dev()
+    xd, wd = x.detach().float().to(d).requires_grad_(True), w.detach().float().to(d).requires_grad_(True)
+    bd = b.detach().float().to(d).requires_grad_(True) if has_b else None
+    ad = a.detach().float().to(d).requires_grad_(True) if has_a else None
+    yd = ops.conv2d(xd, wd, bd, stride, pad, mode, epi, ad)
+    close(yd, yr, "conv fwd")
+    gd = torch.autograd.grad(yd, [t for t in (xd, wd, bd, ad) if t is not None], go.float().to(d))
+    names = ["dx", "dw"] + (["db"] if has_b else []) + (["dadd"] if has_a else [])
+    for name, g1, g0 in zip(names, gd, gr):
+        close(g1, g0, "conv " + name)
+
+
+def test_conv2d_is_transpose_safe():
+    """A = I style check with asymmetric data: 1x1 conv with a permutation weight must permute channels."""
+    from planerecnet_amd import ops
+    d = dev()
+    C = 96
+    perm = torch.randperm(C, generator=torch.Generator().manual_seed(0))
+    w = torch.zeros(C, C, 1, 1)
+    w[torch.arange(C), perm] = 1.0
+    x = torch.arange(2 * C * 5 * 7, dtype=torch.float32).view(2, C, 5, 7)
+    y = ops.conv2d(x.to(d), w.to(d))
+    assert torch.equal(y.cpu(), x[:, perm])
+
+
+@pytest.mark.parametrize("B,C,H,W,M,stride", [(2, 16, 12, 15, 24, 1), (2, 32, 13, 16, 32, 2), (1, 128, 30, 40, 128, 1)])
+def test_deform_conv_fwd_bwd(B, C, H, W, M, stride):
+    from planerecnet_amd import ops
+    from oracle.dcn_ref import deform_conv2d_ref
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    maxoff = max(H, W) / 4.0
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    om = rnd(B, 27, Ho, Wo, seed=2, scale=1.7)
+    om[:, :18] += 0.137                      # keep sampling points off the integer kinks
+    om[0, 3, 0, 0] = 50.0                    # force the clamp branch
+    om[0, 4, 1, 1] = -50.0
+    om = om.requires_grad_(True)
+    w = rnd(M, C, 3, 3, seed=3, scale=(9 * C) ** -0.5).requires_grad_(True)
+    b = rnd(M, seed=4).requires_grad_(True)
+    yr = deform_conv2d_ref(x, om[:, :18].clamp(-maxoff, maxoff), 2 * torch.sigmoid(om[:, 18:]), w, b, stride, 1)
+    go = rnd(*yr.shape, seed=5)
+    gr = torch.autograd.grad(yr, [x, om, w, b], go)
+    d = dev()
+    xs = [t.detach().float().to(d).requires_grad_(True) for t in (x, om, w, b)]
+    yd = ops.deform_conv2d(xs[0], xs[1], xs[2], xs[3], stride, maxoff)
+    close(yd, yr, "dcn fwd")
+    gd = torch.autograd.grad(yd, xs, go.float().to(d))
+    for n, g1, g0 in zip(["dx", "d_om", "dw", "db"], gd, gr):
+        close(g1, g0, "dcn " + n, rtol=5e-4)
+
+
+def test_deform_conv_zero_offsets_equals_conv():
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, 24, 11, 13, seed=1).float()
+    w = rnd(20, 24, 3, 3, seed=2, scale=0.1).float()
+    om = torch.zeros(2, 27, 11, 13)         # offset 0, modulator 2*sigmoid(0) = 1
+    y = ops.deform_conv2d(x.to(d), om.to(d), w.to(d), None, 1, 3.0)
+    close(y, F.conv2d(x.double(), w.double(), padding=1), "dcn(0) == conv")
+
+
+@pytest.mark.parametrize("B,C,H,W,res,relu,training", [(4, 64, 15, 20, False, True, True), (2, 256, 8, 10, True, True, True),
+                                                       (3, 33, 7, 9, False, False, True), (2, 64, 12, 12, True, True, False)])
+def test_batch_norm_fwd_bwd(B, C, H, W, res, relu, training):
+    from planerecnet_amd import ops
+    x = (rnd(B, C, H, W, seed=1) * 1.5 + 0.3).requires_grad_(True)
+    g = (rnd(C, seed=2) * 0.2 + 1).requires_grad_(True)
+    bt = rnd(C, seed=3, scale=0.2).requires_grad_(True)
+    rm, rv = rnd(C, seed=4, scale=0.1), rnd(C, seed=5).abs() + 0.5
+    r = rnd(B, C, H, W, seed=6).requires_grad_(True) if res else None
+    rm0, rv0 = rm.clone(), rv.clone()
+    yr = F.batch_norm(x, rm0, rv0, g, bt, training, 0.1, 1e-5)
+    if res:
+        yr = yr + r
+    if relu:
+        yr = F.relu(yr)
+    go = rnd(*yr.shape, seed=7)
+    leaves = [x, g, bt] + ([r] if res else [])
+    gr = torch.autograd.grad(yr, leaves, go)
+    d = dev()
+    xs = [t.detach().float().to(d).requires_grad_(True) for t in leaves]
+    rmd, rvd = rm.float().to(d), rv.float().to(d)
+    yd = ops.batch_norm(xs[0], xs[1], xs[2], rmd, rvd, training, 1e-5, 0.1, xs[3] if res else None, relu)
+    close(yd, yr, "bn fwd")
+    if training:
+        close(rmd, rm0, "running_mean")
+        close(rvd, rv0, "running_var")
+    gd = torch.autograd.grad(yd, xs, go.float().to(d))
+    for n, g1, g0 in zip(["dx", "dgamma", "dbeta", "dres"], gd, gr):
+        close(g1, g0, "bn " + n, rtol=5e-4)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 16, 16), (2, 128, 30, 40), (1, 128, 9, 7)])
+def test_group_norm_relu_fwd_bwd(B, C, H, W):
+    from planerecnet_amd import ops
+    x = (rnd(B, C, H, W, seed=1) * 2 + 0.5).requires_grad_(True)
+    g = (rnd(C, seed=2) * 0.2 + 1).requires_grad_(True)
+    bt = rnd(C, seed=3, scale=0.3).requires_grad_(True)
+    yr = F.relu(F.group_norm(x, 32, g, bt, 1e-5))
+    go = rnd(*yr.shape, seed=4)
+    gr = torch.autograd.grad(yr, [x, g, bt], go)
+    d = dev()
+    xs = [t.detach().float().to(d).requires_grad_(True) for t in (x, g, bt)]
+    yd = ops.group_norm_relu(xs[0], xs[1], xs[2])
+    close(yd, yr, "gn fwd")
+    gd = torch.autograd.grad(yd, xs, go.float().to(d))
+    for n, g1, g0 in zip(["dx", "dgamma", "dbeta"], gd, gr):
+        close(g1, g0, "gn " + n, rtol=5e-4)
+
+
+@pytest.mark.parametrize("H,W,Ho,Wo", [(12, 16, 6, 8), (6, 8, 12, 16), (15, 20, 40, 40), (30, 40, 36, 36), (16, 24, 4, 6), (15, 20, 24, 24)])
+def test_resize_bilinear_fwd_bwd(H, W, Ho, Wo):
+    from planerecnet_amd import ops
+    x = rnd(2, 5, H, W, seed=1).requires_grad_(True)
+    yr = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    go = rnd(*yr.shape, seed=2)
+    (gr,) = torch.autograd.grad(yr, [x], go)
+    d = dev()
+    xd = x.detach().float().to(d).requires_grad_(True)
+    yd = ops.resize_bilinear(xd, (Ho, Wo))
+    close(yd, yr, "resize fwd", rtol=1e-5)
+    (gd,) = torch.autograd.grad(yd, [xd], go.float().to(d))
+    close(gd, gr, "resize bwd", rtol=1e-5)
+
+
+def test_resize_matches_scale_factor_semantics():
+    """x0.5 / x0.25 / x2 with scale_factor (recompute_scale_factor=False) == size-based resize at these exact ratios."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(1, 3, 16, 24, seed=1)
+    for sf in (0.5, 0.25, 2.0):
+        yr = F.interpolate(x, scale_factor=sf, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+        yd = ops.resize_bilinear(x.float().to(d), yr.shape[2:])
+        close(yd, yr, f"resize x{sf}", rtol=1e-5)
+
+
+@pytest.mark.parametrize("H,W", [(24, 32), (15, 21)])
+def test_maxpool_fwd_bwd(H, W):
+    from planerecnet_amd import ops
+    x = rnd(2, 6, H, W, seed=1).requires_grad_(True)
+    yr = F.max_pool2d(x, 3, 2, 1)
+    go = rnd(*yr.shape, seed=2)
+    (gr,) = torch.autograd.grad(yr, [x], go)
+    d = dev()
+    xd = x.detach().float().to(d).requires_grad_(True)
+    yd = ops.max_pool_3x3_s2(xd)
+    close(yd, yr, "maxpool fwd", rtol=1e-6)
+    (gd,) = torch.autograd.grad(yd, [xd], go.float().to(d))
+    close(gd, gr, "maxpool bwd", rtol=1e-5)
+
+
+def test_ops_reject_cpu_tensors():
+    from planerecnet_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 1, 1))
