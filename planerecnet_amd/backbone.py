@@ -1,0 +1,117 @@
+"""ResNet-DCN backbone (reference: models/backbone.py).
+
+Module tree, parameter names and the plugin contract (`.channels`, `.layers`, `.backbone_modules`,
+`.init_backbone`, `.add_layer`, `forward -> tuple`, `construct_backbone(cfg.backbone)`) are the reference's;
+nn.Conv2d / nn.BatchNorm2d instances are used as parameter containers only -- the arithmetic runs in the HIP
+operators (planerecnet_amd.ops): every BatchNorm launch also applies the ReLU and, for bn3, the residual add.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .dcn import DeformableConv2d
+
+
+def _bn(m, x, residual=None, relu=False):
+    return ops.batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
+
+
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (stride here; plain or deformable) -> 1x1, each + BN, residual, ReLU (backbone.py:5-73)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=nn.BatchNorm2d, dilation=1, use_dcn=False):
+        super().__init__()
+        if dilation != 1:
+            raise NotImplementedError("atrous layers are not used by the PlaneRecNet configs")
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = (DeformableConv2d(planes, planes, 3, stride=stride, padding=1, bias=True) if use_dcn
+                      else nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False))
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = _bn(self.bn1, ops.conv2d(x, self.conv1.weight), relu=True)
+        if isinstance(self.conv2, DeformableConv2d):
+            out = self.conv2(out)
+        else:
+            out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1)
+        out = _bn(self.bn2, out, relu=True)
+        out = ops.conv2d(out, self.conv3.weight)
+        res = x
+        if self.downsample is not None:
+            res = _bn(self.downsample[1], ops.conv2d(x, self.downsample[0].weight, stride=self.downsample[0].stride[0]))
+        return _bn(self.bn3, out, residual=res, relu=True)
+
+
+class ResNetBackbone(nn.Module):
+    def __init__(self, layers, dcn_layers=[0, 0, 0, 0], dcn_interval=1, atrous_layers=[], block=Bottleneck,
+                 norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.num_base_layers = len(layers)
+        self.layers = nn.ModuleList()
+        self.channels = []
+        self.norm_layer = norm_layer
+        self.dilation = 1
+        self.atrous_layers = atrous_layers
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+            self._make_layer(block, planes, n, stride=1 if i == 0 else 2, dcn_layers=dcn_layers[i], dcn_interval=dcn_interval)
+        # modules that a pretrained ImageNet checkpoint initialises (read by PlaneRecNet.init_weights)
+        self.backbone_modules = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
+
+    def _make_layer(self, block, planes, blocks, stride=1, dcn_layers=0, dcn_interval=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            if len(self.layers) in self.atrous_layers:
+                self.dilation += 1
+                stride = 1
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                                       self.norm_layer(planes * block.expansion))
+        # DCN placement rule: backbone.py:170,184
+        stage = [block(self.inplanes, planes, stride, downsample, self.norm_layer, self.dilation, use_dcn=dcn_layers >= blocks)]
+        self.inplanes = planes * block.expansion
+        for i in range(1, blocks):
+            stage.append(block(self.inplanes, planes, norm_layer=self.norm_layer,
+                               use_dcn=((i + dcn_layers) >= blocks) and (i % dcn_interval == 0)))
+        layer = nn.Sequential(*stage)
+        self.channels.append(planes * block.expansion)
+        self.layers.append(layer)
+        return layer
+
+    def forward(self, x):
+        x = _bn(self.bn1, ops.conv2d(x, self.conv1.weight, stride=2, pad=3), relu=True)
+        x = ops.max_pool_3x3_s2(x)
+        outs = []
+        for layer in self.layers:
+            x = layer(x)
+            outs.append(x)
+        return tuple(outs)
+
+    def init_backbone(self, path):
+        """Load torchvision-style ImageNet weights: layerN.* -> layers.(N-1).*, strict=False (backbone.py:211-224)."""
+        sd = torch.load(path, map_location="cpu")
+        for key in list(sd):
+            if key.startswith("layer"):
+                sd["layers." + str(int(key[5]) - 1) + key[6:]] = sd.pop(key)
+        self.load_state_dict(sd, strict=False)
+
+    def add_layer(self, conv_channels=1024, downsample=2, depth=1, block=Bottleneck):
+        self._make_layer(block, conv_channels // block.expansion, blocks=depth, stride=downsample)
+
+
+def construct_backbone(cfg):
+    """cfg.type(*cfg.args) -- the backbone plugin hook (backbone.py:233-243)."""
+    backbone = cfg.type(*cfg.args)
+    while len(backbone.layers) < max(cfg.selected_layers) + 1:
+        backbone.add_layer()
+    return backbone

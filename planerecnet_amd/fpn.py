@@ -1,0 +1,48 @@
+"""FPN (reference: models/fpn.py). NOTE the reference accumulates BOTTOM-UP: the finer lateral is bilinearly
+resized to the next coarser level and added to that level's 1x1 lateral (fpn.py:51-56).  Here the add is the
+`addend` of the lateral's implicit-GEMM epilogue and the ReLU of the 3x3 output conv is its epilogue."""
+from torch import nn
+
+from . import ops
+from .config import cfg
+
+
+class FPN(nn.Module):
+    def __init__(self, in_channels, start_level=0):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        self.in_channels = in_channels
+        self.out_channels = cfg.fpn.num_features
+        self.num_ins = len(in_channels)
+        self.backbone_end_level = self.num_ins
+        self.start_level = start_level
+        self.lateral_convs = nn.ModuleList(nn.Conv2d(in_channels[i], self.out_channels, 1)
+                                           for i in range(start_level, self.backbone_end_level))
+        self.fpn_convs = nn.ModuleList(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)
+                                       for _ in range(start_level, self.backbone_end_level))
+        if cfg.fpn.high_level_mode == "retina":
+            self.downsample_layers = nn.ModuleList(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1, stride=2)
+                                                   for _ in range(2))
+        self.interpolation_mode = cfg.fpn.interpolation_mode
+        self.relu_pred_layers = cfg.fpn.relu_pred_layers
+        self.high_level_mode = cfg.fpn.high_level_mode
+        if self.interpolation_mode != "bilinear":
+            raise NotImplementedError("fpn.interpolation_mode=%r" % self.interpolation_mode)
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals, prev = [], None
+        for i, lat in enumerate(self.lateral_convs):
+            f = inputs[i + self.start_level]
+            add = None if prev is None else ops.resize_bilinear(prev, f.shape[2:])
+            prev = ops.conv2d(f, lat.weight, lat.bias, addend=add)
+            laterals.append(prev)
+        epi = ops.EPI_RELU if self.relu_pred_layers else ops.EPI_NONE
+        outs = [ops.conv2d(l, c.weight, c.bias, pad=1, epilogue=epi) for l, c in zip(laterals, self.fpn_convs)]
+        if self.high_level_mode == "original":
+            outs.append(outs[-1][:, :, ::2, ::2])            # max_pool2d(kernel 1, stride 2)
+        elif self.high_level_mode == "retina":
+            p6 = ops.conv2d(outs[-1], self.downsample_layers[0].weight, self.downsample_layers[0].bias, stride=2, pad=1)
+            p7 = ops.conv2d(p6.relu(), self.downsample_layers[1].weight, self.downsample_layers[1].bias, stride=2, pad=1)
+            outs += [p6, p7]
+        return outs

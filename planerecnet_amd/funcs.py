@@ -1,0 +1,65 @@
+"""Geometry / init helpers on the hot path (reference: models/functions/funcs.py:195-224,329-332 and the
+`imrescale` call of losses.py:243-247).  cv2 is not a dependency: the only cv2 call on the path is a uint8
+bilinear resize at exactly 1/4 scale, restated in closed form below."""
+import math
+
+import numpy as np
+import torch
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-math.log((1 - prior_prob) / prior_prob))
+
+
+def calc_size_preserve_ar(img_w, img_h, max_size):
+    if img_w > img_h:
+        return int(max_size), int(img_h / img_w * max_size)
+    return int(img_w / img_h * max_size), int(max_size)
+
+
+def pad_even_divided(img, divisor=32):
+    """Zero-pad an HxWxC array (numpy) on the bottom/right so both sides divide `divisor`."""
+    h, w, c = img.shape
+    out = np.zeros((h + (-h) % divisor, w + (-w) % divisor, c))
+    out[:h, :w] = img
+    return out
+
+
+def center_of_mass(bitmasks):
+    _, h, w = bitmasks.size()
+    ys = torch.arange(0, h, dtype=torch.float32, device=bitmasks.device)
+    xs = torch.arange(0, w, dtype=torch.float32, device=bitmasks.device)
+    m00 = bitmasks.sum(dim=-1).sum(dim=-1).clamp(min=1e-6)
+    return (bitmasks * xs).sum(dim=-1).sum(dim=-1) / m00, (bitmasks * ys[:, None]).sum(dim=-1).sum(dim=-1) / m00
+
+
+def quarter_mask_u8(masks):
+    """uint8 [N,H,W] -> uint8 [N,H/4,W/4]: OpenCV INTER_LINEAR at exact 1/4 samples the centre of each 4x4 block,
+    i.e. the mean of its 2x2 middle pixels, rounded half up in fixed point."""
+    a = masks.to(torch.int32)
+    s = a[:, 1::4, 1::4] + a[:, 1::4, 2::4] + a[:, 2::4, 1::4] + a[:, 2::4, 2::4]
+    return ((s + 2) >> 2).to(torch.uint8)
+
+
+class FastBaseTransform(torch.nn.Module):
+    """[n,h,w,3] BGR 0..255 -> [n,3,h,w] RGB normalised (reference data/augmentations.py:496-530)."""
+
+    def __init__(self):
+        super().__init__()
+        from .config import MEANS, STD, cfg
+        self.register_buffer("mean", torch.tensor(MEANS, dtype=torch.float32)[None, :, None, None], persistent=False)
+        self.register_buffer("std", torch.tensor(STD, dtype=torch.float32)[None, :, None, None], persistent=False)
+        self.transform = cfg.backbone.transform
+
+    def forward(self, img):
+        img = img.permute(0, 3, 1, 2).contiguous()
+        mean, std = self.mean.to(img.device), self.std.to(img.device)
+        if self.transform.normalize:
+            img = (img - mean) / std
+        elif self.transform.subtract_means:
+            img = img - mean
+        elif self.transform.to_float:
+            img = img / 255.0
+        if self.transform.channel_order != "RGB":
+            raise NotImplementedError
+        return img[:, (2, 1, 0), :, :].contiguous()
