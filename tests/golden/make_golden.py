@@ -78,7 +78,7 @@ def main():
         print(mode, "oracle vs reference max-rel (fp32):", {k: f"{v:.1e}" for k, v in errs.items()})
         # fp32: both sides are deterministic but differ by 1-ulp kernel-selection noise (in-place vs
         # out-of-place ops) that small-batch BN amplifies; semantics are pinned by the fp64 pass below.
-        assert max(errs.values()) < 2e-4, errs
+        assert max(errs.values()) < 5e-5, errs
         net.double()
         sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
         with torch.no_grad():

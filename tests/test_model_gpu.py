@@ -2,9 +2,9 @@
 (oracle/model_ref.py, oracle/loss_ref.py -- proven equal to the real reference by tests/golden/make_golden.py)
 on the same seeded weights and inputs.
 
-Tolerances (fp32, stated per north_star): dense outputs 2e-3 max-abs relative to the tensor's max (a 50-layer
-chain whose train-mode BatchNorm statistics amplify 1-ulp differences; the oracle itself differs from the
-reference by 2e-4 on these inputs), losses rtol 1e-3 / atol 1e-4, parameter gradients 1e-2 of the gradient's max."""
+Tolerances (fp32, stated per north_star): dense outputs 5e-4 max-abs relative to the tensor's max (a 50-layer fp32
+chain with train-mode BatchNorm; on these well-conditioned seeded weights the oracle's own fp32-vs-fp64 spread is
+~1e-5), losses rtol 1e-3 / atol 1e-4, parameter gradients 1e-2 of the gradient's max."""
 import numpy as np
 import pytest
 import torch
@@ -48,11 +48,11 @@ def test_forward_matches_oracle(setup, mode):
     with torch.no_grad():
         mask, cate, kern, depth = net(x.cuda())
         o_mask, o_cate, o_kern, o_depth = model_ref.forward(sd, x, arch, training=(mode == "train"))
-    close(mask, o_mask, 2e-3, "mask_pred")
-    close(depth, o_depth, 2e-3, "depth_pred")
+    close(mask, o_mask, 5e-4, "mask_pred")
+    close(depth, o_depth, 5e-4, "depth_pred")
     for i in range(4):
-        close(cate[i], o_cate[i], 2e-3, f"cate{i}")
-        close(kern[i], o_kern[i], 2e-3, f"kernel{i}")
+        close(cate[i], o_cate[i], 5e-4, f"cate{i}")
+        close(kern[i], o_kern[i], 5e-4, f"kernel{i}")
     if mode == "train":                           # running statistics were updated like nn.BatchNorm2d would
         sd2 = {k: v.clone() for k, v in sd.items()}
         with torch.no_grad():

@@ -38,12 +38,12 @@ def test_model_small_matches_reference(sd, golden_dir, mode):
     x, _, _ = synth.make_batch(2, 64, 96, seed=2)
     with torch.no_grad():
         mask, cate, kern, depth = model_ref.forward(sd, x, ARCH, training=(mode == "train"))
-    # fp32 tolerance: 1-ulp kernel-selection noise amplified by small-batch BN (see make_golden.py)
-    close(mask, fx[f"{mode}_mask"], 2e-4, "mask")
-    close(depth, fx[f"{mode}_depth"], 2e-4, "depth")
+    # fp32 tolerance: 1-ulp kernel-selection noise between in-place/out-of-place ATen paths (see make_golden.py)
+    close(mask, fx[f"{mode}_mask"], 5e-5, "mask")
+    close(depth, fx[f"{mode}_depth"], 5e-5, "depth")
     for i in range(4):
-        close(cate[i], fx[f"{mode}_cate{i}"], 2e-4, f"cate{i}")
-        close(digest(kern[i]), fx[f"{mode}_kern{i}_digest"], 2e-4, f"kern{i}")
+        close(cate[i], fx[f"{mode}_cate{i}"], 5e-5, f"cate{i}")
+        close(digest(kern[i]), fx[f"{mode}_kern{i}_digest"], 5e-5, f"kern{i}")
 
 
 def test_inference_postprocess_matches_reference(sd, golden_dir):
