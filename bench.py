@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of one PlaneRecNet_101 optimisation step (forward + joint loss + backward +
+gradient exchange + Adam) at 480x640, per-GPU batch 8, synthetic data, random-init weights (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` = global images / max-over-ranks wall time of exactly K steps bracketed by
+barrier + device synchronize.  Inputs (images, GT) are resident in HBM / host memory before the timed region.
+
+Extra objects:
+  roofline     -- the dominant kernel family (implicit-GEMM conv on fp32 MFMA: forward + dgrad launches).  Every launch of
+                  one extra, untimed step is bracketed by HIP events on the launch stream; achieved = sum of algorithmic
+                  FLOPs (2*M*K*N of the reference convolution) / sum of event durations.  peak = 157.3 TFLOP/s (fp32 MFMA,
+                  MI355X_MICROARCH.md).  `kernels` lists the other families the same way.
+  cpu_baseline -- the oracle (CPU restatement proven equal to the reference) timed on the host cores on a bounded sample:
+                  ONE image, same model/loss, forward+backward.  kind = "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "img/s fwd+bwd @480×640 ResNet101-DCN, 1/2/4/8 MI355X + roofline %"
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(B, H, W, seed, device):
+    """SURVEY.md 8(d) synthetic batch (same generator as the parity tests; oracle/synth.py is test infrastructure, so the
+    generator is restated here for the product path)."""
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, H, W, generator=g)
+    depths = 0.5 + 4.0 * torch.rand(B, 1, H, W, generator=g)
+    inst = []
+    for _ in range(B):
+        n = int(rng.randint(3, 9))
+        masks = np.zeros((n, H, W), np.uint8)
+        boxes = np.zeros((n, 4), np.float64)
+        for i in range(n):
+            bw, bh = int(rng.randint(max(W // 16, 8), W // 2)), int(rng.randint(max(H // 16, 8), H // 2))
+            x0, y0 = int(rng.randint(0, W - bw)), int(rng.randint(0, H - bh))
+            masks[i, y0:y0 + bh, x0:x0 + bw] = 1
+            boxes[i] = (x0, y0, x0 + bw, y0 + bh)
+        nrm = rng.randn(n, 3)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        paras = np.concatenate([nrm, rng.rand(n, 1) * 3.0, np.zeros((n, 2))], 1)
+        K = np.array([[577.0, 0, W / 2], [0, 577.0, H / 2], [0, 0, 1]], np.float64)
+        inst.append({"masks": torch.from_numpy(masks), "boxes": torch.from_numpy(boxes), "classes": torch.zeros(n, dtype=torch.int64),
+                     "plane_paras": torch.from_numpy(paras), "k_matrix": torch.from_numpy(K)})
+    return images.to(device), [{k: v.to(device) for k, v in d.items()} for d in inst], depths.to(device)
+
+
+def cpu_baseline(config_name, H, W, threads):
+    """Oracle fwd + loss + bwd on ONE image on the host cores."""
+    from oracle import loss_ref, model_ref, synth
+    torch.set_num_threads(threads)
+    arch = model_ref.ARCH[config_name]
+    sd = synth.make_state_dict(config_name, seed=0)
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+    x, inst, gtd = synth.make_batch(1, H, W, seed=0)
+    leaves = [v for v in sd.values() if v.requires_grad]
+    times = []
+    for it in range(2):                               # 1 warm-up + 1 timed (about 10-30 s of CPU work in total)
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        out = model_ref.forward(sd, x, arch, training=True)
+        ls = loss_ref.joint_loss(*out, inst, gtd)
+        torch.autograd.grad(sum(ls.values()).sum(), leaves, allow_unused=True)
+        times.append(time.perf_counter() - t0)
+    return {"value": 1.0 / times[-1], "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": "1 image, %s fwd+loss+bwd at %dx%d, 2nd of 2 iterations, torch CPU fp32 oracle" % (config_name, H, W)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="PlaneRecNet_101_config")
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from planerecnet_amd import ops, profiling
+    from planerecnet_amd.config import cfg, set_cfg
+    from planerecnet_amd.losses import PlaneRecNetLoss
+    from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
+    from planerecnet_amd.planerecnet import PlaneRecNet
+
+    set_cfg(args.config)
+    torch.manual_seed(0)                               # identical replicas on every rank
+    net = PlaneRecNet(cfg)
+    net.init_head_weights()
+    net = net.to(dev).train()
+    crit = PlaneRecNetLoss().to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    exchange = GradAllReduce(list(net.parameters()))
+    images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
+    np.random.seed(rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(images)
+        losses = crit(net, *out, inst, depths)
+        loss = sum(losses.values()).sum()
+        loss.backward()
+        exchange.finish()
+        opt.step()
+        return losses
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_means = all_reduce_mean_scalars([losses[k].detach().sum() for k in sorted(losses)], dev).tolist()
+    finite = all(np.isfinite(v) for v in loss_means)
+
+    roof, kernels = None, None
+    if rank == 0 and not args.no_roofline:
+        profiling.enable()
+        step()
+        torch.cuda.synchronize()
+        fams = profiling.summary()
+        profiling.disable()
+        kernels = fams
+        dom = max((f for f in fams if f["bound"] == "mfma"), key=lambda f: f["time_ms"])
+        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": dom["launches"],
+                "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.config, args.height, args.width, os.cpu_count() or 1)
+
+    if rank == 0:
+        gb = args.batch * world
+        line = {"metric": METRIC, "value": gb * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s train step (fwd + 5-term loss + bwd + grad all-reduce + Adam), per-GPU batch %d, %dx%d synthetic RGB+depth+planes, random-init weights"
+                           % (args.config, args.batch, args.height, args.width), "global_batch": gb, "parallelism": "dp%d" % world},
+                "losses_finite": finite, "losses": dict(zip(sorted(losses), loss_means)),
+                "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

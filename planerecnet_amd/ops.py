@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, profiling
 from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
@@ -51,7 +51,11 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     B, C, H, W = x.shape
     y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
     d = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
-    check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _stream()), "prn_conv2d_fwd")
+    # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
+    # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
+    flops = 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)
+    with profiling.span("conv_igemm_kernel", "mfma", flops):
+        check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _stream()), "prn_conv2d_fwd")
     return y
 
 
@@ -64,7 +68,8 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
         raise RuntimeError(lib.prn_last_error().decode())
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
-    check(lib.prn_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
+    with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo):
+        check(lib.prn_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
     return dw
 
 
@@ -147,7 +152,8 @@ class _DeformConv(torch.autograd.Function):
         Ho, Wo = om.shape[2:]
         assert om.shape[1] == 27 and w.shape[2] == 3
         cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
-        check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
+        with profiling.span("dcn_sample_kernel", "hbm", 4.0 * (x.numel() + om.numel() + cols.numel())):
+            check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
         y = conv_fwd_raw(cols, w, bias, None, M, 1, 1, 0, Ho, Wo)
         ctx.save_for_backward(x, om, w, cols)
         ctx.cfg = (stride, float(max_offset), bias is not None)
@@ -167,8 +173,9 @@ class _DeformConv(torch.autograd.Function):
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[3]) else None
         dx = torch.zeros_like(x)
         dom = torch.empty_like(om)
-        check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
-              "prn_dcn_sample_bwd")
+        with profiling.span("dcn_sample_bwd_kernel", "hbm", 4.0 * (2 * x.numel() + 2 * om.numel() + dcols.numel())):
+            check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
+                  "prn_dcn_sample_bwd")
         return dx, dom, dw, db, None, None
 
 
@@ -189,11 +196,13 @@ class _BatchNorm(torch.autograd.Function):
         if training:
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
-            check(lib.prn_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), _p(ws), B, C, HW, eps, momentum, _stream()), "prn_bn_stats")
+            with profiling.span("bn_stats", "hbm", 4.0 * x.numel()):
+                check(lib.prn_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), _p(ws), B, C, HW, eps, momentum, _stream()), "prn_bn_stats")
         else:
             stats = torch.cat([rmean, torch.rsqrt(rvar + eps)])
         y = torch.empty_like(x)
-        check(lib.prn_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), B, C, HW, int(relu), _stream()), "prn_bn_apply")
+        with profiling.span("bn_apply", "hbm", 4.0 * x.numel() * (3 if residual is not None else 2)):
+            check(lib.prn_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), B, C, HW, int(relu), _stream()), "prn_bn_apply")
         ctx.save_for_backward(x, y if relu else None, stats, gamma)
         ctx.cfg = (training, relu, residual is not None)
         return y
@@ -210,8 +219,9 @@ class _BatchNorm(torch.autograd.Function):
         dg = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
-        check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
-                             B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
+        with profiling.span("bn_bwd", "hbm", 4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
+            check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
+                                 B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
         return dx, dg, db, None, None, dres, None, None, None, None
 
 
@@ -230,7 +240,8 @@ class _GroupNormReLU(torch.autograd.Function):
         B, C, H, W = x.shape
         y = torch.empty_like(x)
         stats = torch.empty(B * groups * 2, device=x.device, dtype=torch.float32)
-        check(lib.prn_gn_relu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, C, H * W, groups, eps, _stream()), "prn_gn_relu_fwd")
+        with profiling.span("gn_relu_fwd", "hbm", 4.0 * x.numel() * 2):
+            check(lib.prn_gn_relu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, C, H * W, groups, eps, _stream()), "prn_gn_relu_fwd")
         ctx.save_for_backward(x, y, stats, gamma)
         ctx.groups = groups
         return y
@@ -243,8 +254,9 @@ class _GroupNormReLU(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgp = torch.empty(B, C, device=x.device, dtype=torch.float32)
         dbp = torch.empty(B, C, device=x.device, dtype=torch.float32)
-        check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), B, C, H * W, ctx.groups, _stream()),
-              "prn_gn_relu_bwd")
+        with profiling.span("gn_relu_bwd", "hbm", 4.0 * x.numel() * 4):
+            check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), B, C, H * W, ctx.groups, _stream()),
+                  "prn_gn_relu_bwd")
         return dx, dgp.sum(0), dbp.sum(0), None, None
 
 

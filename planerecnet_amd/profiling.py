@@ -1,0 +1,66 @@
+"""Live per-kernel-family timing for bench.py's roofline object.
+
+When enabled, ops.py brackets every HIP launch of the heavy kernel families with a pair of HIP events recorded on the
+stream the kernel is launched on (torch's current stream -- the same handle that is passed to the C ABI), and logs the
+launch's ALGORITHMIC work: FLOPs for the MFMA contraction kernels (2*M*K*N of the reference convolution, whatever the
+kernel really executes, e.g. the zero taps of a strided dgrad are not credited), bytes for the HBM-bound families
+(4 B x elements the reference op must read + write).  Disabled (the default) it costs one attribute test per launch.
+"""
+import torch
+
+_enabled = False
+_records = []          # (family, bound, work, start_event, end_event)
+
+
+def enable():
+    global _enabled
+    _records.clear()
+    _enabled = True
+
+
+def disable():
+    global _enabled
+    _enabled = False
+
+
+def active():
+    return _enabled
+
+
+class span:
+    """with span(family, bound, work): <launch>"""
+    __slots__ = ("family", "bound", "work", "s", "e")
+
+    def __init__(self, family, bound, work):
+        self.family, self.bound, self.work = family, bound, work
+
+    def __enter__(self):
+        if _enabled:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if _enabled:
+            self.e.record()
+            _records.append((self.family, self.bound, self.work, self.s, self.e))
+
+
+def summary():
+    """-> list of {kernel, bound, launches, time_ms, work, achieved, unit} sorted by time (call after a device sync)."""
+    fams = {}
+    for fam, bound, work, s, e in _records:
+        f = fams.setdefault(fam, {"kernel": fam, "bound": bound, "launches": 0, "time_ms": 0.0, "work": 0.0})
+        f["launches"] += 1
+        f["time_ms"] += s.elapsed_time(e)
+        f["work"] += float(work)
+    out = []
+    for f in fams.values():
+        if f["bound"] == "mfma":
+            f["achieved"] = f["work"] / (f["time_ms"] * 1e-3) / 1e12 if f["time_ms"] > 0 else 0.0
+            f["unit"] = "TFLOP/s"
+        else:
+            f["achieved"] = f["work"] / (f["time_ms"] * 1e-3) / 1e9 if f["time_ms"] > 0 else 0.0
+            f["unit"] = "GB/s"
+        out.append(f)
+    return sorted(out, key=lambda f: -f["time_ms"])
