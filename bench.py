@@ -56,7 +56,8 @@ def synth_batch(B, H, W, seed, device):
         K = np.array([[577.0, 0, W / 2], [0, 577.0, H / 2], [0, 0, 1]], np.float64)
         inst.append({"masks": torch.from_numpy(masks), "boxes": torch.from_numpy(boxes), "classes": torch.zeros(n, dtype=torch.int64),
                      "plane_paras": torch.from_numpy(paras), "k_matrix": torch.from_numpy(K)})
-    return images.to(device), [{k: v.to(device) for k, v in d.items()} for d in inst], depths.to(device)
+    # annotations stay on the host (the loss's GT-only preparation runs there); images and GT depth live in HBM
+    return images.to(device), inst, depths.to(device)
 
 
 def cpu_baseline(config_name, H, W, threads):
@@ -125,8 +126,9 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
+        targets = crit.prepare(inst, depths, dev)          # GT-only host work + async uploads (overlaps the previous step's backward)
         out = net(images)
-        losses = crit(net, *out, inst, depths)
+        losses = crit(net, *out, inst, depths, targets=targets)
         loss = sum(losses.values()).sum()
         loss.backward()
         exchange.finish()
@@ -169,7 +171,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.config, args.height, args.width, os.cpu_count() or 1)
+        cpu = cpu_baseline(args.config, args.height, args.width, min(16, os.cpu_count() or 1))
 
     if rank == 0:
         gb = args.batch * world

@@ -104,7 +104,7 @@ int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float
 
 /* ---- resampling ---------------------------------------------------------------------------------------------------
  * bilinear, align_corners=False (F.interpolate / nn.Upsample): models/fpn.py:54 ; planerecnet.py:115,381,439,453,594 ;
- * losses.py:143,299.  bwd accumulates into dx (caller zero-fills). */
+ * losses.py:143,299.  bwd is the exact adjoint in gather form (overwrites dx, deterministic). */
 int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
 int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 /* MaxPool2d(3, stride 2, pad 1): models/backbone.py:104 */

@@ -30,19 +30,45 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
   y[i] = a.w0 * (b.w0 * p[a.i0 * W + b.i0] + b.w1 * p[a.i0 * W + b.i1]) + a.w1 * (b.w0 * p[a.i1 * W + b.i0] + b.w1 * p[a.i1 * W + b.i1]);
 }
 
+// Adjoint of the bilinear resize in GATHER form (deterministic, no atomics): one thread per INPUT pixel sums the
+// output pixels whose 2x2 footprint contains it.  Candidate outputs are bounded from the inverse of the source-index
+// map and re-checked with the exact forward index computation, so border clamping is handled by construction.
+__device__ __forceinline__ void cand_range(int i, int out, float scale, int& lo, int& hi) {
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out - 1 ? out - 1 : hi;
+  // the clamp of negative source coordinates maps every leading output onto input 0 / the trailing ones onto in-1
+  if (i == 0) lo = 0;
+}
+
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total,
                                                          int H, int W, int Ho, int Wo, float sh, float sw) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int wo = i % Wo, ho = (i / Wo) % Ho;
-  const int64_t bc = i / ((int64_t)Wo * Ho);
-  const Lerp a = lerp_idx(ho, H, sh), b = lerp_idx(wo, W, sw);
-  float* p = dx + bc * (int64_t)H * W;
-  const float g = dy[i];
-  atomicAdd(p + a.i0 * W + b.i0, g * a.w0 * b.w0);
-  atomicAdd(p + a.i0 * W + b.i1, g * a.w0 * b.w1);
-  atomicAdd(p + a.i1 * W + b.i0, g * a.w1 * b.w0);
-  atomicAdd(p + a.i1 * W + b.i1, g * a.w1 * b.w1);
+  const int w = i % W, h = (i / W) % H;
+  const int64_t bc = i / ((int64_t)W * H);
+  int hlo, hhi, wlo, whi;
+  cand_range(h, Ho, sh, hlo, hhi);
+  cand_range(w, Wo, sw, wlo, whi);
+  if (h == H - 1) hhi = Ho - 1;
+  if (w == W - 1) whi = Wo - 1;
+  const float* p = dy + bc * (int64_t)Ho * Wo;
+  float acc = 0.f;
+  for (int oh = hlo; oh <= hhi; ++oh) {
+    const Lerp a = lerp_idx(oh, H, sh);
+    const float wh = (a.i0 == h ? a.w0 : 0.f) + (a.i1 == h ? a.w1 : 0.f);
+    if (wh == 0.f) continue;
+    float row = 0.f;
+    for (int ow = wlo; ow <= whi; ++ow) {
+      const Lerp b = lerp_idx(ow, W, sw);
+      const float ww = (b.i0 == w ? b.w0 : 0.f) + (b.i1 == w ? b.w1 : 0.f);
+      row += ww * p[(int64_t)oh * Wo + ow];
+    }
+    acc += wh * row;
+  }
+  dx[i] = acc;
 }
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total,
@@ -101,7 +127,7 @@ extern "C" int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, 
 
 extern "C" int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_bwd: bad arguments");
-  const int64_t n = (int64_t)BC * Ho * Wo;
+  const int64_t n = (int64_t)BC * H * W;
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
   PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd");
   return 0;

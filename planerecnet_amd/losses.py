@@ -1,18 +1,21 @@
-"""Joint five-term loss (reference: models/functions/losses.py + vnl.py) on device tensors.
+"""Joint five-term loss (reference: models/functions/losses.py + vnl.py), restructured for a GPU that must not wait
+for the host.
 
-Interface and semantics follow the reference (`PlaneRecNetLoss().forward(net, mask_preds, cate_preds,
-kernel_preds, depth_preds, gt_instances, gt_depths) -> {'ins','cat','dpt','pln','lav'}`), quirks included
-(SURVEY.md A.4).  What changes is where the work runs:
+Interface and semantics follow the reference: `PlaneRecNetLoss().forward(net, mask_preds, cate_preds, kernel_preds,
+depth_preds, gt_instances, gt_depths) -> {'ins','cat','dpt','pln','lav'}` with the quirks of SURVEY.md A.4.  The
+structure is different:
 
-  * SOLOv2 target assignment needs only the GT (never the predictions), so it runs on the host copies of the GT
-    in one pass per image -- the reference's per-level device->host->device round trip of the masks through
-    cv2 (losses.py:243-247) is replaced by a closed-form 1/4-scale resize;
-  * the dynamic mask decoding (losses.py:86-93) is a 1x1 implicit-GEMM launch per (level, image) through
-    ops.conv2d, whose backward provides d(mask_pred) and d(kernel_pred);
-  * resizes go through ops.resize_bilinear; the remaining reductions are small device ops.
-
-The virtual-normal term keeps drawing its triplets from numpy's global RNG in the reference's call order
-(vnl.py:43-55), so a shared `np.random.seed` reproduces the reference stream.
+  * everything that depends only on the ground truth -- SOLOv2 target assignment (losses.py:200-286), the random
+    triplet indices of the virtual-normal loss (vnl.py:43-55, drawn from numpy's global RNG in the reference's call
+    order), the depth-gradient map of the lava term (losses.py:169-185) -- is computed by `prepare()` on HOST copies of
+    the GT and uploaded asynchronously.  A training loop calls `prepare()` before it enqueues the forward, so this host
+    work overlaps with the previous step's backward on the GPU and the step contains no device->host synchronisation.
+    (`forward()` without `targets=` calls it itself and then has to synchronise, like the reference does.)
+  * per-(level, image) Python loops become one batched launch each: one dynamic 1x1 conv per image over all its
+    positive cells (losses.py:86-93), one vectorised Dice / focal / lava evaluation for the batch, and ONE pass over all
+    virtual-normal triplets of all planes of all images (the reference loops planes and images, vnl.py:119-165) with a
+    single segmented sort for the "drop the best 25 %" rule.
+  * lava: sum(up4(s) * g) is evaluated as sum(s * up4^T(g)); the adjoint-resized gradient map depends only on the GT.
 """
 import numpy as np
 import torch
@@ -22,6 +25,11 @@ from torch import nn
 from . import ops
 from .config import cfg
 from .funcs import center_of_mass, quarter_mask_u8
+
+
+class Targets:
+    """Device-resident, GT-only inputs of one loss evaluation (built by PlaneRecNetLoss.prepare)."""
+    __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum")
 
 
 class PlaneRecNetLoss(nn.Module):
@@ -36,7 +44,7 @@ class PlaneRecNetLoss(nn.Module):
         self.depth_resolution, self.dataset_name = cfg.dataset.depth_resolution, cfg.dataset.name
         self.vnl = VNL_Loss((480, 640))                                     # hard-wired size: quirk Q5
 
-    # ------------------------------------------------------------------ targets (host)
+    # ------------------------------------------------------------------ SOLOv2 targets (host)
     @torch.no_grad()
     def prepare_ground_truth(self, inst, mask_feat_size):
         """losses.py:200-286 for one image, on host tensors. Returns per-level lists
@@ -84,69 +92,91 @@ class PlaneRecNetLoss(nn.Module):
             order_l.append(order)
         return ins_l, cate_l, ind_l, order_l
 
+    # ------------------------------------------------------------------ GT-only work, before the forward
+    @torch.no_grad()
+    def prepare(self, gt_instances, gt_depths, device, mask_feat_size=None):
+        """gt_instances: list of dicts of HOST tensors (device tensors are accepted but force a synchronising copy).
+        gt_depths: [B,1,H,W] on `device`.  Returns Targets."""
+        B = len(gt_instances)
+        H, W = gt_depths.shape[-2:]
+        fh, fw = mask_feat_size if mask_feat_size is not None else (H // 4, W // 4)
+        host = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in g.items()} for g in gt_instances]
+        L = len(self.num_grids)
+        level_start = np.concatenate([[0], np.cumsum([g * g for g in self.num_grids])])
+        t = Targets()
+        t.B = B
+        cell_ids, ins_labels, cate_rows, n_pos, num_ins = [], [], [[] for _ in range(L)], [], 0
+        for b in range(B):
+            ins_l, cate_l, ind_l, order_l = self.prepare_ground_truth(host[b], (fh, fw))
+            ids = [level_start[lv] + np.asarray(order_l[lv], dtype=np.int64) for lv in range(L)]
+            cell_ids.append(np.concatenate(ids) if ids else np.zeros(0, np.int64))
+            ins_labels.append(torch.cat(ins_l, 0))
+            n_pos.append(int(cell_ids[-1].shape[0]))
+            num_ins += sum(int(i.sum()) for i in ind_l)
+            for lv in range(L):
+                cate_rows[lv].append(cate_l[lv].flatten())
+        t.n_pos, t.num_ins = n_pos, num_ins
+        t.cell_ids = [torch.from_numpy(c).to(device, non_blocking=True) for c in cell_ids]
+        t.n_pos_dev = torch.as_tensor(n_pos, dtype=torch.float32).to(device, non_blocking=True)
+        t.pos_img = torch.from_numpy(np.repeat(np.arange(B), n_pos)).to(device, non_blocking=True)
+        t.ins_labels = torch.cat(ins_labels, 0).to(device, non_blocking=True)                       # [sum n_pos, fh, fw] uint8
+        # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
+        t.cate_labels = torch.cat([r for lv in range(L) for r in cate_rows[lv]]).to(device, non_blocking=True)
+        t.vnl = self.vnl.prepare(host, (H, W), device) if cfg.use_plane_loss else None
+        if cfg.use_lava_loss:
+            # Q3: dataset_name never equals 'ScanNet' / 'Stanford 2D3DS' (it is 'ScanNetDataset'), so valid_mask is None
+            grad = sobel_sq(gt_depths) / gt_depths.clamp(min=self.depth_resolution) ** 2
+            grad = grad.clamp(max=1e-2)
+            grad = torch.where(grad < 1e-4, torch.zeros_like(grad), grad)
+            t.lava_gsum = grad.flatten(1).sum(1)
+            adj = torch.empty(B, 1, fh, fw, device=device, dtype=torch.float32)
+            ops.check(ops.lib.prn_resize_bilinear_bwd(ops._p(grad.contiguous()), ops._p(adj), B, fh, fw, H, W, ops._stream()), "prn_resize_bilinear_bwd")
+            t.lava_adj = adj
+        else:
+            t.lava_gsum = t.lava_adj = None
+        return t
+
     # ------------------------------------------------------------------ forward
-    def forward(self, net, mask_preds, cate_preds, kernel_preds, depth_preds, gt_instances, gt_depths):
+    def forward(self, net, mask_preds, cate_preds, kernel_preds, depth_preds, gt_instances, gt_depths, targets=None):
         dev = mask_preds.device
         B = mask_preds.shape[0]
         fh, fw = mask_preds.shape[-2:]
-        L = len(self.num_grids)
-        tg = [self.prepare_ground_truth(g, (fh, fw)) for g in gt_instances]
+        t = targets if targets is not None else self.prepare(gt_instances, gt_depths, dev, (fh, fw))
+        E = kernel_preds[0].shape[1]
         losses = {}
 
-        # ---- ins (Dice) -- losses.py:69-118
-        per_img = [[] for _ in range(B)]
-        dice_terms, num_ins = [], 0
-        for lv in range(L):
-            preds, tgts = [], []
-            for b in range(B):
-                order = tg[b][3][lv]
-                num_ins += int(tg[b][2][lv].sum())
-                if not order:
-                    continue
-                idx = torch.as_tensor(order, device=dev)
-                k = kernel_preds[lv][b].reshape(kernel_preds[lv].shape[1], -1)[:, idx]            # [E, n]
-                p = ops.conv2d(mask_preds[b:b + 1], k.t().reshape(len(order), -1, 1, 1).contiguous()).view(-1, fh, fw)
-                preds.append(p)
-                per_img[b].append(p)
-                tgts.append(tg[b][0][lv])
-            if preds:
-                dice_terms.append(dice_loss(torch.sigmoid(torch.cat(preds, 0)), torch.cat(tgts, 0).to(dev, non_blocking=True)))
-        losses["ins"] = torch.cat(dice_terms).mean() * self.ins_loss_weight
+        # ---- ins (Dice) -- losses.py:69-118 : one dynamic conv per image over all of its positive cells
+        flat_k = torch.cat([k.reshape(B, E, -1) for k in kernel_preds], 2)                          # [B, E, 3728]
+        preds = []
+        for b in range(B):
+            if t.n_pos[b] == 0:
+                continue
+            w = flat_k[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
+            preds.append(ops.conv2d(mask_preds[b:b + 1], w).view(t.n_pos[b], fh, fw))
+        ins_sig = torch.sigmoid(torch.cat(preds, 0))                                                # [sum n_pos, fh, fw]
+        losses["ins"] = dice_loss(ins_sig, t.ins_labels).mean() * self.ins_loss_weight
 
         # ---- cat (sigmoid focal, sum / (num_pos + 1)) -- losses.py:121-138
-        flat_lab = torch.cat([tg[b][1][lv].flatten() for lv in range(L) for b in range(B)]).to(dev, non_blocking=True)
         flat_pred = torch.cat([c.permute(0, 2, 3, 1).reshape(-1, self.num_classes) for c in cate_preds])
-        onehot = F.one_hot(flat_lab, self.num_classes + 1)[:, : self.num_classes].to(flat_pred.dtype)
-        losses["cat"] = self.conf_loss_weight * sigmoid_focal_sum(flat_pred, onehot, self.focal_loss_alpha, self.focal_loss_gamma) / (num_ins + 1)
+        onehot = F.one_hot(t.cate_labels, self.num_classes + 1)[:, : self.num_classes].to(flat_pred.dtype)
+        losses["cat"] = self.conf_loss_weight * sigmoid_focal_sum(flat_pred, onehot, self.focal_loss_alpha, self.focal_loss_gamma) / (t.num_ins + 1)
 
         # ---- dpt (RMSE-log at full resolution) -- losses.py:142-147 (the clamp there is discarded: quirk Q2)
         dp = ops.resize_bilinear(depth_preds, (2 * depth_preds.shape[2], 2 * depth_preds.shape[3]))
-        valid = gt_depths > cfg.dataset.min_depth
-        losses["dpt"] = self.depth_loss_weight * rmse_log(dp, gt_depths, valid)
+        losses["dpt"] = self.depth_loss_weight * rmse_log(dp, gt_depths, gt_depths > cfg.dataset.min_depth)
 
         # ---- pln (virtual normals) -- losses.py:151-165
         if cfg.use_plane_loss:
-            terms = []
-            for b in range(B):
-                g = gt_instances[b]
-                terms.append(self.vnl(dp[b], g["masks"].to(dev).bool(), g["plane_paras"].to(dev)[:, :3], gt_depths[b], g["k_matrix"].to(dev)))
-            losses["pln"] = torch.stack(terms).mean() * self.pln_loss_weight
+            losses["pln"] = self.vnl.batched(dp, gt_depths, t.vnl).mean() * self.pln_loss_weight
 
-        # ---- lav (depth-gradient weighted mask energy) -- losses.py:169-197 ; valid_mask is always None (quirk Q3)
+        # ---- lav -- losses.py:169-197 : sum(up(s) * g) / (sum(g) * n)  ==  sum(s * up^T(g)) / (sum(g) * n)
         if cfg.use_lava_loss:
-            with torch.no_grad():
-                grad = sobel_sq(gt_depths) / gt_depths.clamp(min=self.depth_resolution) ** 2
-                grad = grad.clamp(max=1e-2)
-                grad = torch.where(grad < 1e-4, torch.zeros_like(grad), grad)
-                gsum = grad.flatten(1).sum(1)
-                has_grad = (gsum > 0).tolist()
-            terms = []
-            for b in range(B):
-                if per_img[b] and has_grad[b]:
-                    s = torch.cat(per_img[b], 0).sigmoid()
-                    s = ops.resize_bilinear(s.unsqueeze(0), grad.shape[2:]).squeeze(0)
-                    terms.append((s * grad[b]).sum() / (gsum[b] * s.shape[0]))
-            losses["lav"] = torch.stack(terms).mean() * self.lava_loss_weight if terms else torch.tensor([0.], device=dev)
+            seg, npos = t.pos_img, t.n_pos_dev
+            num = torch.zeros(B, device=dev, dtype=ins_sig.dtype).index_add_(0, seg, (ins_sig * t.lava_adj[seg, 0]).flatten(1).sum(1))
+            ok = (t.lava_gsum > 0) & (npos > 0)
+            per_img = torch.where(ok, num / (t.lava_gsum * npos).clamp(min=1e-30), torch.zeros_like(num))
+            # mean over qualifying images; 0 when none qualifies (the reference then returns a [1]-shaped zero, quirk Q4)
+            losses["lav"] = per_img.sum() / ok.sum().clamp(min=1) * self.lava_loss_weight
         return losses
 
 
@@ -184,8 +214,12 @@ def sobel_sq(d):
     return gx ** 2 + gy ** 2
 
 
+class VNLTargets:
+    __slots__ = ("B", "N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal", "n_seg", "n_tot", "has_np")
+
+
 class VNL_Loss(nn.Module):
-    """Virtual-normal plane loss (vnl.py:6-165)."""
+    """Virtual-normal plane loss (vnl.py:6-165), all planes of all images in one pass."""
 
     def __init__(self, input_size, delta_cos=0.867, delta_z=0.0001, sample_ratio=0.3):
         super().__init__()
@@ -195,74 +229,132 @@ class VNL_Loss(nn.Module):
         self.register_buffer("v_v0", torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(1, H, W) - float(H // 2), persistent=False)
         self.delta_cos, self.delta_z, self.sample_ratio = delta_cos, delta_z, sample_ratio
 
-    def transfer_xyz(self, depth, K):
-        u, v = self.u_u0.to(depth.device), self.v_v0.to(depth.device)
-        return torch.cat([u * depth.abs() / K[0, 0], v * depth.abs() / K[1, 1], depth], 0).permute(1, 2, 0)
-
-    def select_index(self, num, device):
+    def _draw(self, num):
+        """vnl.py:43-55: three (choice, shuffle) pairs from numpy's global RNG."""
         H, W = self.input_size
         if not num <= W * H:
             raise AssertionError()
         n = int(num * self.sample_ratio)
         out = []
-        for _ in range(3):                                  # same numpy call order as the reference
+        for _ in range(3):
             p = np.random.choice(num, n, replace=True)
             np.random.shuffle(p)
-            out.append(torch.from_numpy(p).to(device))
+            out.append(p)
         return out
 
-    @staticmethod
-    def form_pw_groups(p123, pw):
-        return torch.stack([pw[p123[0]], pw[p123[1]], pw[p123[2]]], 2)
+    @torch.no_grad()
+    def prepare(self, host_instances, hw, device):
+        """Host: pixel ids of every sampled triplet (global over the batch), segment bookkeeping; async upload."""
+        H, W = hw
+        t = VNLTargets()
+        gids, seg_len, seg_img, seg_plane, normals, N_per, fx, fy, has_np = [], [], [], [], [], [], [], [], []
+        for b, g in enumerate(host_instances):
+            masks = g["masks"].numpy().astype(bool)
+            K = g["k_matrix"].numpy()
+            fx.append(K[0, 0]); fy.append(K[1, 1])
+            N = masks.shape[0]
+            N_per.append(N)
+            planes = g["plane_paras"].numpy()[:, :3]
+            regions = [masks[i] for i in range(N)]
+            nonplanar = ~masks.any(0) if N > 0 else np.ones((H, W), bool)
+            np_count = int(nonplanar.sum())
+            has_np.append(np_count > 0)
+            if np_count > 0:
+                regions.append(nonplanar)
+            for r, m in enumerate(regions):
+                px = np.flatnonzero(m)
+                p123 = self._draw(px.shape[0])
+                gids.append(np.stack([px[p] for p in p123], 0) + b * H * W)           # [3, n]
+                seg_len.append(p123[0].shape[0])
+                seg_img.append(b)
+                seg_plane.append(r < N)
+                normals.append(planes[r] if r < N else np.zeros(3))
+        t.B, t.N = len(host_instances), torch.as_tensor(N_per, dtype=torch.float64).to(device, non_blocking=True)
+        t.fx = torch.as_tensor(np.asarray(fx), dtype=torch.float64).to(device, non_blocking=True)
+        t.fy = torch.as_tensor(np.asarray(fy), dtype=torch.float64).to(device, non_blocking=True)
+        seg_len = np.asarray(seg_len, dtype=np.int64)
+        t.n_seg, t.n_tot = len(seg_len), int(seg_len.sum())
+        t.gid = torch.from_numpy(np.concatenate(gids, 1) if gids else np.zeros((3, 0), np.int64)).to(device, non_blocking=True)
+        t.seg = torch.from_numpy(np.repeat(np.arange(t.n_seg), seg_len)).to(device, non_blocking=True)
+        t.seg_start = torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if t.n_seg else np.zeros(0, np.int64)).to(device, non_blocking=True)
+        t.seg_img = torch.as_tensor(seg_img, dtype=torch.int64).to(device, non_blocking=True)
+        t.seg_is_plane = torch.as_tensor(seg_plane, dtype=torch.bool).to(device, non_blocking=True)
+        t.seg_normal = torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3)).to(device, non_blocking=True)
+        t.has_np = torch.as_tensor(has_np, dtype=torch.bool).to(device, non_blocking=True)
+        return t
 
-    def filter_mask(self, p123, pc, delta_cos=0.985, delta_diff=0.005):
-        pw = self.form_pw_groups(p123, pc)
-        d = torch.stack([pw[:, :, 1] - pw[:, :, 0], pw[:, :, 2] - pw[:, :, 0], pw[:, :, 2] - pw[:, :, 1]], 2)
-        q = d.permute(0, 2, 1)
-        qn = q.norm(2, dim=2)
-        e = (torch.bmm(q, d) / (torch.bmm(qn.unsqueeze(2), qn.unsqueeze(1)) + 1e-8)).reshape(d.shape[0], -1)
-        m_cos = ((e > delta_cos) + (e < -delta_cos)).sum(1) > 3
+    def _cloud(self, depth, t):
+        """vnl.py:34-41 for the batch: [B,1,H,W] -> [B*H*W, 3]."""
+        u, v = self.u_u0.to(depth.device), self.v_v0.to(depth.device)
+        fx, fy = t.fx.to(depth.dtype).view(-1, 1, 1, 1), t.fy.to(depth.dtype).view(-1, 1, 1, 1)
+        ad = depth.abs()
+        return torch.stack([u * ad / fx, v * ad / fy, depth], -1).reshape(-1, 3)
+
+    @staticmethod
+    def _triplets(cloud, gid):
+        return torch.stack([cloud[gid[0]], cloud[gid[1]], cloud[gid[2]]], 2)                     # [n, xyz, p]
+
+    def _filter(self, pw, delta_diff, delta_cos=0.985):
+        """vnl.py:71-104 with the 3x3 Gram matrix written out (no batched GEMM): delta_diff is per-triplet."""
+        d = torch.stack([pw[:, :, 1] - pw[:, :, 0], pw[:, :, 2] - pw[:, :, 0], pw[:, :, 2] - pw[:, :, 1]], 2)   # [n, xyz, pair]
+        qn = d.norm(2, dim=1)                                                                    # [n, pair]
+        energy = (d.unsqueeze(3) * d.unsqueeze(2)).sum(1)                                        # [n, pair, pair]
+        ne = (energy / (qn.unsqueeze(2) * qn.unsqueeze(1) + 1e-8)).reshape(-1, 9)
+        m_cos = ((ne > delta_cos) | (ne < -delta_cos)).sum(1) > 3
         m_pad = (pw[:, 2, :] > self.delta_z).sum(1) == 3
-        near = [(d[:, a, :].abs() < delta_diff).sum(1) > 0 for a in range(3)]
-        return m_pad & ~((near[0] & near[1] & near[2]) | m_cos), pw
+        dd = delta_diff.view(-1, 1)
+        near = ((d[:, 0, :].abs() < dd).sum(1) > 0) & ((d[:, 1, :].abs() < dd).sum(1) > 0) & ((d[:, 2, :].abs() < dd).sum(1) > 0)
+        return m_pad & ~(near | m_cos)
 
     @staticmethod
-    def normal_from_triplets(tri, m):
-        t = tri[m]
-        n = torch.cross(t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 0], dim=1)
+    def _normals(tri):
+        n = torch.cross(tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0], dim=1)
         nn_ = n.norm(2, dim=1, keepdim=True)
         return n / (nn_ + (nn_ == 0.0).float() * 0.01)
 
-    @staticmethod
-    def _trimmed(loss):
-        loss = torch.sort(loss, dim=0)[0]
-        loss = loss[int(loss.shape[0] * 0.25):]
-        return torch.nansum(loss) / loss.shape[0]
-
-    def forward(self, pred_depth, gt_masks, gt_planes, gt_depth, K, select=True):
+    def batched(self, pred_depth, gt_depth, t):
+        """-> per-image loss [B] (float64), equal to vnl.py:119-165 evaluated image by image."""
         dev = pred_depth.device
-        pc = self.transfer_xyz(pred_depth, K)
-        N = gt_planes.shape[0]
-        total = 0
-        nonplanar = torch.logical_not(gt_masks.sum(dim=0).bool())
-        counts = gt_masks.flatten(1).sum(1).tolist() + [int(nonplanar.sum())]      # one sync for all sample sizes
-        for i in range(N):
-            seg = pc[gt_masks[i]]
-            p123 = self.select_index(int(counts[i]), dev)
-            m, pw = self.filter_mask(p123, seg)
-            dn = self.normal_from_triplets(pw, m)
-            loss = 1 - F.cosine_similarity(dn, gt_planes[i].unsqueeze(0), dim=1).abs()
-            total = total + (self._trimmed(loss) if select else torch.nansum(loss) / loss.shape[0])
-        if counts[-1] > 0:
-            gpc = self.transfer_xyz(gt_depth, K)
-            pp, gp = pc[nonplanar], gpc[nonplanar]
-            p123 = self.select_index(int(counts[-1]), dev)
-            m, pw_gt = self.filter_mask(p123, gp, delta_diff=0.1)
-            if m.sum() == 0:
-                return total / N
-            pw_pred = self.form_pw_groups(p123, pp)
-            pw_pred[pw_pred[:, 2, :] == 0] = 0.0001
-            loss = 1 - F.cosine_similarity(self.normal_from_triplets(pw_pred, m), self.normal_from_triplets(pw_gt, m), dim=1).abs()
-            total = total + (self._trimmed(loss) if select else torch.nansum(loss) / loss.shape[0])
-            return total / (N + 1)
-        return total / N
+        pc_pred, pc_gt = self._cloud(pred_depth, t), self._cloud(gt_depth, t)
+        is_plane = t.seg_is_plane[t.seg]                                                          # per triplet
+        tri_pred = self._triplets(pc_pred, t.gid)
+        tri_gt = self._triplets(pc_gt, t.gid)
+        # planes filter on the predicted cloud (delta_diff 0.005); the non-planar region on the GT cloud (0.1)
+        tri_f = torch.where(is_plane.view(-1, 1, 1), tri_pred.detach(), tri_gt)
+        delta = torch.where(is_plane, torch.full((), 0.005, dtype=tri_f.dtype, device=dev), torch.full((), 0.1, dtype=tri_f.dtype, device=dev))
+        with torch.no_grad():
+            valid = self._filter(tri_f, delta)
+        # predicted normals; the non-planar branch zero-fixes its predicted triplets first (vnl.py:151: rows whose
+        # z-coordinates of a point are exactly 0 are overwritten with 1e-4 -- indexed the reference's quirky way)
+        zero_row = (tri_pred[:, 2, :] == 0) & (~is_plane).view(-1, 1)                             # [n, 3] -> rows of dim 1
+        tri_p = torch.where(zero_row.unsqueeze(2), torch.full_like(tri_pred, 0.0001), tri_pred)
+        dn = self._normals(tri_p)
+        gn_np = self._normals(tri_gt)
+        cos_plane = F.cosine_similarity(dn.double(), t.seg_normal[t.seg], dim=1).abs()
+        cos_np = F.cosine_similarity(dn, gn_np, dim=1).abs().double()
+        loss = 1 - torch.where(is_plane, cos_plane, cos_np)                                       # [n_tot] float64
+        # segmented "sort ascending, drop the first 25 % of the valid ones, nansum / remaining"
+        m = torch.zeros(t.n_seg, device=dev, dtype=torch.int64).index_add_(0, t.seg, valid.long())
+        key = t.seg.double() * 4.0 + torch.where(valid, torch.nan_to_num(loss.detach(), nan=1.5), torch.full_like(loss, 2.0))
+        order = torch.argsort(key)
+        seg_s = t.seg[order]
+        rank = torch.arange(t.n_tot, device=dev) - t.seg_start[seg_s]
+        drop = m // 4
+        keep = valid[order] & (rank >= drop[seg_s])
+        contrib = torch.where(keep, torch.nan_to_num(loss[order], nan=0.0), torch.zeros_like(loss))
+        seg_sum = torch.zeros(t.n_seg, device=dev, dtype=torch.float64).index_add_(0, seg_s, contrib)
+        # per image: sum over planes (+ non-planar term unless it sampled nothing valid) / (N or N+1)
+        np_ok = (~t.seg_is_plane) & (m > 0)
+        use = t.seg_is_plane | np_ok
+        den = torch.where(use, (m - drop).double(), torch.ones_like(seg_sum))                     # plane with no valid triplet: 0/0 -> NaN like the reference
+        seg_loss = seg_sum / den
+        img_sum = torch.zeros(t.B, device=dev, dtype=torch.float64).index_add_(0, t.seg_img, torch.where(use, seg_loss, torch.zeros_like(seg_loss)))
+        extra = torch.zeros(t.B, device=dev, dtype=torch.float64).index_add_(0, t.seg_img, np_ok.double())
+        return img_sum / (t.N + extra)
+
+    def forward(self, pred_depth, gt_masks, gt_planes, gt_depth, k_matrix, select=True):
+        """Single-image entry with the reference's signature (vnl.py:119); routes through the batched path."""
+        assert select, "select=False is unused by the reference's loss"
+        inst = [{"masks": gt_masks.cpu(), "plane_paras": gt_planes.cpu(), "k_matrix": k_matrix.cpu()}]
+        t = self.prepare(inst, tuple(pred_depth.shape[-2:]), pred_depth.device)
+        return self.batched(pred_depth.unsqueeze(0), gt_depth.unsqueeze(0), t)[0]

@@ -280,7 +280,7 @@ class _Resize(torch.autograd.Function):
     def backward(ctx, dy):
         B, C, H, W, Ho, Wo = ctx.shape
         dy = _c(dy)
-        dx = torch.zeros(B, C, H, W, device=dy.device, dtype=torch.float32)
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
         check(lib.prn_resize_bilinear_bwd(_p(dy), _p(dx), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_bwd")
         return dx, None, None
 

@@ -110,3 +110,32 @@ def test_nms_and_helpers_cpu():
     assert keep[0] and keep.shape == (6,)
     assert funcs.calc_size_preserve_ar(640, 480, 960) == (960, 720)
     assert funcs.pad_even_divided(np.ones((720, 960, 3))).shape == (736, 960, 3)
+
+
+def test_batched_virtual_normal_loss_matches_oracle_per_image():
+    """The one-pass, all-planes-all-images VNL (segmented sort) against the oracle's per-image, per-plane loops
+    (which are pinned against the real reference), with the same numpy RNG stream; gradients included."""
+    from oracle import loss_ref, synth
+    from planerecnet_amd import config as C
+    from planerecnet_amd.losses import VNL_Loss
+    C.set_cfg("PlaneRecNet_50_config")
+    B = 3
+    _, inst, gtd = synth.make_batch(B, 480, 640, seed=21)
+    inst[2]["masks"][:] = 1                       # no non-planar pixels in image 2
+    g = torch.Generator().manual_seed(3)
+    pred = (torch.rand(B, 1, 480, 640, generator=g) * 4 + 0.3)
+    pred[0, 0, 100:110, 200:260] = 0.0            # exercises the zero-depth fix of the non-planar branch
+    pred.requires_grad_(True)
+    vnl = VNL_Loss((480, 640))
+    np.random.seed(5)
+    t = vnl.prepare(inst, (480, 640), torch.device("cpu"))
+    got = vnl.batched(pred, gtd, t)
+    ref_vnl = loss_ref.VNL((480, 640))
+    np.random.seed(5)
+    ref = torch.stack([ref_vnl(pred[b], inst[b]["masks"].bool(), inst[b]["plane_paras"][:, :3], gtd[b], inst[b]["k_matrix"]) for b in range(B)])
+    assert got.dtype == torch.float64 and ref.dtype == torch.float64
+    ok = torch.tensor([0, 1, 2])
+    assert torch.allclose(got[ok], ref[ok], rtol=1e-6, atol=1e-9), (got, ref)
+    (gg,) = torch.autograd.grad(got[ok].sum(), pred)
+    (gr,) = torch.autograd.grad(ref[ok].sum(), pred)
+    assert torch.allclose(gg[ok], gr[ok], rtol=1e-4, atol=1e-9)
