@@ -109,10 +109,11 @@ def main():
 
     from planerecnet_amd import ops, profiling
     from planerecnet_amd.config import cfg, set_cfg
-    from planerecnet_amd.losses import PlaneRecNetLoss
+    from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
     from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
     from planerecnet_amd.planerecnet import PlaneRecNet
 
+    torch.set_num_threads(4)                           # host-side tensor ops are small: a wide OpenMP team only adds fork/join latency
     set_cfg(args.config)
     torch.manual_seed(0)                               # identical replicas on every rank
     net = PlaneRecNet(cfg)
@@ -124,9 +125,14 @@ def main():
     images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
     np.random.seed(rank)
 
+    hw = (args.height, args.width)
+    prefetch = TargetPrefetcher(crit)
+    prefetch.submit(inst, hw)
+
     def step():
         opt.zero_grad(set_to_none=True)
-        targets = crit.prepare(inst, depths, dev)          # GT-only host work + async uploads (overlaps the previous step's backward)
+        targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared on the worker thread) + async uploads
+        prefetch.submit(inst, hw)                           # next step's targets: recomputed every step, overlapping this step's GPU work
         out = net(images)
         losses = crit(net, *out, inst, depths, targets=targets)
         loss = sum(losses.values()).sum()
@@ -183,6 +189,7 @@ def main():
                 "losses_finite": finite, "losses": dict(zip(sorted(losses), loss_means)),
                 "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(line), flush=True)
+    prefetch.close()
     if world > 1:
         dist.destroy_process_group()
 

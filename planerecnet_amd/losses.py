@@ -94,36 +94,43 @@ class PlaneRecNetLoss(nn.Module):
 
     # ------------------------------------------------------------------ GT-only work, before the forward
     @torch.no_grad()
-    def prepare(self, gt_instances, gt_depths, device, mask_feat_size=None):
-        """gt_instances: list of dicts of HOST tensors (device tensors are accepted but force a synchronising copy).
-        gt_depths: [B,1,H,W] on `device`.  Returns Targets."""
-        B = len(gt_instances)
-        H, W = gt_depths.shape[-2:]
+    def prepare_host(self, gt_instances, hw, mask_feat_size=None):
+        """Pure host part (numpy / CPU torch; safe to run on a worker thread -- see TargetPrefetcher): SOLOv2 targets and
+        the virtual-normal triplet indices for a list of per-image GT dicts."""
+        H, W = hw
         fh, fw = mask_feat_size if mask_feat_size is not None else (H // 4, W // 4)
         host = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in g.items()} for g in gt_instances]
-        L = len(self.num_grids)
+        B, L = len(host), len(self.num_grids)
         level_start = np.concatenate([[0], np.cumsum([g * g for g in self.num_grids])])
-        t = Targets()
-        t.B = B
         cell_ids, ins_labels, cate_rows, n_pos, num_ins = [], [], [[] for _ in range(L)], [], 0
         for b in range(B):
             ins_l, cate_l, ind_l, order_l = self.prepare_ground_truth(host[b], (fh, fw))
-            ids = [level_start[lv] + np.asarray(order_l[lv], dtype=np.int64) for lv in range(L)]
-            cell_ids.append(np.concatenate(ids) if ids else np.zeros(0, np.int64))
+            cell_ids.append(np.concatenate([level_start[lv] + np.asarray(order_l[lv], dtype=np.int64) for lv in range(L)]))
             ins_labels.append(torch.cat(ins_l, 0))
             n_pos.append(int(cell_ids[-1].shape[0]))
             num_ins += sum(int(i.sum()) for i in ind_l)
             for lv in range(L):
                 cate_rows[lv].append(cate_l[lv].flatten())
-        t.n_pos, t.num_ins = n_pos, num_ins
-        t.cell_ids = [torch.from_numpy(c).to(device, non_blocking=True) for c in cell_ids]
-        t.n_pos_dev = torch.as_tensor(n_pos, dtype=torch.float32).to(device, non_blocking=True)
-        t.pos_img = torch.from_numpy(np.repeat(np.arange(B), n_pos)).to(device, non_blocking=True)
-        t.ins_labels = torch.cat(ins_labels, 0).to(device, non_blocking=True)                       # [sum n_pos, fh, fw] uint8
-        # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
-        t.cate_labels = torch.cat([r for lv in range(L) for r in cate_rows[lv]]).to(device, non_blocking=True)
-        t.vnl = self.vnl.prepare(host, (H, W), device) if cfg.use_plane_loss else None
+        return {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
+                "cell_ids": [torch.from_numpy(c) for c in cell_ids], "pos_img": torch.from_numpy(np.repeat(np.arange(B), n_pos)),
+                "ins_labels": torch.cat(ins_labels, 0),
+                # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
+                "cate_labels": torch.cat([r for lv in range(L) for r in cate_rows[lv]]),
+                "vnl": self.vnl.prepare_host(host, (H, W)) if cfg.use_plane_loss else None}
+
+    @torch.no_grad()
+    def upload(self, h, gt_depths, device):
+        """Asynchronous uploads of prepare_host()'s result + the GT-only device work of the lava term."""
+        t = Targets()
+        t.B, t.n_pos, t.num_ins = h["B"], h["n_pos"], h["num_ins"]
+        up = lambda x: x.to(device, non_blocking=True)
+        t.cell_ids = [up(c) for c in h["cell_ids"]]
+        t.n_pos_dev = up(torch.as_tensor(h["n_pos"], dtype=torch.float32))
+        t.pos_img, t.ins_labels, t.cate_labels = up(h["pos_img"]), up(h["ins_labels"]), up(h["cate_labels"])
+        t.vnl = self.vnl.upload(h["vnl"], device) if h["vnl"] is not None else None
+        t.lava_gsum = t.lava_adj = None
         if cfg.use_lava_loss:
+            B, (H, W), (fh, fw) = h["B"], h["hw"], h["feat"]
             # Q3: dataset_name never equals 'ScanNet' / 'Stanford 2D3DS' (it is 'ScanNetDataset'), so valid_mask is None
             grad = sobel_sq(gt_depths) / gt_depths.clamp(min=self.depth_resolution) ** 2
             grad = grad.clamp(max=1e-2)
@@ -132,9 +139,12 @@ class PlaneRecNetLoss(nn.Module):
             adj = torch.empty(B, 1, fh, fw, device=device, dtype=torch.float32)
             ops.check(ops.lib.prn_resize_bilinear_bwd(ops._p(grad.contiguous()), ops._p(adj), B, fh, fw, H, W, ops._stream()), "prn_resize_bilinear_bwd")
             t.lava_adj = adj
-        else:
-            t.lava_gsum = t.lava_adj = None
         return t
+
+    def prepare(self, gt_instances, gt_depths, device, mask_feat_size=None):
+        """gt_instances: list of dicts of HOST tensors (device tensors are accepted but force a synchronising copy).
+        gt_depths: [B,1,H,W] on `device`.  Returns Targets."""
+        return self.upload(self.prepare_host(gt_instances, tuple(gt_depths.shape[-2:]), mask_feat_size), gt_depths, device)
 
     # ------------------------------------------------------------------ forward
     def forward(self, net, mask_preds, cate_preds, kernel_preds, depth_preds, gt_instances, gt_depths, targets=None):
@@ -215,7 +225,7 @@ def sobel_sq(d):
 
 
 class VNLTargets:
-    __slots__ = ("B", "N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal", "n_seg", "n_tot", "has_np")
+    __slots__ = ("B", "N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal", "n_seg", "n_tot")
 
 
 class VNL_Loss(nn.Module):
@@ -243,11 +253,10 @@ class VNL_Loss(nn.Module):
         return out
 
     @torch.no_grad()
-    def prepare(self, host_instances, hw, device):
-        """Host: pixel ids of every sampled triplet (global over the batch), segment bookkeeping; async upload."""
+    def prepare_host(self, host_instances, hw):
+        """Host: pixel ids of every sampled triplet (global over the batch) + segment bookkeeping, as CPU tensors."""
         H, W = hw
-        t = VNLTargets()
-        gids, seg_len, seg_img, seg_plane, normals, N_per, fx, fy, has_np = [], [], [], [], [], [], [], [], []
+        gids, seg_len, seg_img, seg_plane, normals, N_per, fx, fy = [], [], [], [], [], [], [], []
         for b, g in enumerate(host_instances):
             masks = g["masks"].numpy().astype(bool)
             K = g["k_matrix"].numpy()
@@ -257,9 +266,7 @@ class VNL_Loss(nn.Module):
             planes = g["plane_paras"].numpy()[:, :3]
             regions = [masks[i] for i in range(N)]
             nonplanar = ~masks.any(0) if N > 0 else np.ones((H, W), bool)
-            np_count = int(nonplanar.sum())
-            has_np.append(np_count > 0)
-            if np_count > 0:
+            if int(nonplanar.sum()) > 0:
                 regions.append(nonplanar)
             for r, m in enumerate(regions):
                 px = np.flatnonzero(m)
@@ -269,19 +276,27 @@ class VNL_Loss(nn.Module):
                 seg_img.append(b)
                 seg_plane.append(r < N)
                 normals.append(planes[r] if r < N else np.zeros(3))
-        t.B, t.N = len(host_instances), torch.as_tensor(N_per, dtype=torch.float64).to(device, non_blocking=True)
-        t.fx = torch.as_tensor(np.asarray(fx), dtype=torch.float64).to(device, non_blocking=True)
-        t.fy = torch.as_tensor(np.asarray(fy), dtype=torch.float64).to(device, non_blocking=True)
         seg_len = np.asarray(seg_len, dtype=np.int64)
-        t.n_seg, t.n_tot = len(seg_len), int(seg_len.sum())
-        t.gid = torch.from_numpy(np.concatenate(gids, 1) if gids else np.zeros((3, 0), np.int64)).to(device, non_blocking=True)
-        t.seg = torch.from_numpy(np.repeat(np.arange(t.n_seg), seg_len)).to(device, non_blocking=True)
-        t.seg_start = torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if t.n_seg else np.zeros(0, np.int64)).to(device, non_blocking=True)
-        t.seg_img = torch.as_tensor(seg_img, dtype=torch.int64).to(device, non_blocking=True)
-        t.seg_is_plane = torch.as_tensor(seg_plane, dtype=torch.bool).to(device, non_blocking=True)
-        t.seg_normal = torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3)).to(device, non_blocking=True)
-        t.has_np = torch.as_tensor(has_np, dtype=torch.bool).to(device, non_blocking=True)
+        n_seg = len(seg_len)
+        return {"B": len(host_instances), "n_seg": n_seg, "n_tot": int(seg_len.sum()),
+                "N": torch.as_tensor(N_per, dtype=torch.float64), "fx": torch.as_tensor(np.asarray(fx), dtype=torch.float64),
+                "fy": torch.as_tensor(np.asarray(fy), dtype=torch.float64),
+                "gid": torch.from_numpy(np.concatenate(gids, 1) if gids else np.zeros((3, 0), np.int64)),
+                "seg": torch.from_numpy(np.repeat(np.arange(n_seg), seg_len)),
+                "seg_start": torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64)),
+                "seg_img": torch.as_tensor(seg_img, dtype=torch.int64), "seg_is_plane": torch.as_tensor(seg_plane, dtype=torch.bool),
+                "seg_normal": torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3))}
+
+    @staticmethod
+    def upload(h, device):
+        t = VNLTargets()
+        t.B, t.n_seg, t.n_tot = h["B"], h["n_seg"], h["n_tot"]
+        for k in ("N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal"):
+            setattr(t, k, h[k].to(device, non_blocking=True))
         return t
+
+    def prepare(self, host_instances, hw, device):
+        return self.upload(self.prepare_host(host_instances, hw), device)
 
     def _cloud(self, depth, t):
         """vnl.py:34-41 for the batch: [B,1,H,W] -> [B*H*W, 3]."""
@@ -358,3 +373,27 @@ class VNL_Loss(nn.Module):
         inst = [{"masks": gt_masks.cpu(), "plane_paras": gt_planes.cpu(), "k_matrix": k_matrix.cpu()}]
         t = self.prepare(inst, tuple(pred_depth.shape[-2:]), pred_depth.device)
         return self.batched(pred_depth.unsqueeze(0), gt_depth.unsqueeze(0), t)[0]
+
+
+class TargetPrefetcher:
+    """Runs PlaneRecNetLoss.prepare_host for the NEXT batch on a worker thread while the GPU executes the current step
+    (the role the reference gives to its DataLoader workers + the host part of its loss).  One job at a time, submitted in
+    step order, so the numpy RNG stream of the virtual-normal sampling stays deterministic."""
+
+    def __init__(self, criterion):
+        from concurrent.futures import ThreadPoolExecutor
+        self.criterion = criterion
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
+        self.pending = None
+
+    def submit(self, gt_instances, hw, mask_feat_size=None):
+        self.pending = self.pool.submit(self.criterion.prepare_host, gt_instances, hw, mask_feat_size)
+
+    def get(self, gt_depths, device):
+        """Targets of the batch submitted last (blocks only if the worker has not finished yet)."""
+        h = self.pending.result()
+        self.pending = None
+        return self.criterion.upload(h, gt_depths, device)
+
+    def close(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)

@@ -124,8 +124,9 @@ def test_loss_matches_oracle_and_golden(setup, golden_dir):
     assert out["pln"].dtype == torch.float64
     dg = torch.autograd.grad(sum(out.values()).sum(), dl, allow_unused=True)
     for i, (a, b) in enumerate(zip(dg, og)):
-        assert (a is None) == (b is None), i
-        if a is not None:
+        if b is None:                       # a level without positive cells: the batched path yields an all-zero gradient
+            assert a is None or float(a.abs().max()) == 0.0, i
+        else:
             close(a, b, 2e-3, f"loss grad {i}")
 
 
