@@ -47,9 +47,12 @@ typedef struct prn_conv_desc {
 } prn_conv_desc;
 
 /* y[b,m,oh,ow] = epi( sum_{c,r,s} w[m,c,r,s] * gather(x)[b,c,oh*stride-pad+r, ow*stride-pad+s] + bias[m] + addend[b,m,oh,ow] )
- * w is [M, C*KH*KW] row-major; bias and addend may be NULL. */
+ * w is [M, C*KH*KW] row-major; bias and addend may be NULL.  Layers whose output cannot fill the 256 CUs are split
+ * along K: `ws` is a caller-owned workspace of prn_conv2d_fwd_ws_bytes(d) bytes (0 => may be NULL); the split partials
+ * are summed in a fixed order, so results are deterministic. */
+int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
-                   const float* addend, float* y, void* stream);
+                   const float* addend, float* y, void* ws, void* stream);
 
 /* wt[c][m][KH-1-r][KW-1-s] = w[m][c][r][s]   (operand layout for dgrad-as-forward) */
 int prn_weight_flip_transpose(const float* w, float* wt, int M, int C, int KH, int KW, void* stream);

@@ -10,6 +10,7 @@
 // through LDS in 16-deep K slices, double buffered, with the next slice's global loads in flight during the
 // MFMA loop.  LDS rows that are read "down a column" by the MFMA operand pattern use a 17-float pitch, which
 // makes the 32-lane-group reads conflict-free.
+#include <stdlib.h>
 #include "prn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -18,8 +19,9 @@ namespace {
 
 struct ConvArgs {
   const float* x; const float* w; const float* bias; const float* addend; float* y;
-  int B, C, H, W, M, stride, pad, Ho, Wo, mode, epi;
-  int K, N, HoWo, HW, tilesM, nblocks;
+  int B, C, H, W, M, stride, pad, Ho, Wo, epi;
+  int K, N, HoWo, HW, tilesM, nblocks, splits;
+  float* ws;
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -27,16 +29,18 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
   return i >= n ? 2 * n - 2 - i : i;
 }
 
-// One element of the virtual im2col matrix. (coff = c*H*W, r, s) identify the K row, (ih0, iw0) the pixel.
-__device__ __forceinline__ float gather_px(const float* __restrict__ xb, int coff, int r, int s, int ih0, int iw0,
-                                           bool ok, int mode, int H, int W) {
-  int ih = ih0 + r, iw = iw0 + s;
-  if (mode == PRN_IN_ZERO) {
+// Offset (inside one channel plane) of the input sample that virtual im2col position (ih, iw) reads, or -1 when that
+// position contributes zero.  All loads built on it are UNCONDITIONAL (clamped address + select): a per-lane branch
+// around a load makes hipcc serialise the gather behind s_waitcnt, which left the first version of this kernel
+// latency-bound at ~30 % of the MFMA rate.
+template <int MODE>
+__device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W) {
+  if (MODE == PRN_IN_ZERO) {
     ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-  } else if (mode == PRN_IN_REFLECT) {
+  } else if (MODE == PRN_IN_REFLECT) {
     ih = reflect_idx(ih, H);
     iw = reflect_idx(iw, W);
-  } else if (mode == PRN_IN_UP2_REFLECT) {
+  } else if (MODE == PRN_IN_UP2_REFLECT) {
     ih = reflect_idx(ih, 2 * H) >> 1;
     iw = reflect_idx(iw, 2 * W) >> 1;
   } else {  // PRN_IN_DILATED (factor 2): only even virtual coordinates carry data
@@ -45,27 +49,33 @@ __device__ __forceinline__ float gather_px(const float* __restrict__ xb, int cof
     iw >>= 1;
     ok = ok && ih < H && iw < W;
   }
-  float v = 0.f;
-  if (ok) v = xb[(size_t)coff + (size_t)(ih * W + iw)];
-  return v;
+  return ok ? ih * W + iw : -1;
 }
 
-template <int KS, int TM, int TN>
+// BK = K-slice depth per staging round.  Small-N layers (backbone stages 3-4: N = 9600 / 2400 pixels) cannot fill 256 CUs
+// with output tiles alone, so the launcher also splits K across blockIdx.y (deterministic: partial tiles go to a
+// workspace that reduce_epilogue_kernel sums in fixed order before bias / addend / activation).
+template <int KS, int MODE, int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16, LDA = 17;
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BK + 1;
   constexpr int KSTEP = 256 / BN;  // K rows covered by one sweep of the block
   constexpr int NB = BK / KSTEP;   // gathered elements per thread per K slice
+  constexpr int AQ = BK / 4;       // float4 groups per A row
+  constexpr int AROWS = 256 / AQ;  // A rows covered by one sweep
+  constexpr int NA = BM / AROWS;   // float4 loads per thread per K slice
   constexpr int KK = KS * KS;
   __shared__ float As[2][BM * LDA];
   __shared__ float Bs[2][BK * BN];
+  __shared__ int taps[KS > 1 ? KK * BN : 1];   // per-pixel tap offsets (or -1), built once per workgroup
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
   const int m0 = (id % a.tilesM) * BM, n0 = (id / a.tilesM) * BN;
 
-  // pixel owned by this thread in the B (im2col) operand
-  const int nl = tid % BN, krow0 = tid / BN;
+  // pixel owned by this thread in the B (im2col) operand; its K rows are wave-uniform
+  const int nl = tid % BN;
+  const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
   const int n = n0 + nl;
   const bool nvalid = n < a.N;
   int b = 0, oh = 0, ow = 0;
@@ -77,11 +87,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
   const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
   const float* __restrict__ xb = a.x + (size_t)b * a.C * a.HW;
+  int off1 = -1;
+  if (KS == 1) {
+    off1 = tap_offset<MODE>(ih0, iw0, nvalid, a.H, a.W);
+  } else {
+    for (int t = krow0; t < KK; t += KSTEP) {
+      const int r = t / KS, s = t - r * KS;
+      taps[t * BN + nl] = tap_offset<MODE>(ih0 + r, iw0 + s, nvalid, a.H, a.W);
+    }
+    __syncthreads();
+  }
 
-  const int arow = tid >> 2, akq = (tid & 3) * 4;
+  const int arow = tid / AQ, akq = (tid % AQ) * 4;
   const bool k4 = ((a.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0);
 
-  float ra[TM][4];
+  float ra[NA][4];
   float rb[NB];
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -92,39 +112,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto load_tile = [&](int k0) {
+    const int k = k0 + akq;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + arow + 64 * i, k = k0 + akq;
-      const float* wp = a.w + (size_t)m * a.K + k;
-      if (m < a.M && k4 && k < a.K) {
-        const float4 v = *reinterpret_cast<const float4*>(wp);
-        ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+    for (int i = 0; i < NA; ++i) {
+      const int m = m0 + arow + AROWS * i;
+      const int mc = m < a.M ? m : a.M - 1;
+      const float* wrow = a.w + (size_t)mc * a.K;
+      if (k4) {
+        const bool ok = (m < a.M) && (k < a.K);
+        const float4 v = *reinterpret_cast<const float4*>(wrow + (ok ? k : 0));
+        ra[i][0] = ok ? v.x : 0.f; ra[i][1] = ok ? v.y : 0.f; ra[i][2] = ok ? v.z : 0.f; ra[i][3] = ok ? v.w : 0.f;
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[i][j] = (m < a.M && k + j < a.K) ? wp[j] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = (m < a.M) && (k + j < a.K);
+          const float v = wrow[ok ? k + j : 0];
+          ra[i][j] = ok ? v : 0.f;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int k = k0 + krow0 + i * KSTEP;
-      const int c = k / KK, rs = k - c * KK, r = rs / KS, s = rs - r * KS;
-      rb[i] = gather_px(xb, c * a.HW, r, s, ih0, iw0, nvalid && k < a.K, a.mode, a.H, a.W);
+      const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform
+      const int c = kr / KK, rs = kr - c * KK;
+      const int off = (KS == 1) ? off1 : taps[rs * BN + nl];
+      const bool ok = (off >= 0) && (kr < a.K);
+      const float v = xb[ok ? c * a.HW + off : 0];
+      rb[i] = ok ? v : 0.f;
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) As[buf][(arow + 64 * i) * LDA + akq + j] = ra[i][j];
+      for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
 #pragma unroll
     for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[i];
   };
 
-  const int KT = (a.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  const int KTall = (a.K + BK - 1) / BK;
+  const int kt0 = (int)((int64_t)blockIdx.y * KTall / a.splits), KT = (int)((int64_t)(blockIdx.y + 1) * KTall / a.splits);
+  load_tile(kt0 * BK);
+  store_tile(kt0 & 1);
   __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = kt0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) load_tile((kt + 1) * BK);
 #pragma unroll
@@ -144,6 +175,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel)
+  const bool partial = a.splits > 1;
+  float* __restrict__ outp = partial ? a.ws + (size_t)blockIdx.y * a.B * a.M * a.HoWo : a.y;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nn = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -158,6 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         if (m < a.M) {
           const size_t idx = base + (size_t)m * a.HoWo;
           float v = acc[i][j][r];
+          if (partial) { outp[idx] = v; continue; }
           if (a.bias) v += a.bias[m];
           if (a.addend) v += a.addend[idx];
           if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
@@ -172,11 +206,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // ---------------------------------------------------------------------------------------------- wgrad
 struct WgArgs {
   const float* x; const float* dy; float* out;
-  int B, C, H, W, M, stride, pad, Ho, Wo, mode;
+  int B, C, H, W, M, stride, pad, Ho, Wo;
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
 };
 
-template <int KS, int TM, int TJ>
+template <int KS, int MODE, int TM, int TJ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   constexpr int BM = 64 * TM, BJ = 64 * TJ, LD = 17, KK = KS * KS;
   constexpr int NBJ = BJ / 16;
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const int j = j0 + jrow + 16 * i;
     const int c = j / KK, rs = j - c * KK;
     jok[i] = j < a.K;
-    jcoff[i] = c * a.HW;
+    jcoff[i] = jok[i] ? c * a.HW : 0;
     jr[i] = rs / KS;
     js[i] = rs - jr[i] * KS;
   }
@@ -213,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto load_chunk = [&](int ch) {
-    {  // dY rows: 4 consecutive pixels of one output channel
+    {  // dY rows: 4 consecutive pixels of one output channel (unconditional, clamped loads)
       const int n = ch * 16 + anq;
       if (n4) {
         const bool ok = n < a.N;
@@ -222,12 +256,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int m = m0 + arow + 64 * i;
-          if (ok && m < a.M) {
-            const float4 v = *reinterpret_cast<const float4*>(a.dy + ((size_t)b * a.M + m) * a.HoWo + p);
-            ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
-          } else {
-            ra[i][0] = ra[i][1] = ra[i][2] = ra[i][3] = 0.f;
-          }
+          const int mc = m < a.M ? m : a.M - 1;
+          const float4 v = *reinterpret_cast<const float4*>(a.dy + ((size_t)b * a.M + mc) * a.HoWo + p);
+          const bool okm = ok && m < a.M;
+          ra[i][0] = okm ? v.x : 0.f; ra[i][1] = okm ? v.y : 0.f; ra[i][2] = okm ? v.z : 0.f; ra[i][3] = okm ? v.w : 0.f;
         }
       } else {
 #pragma unroll
@@ -239,7 +271,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int m = m0 + arow + 64 * i;
-            ra[i][q] = (ok && m < a.M) ? a.dy[((size_t)b * a.M + m) * a.HoWo + p] : 0.f;
+            const int mc = m < a.M ? m : a.M - 1;
+            const float v = a.dy[((size_t)b * a.M + mc) * a.HoWo + p];
+            ra[i][q] = (ok && m < a.M) ? v : 0.f;
           }
         }
       }
@@ -257,7 +291,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
       const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
       const float* __restrict__ xb = a.x + (size_t)b * a.C * a.HW;
 #pragma unroll
-      for (int i = 0; i < NBJ; ++i) rb[i] = gather_px(xb, jcoff[i], jr[i], js[i], ih0, iw0, ok && jok[i], a.mode, a.H, a.W);
+      for (int i = 0; i < NBJ; ++i) {
+        const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], ok && jok[i], a.H, a.W);
+        const float v = xb[off >= 0 ? jcoff[i] + off : 0];
+        rb[i] = off >= 0 ? v : 0.f;
+      }
     }
   };
   auto store_chunk = [&](int buf) {
@@ -305,6 +343,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
         const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < a.M) out[(size_t)m * a.K + jj] = acc[i][j][r];
       }
+  }
+}
+
+// y = epi( sum_s ws[s] + bias[m] + addend ) for split-K launches (fixed summation order)
+__global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                               const float* __restrict__ addend, float* __restrict__ y, int64_t total,
+                                                               int M, int HoWo, int splits, int epi) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  if (i + 3 < total && (HoWo & 3) == 0) {
+    float4 v = *reinterpret_cast<const float4*>(ws + i);
+    for (int s = 1; s < splits; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(ws + (size_t)s * total + i);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const int m = (int)((i / HoWo) % M);
+    if (bias) { const float bm = bias[m]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+    if (addend) { const float4 t = *reinterpret_cast<const float4*>(addend + i); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y)); v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w)); }
+    *reinterpret_cast<float4*>(y + i) = v;
+  } else {
+    for (int64_t q = i; q < total && q < i + 4; ++q) {
+      float v = ws[q];
+      for (int s = 1; s < splits; ++s) v += ws[(size_t)s * total + q];
+      if (bias) v += bias[(q / HoWo) % M];
+      if (addend) v += addend[q];
+      if (epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+      else if (epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + __expf(-v));
+      y[q] = v;
+    }
   }
 }
 
@@ -370,21 +439,51 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   if (threadIdx.x == 0) out[c] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
-template <int KS>
-int launch_fwd(const ConvArgs& a0, hipStream_t st) {
+struct FwdPlan { int tm, tn, bk, splits; };
+
+// Tile / slice / split choice.  PRN_CONV_FORCE="tm,tn,bk,splits" overrides it (tuning sweeps: tools/conv_bench.py).
+FwdPlan plan_fwd(int M, int64_t N, int K) {
+  static int forced[4] = {-1, 0, 0, 0};
+  if (forced[0] == -1) {
+    forced[0] = 0;
+    if (const char* e = getenv("PRN_CONV_FORCE")) sscanf(e, "%d,%d,%d,%d", &forced[0], &forced[1], &forced[2], &forced[3]);
+  }
+  FwdPlan p;
+  if (forced[0] > 0) {
+    p.tm = forced[0]; p.tn = forced[1]; p.bk = 16; p.splits = forced[3];
+  } else {
+    // Rule fitted to the sweep of tools/conv_sweep.py over the PlaneRecNet shapes (profiles/r01_conv_sweep.txt):
+    // 16-deep slices always; 128x128 tiles only for wide-M, deep-K layers with enough tiles; otherwise 64x128, or 64x64
+    // when even that leaves CUs idle; then split K until ~4 workgroups per CU exist (latency hiding on small-N layers).
+    auto tiles = [&](int tm, int tn) { return (int64_t)cdiv(M, 64 * tm) * cdiv(N, 64 * tn); };
+    p.bk = 16;
+    if (M >= 128 && K >= 1152 && tiles(2, 2) >= 512) { p.tm = 2; p.tn = 2; }
+    else if (tiles(1, 2) >= 256) { p.tm = 1; p.tn = 2; }
+    else { p.tm = 1; p.tn = 1; }
+    const int64_t t = tiles(p.tm, p.tn);
+    p.splits = t < 1024 ? (int)((1024 + t - 1) / t) : 1;
+    if (p.splits > 8) p.splits = 8;
+  }
+  const int kt = cdiv(K, p.bk);
+  if (p.splits > kt / 4) p.splits = kt / 4;        // at least 4 K slices per split
+  if (p.splits > 16) p.splits = 16;
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+template <int KS, int MODE>
+int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
   ConvArgs a = a0;
-  auto ntiles = [&](int tm, int tn) { return (int64_t)cdiv(a.M, 64 * tm) * cdiv(a.N, 64 * tn); };
-  int tm = 1, tn = 1;
-  if (a.M > 64 && ntiles(2, 2) >= 384) { tm = 2; tn = 2; }
-  else if (ntiles(1, 2) >= 384) { tm = 1; tn = 2; }
-  if (KS == 7) { tm = 1; tn = 2; }
-  a.tilesM = cdiv(a.M, 64 * tm);
-  a.nblocks = a.tilesM * cdiv(a.N, 64 * tn);
-  dim3 grid(a.nblocks), block(256);
-  if (KS == 7) hipLaunchKernelGGL((conv_igemm_kernel<KS, 1, 2>), grid, block, 0, st, a);
-  else if (tm == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS == 7 ? 3 : KS, 2, 2>), grid, block, 0, st, a);
-  else if (tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS == 7 ? 3 : KS, 1, 2>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((conv_igemm_kernel<KS == 7 ? 3 : KS, 1, 1>), grid, block, 0, st, a);
+  a.tilesM = cdiv(a.M, 64 * p.tm);
+  a.nblocks = a.tilesM * cdiv(a.N, 64 * p.tn);
+  a.splits = p.splits;
+  dim3 grid(a.nblocks, p.splits), block(256);
+#define PRN_LAUNCH(TM_, TN_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, TM_, TN_, BK_>), grid, block, 0, st, a)
+  // (deeper slices were measured slower on every shape -- only BK = 16 is instantiated)
+  if (p.tm == 2 && p.tn == 2) PRN_LAUNCH(2, 2, 16);
+  else if (p.tm == 1 && p.tn == 2) PRN_LAUNCH(1, 2, 16);
+  else PRN_LAUNCH(1, 1, 16);
+#undef PRN_LAUNCH
   return 0;
 }
 
@@ -406,13 +505,13 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
   return p;
 }
 
-template <int KS>
+template <int KS, int MODE>
 int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st) {
   dim3 grid(p.tilesM * p.tilesJ, p.splits), block(256);
-  if (p.tm == 2 && p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2, 2>), grid, block, 0, st, a);
-  else if (p.tm == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2, 1>), grid, block, 0, st, a);
-  else if (p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 2>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 1>), grid, block, 0, st, a);
+  if (p.tm == 2 && p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 2>), grid, block, 0, st, a);
+  else if (p.tm == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 1>), grid, block, 0, st, a);
+  else if (p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1>), grid, block, 0, st, a);
   return 0;
 }
 
@@ -424,26 +523,50 @@ int check_desc(const prn_conv_desc* d, const char* who) {
   PRN_REQUIRE(d->in_mode != PRN_IN_DILATED || d->dil == 2, "%s: only dilation 2 is implemented", who);
   PRN_REQUIRE((d->in_mode != PRN_IN_REFLECT && d->in_mode != PRN_IN_UP2_REFLECT) || (d->pad == 1 && d->stride == 1 && d->KH == 3),
               "%s: reflect modes need a 3x3 stride-1 pad-1 conv", who);
+  PRN_REQUIRE(d->KH != 7 || d->in_mode == PRN_IN_ZERO || d->in_mode == PRN_IN_DILATED, "%s: 7x7 kernels only with zero padding", who);
   PRN_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1LL << 31) && (int64_t)d->C * d->H * d->W < (1LL << 31), "%s: tensor too large for int32 pixel index", who);
   return 0;
 }
 
 }  // namespace
 
+extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
+  if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
+  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * d->Ho * d->Wo, d->C * d->KH * d->KW);
+  return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
+}
+
 extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
-                              const float* addend, float* y, void* stream) {
+                              const float* addend, float* y, void* ws, void* stream) {
   if (int e = check_desc(d, "prn_conv2d_fwd")) return e;
   PRN_REQUIRE(x && w && y, "prn_conv2d_fwd: null tensor");
   ConvArgs a;
-  a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.y = y; a.ws = (float*)ws;
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
-  a.Ho = d->Ho; a.Wo = d->Wo; a.mode = d->in_mode; a.epi = d->epilogue;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.epi = d->epilogue;
   a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
+  const FwdPlan p = plan_fwd(a.M, a.N, a.K);
+  PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
-  if (d->KH == 1) launch_fwd<1>(a, st);
-  else if (d->KH == 3) launch_fwd<3>(a, st);
-  else launch_fwd<7>(a, st);
+  const int mode = d->in_mode;
+  if (d->KH == 1) {
+    PRN_REQUIRE(mode == PRN_IN_ZERO || mode == PRN_IN_DILATED, "prn_conv2d_fwd: 1x1 kernels take zero or dilated input mode");
+    if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st); else launch_fwd<1, PRN_IN_DILATED>(a, p, st);
+  } else if (d->KH == 3) {
+    if (mode == PRN_IN_ZERO) launch_fwd<3, PRN_IN_ZERO>(a, p, st);
+    else if (mode == PRN_IN_REFLECT) launch_fwd<3, PRN_IN_REFLECT>(a, p, st);
+    else if (mode == PRN_IN_UP2_REFLECT) launch_fwd<3, PRN_IN_UP2_REFLECT>(a, p, st);
+    else launch_fwd<3, PRN_IN_DILATED>(a, p, st);
+  } else {
+    if (mode == PRN_IN_ZERO) launch_fwd<7, PRN_IN_ZERO>(a, p, st); else launch_fwd<7, PRN_IN_DILATED>(a, p, st);
+  }
   PRN_CHECK_LAUNCH("prn_conv2d_fwd");
+  if (p.splits > 1) {
+    const int64_t total = (int64_t)a.B * a.M * a.HoWo;
+    hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, (const float*)ws, bias, addend, y, total, a.M, a.HoWo,
+                       p.splits, a.epi);
+    PRN_CHECK_LAUNCH("prn_conv2d_fwd/reduce");
+  }
   return 0;
 }
 
@@ -461,16 +584,24 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
   WgArgs a;
   a.x = x; a.dy = dy;
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
-  a.Ho = d->Ho; a.Wo = d->Wo; a.mode = d->in_mode;
+  a.Ho = d->Ho; a.Wo = d->Wo;
   a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
   WgPlan p = plan_wgrad(a.M, a.K, a.N);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;
   hipStream_t st = (hipStream_t)stream;
-  if (d->KH == 1) launch_wgrad<1>(a, p, st);
-  else if (d->KH == 3) launch_wgrad<3>(a, p, st);
-  else launch_wgrad<7>(a, p, st);
+  const int mode = d->in_mode;
+  if (d->KH == 1) {
+    PRN_REQUIRE(mode == PRN_IN_ZERO, "prn_conv2d_wgrad: 1x1 kernels take zero input mode");
+    launch_wgrad<1, PRN_IN_ZERO>(a, p, st);
+  } else if (d->KH == 3) {
+    if (mode == PRN_IN_ZERO) launch_wgrad<3, PRN_IN_ZERO>(a, p, st);
+    else if (mode == PRN_IN_REFLECT) launch_wgrad<3, PRN_IN_REFLECT>(a, p, st);
+    else launch_wgrad<3, PRN_IN_UP2_REFLECT>(a, p, st);
+  } else {
+    launch_wgrad<7, PRN_IN_ZERO>(a, p, st);
+  }
   PRN_CHECK_LAUNCH("prn_conv2d_wgrad");
   if (p.splits > 1) {
     const int64_t n = (int64_t)a.M * a.K;

@@ -54,8 +54,12 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
     # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
     flops = 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)
+    nbytes = lib.prn_conv2d_fwd_ws_bytes(ctypes.byref(d))
+    if nbytes < 0:
+        raise RuntimeError(lib.prn_last_error().decode())
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     with profiling.span("conv_igemm_kernel", "mfma", flops):
-        check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _stream()), "prn_conv2d_fwd")
+        check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
     return y
 
 

@@ -38,5 +38,5 @@ def test_argument_validation_without_gpu():
     """Descriptor validation happens on the host before any launch: must fail cleanly (rc != 0 + message)."""
     from planerecnet_amd import _lib
     d = _lib.ConvDesc(1, 4, 8, 8, 4, 5, 5, 1, 2, 8, 8, 0, 1, 0)       # 5x5 kernels are not part of the path
-    rc = _lib.lib.prn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None)
+    rc = _lib.lib.prn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
     assert rc != 0 and b"unsupported" in _lib.lib.prn_last_error()
