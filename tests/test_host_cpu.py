@@ -139,3 +139,26 @@ def test_batched_virtual_normal_loss_matches_oracle_per_image():
     (gg,) = torch.autograd.grad(got[ok].sum(), pred)
     (gr,) = torch.autograd.grad(ref[ok].sum(), pred)
     assert torch.allclose(gg[ok], gr[ok], rtol=1e-4, atol=1e-9)
+
+
+def test_train_cli_surface_and_synthetic_dataset_contract():
+    import train
+    a = train.parser.parse_args(["--config", "PlaneRecNet_101_config", "--batch_size", "16", "--resume", "latest", "--keep_latest",
+                                 "--no_autoscale", "--lr", "0.001", "--batch_alloc", "8,8"])
+    assert a.config == "PlaneRecNet_101_config" and a.batch_size == 16 and a.keep_latest and not a.autoscale and a.lr == 0.001
+    for flag in ("dataset", "save_folder", "log_folder", "backbone_folder", "start_iter", "validation_size", "validation_epoch", "no_tensorboard",
+                 "reproductablity", "momentum", "decay", "gamma", "num_workers", "save_interval", "keep_latest_interval", "interrupt"):
+        assert hasattr(a, flag), flag
+    img, inst, depth = train.SyntheticPlaneDataset(4)[1]
+    assert img.shape == (3, 480, 640) and depth.shape == (1, 480, 640)
+    assert inst["masks"].dtype == torch.uint8 and inst["boxes"].dtype == torch.float64 and inst["classes"].dtype == torch.int64
+    imgs, insts, depths = train.detection_collate([train.SyntheticPlaneDataset(4)[0], train.SyntheticPlaneDataset(4)[1]])
+    assert len(imgs) == len(insts) == len(depths) == 2
+
+
+def test_simple_inference_cli_surface():
+    import simple_inference as si
+    a = si.parse_args(["--image", "a.png:b.png", "--nms_mode", "mask", "--score_threshold", "0.2", "--top_k", "7", "--depth_mode", "gray"])
+    assert a.image == "a.png:b.png" and a.nms_mode == "mask" and a.score_threshold == 0.2 and a.top_k == 7 and a.depth_mode == "gray"
+    for flag in ("trained_model", "config", "images", "max_img", "ibims1", "ibims1_pd", "no_mask", "no_box", "no_text", "depth_shift"):
+        assert hasattr(a, flag), flag

@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""Training entry point (drop-in for the reference's train.py: same flags, config autoscaling, Adam param groups,
+LR warm-up / steps, `<name>_<epoch>_<iter>.pth` checkpoints, resume / interrupt handling, 100-iteration console line).
+
+What differs is the machinery underneath:
+  * the model and loss run on the HIP kernels (planerecnet_amd), the device comes from `cfg.device`;
+  * multi-GPU is one process per GPU (`python -m torch.distributed.run --nproc-per-node N train.py ...`): each rank takes
+    batch_size // N samples, BatchNorm statistics stay per rank (as in the reference's DataParallel replicas), gradients
+    are mean-all-reduced over RCCL on a side stream overlapped with backward (planerecnet_amd/parallel.py), the loss that
+    is logged is the mean over ranks (reference train.py:348), and the "skip the step on a non-finite loss" decision
+    (train.py:353) is taken collectively so ranks cannot diverge;
+  * GT-only loss preparation for batch k+1 runs on a worker thread while the GPU executes batch k (losses.TargetPrefetcher);
+  * `--dataset synthetic` (the default when the annotated datasets are not on disk) feeds seeded synthetic batches with the
+    reference's batch contract (data/datasets.py:54-57,250-273) -- the ScanNet / NYU readers need cv2 + pycocotools and are
+    outside this hot-path build.
+"""
+import argparse
+import datetime
+import math
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from planerecnet_amd.config import cfg, set_cfg, set_dataset
+from planerecnet_amd.utils import MovingAverage, SavePath
+
+parser = argparse.ArgumentParser(description="PlaneRecNet Training Script (MI355X)")
+parser.add_argument("--dataset", default=None, type=str, help="Override the config's dataset ('synthetic' for seeded synthetic batches).")
+parser.add_argument("--config", default="PlaneRecNet_50_config", help="The config object to use.")
+parser.add_argument("--save_folder", default="./weights/", help="Directory for saving checkpoint models.")
+parser.add_argument("--log_folder", default="./logs/", help="Directory for saving logs.")
+parser.add_argument("--backbone_folder", default="./weights/", help="Directory for loading Backbone.")
+parser.add_argument("--resume", default=None, type=str, help='Checkpoint to resume from ("interrupt" / "latest" / path).')
+parser.add_argument("--start_iter", default=-1, type=int, help="Resume at this iteration (-1: parse it from the file name).")
+parser.add_argument("--validation_size", default=2000, type=int)
+parser.add_argument("--validation_epoch", default=1, type=int)
+parser.add_argument("--no_tensorboard", dest="no_tensorboard", action="store_true")
+parser.add_argument("--no_autoscale", dest="autoscale", action="store_false")
+parser.add_argument("--reproductablity", dest="reproductablity", action="store_true")
+parser.add_argument("--batch_size", default=8, type=int, help="GLOBAL batch size (split evenly over the ranks).")
+parser.add_argument("--lr", "--learning_rate", default=None, type=float)
+parser.add_argument("--momentum", default=None, type=float)
+parser.add_argument("--decay", "--weight_decay", default=None, type=float)
+parser.add_argument("--gamma", default=None, type=float)
+parser.add_argument("--num_workers", default=2, type=int)
+parser.add_argument("--save_interval", default=12500, type=int)
+parser.add_argument("--keep_latest", dest="keep_latest", action="store_true")
+parser.add_argument("--keep_latest_interval", default=10000, type=int)
+parser.add_argument("--no_interrupt", dest="interrupt", action="store_false")
+parser.add_argument("--batch_alloc", default=None, type=str, help="Accepted for CLI compatibility; ranks always take equal shares.")
+parser.add_argument("--max_iter", default=None, type=int, help="(extension) stop after this many iterations.")
+parser.add_argument("--synthetic_size", default=64, type=int, help="(extension) samples per synthetic epoch.")
+parser.set_defaults(keep_latest=False, interrupt=True, autoscale=True)
+
+LOSS_TYPES = ["ins", "lav", "cat", "dpt", "pln"]
+
+
+class SyntheticPlaneDataset(torch.utils.data.Dataset):
+    """Seeded samples with the reference's contract: (image [3,H,W] float, instances dict, depth [1,H,W] metres)."""
+
+    def __init__(self, length, hw=(480, 640)):
+        self.length, self.hw = length, hw
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        H, W = self.hw
+        rng = np.random.RandomState(idx)
+        g = torch.Generator().manual_seed(idx)
+        n = int(rng.randint(3, 9))
+        masks, boxes = np.zeros((n, H, W), np.uint8), np.zeros((n, 4), np.float64)
+        for i in range(n):
+            bw, bh = int(rng.randint(max(W // 16, 8), W // 2)), int(rng.randint(max(H // 16, 8), H // 2))
+            x0, y0 = int(rng.randint(0, W - bw)), int(rng.randint(0, H - bh))
+            masks[i, y0:y0 + bh, x0:x0 + bw] = 1
+            boxes[i] = (x0, y0, x0 + bw, y0 + bh)
+        nrm = rng.randn(n, 3)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        inst = {"masks": torch.from_numpy(masks), "boxes": torch.from_numpy(boxes), "classes": torch.zeros(n, dtype=torch.int64),
+                "plane_paras": torch.from_numpy(np.concatenate([nrm, rng.rand(n, 1) * 3.0, np.zeros((n, 2))], 1)),
+                "k_matrix": torch.tensor([[577.0, 0, W / 2], [0, 577.0, H / 2], [0, 0, 1]], dtype=torch.float64)}
+        return torch.randn(3, H, W, generator=g), inst, 0.5 + 4.0 * torch.rand(1, H, W, generator=g)
+
+
+def detection_collate(batch):
+    """lists of images / instance dicts / depths (reference data/datasets.py:250-273)"""
+    return [s[0] for s in batch], [s[1] for s in batch], [s[2] for s in batch]
+
+
+class NetLoss(torch.nn.Module):
+    """net + criterion as one unit of work (reference train.py:128-150), with the GT-only targets passed in."""
+
+    def __init__(self, net, criterion):
+        super().__init__()
+        self.net, self.criterion = net, criterion
+
+    def forward(self, images, gt_instances, gt_depths, targets=None):
+        return self.criterion(self.net, *self.net(images), gt_instances, gt_depths, targets=targets)
+
+
+def set_lr(optimizer, new_lr):
+    for group in optimizer.param_groups:      # like the reference (train.py:415-417) this flattens the per-group multipliers (quirk Q7)
+        group["lr"] = new_lr
+
+
+def main():
+    args = parser.parse_args()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    set_cfg(args.config)
+    if args.dataset not in (None, "synthetic"):
+        set_dataset(args.dataset)
+    if args.autoscale and args.batch_size != 8:
+        factor = args.batch_size / 8
+        if rank == 0:
+            print("Scaling parameters by %.2f to account for a batch size of %d." % (factor, args.batch_size))
+        cfg.lr *= factor
+        cfg.max_iter //= factor
+        cfg.lr_steps = [x // factor for x in cfg.lr_steps]
+    for name in ("lr", "decay", "gamma", "momentum"):
+        if getattr(args, name) is None:
+            setattr(args, name, getattr(cfg, name))
+    if args.max_iter is not None:
+        cfg.max_iter = args.max_iter
+    if not torch.cuda.is_available():
+        raise SystemExit("No GPUs detected. The HIP path has no CPU fallback.")
+    if args.batch_size % world:
+        raise SystemExit("batch_size must be divisible by the number of ranks")
+    per_rank = args.batch_size // world
+    if per_rank < 6:
+        if rank == 0:
+            print("Per-GPU batch size is less than the recommended limit for batch norm. Disabling batch norm.")
+        cfg.freeze_bn = True
+    if args.reproductablity:
+        for seed_fn in (random.seed, np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all):
+            seed_fn(0)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg.device = str(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.set_num_threads(4)
+
+    from planerecnet_amd import timer
+    from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
+    from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
+    from planerecnet_amd.planerecnet import PlaneRecNet
+
+    os.makedirs(args.save_folder, exist_ok=True)
+    synthetic = args.dataset == "synthetic" or not os.path.exists(cfg.dataset.train_info)
+    if not synthetic:
+        raise SystemExit("The annotated dataset readers (cv2 + pycocotools) are outside this build; use --dataset synthetic.")
+    dataset = SyntheticPlaneDataset(args.synthetic_size)
+
+    torch.manual_seed(0)
+    prn_net = PlaneRecNet(cfg).train()
+    timer.disable_all()
+    if args.resume == "interrupt":
+        args.resume = SavePath.get_interrupt(args.save_folder)
+    elif args.resume == "latest":
+        args.resume = SavePath.get_latest(args.save_folder, cfg.name)
+    if args.resume is not None:
+        print("Resuming training, loading {}...".format(args.resume))
+        prn_net.load_weights(args.resume)
+        if args.start_iter == -1:
+            args.start_iter = SavePath.from_str(args.resume).iteration
+    else:
+        backbone_path = os.path.join(args.backbone_folder, cfg.backbone.path)
+        if os.path.exists(backbone_path):
+            prn_net.init_weights(backbone_path=backbone_path)
+        else:
+            if rank == 0:
+                print("Pretrained backbone %s not found: random backbone init." % backbone_path)
+            prn_net.init_head_weights()
+    prn_net = prn_net.to(dev)
+    criterion = PlaneRecNetLoss().to(dev)
+    net = NetLoss(prn_net, criterion)
+    optimizer = torch.optim.Adam([
+        {"params": prn_net.backbone.parameters(), "lr": 5 * args.lr}, {"params": prn_net.fpn.parameters(), "lr": args.lr},
+        {"params": prn_net.inst_head.parameters(), "lr": args.lr}, {"params": prn_net.mask_head.parameters(), "lr": args.lr},
+        {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr)
+    exchange = GradAllReduce([p for p in prn_net.parameters()])
+
+    # BN-safe warm-up forward with frozen statistics (reference train.py:270-272)
+    if not cfg.freeze_bn:
+        prn_net.freeze_bn()
+    with torch.no_grad():
+        prn_net(torch.zeros(1, 3, cfg.max_size, cfg.max_size, device=dev))
+    if not cfg.freeze_bn:
+        prn_net.freeze_bn(True)
+
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
+    loader = torch.utils.data.DataLoader(dataset, per_rank, num_workers=args.num_workers, shuffle=sampler is None, sampler=sampler,
+                                         collate_fn=detection_collate, pin_memory=True, drop_last=True)
+    iteration = max(args.start_iter, 0)
+    epoch_size = max(len(loader), 1)
+    num_epochs = math.ceil(cfg.max_iter / epoch_size)
+    step_index, last_time = 0, time.time()
+    time_avg, loss_avgs = MovingAverage(), {k: MovingAverage(100) for k in LOSS_TYPES}
+    save_path = lambda epoch, it: SavePath(cfg.name, epoch, it).get_path(root=args.save_folder)
+    prefetch = TargetPrefetcher(criterion)
+    if rank == 0:
+        print("Begin training!\n")
+    epoch = 0
+    try:
+        for epoch in range(num_epochs):
+            if (epoch + 1) * epoch_size < iteration:
+                continue
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            it = iter(loader)
+            nxt = next(it, None)
+            if nxt is not None:
+                prefetch.submit(nxt[1], tuple(nxt[0][0].shape[-2:]))
+            while nxt is not None:
+                images, gt_instances, gt_depths = nxt
+                if iteration == (epoch + 1) * epoch_size or iteration == cfg.max_iter:
+                    break
+                changed = [c for c in cfg.delayed_settings if iteration >= c[0]]
+                for c in changed:
+                    cfg.replace(c[1])
+                    for avg in loss_avgs.values():
+                        avg.reset()
+                if changed:
+                    cfg.delayed_settings = [x for x in cfg.delayed_settings if x[0] > iteration]
+                if cfg.lr_warmup_until > 0 and iteration <= cfg.lr_warmup_until:
+                    set_lr(optimizer, (args.lr - cfg.lr_warmup_init) * (iteration / cfg.lr_warmup_until) + cfg.lr_warmup_init)
+                while step_index < len(cfg.lr_steps) and iteration >= cfg.lr_steps[step_index]:
+                    step_index += 1
+                    set_lr(optimizer, args.lr * (args.gamma ** step_index))
+
+                optimizer.zero_grad(set_to_none=True)
+                x = torch.stack(images).to(dev, non_blocking=True)
+                d = torch.stack(gt_depths).to(dev, non_blocking=True)
+                targets = prefetch.get(d, dev)
+                nxt = next(it, None)                       # fetch + start preparing the next batch while this one runs
+                if nxt is not None:
+                    prefetch.submit(nxt[1], tuple(nxt[0][0].shape[-2:]))
+                losses = net(x, gt_instances, d, targets=targets)
+                loss = sum(losses[k].sum() for k in losses)
+                loss.backward()
+                exchange.finish()
+                stats = all_reduce_mean_scalars([losses[k].detach().sum() for k in LOSS_TYPES if k in losses] + [loss.detach()], dev).tolist()
+                if math.isfinite(stats[-1]):               # collective decision: every rank sees the same mean
+                    optimizer.step()
+                for k, v in zip([k for k in LOSS_TYPES if k in losses], stats):
+                    loss_avgs[k].add(v)
+                now = time.time()
+                elapsed, last_time = now - last_time, now
+                if iteration != args.start_iter:
+                    time_avg.add(elapsed)
+                if iteration % 100 == 0 and rank == 0:
+                    eta = str(datetime.timedelta(seconds=(cfg.max_iter - iteration) * time_avg.get_avg())).split(".")[0]
+                    shown = [k for k in LOSS_TYPES if k in losses]
+                    total = sum(loss_avgs[k].get_avg() for k in shown)
+                    labels = sum([[k, loss_avgs[k].get_avg()] for k in shown], [])
+                    print(("[%3d] %7d ||" + (" %s: %.3f |" * len(shown)) + " total: %.3f || ETA: %s || time/batch: %.3fs")
+                          % tuple([epoch, iteration] + labels + [total, eta, elapsed]), flush=True)
+                iteration += 1
+                if iteration % args.save_interval == 0 and iteration != args.start_iter and rank == 0:
+                    latest = SavePath.get_latest(args.save_folder, cfg.name) if args.keep_latest else None
+                    print("Saving state, iter:", iteration)
+                    prn_net.save_weights(save_path(epoch, iteration))
+                    if latest is not None and (args.keep_latest_interval <= 0 or iteration % args.keep_latest_interval != args.save_interval):
+                        print("Deleting old save...")
+                        os.remove(latest)
+            if iteration >= cfg.max_iter:
+                break
+    except KeyboardInterrupt:
+        if args.interrupt and rank == 0:
+            print("Stopping early. Saving network...")
+            SavePath.remove_interrupt(args.save_folder)
+            prn_net.save_weights(save_path(epoch, repr(iteration) + "_interrupt"))
+        raise SystemExit
+    finally:
+        prefetch.close()
+    if rank == 0:
+        prn_net.save_weights(save_path(epoch, iteration))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
