@@ -60,6 +60,18 @@ def synth_batch(B, H, W, seed, device):
     return images.to(device), inst, depths.to(device)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the latest committed PMC summary (profiles/*pmc_traffic.json, produced by
+    tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction). PMC counters cannot be
+    read inside this process, so this is the profiled value of the same command, or None when no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    fam = json.load(open(files[-1])).get("families", {}).get(kernel)
+    return None if fam is None else {"bytes_per_launch": fam["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
+
+
 def cpu_baseline(config_name, H, W, threads):
     """Oracle fwd + loss + bwd on ONE image on the host cores."""
     from oracle import loss_ref, model_ref, synth
@@ -92,6 +104,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel launch from Python instead of replaying hipGraphs")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -125,15 +138,28 @@ def main():
     images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
     np.random.seed(rank)
 
+    # The network's forward and backward are static: capture each as ONE hipGraph (torch.cuda.make_graphed_callables:
+    # stream capture of every HIP launch our C ABI issues on torch's current stream) so a step costs two graph launches
+    # instead of ~2000 Python-issued kernel launches.  The loss (data-dependent shapes) and Adam stay eager.
+    graphed, run_net = False, net
+    if not args.no_graph:
+        try:
+            run_net = torch.cuda.make_graphed_callables(net, (images,))
+            graphed = True
+        except Exception as e:                                   # noqa: BLE001
+            print("bench.py: hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            run_net = net
+
     hw = (args.height, args.width)
     prefetch = TargetPrefetcher(crit)
     prefetch.submit(inst, hw)
 
     def step():
+        nonlocal run_net
         opt.zero_grad(set_to_none=True)
         targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared on the worker thread) + async uploads
         prefetch.submit(inst, hw)                           # next step's targets: recomputed every step, overlapping this step's GPU work
-        out = net(images)
+        out = run_net(images)
         losses = crit(net, *out, inst, depths, targets=targets)
         loss = sum(losses.values()).sum()
         loss.backward()
@@ -164,6 +190,9 @@ def main():
 
     roof, kernels = None, None
     if rank == 0 and not args.no_roofline:
+        run_net = net                                   # per-launch HIP events need eagerly issued launches (same kernels, same shapes)
+        step()
+        torch.cuda.synchronize()
         profiling.enable()
         step()
         torch.cuda.synchronize()
@@ -172,7 +201,7 @@ def main():
         kernels = fams
         dom = max((f for f in fams if f["bound"] == "mfma"), key=lambda f: f["time_ms"])
         roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": dom["launches"],
+                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["kernel"]), "launches": dom["launches"],
                 "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"]}
 
     cpu = None
@@ -186,7 +215,7 @@ def main():
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s train step (fwd + 5-term loss + bwd + grad all-reduce + Adam), per-GPU batch %d, %dx%d synthetic RGB+depth+planes, random-init weights"
                            % (args.config, args.batch, args.height, args.width), "global_batch": gb, "parallelism": "dp%d" % world},
-                "losses_finite": finite, "losses": dict(zip(sorted(losses), loss_means)),
+                "hip_graph": graphed, "losses_finite": finite, "losses": dict(zip(sorted(losses), loss_means)),
                 "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(line), flush=True)
     prefetch.close()

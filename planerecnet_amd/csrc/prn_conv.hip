@@ -246,13 +246,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // pixel cursors of this thread (dY column group and im2col pixel), advanced by 16 pixels per chunk -- no divisions in the loop
+  int a_b, a_p, g_b, g_oh, g_ow;
+  {
+    const int n = cbeg * 16 + anq;
+    a_b = n / a.HoWo; a_p = n - a_b * a.HoWo;
+    const int g = cbeg * 16 + nl;
+    g_b = g / a.HoWo;
+    const int p = g - g_b * a.HoWo;
+    g_oh = p / a.Wo; g_ow = p - g_oh * a.Wo;
+  }
   auto load_chunk = [&](int ch) {
     {  // dY rows: 4 consecutive pixels of one output channel (unconditional, clamped loads)
       const int n = ch * 16 + anq;
       if (n4) {
         const bool ok = n < a.N;
-        int b = 0, p = 0;
-        if (ok) { b = n / a.HoWo; p = n - b * a.HoWo; }
+        const int b = ok ? a_b : 0, p = ok ? a_p : 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int m = m0 + arow + 64 * i;
@@ -262,12 +271,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
           ra[i][0] = okm ? v.x : 0.f; ra[i][1] = okm ? v.y : 0.f; ra[i][2] = okm ? v.z : 0.f; ra[i][3] = okm ? v.w : 0.f;
         }
       } else {
+        int qb = a_b, qp = a_p;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int nq = n + q;
-          const bool ok = nq < a.N;
-          int b = 0, p = 0;
-          if (ok) { b = nq / a.HoWo; p = nq - b * a.HoWo; }
+          const bool ok = n + q < a.N;
+          const int b = ok ? qb : 0, p = ok ? qp : 0;
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int m = m0 + arow + 64 * i;
@@ -275,27 +283,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
             const float v = a.dy[((size_t)b * a.M + mc) * a.HoWo + p];
             ra[i][q] = (ok && m < a.M) ? v : 0.f;
           }
+          if (++qp >= a.HoWo) { qp = 0; ++qb; }
         }
       }
+      a_p += 16;
+      while (a_p >= a.HoWo) { a_p -= a.HoWo; ++a_b; }
     }
     {  // im2col rows
-      const int n = ch * 16 + nl;
-      const bool ok = n < a.N;
-      int b = 0, oh = 0, ow = 0;
-      if (ok) {
-        b = n / a.HoWo;
-        const int p = n - b * a.HoWo;
-        oh = p / a.Wo;
-        ow = p - oh * a.Wo;
-      }
-      const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-      const float* __restrict__ xb = a.x + (size_t)b * a.C * a.HW;
+      const bool ok = ch * 16 + nl < a.N;
+      const int ih0 = g_oh * a.stride - a.pad, iw0 = g_ow * a.stride - a.pad;
+      const float* __restrict__ xb = a.x + (size_t)(ok ? g_b : 0) * a.C * a.HW;
 #pragma unroll
       for (int i = 0; i < NBJ; ++i) {
         const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], ok && jok[i], a.H, a.W);
         const float v = xb[off >= 0 ? jcoff[i] + off : 0];
         rb[i] = off >= 0 ? v : 0.f;
       }
+      g_ow += 16;
+      while (g_ow >= a.Wo) { g_ow -= a.Wo; ++g_oh; }
+      while (g_oh >= a.Ho) { g_oh -= a.Ho; ++g_b; }
     }
   };
   auto store_chunk = [&](int buf) {
@@ -496,7 +502,14 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
   p.tilesJ = cdiv(K, 64 * p.tj);
   p.chunks = cdiv(N, 16);
   const int tiles = p.tilesM * p.tilesJ;
-  int s = cdiv(1024, tiles);
+  // Splits: the kernel hides its gather latency only with several workgroups per CU, so aim for ~8 per CU, but bound
+  // the workspace round trip (2 * splits * M*K*4 bytes) to a fraction of the MFMA time: splits <= 0.0035 * pixels
+  // (fit to the PRN_WGRAD_TARGET sweep in profiles/r01_conv_sweep.txt).
+  static int target = -1;          // PRN_WGRAD_TARGET overrides (tuning sweeps)
+  if (target < 0) { const char* e = getenv("PRN_WGRAD_TARGET"); target = e ? atoi(e) : 2048; }
+  int s = cdiv(target, tiles);
+  const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;
+  if (s > sbw) s = sbw;
   const int smax = p.chunks / 8 > 0 ? p.chunks / 8 : 1;   // at least 128 pixels per split
   if (s > smax) s = smax;
   if (s > 256) s = 256;

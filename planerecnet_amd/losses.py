@@ -27,6 +27,10 @@ from .config import cfg
 from .funcs import center_of_mass, quarter_mask_u8
 
 
+def _pin(x):
+    return x.pin_memory()
+
+
 class Targets:
     """Device-resident, GT-only inputs of one loss evaluation (built by PlaneRecNetLoss.prepare)."""
     __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum")
@@ -111,11 +115,12 @@ class PlaneRecNetLoss(nn.Module):
             num_ins += sum(int(i.sum()) for i in ind_l)
             for lv in range(L):
                 cate_rows[lv].append(cate_l[lv].flatten())
+        pin = _pin if torch.cuda.is_available() else (lambda x: x)       # page-locked staging: the later H2D copies are truly async
         return {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
-                "cell_ids": [torch.from_numpy(c) for c in cell_ids], "pos_img": torch.from_numpy(np.repeat(np.arange(B), n_pos)),
-                "ins_labels": torch.cat(ins_labels, 0),
+                "cell_ids": pin(torch.from_numpy(np.concatenate(cell_ids))), "pos_img": pin(torch.from_numpy(np.repeat(np.arange(B), n_pos))),
+                "ins_labels": pin(torch.cat(ins_labels, 0)),
                 # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
-                "cate_labels": torch.cat([r for lv in range(L) for r in cate_rows[lv]]),
+                "cate_labels": pin(torch.cat([r for lv in range(L) for r in cate_rows[lv]])),
                 "vnl": self.vnl.prepare_host(host, (H, W)) if cfg.use_plane_loss else None}
 
     @torch.no_grad()
@@ -124,7 +129,7 @@ class PlaneRecNetLoss(nn.Module):
         t = Targets()
         t.B, t.n_pos, t.num_ins = h["B"], h["n_pos"], h["num_ins"]
         up = lambda x: x.to(device, non_blocking=True)
-        t.cell_ids = [up(c) for c in h["cell_ids"]]
+        t.cell_ids = list(up(h["cell_ids"]).split(h["n_pos"]))
         t.n_pos_dev = up(torch.as_tensor(h["n_pos"], dtype=torch.float32))
         t.pos_img, t.ins_labels, t.cate_labels = up(h["pos_img"]), up(h["ins_labels"]), up(h["cate_labels"])
         t.vnl = self.vnl.upload(h["vnl"], device) if h["vnl"] is not None else None
@@ -278,11 +283,13 @@ class VNL_Loss(nn.Module):
                 normals.append(planes[r] if r < N else np.zeros(3))
         seg_len = np.asarray(seg_len, dtype=np.int64)
         n_seg = len(seg_len)
+        pin = _pin if torch.cuda.is_available() else (lambda x: x)
         return {"B": len(host_instances), "n_seg": n_seg, "n_tot": int(seg_len.sum()),
                 "N": torch.as_tensor(N_per, dtype=torch.float64), "fx": torch.as_tensor(np.asarray(fx), dtype=torch.float64),
                 "fy": torch.as_tensor(np.asarray(fy), dtype=torch.float64),
-                "gid": torch.from_numpy(np.concatenate(gids, 1) if gids else np.zeros((3, 0), np.int64)),
-                "seg": torch.from_numpy(np.repeat(np.arange(n_seg), seg_len)),
+                # the two big index arrays travel as int32 over PCIe (12 B per triplet less) and are widened on the device
+                "gid": pin(torch.from_numpy((np.concatenate(gids, 1) if gids else np.zeros((3, 0), np.int64)).astype(np.int32))),
+                "seg": pin(torch.from_numpy(np.repeat(np.arange(n_seg, dtype=np.int32), seg_len))),
                 "seg_start": torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64)),
                 "seg_img": torch.as_tensor(seg_img, dtype=torch.int64), "seg_is_plane": torch.as_tensor(seg_plane, dtype=torch.bool),
                 "seg_normal": torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3))}
@@ -293,6 +300,7 @@ class VNL_Loss(nn.Module):
         t.B, t.n_seg, t.n_tot = h["B"], h["n_seg"], h["n_tot"]
         for k in ("N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal"):
             setattr(t, k, h[k].to(device, non_blocking=True))
+        t.gid, t.seg = t.gid.long(), t.seg.long()
         return t
 
     def prepare(self, host_instances, hw, device):

@@ -304,6 +304,15 @@ class DepthDecoder_FPN(nn.Module):
         y = ops.conv2d(x, conv.weight, conv.bias, pad=1, in_mode=ops.IN_UP2_REFLECT if up else ops.IN_REFLECT)
         return ops.batch_norm(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps, bn.momentum, None, True)
 
+    def _centre_index(self, n, device):
+        """Indices {4k+1, 4k+2}: the two centre samples of every 4-block (what the x0.25 bilinear resize reads). Cached per
+        (size, device) so that the forward stays free of host->device copies (HIP-graph capturable)."""
+        key = (n, str(device))
+        cache = self.__dict__.setdefault("_centre_cache", {})
+        if key not in cache:
+            cache[key] = (torch.arange(n // 4)[:, None] * 4 + torch.tensor([1, 2])).flatten().to(device)
+        return cache[key]
+
     def plane_prior(self, seg_preds, kernel_preds):
         B = seg_preds.shape[0]
         with torch.no_grad():
@@ -311,8 +320,7 @@ class DepthDecoder_FPN(nn.Module):
             h, w = seg_preds.shape[2:]
             if h % 4 or w % 4:
                 raise NotImplementedError("plane prior expects a mask feature size divisible by 4")
-            hi = (torch.arange(h // 4, device=seg_preds.device)[:, None] * 4 + torch.tensor([1, 2], device=seg_preds.device)).flatten()
-            wi = (torch.arange(w // 4, device=seg_preds.device)[:, None] * 4 + torch.tensor([1, 2], device=seg_preds.device)).flatten()
+            hi, wi = self._centre_index(h, seg_preds.device), self._centre_index(w, seg_preds.device)
             centre = seg_preds.detach()[:, :, hi][:, :, :, wi].contiguous()                                            # [B,E,h/2,w/2]
             sig = torch.cat([ops.conv2d(centre[b:b + 1], flat[b].reshape(-1, self.num_kernels, 1, 1).contiguous(),
                                         epilogue=ops.EPI_SIGMOID) for b in range(B)], 0)                                # [B,3728,h/2,w/2]

@@ -1,0 +1,32 @@
+#!/bin/bash
+# HBM traffic per kernel family for one bench step: two separate PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass).
+# Prints per-family average bytes/launch plus the calibration ratios on kernels whose algorithmic bytes are known.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/pmc_traffic
+mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.log 2>&1
+  ls /tmp/pmc_$c | head -5
+done
+python3 - <<'PY'
+import csv, glob, collections, json, os
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob('/tmp/pmc_%s/*counter_collection.csv' % c)
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r['Counter_Name'] != c: continue
+        k = r['Kernel_Name']
+        fam = None
+        for key in ("conv_igemm_kernel", "conv_wgrad_kernel", "reduce_epilogue_kernel", "reduce_splits_kernel", "bn_partial_kernel", "bn_apply_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "dcn_sample_bwd_kernel", "dcn_sample_kernel", "gn_relu_fwd", "gn_relu_bwd", "resize_fwd", "resize_bwd"):
+            if key in k: fam = key; break
+        if fam: acc[fam].append(float(r['Counter_Value']))
+    out[c] = {k: {"launches": len(v), "sum_kb": sum(v), "avg_kb": sum(v)/len(v)} for k, v in acc.items()}
+json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+for c, d in out.items():
+    print(c)
+    for k, v in sorted(d.items(), key=lambda kv: -kv[1]["sum_kb"]):
+        print("  %-26s launches %5d  total %10.1f MB   avg %9.1f KB" % (k, v["launches"], v["sum_kb"]/1024, v["avg_kb"]))
+PY
