@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="issue every kernel launch from Python instead of replaying hipGraphs")
+    ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
+                    "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -120,13 +121,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from planerecnet_amd import ops, profiling
+    from planerecnet_amd import ops, profiling, timer
     from planerecnet_amd.config import cfg, set_cfg
     from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
     from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
     from planerecnet_amd.planerecnet import PlaneRecNet
 
     torch.set_num_threads(4)                           # host-side tensor ops are small: a wide OpenMP team only adds fork/join latency
+    timer.disable_all()                                # like the reference's train.py:233 (enabled timers synchronise per stage)
     set_cfg(args.config)
     torch.manual_seed(0)                               # identical replicas on every rank
     net = PlaneRecNet(cfg)
@@ -138,11 +140,11 @@ def main():
     images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
     np.random.seed(rank)
 
-    # The network's forward and backward are static: capture each as ONE hipGraph (torch.cuda.make_graphed_callables:
-    # stream capture of every HIP launch our C ABI issues on torch's current stream) so a step costs two graph launches
-    # instead of ~2000 Python-issued kernel launches.  The loss (data-dependent shapes) and Adam stay eager.
+    # --graph: the network's forward and backward are static, so each can be captured as ONE hipGraph
+    # (torch.cuda.make_graphed_callables: stream capture of every HIP launch our C ABI issues on torch's current stream).
+    # The loss (data-dependent shapes) and Adam stay eager.  Off by default: see the flag's help text.
     graphed, run_net = False, net
-    if not args.no_graph:
+    if args.graph:
         try:
             run_net = torch.cuda.make_graphed_callables(net, (images,))
             graphed = True
@@ -155,7 +157,6 @@ def main():
     prefetch.submit(inst, hw)
 
     def step():
-        nonlocal run_net
         opt.zero_grad(set_to_none=True)
         targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared on the worker thread) + async uploads
         prefetch.submit(inst, hw)                           # next step's targets: recomputed every step, overlapping this step's GPU work
@@ -190,9 +191,8 @@ def main():
 
     roof, kernels = None, None
     if rank == 0 and not args.no_roofline:
-        run_net = net                                   # per-launch HIP events need eagerly issued launches (same kernels, same shapes)
-        step()
-        torch.cuda.synchronize()
+        if graphed:
+            raise SystemExit("bench.py: the roofline leg needs eagerly issued launches; combine --graph with --no-roofline")
         profiling.enable()
         step()
         torch.cuda.synchronize()

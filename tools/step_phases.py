@@ -12,6 +12,9 @@ import bench  # noqa: E402
 from planerecnet_amd.config import cfg, set_cfg  # noqa: E402
 from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher  # noqa: E402
 from planerecnet_amd.planerecnet import PlaneRecNet  # noqa: E402
+from planerecnet_amd import timer  # noqa: E402
+
+timer.disable_all()
 
 torch.set_num_threads(int(os.environ.get("HOST_THREADS", "4")))
 dev = torch.device("cuda:0")
