@@ -19,6 +19,8 @@
 extern "C" {
 #endif
 
+#define PRN_BN_SPLITS 32   /* upper bound of per-channel partials in the double workspaces below */
+
 int prn_version(void);
 const char* prn_last_error(void);
 
@@ -66,8 +68,8 @@ int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, fl
  * virtual padded tensor, Hv = H or 2H) back onto dx [B,C,H,W]. */
 int prn_pad_fold(const float* dp, float* dx, int B, int C, int H, int W, int up2, void* stream);
 
-/* out[c] = sum_{b,h,w} x[b,c,h,w]    (bias gradients) */
-int prn_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+/* out[c] = sum_{b,h,w} x[b,c,h,w]    (bias gradients); ws: C*PRN_BN_SPLITS doubles (fixed-order partials) */
+int prn_channel_sum(const float* x, float* out, double* ws, int B, int C, int HW, void* stream);
 
 /* ---- modulated deformable convolution (DCNv2) ------------------------------------------------------------
  * replaces torchvision.ops.deform_conv2d (models/dcn.py:59-66) together with the clamp / 2*sigmoid the
@@ -85,7 +87,6 @@ int prn_dcn_sample_bwd(const float* x, const float* om, const float* dcols, floa
  * replaces ATen batch_norm fwd/bwd: models/backbone.py:24,44,48,102,166 ; planerecnet.py:518..582           */
 /* training statistics: stats[0:C]=mean, stats[C:2C]=invstd; updates running_mean/var (momentum, unbiased var).
  * ws: 2*C*PRN_BN_SPLITS doubles. */
-#define PRN_BN_SPLITS 32
 int prn_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, double* ws,
                  int B, int C, int HW, float eps, float momentum, void* stream);
 /* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) ; for eval mode pass stats built from running stats */

@@ -428,21 +428,28 @@ __global__ void pad_fold_kernel(const float* __restrict__ dp, float* __restrict_
   dx[i] = acc;
 }
 
-// out[c] = sum_{b,hw} x[b,c,hw] : one block per channel, fp64 block combine
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int HW) {
-  const int c = blockIdx.x;
-  double s = 0.0;
+// out[c] = sum_{b,hw} x[b,c,hw]: grid (C, S) fixed-order fp64 partials, then one thread per channel sums them
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int B, int C, int HW) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int beg = (int)((int64_t)HW * s / S), end = (int)((int64_t)HW * (s + 1) / S);
+  float part = 0.f;
   for (int b = 0; b < B; ++b) {
     const float* p = x + ((size_t)b * C + c) * HW;
-    float part = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) part += p[i];
-    s += (double)part;
+    for (int i = beg + threadIdx.x; i < end; i += 256) part += p[i];
   }
-  s = wave_sum_d(s);
+  double d = wave_sum_d((double)part);
   __shared__ double sm[4];
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) out[c] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
+  if (threadIdx.x == 0) ws[(size_t)c * S + s] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void channel_sum_final_kernel(const double* __restrict__ ws, float* __restrict__ out, int C, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double t = 0.0;
+  for (int s = 0; s < S; ++s) t += ws[(size_t)c * S + s];
+  out[c] = (float)t;
 }
 
 struct FwdPlan { int tm, tn, bk, splits; };
@@ -640,9 +647,14 @@ extern "C" int prn_pad_fold(const float* dp, float* dx, int B, int C, int H, int
   return 0;
 }
 
-extern "C" int prn_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
-  PRN_REQUIRE(x && out && B > 0 && C > 0 && HW > 0, "prn_channel_sum: bad arguments");
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
-  PRN_CHECK_LAUNCH("prn_channel_sum");
+extern "C" int prn_channel_sum(const float* x, float* out, double* ws, int B, int C, int HW, void* stream) {
+  PRN_REQUIRE(x && out && ws && B > 0 && C > 0 && HW > 0, "prn_channel_sum: bad arguments");
+  int S = (int)(((int64_t)B * HW + 8191) / 8192);
+  S = S > PRN_BN_SPLITS ? PRN_BN_SPLITS : (S < 1 ? 1 : S);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
+  PRN_CHECK_LAUNCH("prn_channel_sum/partial");
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, out, C, S);
+  PRN_CHECK_LAUNCH("prn_channel_sum/final");
   return 0;
 }

@@ -18,16 +18,39 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
 }
 
 // ------------------------------------------------------------------------------------------- BatchNorm
-// grid (C, SPLITS): block (c, s) reduces a fixed slice of the B*HW elements of channel c.
+// grid (C, S): block (c, s) reduces slice s of every image plane of channel c.  S is chosen by the launcher so that a
+// block owns >= ~8k elements (one block per channel for the 15x20 maps, up to PRN_BN_SPLITS for 120x160 ones);
+// float4 streams whenever HW % 4 == 0.
+__device__ __forceinline__ void slice_bounds(int HW, int s, int S, bool vec, int& beg, int& end) {
+  if (vec) {
+    const int n4 = HW >> 2;
+    beg = (int)((int64_t)n4 * s / S) * 4;
+    end = (int)((int64_t)n4 * (s + 1) / S) * 4;
+  } else {
+    beg = (int)((int64_t)HW * s / S);
+    end = (int)((int64_t)HW * (s + 1) / S);
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int B, int C, int HW) {
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-  const int beg = (int)((int64_t)HW * s / S), end = (int)((int64_t)HW * (s + 1) / S);   // slice of every image plane
+  const bool vec = (HW & 3) == 0;
+  int beg, end;
+  slice_bounds(HW, s, S, vec, beg, end);
   float s1 = 0.f, s2 = 0.f;
   for (int b = 0; b < B; ++b) {
     const float* xp = x + ((size_t)b * C + c) * HW;
-    for (int p = beg + threadIdx.x; p < end; p += 256) {
-      const float v = xp[p];
-      s1 += v; s2 += v * v;
+    if (vec) {
+      for (int p = beg + threadIdx.x * 4; p < end; p += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + p);
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+      for (int p = beg + threadIdx.x; p < end; p += 256) {
+        const float v = xp[p];
+        s1 += v; s2 += v * v;
+      }
     }
   }
   __shared__ double sm[16];
@@ -88,17 +111,33 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ y, const float* __restrict__ stats,
                                                              double* __restrict__ ws, int B, int C, int HW, int relu) {
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-  const int beg = (int)((int64_t)HW * s / S), end = (int)((int64_t)HW * (s + 1) / S);
+  const bool vec = (HW & 3) == 0;
+  int beg, end;
+  slice_bounds(HW, s, S, vec, beg, end);
   const float mean = stats[c], istd = stats[C + c];
   float s1 = 0.f, s2 = 0.f;
   for (int b = 0; b < B; ++b) {
     const size_t base = ((size_t)b * C + c) * HW;
-    for (int p = beg + threadIdx.x; p < end; p += 256) {
-      float g = dy[base + p];
-      if (relu && !(y[base + p] > 0.f)) g = 0.f;
-      s1 += g; s2 += g * (x[base + p] - mean) * istd;
+    if (vec) {
+      for (int p = beg + threadIdx.x * 4; p < end; p += 1024) {
+        float4 g = *reinterpret_cast<const float4*>(dy + base + p);
+        const float4 xv = *reinterpret_cast<const float4*>(x + base + p);
+        if (relu) {
+          const float4 yv = *reinterpret_cast<const float4*>(y + base + p);
+          g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        s1 += (g.x + g.y) + (g.z + g.w);
+        s2 += (g.x * (xv.x - mean) + g.y * (xv.y - mean)) + (g.z * (xv.z - mean) + g.w * (xv.w - mean));
+      }
+    } else {
+      for (int p = beg + threadIdx.x; p < end; p += 256) {
+        float g = dy[base + p];
+        if (relu && !(y[base + p] > 0.f)) g = 0.f;
+        s1 += g; s2 += g * (x[base + p] - mean);
+      }
     }
   }
+  s2 *= istd;
   __shared__ double sm[16];
   double d1 = s1, d2 = s2;
   block_sum2(d1, d2, sm);
@@ -127,6 +166,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float m1 = frozen ? 0.f : (float)ws[(size_t)c * S * 2] * inv_count;
   const float m2 = frozen ? 0.f : (float)ws[(size_t)c * S * 2 + 1] * inv_count;
   const size_t base = (size_t)bc * HW;
+  if ((HW & 3) == 0) {
+    const int n4 = HW >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+      float4 g = reinterpret_cast<const float4*>(dy + base)[i];
+      const float4 xv = reinterpret_cast<const float4*>(x + base)[i];
+      if (relu) {
+        const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      if (dres) reinterpret_cast<float4*>(dres + base)[i] = g;
+      float4 o;
+      o.x = gi * (g.x - m1 - (xv.x - mean) * istd * m2); o.y = gi * (g.y - m1 - (xv.y - mean) * istd * m2);
+      o.z = gi * (g.z - m1 - (xv.z - mean) * istd * m2); o.w = gi * (g.w - m1 - (xv.w - mean) * istd * m2);
+      reinterpret_cast<float4*>(dx + base)[i] = o;
+    }
+    return;
+  }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     float g = dy[base + i];
     if (relu && !(y[base + i] > 0.f)) g = 0.f;
@@ -199,16 +255,26 @@ __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restric
   (void)tot;
 }
 
+// splits per channel: >= ~8k elements per block, at most PRN_BN_SPLITS (the workspace contract)
+int bn_splits(int B, int HW) {
+  int s = (int)(((int64_t)B * HW + 8191) / 8192);
+  if (s > PRN_BN_SPLITS) s = PRN_BN_SPLITS;
+  if (s < 1) s = 1;
+  if (s > HW / 4 && HW >= 4) s = HW / 4;
+  return s < 1 ? 1 : s;
+}
+
 }  // namespace
 
 extern "C" int prn_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, double* ws,
                             int B, int C, int HW, float eps, float momentum, void* stream) {
   PRN_REQUIRE(x && stats && ws && B > 0 && C > 0 && HW > 0, "prn_bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, PRN_BN_SPLITS), dim3(256), 0, st, x, ws, B, C, HW);
+  const int S = bn_splits(B, HW);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
   PRN_CHECK_LAUNCH("prn_bn_stats/partial");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, stats, running_mean, running_var, C,
-                     PRN_BN_SPLITS, (double)B * HW, eps, momentum);
+                     S, (double)B * HW, eps, momentum);
   PRN_CHECK_LAUNCH("prn_bn_stats/finalize");
   return 0;
 }
@@ -231,16 +297,17 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
   PRN_REQUIRE(!relu || y, "prn_bn_bwd: relu needs the forward output");
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_bwd: B*C too large for grid.y");
   hipStream_t st = (hipStream_t)stream;
+  const int S = bn_splits(B, HW);
   if (!frozen || dgamma || dbeta) {
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, PRN_BN_SPLITS), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu);
     PRN_CHECK_LAUNCH("prn_bn_bwd/partial");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, dgamma, dbeta, C, PRN_BN_SPLITS);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, dgamma, dbeta, C, S);
     PRN_CHECK_LAUNCH("prn_bn_bwd/finalize");
   }
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, st, dy, x, y, stats, gamma, (const double*)ws, dx, dres, C, HW,
-                     PRN_BN_SPLITS, 1.f / ((float)B * HW), relu, frozen);
+                     S, 1.f / ((float)B * HW), relu, frozen);
   PRN_CHECK_LAUNCH("prn_bn_bwd/apply");
   return 0;
 }

@@ -357,7 +357,14 @@ class VNL_Loss(nn.Module):
         cos_np = F.cosine_similarity(dn, gn_np, dim=1).abs().double()
         loss = 1 - torch.where(is_plane, cos_plane, cos_np)                                       # [n_tot] float64
         # segmented "sort ascending, drop the first 25 % of the valid ones, nansum / remaining"
-        m = torch.zeros(t.n_seg, device=dev, dtype=torch.int64).index_add_(0, t.seg, valid.long())
+        # segments are contiguous runs in triplet order: segment sums are differences of one prefix sum (no atomics)
+        seg_end = torch.cat([t.seg_start[1:], t.seg_start.new_full((1,), t.n_tot)])
+
+        def seg_total(v):
+            cs = torch.cat([v.new_zeros(1), torch.cumsum(v, 0)])
+            return cs[seg_end] - cs[t.seg_start]
+
+        m = seg_total(valid.long())
         key = t.seg.double() * 4.0 + torch.where(valid, torch.nan_to_num(loss.detach(), nan=1.5), torch.full_like(loss, 2.0))
         order = torch.argsort(key)
         seg_s = t.seg[order]
@@ -365,7 +372,7 @@ class VNL_Loss(nn.Module):
         drop = m // 4
         keep = valid[order] & (rank >= drop[seg_s])
         contrib = torch.where(keep, torch.nan_to_num(loss[order], nan=0.0), torch.zeros_like(loss))
-        seg_sum = torch.zeros(t.n_seg, device=dev, dtype=torch.float64).index_add_(0, seg_s, contrib)
+        seg_sum = seg_total(contrib)                                                               # sorted order keeps segments contiguous
         # per image: sum over planes (+ non-planar term unless it sampled nothing valid) / (N or N+1)
         np_ok = (~t.seg_is_plane) & (m > 0)
         use = t.seg_is_plane | np_ok

@@ -87,7 +87,8 @@ def flip_transpose(w):
 def channel_sum(g):
     B, C, H, W = g.shape
     out = torch.empty(C, device=g.device, dtype=torch.float32)
-    check(lib.prn_channel_sum(_p(g), _p(out), B, C, H * W, _stream()), "prn_channel_sum")
+    ws = torch.empty(C * _lib.BN_SPLITS, device=g.device, dtype=torch.float64)
+    check(lib.prn_channel_sum(_p(g), _p(out), _p(ws), B, C, H * W, _stream()), "prn_channel_sum")
     return out
 
 
