@@ -55,8 +55,11 @@ __device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W)
 // BK = K-slice depth per staging round.  Small-N layers (backbone stages 3-4: N = 9600 / 2400 pixels) cannot fill 256 CUs
 // with output tiles alone, so the launcher also splits K across blockIdx.y (deterministic: partial tiles go to a
 // workspace that reduce_epilogue_kernel sums in fixed order before bias / addend / activation).
-template <int KS, int MODE, int TM, int TN, int BK>
+// VEC (1x1, stride 1, no padding, H*W % 4 == 0): the im2col operand is the activation matrix itself, staged with float4
+// loads along the pixel axis and 128-bit LDS stores.
+template <int KS, int MODE, int TM, int TN, int BK, bool VEC = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(!VEC || (KS == 1 && MODE == PRN_IN_ZERO), "vector staging is the plain-GEMM case");
   constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BK + 1;
   constexpr int KSTEP = 256 / BN;  // K rows covered by one sweep of the block
   constexpr int NB = BK / KSTEP;   // gathered elements per thread per K slice
@@ -64,8 +67,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int AROWS = 256 / AQ;  // A rows covered by one sweep
   constexpr int NA = BM / AROWS;   // float4 loads per thread per K slice
   constexpr int KK = KS * KS;
+  constexpr int VG = BN / 4;       // VEC: float4 pixel groups per K row
+  constexpr int VROWS = 256 / VG;  // VEC: K rows per sweep
+  constexpr int NBV = BK / VROWS;  // VEC: float4 loads per thread per K slice
   __shared__ float As[2][BM * LDA];
-  __shared__ float Bs[2][BK * BN];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
   __shared__ int taps[KS > 1 ? KK * BN : 1];   // per-pixel tap offsets (or -1), built once per workgroup
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,8 +107,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int arow = tid / AQ, akq = (tid % AQ) * 4;
   const bool k4 = ((a.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0);
 
+  // VEC staging: this thread's group of 4 consecutive pixels
+  const int vg = tid % VG, vrow0 = tid / VG;
+  const float* __restrict__ xv = a.x;
+  bool vvalid = false;
+  if (VEC) {
+    const int nv = n0 + vg * 4;
+    vvalid = nv < a.N;
+    if (vvalid) {
+      const int bv = nv / a.HoWo;
+      xv = a.x + (size_t)bv * a.C * a.HW + (nv - bv * a.HoWo);
+    }
+  }
+
   float ra[NA][4];
-  float rb[NB];
+  float rb[VEC ? 1 : NB];
+  float4 rv[VEC ? NBV : 1];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -131,14 +151,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
       }
     }
+    if (VEC) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform
-      const int c = kr / KK, rs = kr - c * KK;
-      const int off = (KS == 1) ? off1 : taps[rs * BN + nl];
-      const bool ok = (off >= 0) && (kr < a.K);
-      const float v = xb[ok ? c * a.HW + off : 0];
-      rb[i] = ok ? v : 0.f;
+      for (int i = 0; i < NBV; ++i) {
+        const int kr = k0 + vrow0 + i * VROWS;
+        const bool ok = vvalid && (kr < a.K);
+        const float4 v = *reinterpret_cast<const float4*>(xv + (ok ? (size_t)kr * a.HW : 0));
+        rv[i].x = ok ? v.x : 0.f; rv[i].y = ok ? v.y : 0.f; rv[i].z = ok ? v.z : 0.f; rv[i].w = ok ? v.w : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform
+        const int c = kr / KK, rs = kr - c * KK;
+        const int off = (KS == 1) ? off1 : taps[rs * BN + nl];
+        const bool ok = (off >= 0) && (kr < a.K);
+        const float v = xb[ok ? c * a.HW + off : 0];
+        rb[VEC ? 0 : i] = ok ? v : 0.f;
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -146,8 +176,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
+    if (VEC) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[i];
+      for (int i = 0; i < NBV; ++i) *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = rv[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[VEC ? 0 : i];
+    }
   };
 
   const int KTall = (a.K + BK - 1) / BK;
@@ -174,30 +209,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     __syncthreads();
   }
 
-  // epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel)
+  // epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel).
+  // Uniform decisions (split partial / bias / addend / activation / interior tile) are hoisted out of the element loops.
   const bool partial = a.splits > 1;
   float* __restrict__ outp = partial ? a.ws + (size_t)blockIdx.y * a.B * a.M * a.HoWo : a.y;
+  const bool has_bias = !partial && a.bias != nullptr, has_add = !partial && a.addend != nullptr;
+  const int epi = partial ? PRN_EPI_NONE : a.epi;
+  const bool interior = (m0 + BM <= a.M) && (n0 + BN <= a.N);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nn = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    if (nn >= a.N) continue;
+    if (!interior && nn >= a.N) continue;
     const int bb = nn / a.HoWo, p = nn - bb * a.HoWo;
     const size_t base = (size_t)bb * a.M * a.HoWo + p;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < a.M) {
-          const size_t idx = base + (size_t)m * a.HoWo;
-          float v = acc[i][j][r];
-          if (partial) { outp[idx] = v; continue; }
-          if (a.bias) v += a.bias[m];
-          if (a.addend) v += a.addend[idx];
-          if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
-          else if (a.epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + __expf(-v));
-          a.y[idx] = v;
-        }
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (!interior && m >= a.M) continue;
+        const size_t idx = base + (size_t)m * a.HoWo;
+        float v = acc[i][j][r];
+        if (has_bias) v += a.bias[m];
+        if (has_add) v += a.addend[idx];
+        if (epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+        else if (epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        outp[idx] = v;
       }
     }
   }
@@ -491,6 +529,15 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
   a.nblocks = a.tilesM * cdiv(a.N, 64 * p.tn);
   a.splits = p.splits;
   dim3 grid(a.nblocks, p.splits), block(256);
+  if constexpr (KS == 1 && MODE == PRN_IN_ZERO) {
+    const bool vec = a.stride == 1 && a.pad == 0 && (a.HW & 3) == 0 && a.HW == a.HoWo && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+    if (vec) {
+      if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 2, 2, 16, true>), grid, block, 0, st, a);
+      else if (p.tm == 1 && p.tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 1, 2, 16, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 1, 1, 16, true>), grid, block, 0, st, a);
+      return 0;
+    }
+  }
 #define PRN_LAUNCH(TM_, TN_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, TM_, TN_, BK_>), grid, block, 0, st, a)
   // (deeper slices were measured slower on every shape -- only BK = 16 is instantiated)
   if (p.tm == 2 && p.tn == 2) PRN_LAUNCH(2, 2, 16);

@@ -38,6 +38,8 @@ SHAPES = [
     ("dec deconv3 up2 256->128 @60x80", 256, 60, 80, 128, 3, 1, 1, 2),
     ("dec depth_pred 64->1 @240x320", 64, 240, 320, 1, 3, 1, 1, 1),
     ("prior 1x1 3728->256 @30x40", 3728, 30, 40, 256, 1, 1, 0, 0),
+    ("gemm-like 1x1 4096->4096 @64x64", 4096, 64, 64, 4096, 1, 1, 0, 0),
+    ("gemm-like 3x3 512->512 @64x64", 512, 64, 64, 512, 3, 1, 1, 0),
 ]
 
 
