@@ -58,7 +58,7 @@ __device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W)
 // VEC (1x1, stride 1, no padding, H*W % 4 == 0): the im2col operand is the activation matrix itself, staged with float4
 // loads along the pixel axis and 128-bit LDS stores.
 template <int KS, int MODE, int TM, int TN, int BK, bool VEC = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel(ConvArgs a) {   // 128x128: cap at 128 VGPRs -> 4 waves/SIMD (+7..15 %)
   static_assert(!VEC || (KS == 1 && MODE == PRN_IN_ZERO), "vector staging is the plain-GEMM case");
   constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BK + 1;
   constexpr int KSTEP = 256 / BN;  // K rows covered by one sweep of the block

@@ -176,10 +176,11 @@ class _DeformConv(torch.autograd.Function):
         dcols = conv_dgrad_raw(dy, w1, cols.shape, 1, 0, IN_ZERO)
         dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[2] else None
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[3]) else None
-        dx = torch.zeros_like(x)
+        dx = torch.empty_like(x)
         dom = torch.empty_like(om)
+        ws = torch.empty(lib.prn_dcn_sample_bwd_ws_bytes(B, C, Ho, Wo) // 4, device=x.device, dtype=torch.float32)
         with profiling.span("dcn_sample_bwd_kernel", "hbm", 4.0 * (2 * x.numel() + 2 * om.numel() + dcols.numel())):
-            check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
+            check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), _p(ws), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
                   "prn_dcn_sample_bwd")
         return dx, dom, dw, db, None, None
 
