@@ -65,6 +65,8 @@ def main():
             continue
         x = torch.randn(B, C, H, W, device=dev)
         w = torch.randn(M, C, K, K, device=dev) * (C * K * K) ** -0.5
+        if os.environ.get("ZERO"):            # DVFS probe: all-zero operands draw less power -> higher clock (MI355X_MICROARCH.md)
+            x.zero_(); w.zero_()
         Ho, Wo = ops._out_hw(H, W, K, stride, pad, mode)
         dy = torch.randn(B, M, Ho, Wo, device=dev)
         fl = 2.0 * M * C * K * K * B * Ho * Wo
