@@ -135,7 +135,7 @@ def main():
     net.init_head_weights()
     net = net.to(dev).train()
     crit = PlaneRecNetLoss().to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
     exchange = GradAllReduce(list(net.parameters()))
     images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
     np.random.seed(rank)

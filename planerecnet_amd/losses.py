@@ -98,7 +98,7 @@ class PlaneRecNetLoss(nn.Module):
 
     # ------------------------------------------------------------------ GT-only work, before the forward
     @torch.no_grad()
-    def prepare_host(self, gt_instances, hw, mask_feat_size=None):
+    def prepare_host(self, gt_instances, hw, mask_feat_size=None, with_vnl=True):
         """Pure host part (numpy / CPU torch; safe to run on a worker thread -- see TargetPrefetcher): SOLOv2 targets and
         the virtual-normal triplet indices for a list of per-image GT dicts."""
         H, W = hw
@@ -121,7 +121,7 @@ class PlaneRecNetLoss(nn.Module):
                 "ins_labels": pin(torch.cat(ins_labels, 0)),
                 # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
                 "cate_labels": pin(torch.cat([r for lv in range(L) for r in cate_rows[lv]])),
-                "vnl": self.vnl.prepare_host(host, (H, W)) if cfg.use_plane_loss else None}
+                "vnl": (self.vnl.prepare_host(host, (H, W)) if cfg.use_plane_loss else None) if with_vnl else "deferred"}
 
     @torch.no_grad()
     def upload(self, h, gt_depths, device):
@@ -391,24 +391,34 @@ class VNL_Loss(nn.Module):
 
 
 class TargetPrefetcher:
-    """Runs PlaneRecNetLoss.prepare_host for the NEXT batch on a worker thread while the GPU executes the current step
-    (the role the reference gives to its DataLoader workers + the host part of its loss).  One job at a time, submitted in
-    step order, so the numpy RNG stream of the virtual-normal sampling stays deterministic."""
+    """Runs the GT-only host work for the NEXT batch on worker threads while the GPU executes the current step (the role
+    the reference gives to its DataLoader workers + the host part of its loss).  Two jobs per batch -- SOLOv2 targets
+    (CPU torch ops) and virtual-normal triplet draws (numpy) -- run side by side; each kind is processed one batch at a
+    time in submission order, so the numpy RNG stream of the sampling stays deterministic."""
 
     def __init__(self, criterion):
         from concurrent.futures import ThreadPoolExecutor
         self.criterion = criterion
-        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
+        self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
+        self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
         self.pending = None
 
     def submit(self, gt_instances, hw, mask_feat_size=None):
-        self.pending = self.pool.submit(self.criterion.prepare_host, gt_instances, hw, mask_feat_size)
+        ft = self.pool_t.submit(self.criterion.prepare_host, gt_instances, hw, mask_feat_size, False)
+        fv = None
+        if cfg.use_plane_loss:
+            host = [{k: g[k].cpu() for k in ("masks", "plane_paras", "k_matrix")} for g in gt_instances]
+            fv = self.pool_v.submit(self.criterion.vnl.prepare_host, host, hw)
+        self.pending = (ft, fv)
 
     def get(self, gt_depths, device):
-        """Targets of the batch submitted last (blocks only if the worker has not finished yet)."""
-        h = self.pending.result()
+        """Targets of the batch submitted last (blocks only if a worker has not finished yet)."""
+        ft, fv = self.pending
+        h = ft.result()
+        h["vnl"] = fv.result() if fv is not None else None
         self.pending = None
         return self.criterion.upload(h, gt_depths, device)
 
     def close(self):
-        self.pool.shutdown(wait=False, cancel_futures=True)
+        self.pool_t.shutdown(wait=False, cancel_futures=True)
+        self.pool_v.shutdown(wait=False, cancel_futures=True)

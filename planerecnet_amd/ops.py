@@ -15,6 +15,17 @@ from . import _lib, profiling
 from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
+OVERLAP_WGRAD = False         # (measured: no gain at B=8 -- 119.1 vs 116.6 ms/step -- the extra stream traffic costs host time) backward: weight-gradient kernels on a side stream, concurrent with the data-gradient kernel
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -134,8 +145,20 @@ class _Conv2d(torch.autograd.Function):
         elif epi == EPI_SIGMOID:
             dy = dy * y * (1 - y)
         M, C, K, _ = w.shape
-        dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode) if ctx.needs_input_grad[0] else None
-        dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and OVERLAP_WGRAD and not profiling.active():
+            # dgrad and wgrad only share their inputs: run wgrad on a side HIP stream so the two kernels fill each other's
+            # idle CUs (most backbone layers launch fewer workgroups than one GPU-wide wave), then join.
+            main = torch.cuda.current_stream()
+            side = _side_stream(dy.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode)
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode)
+            main.wait_stream(side)
+            dw.record_stream(main)
+        else:
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode) if ctx.needs_input_grad[0] else None
+            dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode) if ctx.needs_input_grad[1] else None
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[2]) else None
         da = dy if (has_add and ctx.needs_input_grad[3]) else None
         return dx, dw, db, da, None, None, None, None

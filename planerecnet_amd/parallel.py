@@ -57,6 +57,9 @@ class GradAllReduce:
 
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
+        for p in bucket:                                  # the pack / unpack below work on flat VIEWS of the gradients
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
             ctx = torch.cuda.stream(self.stream)
@@ -64,7 +67,7 @@ class GradAllReduce:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [p.grad.reshape(-1) for p in bucket])
+            torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [p.grad.view(-1) for p in bucket])
             flat.div_(self.world)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((bi, work))
@@ -80,14 +83,14 @@ class GradAllReduce:
                         p.grad = torch.zeros_like(p)
                 self._launch(bi)
         for bi, work in self._pending:
-            work.wait()
             bucket, flat = self.buckets[bi], self.flat[bi]
-            ctx = torch.cuda.stream(self.stream) if self.on_gpu else None
-            if ctx:
-                with ctx:
-                    torch._foreach_copy_([p.grad.reshape(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
+            if self.on_gpu:
+                with torch.cuda.stream(self.stream):
+                    work.wait()                           # orders the SIDE stream (current here) after RCCL's completion
+                    torch._foreach_copy_([p.grad.view(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
             else:
-                torch._foreach_copy_([p.grad.reshape(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
+                work.wait()
+                torch._foreach_copy_([p.grad.view(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending.clear()

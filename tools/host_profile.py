@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""cProfile of the main thread over a few bench steps: where does the host spend its per-step enqueue time?"""
+import cProfile
+import os
+import pstats
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from planerecnet_amd import ops, timer  # noqa: E402
+from planerecnet_amd.config import cfg, set_cfg  # noqa: E402
+from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher  # noqa: E402
+from planerecnet_amd.planerecnet import PlaneRecNet  # noqa: E402
+
+ops.OVERLAP_WGRAD = bool(int(os.environ.get("OVERLAP", "0")))
+timer.disable_all()
+torch.set_num_threads(4)
+dev = torch.device("cuda:0")
+set_cfg("PlaneRecNet_101_config")
+torch.manual_seed(0)
+net = PlaneRecNet(cfg)
+net.init_head_weights()
+net = net.to(dev).train()
+crit = PlaneRecNetLoss().to(dev)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+images, inst, depths = bench.synth_batch(8, 480, 640, 1000, dev)
+pf = TargetPrefetcher(crit)
+pf.submit(inst, (480, 640))
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    t = pf.get(depths, dev)
+    pf.submit(inst, (480, 640))
+    out = net(images)
+    losses = crit(net, *out, inst, depths, targets=t)
+    sum(losses.values()).sum().backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(4):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
+pf.close()

@@ -24,7 +24,7 @@ net = PlaneRecNet(cfg)
 net.init_head_weights()
 net = net.to(dev).train()
 crit = PlaneRecNetLoss().to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
 images, inst, depths = bench.synth_batch(8, 480, 640, 1000, dev)
 pf = TargetPrefetcher(crit)
 pf.submit(inst, (480, 640))
@@ -36,7 +36,7 @@ def mark(name, t0):
 
 
 def step():
-    t0 = time.perf_counter(); opt.zero_grad(set_to_none=True); h = pf.pending.result(); mark("wait_worker", t0)
+    t0 = time.perf_counter(); opt.zero_grad(set_to_none=True); ft, fv = pf.pending; h = ft.result(); h["vnl"] = fv.result(); mark("wait_worker", t0)
     t0 = time.perf_counter(); pf.pending = None; targets = crit.upload(h, depths, dev); pf.submit(inst, (480, 640)); mark("upload", t0)
     t0 = time.perf_counter(); out = net(images); mark("net_fwd", t0)
     t0 = time.perf_counter(); losses = crit(net, *out, inst, depths, targets=targets); loss = sum(losses.values()).sum(); mark("loss_fwd", t0)

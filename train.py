@@ -183,7 +183,7 @@ def main():
     optimizer = torch.optim.Adam([
         {"params": prn_net.backbone.parameters(), "lr": 5 * args.lr}, {"params": prn_net.fpn.parameters(), "lr": args.lr},
         {"params": prn_net.inst_head.parameters(), "lr": args.lr}, {"params": prn_net.mask_head.parameters(), "lr": args.lr},
-        {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr)
+        {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr, fused=True)
     exchange = GradAllReduce([p for p in prn_net.parameters()])
 
     # BN-safe warm-up forward with frozen statistics (reference train.py:270-272)
