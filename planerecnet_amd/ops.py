@@ -26,8 +26,11 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream      # raw hipStream_t of the calling thread's current stream (0.3 us vs 10 us)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
 
 
 def _p(t):
@@ -45,8 +48,21 @@ def _c(t):
     return t if (t is None or t.is_contiguous()) else t.contiguous()
 
 
+_DESC = {}        # (shape key) -> (ConvDesc, byref, fwd workspace bytes, wgrad workspace bytes): built once per distinct launch shape
+
+
 def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE):
-    return ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi)
+    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+    e = _DESC.get(key)
+    if e is None:
+        d = ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi)
+        ref = ctypes.byref(d)
+        fb = lib.prn_conv2d_fwd_ws_bytes(ref)
+        wb = lib.prn_conv2d_wgrad_ws_bytes(ref) if mode != IN_DILATED else 0
+        if fb < 0 or wb < 0:
+            raise RuntimeError(lib.prn_last_error().decode())
+        e = _DESC[key] = (d, ref, fb, wb)
+    return e
 
 
 def _out_hw(H, W, K, stride, pad, mode):
@@ -61,30 +77,29 @@ def _out_hw(H, W, K, stride, pad, mode):
 def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE):
     B, C, H, W = x.shape
     y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
-    d = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
-    # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
-    # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
-    flops = 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)
-    nbytes = lib.prn_conv2d_fwd_ws_bytes(ctypes.byref(d))
-    if nbytes < 0:
-        raise RuntimeError(lib.prn_last_error().decode())
+    _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
-    with profiling.span("conv_igemm_kernel", "mfma", flops):
-        check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
+    if profiling._enabled:
+        # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
+        # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)):
+            check(lib.prn_conv2d_fwd(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
+    else:
+        check(lib.prn_conv2d_fwd(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
     return y
 
 
 def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     B, C, H, W = x.shape
     Ho, Wo = dy.shape[2:]
-    d = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
-    nbytes = lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d))
-    if nbytes < 0:
-        raise RuntimeError(lib.prn_last_error().decode())
+    _, ref, _, nbytes = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
-    with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo):
-        check(lib.prn_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
+    if profiling._enabled:
+        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo):
+            check(lib.prn_conv2d_wgrad(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
+    else:
+        check(lib.prn_conv2d_wgrad(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
     return dw
 
 
