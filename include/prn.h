@@ -94,6 +94,11 @@ int prn_bn_stats(const float* x, float* stats, float* running_mean, float* runni
 /* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) ; for eval mode pass stats built from running stats */
 int prn_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                  float* y, int B, int C, int HW, int relu, void* stream);
+/* training forward in two launches (per-channel partial sums, then normalise with the statistics finalised inside the apply
+ * kernel): equivalent to prn_bn_stats + prn_bn_apply; stats[2C] receives mean / invstd for the backward. */
+int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
+                     float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps, float momentum,
+                     int relu, void* stream);
 /* backward (training statistics). g = dy * (y>0 if relu). Outputs dx, dgamma, dbeta and, if dres != NULL, dres = g.
  * ws: 2*C*PRN_BN_SPLITS doubles. */
 int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,

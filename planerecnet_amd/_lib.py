@@ -39,6 +39,7 @@ SIGNATURES = {
     "prn_dcn_sample_bwd": (c_int, [P, P, P, P, P, P] + [c_int] * 7 + [c_float, P]),
     "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "prn_bn_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_bn_train_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "prn_bn_bwd": (c_int, [P] * 10 + [c_int] * 5 + [P]),
     "prn_gn_relu_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "prn_gn_relu_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),

@@ -11,6 +11,7 @@
 // MFMA loop.  LDS rows that are read "down a column" by the MFMA operand pattern use a 17-float pitch, which
 // makes the 32-lane-group reads conflict-free.
 #include <stdlib.h>
+#include <type_traits>
 #include "prn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -21,8 +22,27 @@ struct ConvArgs {
   const float* x; const float* w; const float* bias; const float* addend; float* y;
   int B, C, H, W, M, stride, pad, Ho, Wo, epi;
   int K, N, HoWo, HW, tilesM, nblocks, splits;
+  int xbytes, wbytes;
   float* ws;
 };
+
+// Operand fetches go through buffer descriptors: a lane whose element does not exist (padding, tile tails) carries the
+// byte offset OOB, which the hardware range check turns into a 0.0 result without touching memory.  No select depends
+// on the loaded value, so the loads of slice k+1 stay in flight across the whole MFMA loop of slice k and are first
+// waited for at the LDS stores (with value-side selects hipcc put s_waitcnt vmcnt(0) in front of the MFMAs).
+constexpr unsigned OOB = 0x80000000u;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  // (bit_cast the whole vector: __builtin_bit_cast on a single vector element reads element 0 with hipcc 7.2)
+  const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+  return make_float4(q.x, q.y, q.z, q.w);
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
   i = i < 0 ? -i : i;
@@ -30,9 +50,9 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 // Offset (inside one channel plane) of the input sample that virtual im2col position (ih, iw) reads, or -1 when that
-// position contributes zero.  All loads built on it are UNCONDITIONAL (clamped address + select): a per-lane branch
-// around a load makes hipcc serialise the gather behind s_waitcnt, which left the first version of this kernel
-// latency-bound at ~30 % of the MFMA rate.
+// position contributes zero.  All loads built on it are UNCONDITIONAL: a per-lane branch around a load makes hipcc
+// serialise the gather behind s_waitcnt, which left the first version of this kernel latency-bound at ~30 % of the
+// MFMA rate.
 template <int MODE>
 __device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W) {
   if (MODE == PRN_IN_ZERO) {
@@ -72,12 +92,14 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel
   constexpr int NBV = BK / VROWS;  // VEC: float4 loads per thread per K slice
   __shared__ float As[2][BM * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-  __shared__ int taps[KS > 1 ? KK * BN : 1];   // per-pixel tap offsets (or -1), built once per workgroup
+  __shared__ unsigned taps[KS > 1 ? KK * BN : 1];   // per-pixel tap byte offsets (or OOB), built once per workgroup
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
   const int m0 = (id % a.tilesM) * BM, n0 = (id / a.tilesM) * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), wr = make_rsrc(a.w, a.wbytes);
 
   // pixel owned by this thread in the B (im2col) operand; its K rows are wave-uniform
   const int nl = tid % BN;
@@ -92,31 +114,38 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel
     ow = p - oh * a.Wo;
   }
   const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-  const float* __restrict__ xb = a.x + (size_t)b * a.C * a.HW;
-  int off1 = -1;
+  const int pix0 = b * a.C * a.HW;                      // element offset of this pixel's image
+  unsigned off1 = OOB;                                   // byte offsets (or OOB) relative to a.x, channel 0
   if (KS == 1) {
-    off1 = tap_offset<MODE>(ih0, iw0, nvalid, a.H, a.W);
+    const int o = tap_offset<MODE>(ih0, iw0, nvalid, a.H, a.W);
+    off1 = o >= 0 ? (unsigned)(pix0 + o) * 4u : OOB;
   } else {
     for (int t = krow0; t < KK; t += KSTEP) {
       const int r = t / KS, s = t - r * KS;
-      taps[t * BN + nl] = tap_offset<MODE>(ih0 + r, iw0 + s, nvalid, a.H, a.W);
+      const int o = tap_offset<MODE>(ih0 + r, iw0 + s, nvalid, a.H, a.W);
+      taps[t * BN + nl] = o >= 0 ? (unsigned)(pix0 + o) * 4u : OOB;
     }
     __syncthreads();
   }
 
+  // A (weight) operand: NA float4 groups per thread; rows beyond M fall outside the descriptor by themselves
   const int arow = tid / AQ, akq = (tid % AQ) * 4;
   const bool k4 = ((a.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0);
+  unsigned abase[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + arow + AROWS * i;
+    abase[i] = m < a.M ? (unsigned)(m * a.K + akq) * 4u : OOB;
+  }
 
-  // VEC staging: this thread's group of 4 consecutive pixels
+  // VEC staging: this thread's group of 4 consecutive pixels, K row vrow0 (+ VROWS * i)
   const int vg = tid % VG, vrow0 = tid / VG;
-  const float* __restrict__ xv = a.x;
-  bool vvalid = false;
+  unsigned vbase = OOB;
   if (VEC) {
     const int nv = n0 + vg * 4;
-    vvalid = nv < a.N;
-    if (vvalid) {
+    if (nv < a.N) {
       const int bv = nv / a.HoWo;
-      xv = a.x + (size_t)bv * a.C * a.HW + (nv - bv * a.HoWo);
+      vbase = (unsigned)((bv * a.C + vrow0) * a.HW + (nv - bv * a.HoWo)) * 4u;
     }
   }
 
@@ -131,83 +160,85 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto load_tile = [&](int k0) {
-    const int k = k0 + akq;
+  // K4 (weight rows readable as float4) is a compile-time tag and the last slice is peeled, so the steady-state loop
+  // body is branch-free: with a uniform branch around the loads, or "if (kt + 1 < KT)" around load and store, hipcc's
+  // waitcnt insertion has to assume loads left pending by the not-taken path and drains vmcnt before the next gather.
+  auto run = [&](auto k4tag) {
+    constexpr bool K4 = decltype(k4tag)::value;
+    auto load_tile = [&](int k0) {
+      const int k = k0 + akq;
+      if (K4) {
+        const unsigned tail = k < a.K ? 0u : OOB;           // OR-ed in: stays branch-free (a select here became an exec-masked branch)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int m = m0 + arow + AROWS * i;
-      const int mc = m < a.M ? m : a.M - 1;
-      const float* wrow = a.w + (size_t)mc * a.K;
-      if (k4) {
-        const bool ok = (m < a.M) && (k < a.K);
-        const float4 v = *reinterpret_cast<const float4*>(wrow + (ok ? k : 0));
-        ra[i][0] = ok ? v.x : 0.f; ra[i][1] = ok ? v.y : 0.f; ra[i][2] = ok ? v.z : 0.f; ra[i][3] = ok ? v.w : 0.f;
+        for (int i = 0; i < NA; ++i) {
+          const float4 v = bload4(wr, abase[i] | tail, k0 * 4);
+          ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool ok = (m < a.M) && (k + j < a.K);
-          const float v = wrow[ok ? k + j : 0];
-          ra[i][j] = ok ? v : 0.f;
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ra[i][j] = bload(wr, (k + j < a.K) ? abase[i] + 4u * j : OOB, k0 * 4);
+      }
+      if (VEC) {
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+          const int kr = k0 + i * VROWS;                         // + vrow0 is folded into vbase
+          rv[i] = bload4(xr, (kr + vrow0 < a.K) ? vbase : OOB, kr * a.HW * 4);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform
+          const int c = kr / KK, rs = kr - c * KK;
+          const unsigned off = (KS == 1) ? off1 : taps[rs * BN + nl];
+          rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off : OOB, c * a.HW * 4);
         }
       }
-    }
-    if (VEC) {
+    };
+    auto store_tile = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < NBV; ++i) {
-        const int kr = k0 + vrow0 + i * VROWS;
-        const bool ok = vvalid && (kr < a.K);
-        const float4 v = *reinterpret_cast<const float4*>(xv + (ok ? (size_t)kr * a.HW : 0));
-        rv[i].x = ok ? v.x : 0.f; rv[i].y = ok ? v.y : 0.f; rv[i].z = ok ? v.z : 0.f; rv[i].w = ok ? v.w : 0.f;
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
+      if (VEC) {
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = rv[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[VEC ? 0 : i];
       }
-    } else {
+    };
+    auto mma_tile = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform
-        const int c = kr / KK, rs = kr - c * KK;
-        const int off = (KS == 1) ? off1 : taps[rs * BN + nl];
-        const bool ok = (off >= 0) && (kr < a.K);
-        const float v = xb[ok ? c * a.HW + off : 0];
-        rb[VEC ? 0 : i] = ok ? v : 0.f;
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + kk * 2 + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][(kk * 2 + (lane >> 5)) * BN + wn * TN * 32 + j * 32 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
-    if (VEC) {
-#pragma unroll
-      for (int i = 0; i < NBV; ++i) *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = rv[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[VEC ? 0 : i];
-    }
-  };
-
-  const int KTall = (a.K + BK - 1) / BK;
-  const int kt0 = (int)((int64_t)blockIdx.y * KTall / a.splits), KT = (int)((int64_t)(blockIdx.y + 1) * KTall / a.splits);
-  load_tile(kt0 * BK);
-  store_tile(kt0 & 1);
-  __syncthreads();
-  for (int kt = kt0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile((kt + 1) * BK);
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + kk * 2 + (lane >> 5)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][(kk * 2 + (lane >> 5)) * BN + wn * TN * 32 + j * 32 + (lane & 31)];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+    };
+    const int KTall = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((int64_t)blockIdx.y * KTall / a.splits), KT = (int)((int64_t)(blockIdx.y + 1) * KTall / a.splits);
+    load_tile(kt0 * BK);
+    store_tile(kt0 & 1);
     __syncthreads();
-  }
+    for (int kt = kt0; kt + 1 < KT; ++kt) {
+      load_tile((kt + 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);          // keep the gather issued BEFORE the MFMA loop (hipcc otherwise sinks it to the stores)
+      mma_tile(kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tile((kt + 1) & 1);
+      __syncthreads();
+    }
+    mma_tile((KT - 1) & 1);
+  };
+  if (k4) run(std::true_type{}); else run(std::false_type{});
 
   // epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel).
   // Uniform decisions (split partial / bias / addend / activation / interior tile) are hoisted out of the element loops.
@@ -246,6 +277,7 @@ struct WgArgs {
   const float* x; const float* dy; float* out;
   int B, C, H, W, M, stride, pad, Ho, Wo;
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
+  int xbytes, dybytes;
 };
 
 template <int KS, int MODE, int TM, int TJ>
@@ -260,6 +292,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   const int split = blockIdx.y;
   const int cbeg = (int)((int64_t)split * a.chunks / a.splits), cend = (int)((int64_t)(split + 1) * a.chunks / a.splits);
 
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(a.dy, a.dybytes);
   const int arow = tid >> 2, anq = (tid & 3) * 4;
   const bool n4 = ((a.HoWo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dy) & 15) == 0);
   const int nl = tid & 15, jrow = tid >> 4;
@@ -274,6 +307,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     jr[i] = rs / KS;
     js[i] = rs - jr[i] * KS;
   }
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) mok[i] = m0 + arow + 64 * i < a.M;
 
   float ra[TM][4], rb[NBJ];
   f32x16 acc[TM][TJ];
@@ -294,86 +330,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const int p = g - g_b * a.HoWo;
     g_oh = p / a.Wo; g_ow = p - g_oh * a.Wo;
   }
-  auto load_chunk = [&](int ch) {
-    {  // dY rows: 4 consecutive pixels of one output channel (unconditional, clamped loads)
-      const int n = ch * 16 + anq;
-      if (n4) {
-        const bool ok = n < a.N;
-        const int b = ok ? a_b : 0, p = ok ? a_p : 0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int m = m0 + arow + 64 * i;
-          const int mc = m < a.M ? m : a.M - 1;
-          const float4 v = *reinterpret_cast<const float4*>(a.dy + ((size_t)b * a.M + mc) * a.HoWo + p);
-          const bool okm = ok && m < a.M;
-          ra[i][0] = okm ? v.x : 0.f; ra[i][1] = okm ? v.y : 0.f; ra[i][2] = okm ? v.z : 0.f; ra[i][3] = okm ? v.w : 0.f;
-        }
-      } else {
-        int qb = a_b, qp = a_p;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool ok = n + q < a.N;
-          const int b = ok ? qb : 0, p = ok ? qp : 0;
+  // every fetch is a buffer load whose offset is OOB (-> 0.0) for elements that do not exist; nothing depends on the
+  // loaded values until store_chunk, so the loads overlap the MFMA loop of the previous chunk.  N4 is a compile-time
+  // tag and the last chunk is peeled (branch-free loop body, see conv_igemm_kernel).
+  auto run = [&](auto n4tag) {
+    constexpr bool N4 = decltype(n4tag)::value;
+    auto load_chunk = [&](int ch) {
+      {  // dY rows: 4 consecutive pixels of one output channel
+        const int n = ch * 16 + anq;
+        if (N4) {
+          const bool ok = n < a.N;
+          const unsigned base = (unsigned)((a_b * a.M + m0 + arow) * a.HoWo + a_p) * 4u;
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const int m = m0 + arow + 64 * i;
-            const int mc = m < a.M ? m : a.M - 1;
-            const float v = a.dy[((size_t)b * a.M + mc) * a.HoWo + p];
-            ra[i][q] = (ok && m < a.M) ? v : 0.f;
+            const float4 v = bload4(dyr, (ok && mok[i]) ? base : OOB, i * 64 * a.HoWo * 4);
+            ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
           }
-          if (++qp >= a.HoWo) { qp = 0; ++qb; }
+        } else {
+          int qb = a_b, qp = a_p;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool ok = n + q < a.N;
+            const unsigned base = (unsigned)((qb * a.M + m0 + arow) * a.HoWo + qp) * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ra[i][q] = bload(dyr, (ok && mok[i]) ? base : OOB, i * 64 * a.HoWo * 4);
+            if (++qp >= a.HoWo) { qp = 0; ++qb; }
+          }
         }
+        a_p += 16;
+        while (a_p >= a.HoWo) { a_p -= a.HoWo; ++a_b; }
       }
-      a_p += 16;
-      while (a_p >= a.HoWo) { a_p -= a.HoWo; ++a_b; }
-    }
-    {  // im2col rows
-      const bool ok = ch * 16 + nl < a.N;
-      const int ih0 = g_oh * a.stride - a.pad, iw0 = g_ow * a.stride - a.pad;
-      const float* __restrict__ xb = a.x + (size_t)(ok ? g_b : 0) * a.C * a.HW;
+      {  // im2col rows
+        const bool ok = ch * 16 + nl < a.N;
+        const int ih0 = g_oh * a.stride - a.pad, iw0 = g_ow * a.stride - a.pad;
+        const int pix0 = g_b * a.C * a.HW;
 #pragma unroll
-      for (int i = 0; i < NBJ; ++i) {
-        const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], ok && jok[i], a.H, a.W);
-        const float v = xb[off >= 0 ? jcoff[i] + off : 0];
-        rb[i] = off >= 0 ? v : 0.f;
+        for (int i = 0; i < NBJ; ++i) {
+          const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], ok && jok[i], a.H, a.W);
+          rb[i] = bload(xr, off >= 0 ? (unsigned)(pix0 + jcoff[i] + off) * 4u : OOB, 0);
+        }
+        g_ow += 16;
+        while (g_ow >= a.Wo) { g_ow -= a.Wo; ++g_oh; }
+        while (g_oh >= a.Ho) { g_oh -= a.Ho; ++g_b; }
       }
-      g_ow += 16;
-      while (g_ow >= a.Wo) { g_ow -= a.Wo; ++g_oh; }
-      while (g_oh >= a.Ho) { g_oh -= a.Ho; ++g_b; }
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) As[buf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
-#pragma unroll
-    for (int i = 0; i < NBJ; ++i) Bs[buf][(jrow + 16 * i) * LD + nl] = rb[i];
-  };
-
-  if (cbeg < cend) {
-    load_chunk(cbeg);
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (int ch = cbeg; ch < cend; ++ch) {
-    const int buf = (ch - cbeg) & 1;
-    if (ch + 1 < cend) load_chunk(ch + 1);
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      float av[TM], bv[TJ];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + kk * 2 + (lane >> 5)];
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) bv[j] = Bs[buf][(wj * TJ * 32 + j * 32 + (lane & 31)) * LD + kk * 2 + (lane >> 5)];
+    };
+    auto store_chunk = [&](int buf) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-    if (ch + 1 < cend) store_chunk(buf ^ 1);
+        for (int q = 0; q < 4; ++q) As[buf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
+#pragma unroll
+      for (int i = 0; i < NBJ; ++i) Bs[buf][(jrow + 16 * i) * LD + nl] = rb[i];
+    };
+    auto mma_chunk = [&](int buf) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float av[TM], bv[TJ];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + kk * 2 + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bv[j] = Bs[buf][(wj * TJ * 32 + j * 32 + (lane & 31)) * LD + kk * 2 + (lane >> 5)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    };
+    if (cbeg >= cend) return;
+    load_chunk(cbeg);
+    store_chunk(0);
     __syncthreads();
-  }
+    for (int ch = cbeg; ch + 1 < cend; ++ch) {
+      load_chunk(ch + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk((ch - cbeg) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk((ch + 1 - cbeg) & 1);
+      __syncthreads();
+    }
+    mma_chunk((cend - 1 - cbeg) & 1);
+  };
+  if (n4) run(std::true_type{}); else run(std::false_type{});
 
   float* out = a.out + (size_t)split * a.M * a.K;
 #pragma unroll
@@ -591,7 +628,9 @@ int check_desc(const prn_conv_desc* d, const char* who) {
   PRN_REQUIRE((d->in_mode != PRN_IN_REFLECT && d->in_mode != PRN_IN_UP2_REFLECT) || (d->pad == 1 && d->stride == 1 && d->KH == 3),
               "%s: reflect modes need a 3x3 stride-1 pad-1 conv", who);
   PRN_REQUIRE(d->KH != 7 || d->in_mode == PRN_IN_ZERO || d->in_mode == PRN_IN_DILATED, "%s: 7x7 kernels only with zero padding", who);
-  PRN_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1LL << 31) && (int64_t)d->C * d->H * d->W < (1LL << 31), "%s: tensor too large for int32 pixel index", who);
+  // operands are addressed through buffer descriptors with 31-bit byte offsets
+  PRN_REQUIRE((int64_t)d->B * d->C * d->H * d->W < (1LL << 29) && (int64_t)d->B * d->M * d->Ho * d->Wo < (1LL << 29) &&
+              ((int64_t)d->M + 128) * d->C * d->KH * d->KW < (1LL << 29), "%s: tensor larger than 2 GiB", who);
   return 0;
 }
 
@@ -612,6 +651,7 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
   a.Ho = d->Ho; a.Wo = d->Wo; a.epi = d->epilogue;
   a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
+  a.xbytes = d->B * d->C * d->H * d->W * 4; a.wbytes = d->M * a.K * 4;
   const FwdPlan p = plan_fwd(a.M, a.N, a.K);
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
@@ -653,6 +693,7 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
   a.Ho = d->Ho; a.Wo = d->Wo;
   a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
+  a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * d->Ho * d->Wo * 4;
   WgPlan p = plan_wgrad(a.M, a.K, a.N);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", p.splits);

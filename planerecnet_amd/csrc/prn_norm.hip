@@ -78,11 +78,39 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restr
 }
 
 // y = relu?(x*scale + shift + res?) ; one block row per (b,c) plane chunk, float4 when HW % 4 == 0
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+// FIN: training forward -- every block first reduces its channel's S fixed-order fp64 partials (written by bn_partial_kernel)
+// to mean / invstd itself, so no separate finalize launch is needed; block (0, image 0) of each channel publishes the
+// statistics and updates the running buffers.
+template <bool FIN>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ res, float* __restrict__ y, int C, int HW, int relu) {
+                                                       const float* __restrict__ res, float* __restrict__ y, int C, int HW, int relu,
+                                                       const double* __restrict__ ws, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       int S, double count, float eps, float momentum) {
   const int bc = blockIdx.y, c = bc % C;
-  const float sc = stats[C + c] * gamma[c], sh = beta[c] - stats[c] * sc;
+  float mean_f, istd_f;
+  if (FIN) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) { s1 += ws[((size_t)c * S + s) * 2]; s2 += ws[((size_t)c * S + s) * 2 + 1]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_f = (float)mean;
+    istd_f = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && bc == c && threadIdx.x == 0) {
+      stats[c] = mean_f;
+      stats[C + c] = istd_f;
+      if (rmean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean_f;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+      }
+    }
+  } else {
+    mean_f = stats[c];
+    istd_f = stats[C + c];
+  }
+  const float sc = istd_f * gamma[c], sh = beta[c] - mean_f * sc;
   const size_t base = (size_t)bc * HW;
   if ((HW & 3) == 0) {
     const int n4 = HW >> 2;
@@ -144,27 +172,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   if (threadIdx.x == 0) { ws[((size_t)c * S + s) * 2] = d1; ws[((size_t)c * S + s) * 2 + 1] = d2; }
 }
 
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int S) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < S; ++s) { s1 += ws[((size_t)c * S + s) * 2]; s2 += ws[((size_t)c * S + s) * 2 + 1]; }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  ws[(size_t)c * S * 2] = s1;       // totals for the apply pass
-  ws[(size_t)c * S * 2 + 1] = s2;
-}
-
 // dx = gamma*istd*(g - sum_g/N - xhat*sum_gx/N)   (training)   |   dx = gamma*istd*g   (frozen / eval stats)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const double* __restrict__ ws,
                                                            float* __restrict__ dx, float* __restrict__ dres, int C, int HW,
-                                                           int S, float inv_count, int relu, int frozen) {
+                                                           int S, float inv_count, int relu, int frozen, int have_partials,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int bc = blockIdx.y, c = bc % C;
   const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
-  const float m1 = frozen ? 0.f : (float)ws[(size_t)c * S * 2] * inv_count;
-  const float m2 = frozen ? 0.f : (float)ws[(size_t)c * S * 2 + 1] * inv_count;
+  double t1 = 0.0, t2 = 0.0;                      // every block sums its channel's fixed-order partials (no finalize launch)
+  if (have_partials)
+    for (int s = 0; s < S; ++s) { t1 += ws[((size_t)c * S + s) * 2]; t2 += ws[((size_t)c * S + s) * 2 + 1]; }
+  if (have_partials && blockIdx.x == 0 && bc == c && threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = (float)t1;
+    if (dgamma) dgamma[c] = (float)t2;
+  }
+  const float m1 = frozen ? 0.f : (float)t1 * inv_count;
+  const float m2 = frozen ? 0.f : (float)t2 * inv_count;
   const size_t base = (size_t)bc * HW;
   if ((HW & 3) == 0) {
     const int n4 = HW >> 2;
@@ -285,8 +310,26 @@ extern "C" int prn_bn_apply(const float* x, const float* stats, const float* gam
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_apply: B*C too large for grid.y");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, residual, y, C, HW, relu);
+  hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, const_cast<float*>(stats), gamma, beta,
+                     residual, y, C, HW, relu, (const double*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0.0, 0.f, 0.f);
   PRN_CHECK_LAUNCH("prn_bn_apply");
+  return 0;
+}
+
+extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
+                                float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps, float momentum,
+                                int relu, void* stream) {
+  PRN_REQUIRE(x && stats && gamma && beta && y && ws && B > 0 && C > 0 && HW > 0, "prn_bn_train_fwd: bad arguments");
+  PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_train_fwd: B*C too large for grid.y");
+  hipStream_t st = (hipStream_t)stream;
+  const int S = bn_splits(B, HW);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
+  PRN_CHECK_LAUNCH("prn_bn_train_fwd/partial");
+  int gx = cdiv(HW, 256 * 8);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(gx, B * C), dim3(256), 0, st, x, stats, gamma, beta, residual, y, C, HW, relu,
+                     (const double*)ws, running_mean, running_var, S, (double)B * HW, eps, momentum);
+  PRN_CHECK_LAUNCH("prn_bn_train_fwd/apply");
   return 0;
 }
 
@@ -298,16 +341,15 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_bwd: B*C too large for grid.y");
   hipStream_t st = (hipStream_t)stream;
   const int S = bn_splits(B, HW);
-  if (!frozen || dgamma || dbeta) {
+  const int have = (!frozen || dgamma || dbeta) ? 1 : 0;
+  if (have) {
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu);
     PRN_CHECK_LAUNCH("prn_bn_bwd/partial");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, dgamma, dbeta, C, S);
-    PRN_CHECK_LAUNCH("prn_bn_bwd/finalize");
   }
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, st, dy, x, y, stats, gamma, (const double*)ws, dx, dres, C, HW,
-                     S, 1.f / ((float)B * HW), relu, frozen);
+                     S, 1.f / ((float)B * HW), relu, frozen, have, dgamma, dbeta);
   PRN_CHECK_LAUNCH("prn_bn_bwd/apply");
   return 0;
 }

@@ -237,16 +237,21 @@ class _BatchNorm(torch.autograd.Function):
         x, residual = _c(x), _c(residual)
         B, C, H, W = x.shape
         HW = H * W
+        y = torch.empty_like(x)
         if training:
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
-            with profiling.span("bn_stats", "hbm", 4.0 * x.numel()):
-                check(lib.prn_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), _p(ws), B, C, HW, eps, momentum, _stream()), "prn_bn_stats")
+            if profiling._enabled:
+                with profiling.span("bn_train_fwd", "hbm", 4.0 * x.numel() * (4 if residual is not None else 3)):
+                    check(lib.prn_bn_train_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean), _p(rvar), _p(ws),
+                                               B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd")
+            else:
+                check(lib.prn_bn_train_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean), _p(rvar), _p(ws),
+                                           B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd")
         else:
             stats = torch.cat([rmean, torch.rsqrt(rvar + eps)])
-        y = torch.empty_like(x)
-        with profiling.span("bn_apply", "hbm", 4.0 * x.numel() * (3 if residual is not None else 2)):
-            check(lib.prn_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), B, C, HW, int(relu), _stream()), "prn_bn_apply")
+            with profiling.span("bn_apply", "hbm", 4.0 * x.numel() * (3 if residual is not None else 2)):
+                check(lib.prn_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), B, C, HW, int(relu), _stream()), "prn_bn_apply")
         ctx.save_for_backward(x, y if relu else None, stats, gamma)
         ctx.cfg = (training, relu, residual is not None)
         return y
