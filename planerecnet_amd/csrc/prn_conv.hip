@@ -458,12 +458,29 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
   }
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * n + i];
-  out[i] = s;
+// out[i] = sum_k ws[k][i] in a fixed order: four wave-sized groups each take every 4th split (four loads in flight per
+// thread), then one LDS step adds the four partials.  n/64 workgroups instead of n/256 single-chain threads: the weight
+// matrices are small (3e4 .. 2e6 elements), so the one-thread-per-element version left most CUs idle and latency-bound.
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float acc = 0.f;
+  if (i < n) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = g;
+    for (; k + 12 < splits; k += 16) {
+      a0 += ws[(size_t)k * n + i];
+      a1 += ws[(size_t)(k + 4) * n + i];
+      a2 += ws[(size_t)(k + 8) * n + i];
+      a3 += ws[(size_t)(k + 12) * n + i];
+    }
+    for (; k < splits; k += 4) a0 += ws[(size_t)k * n + i];
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  sm[g][e] = acc;
+  __syncthreads();
+  if (g == 0 && i < n) out[i] = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
 }
 
 __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C, int KH, int KW) {
@@ -529,6 +546,21 @@ __global__ void channel_sum_final_kernel(const double* __restrict__ ws, float* _
 
 struct FwdPlan { int tm, tn, bk, splits; };
 
+// All workgroups of these launches are resident at once, so the launch lasts as long as its most loaded CU: 528 workgroups
+// (16 CUs with 3, the rest with 2) ran 27 % longer than 512.  Round the split count down so that tiles * splits lands on
+// (just below) a multiple of the 256 CUs when only a few workgroups per CU exist (never below 3/4 of the request).
+int quantise_splits(int64_t tiles, int splits) {
+  if (splits <= 1 || tiles * splits >= 256 * 12) return splits;
+  int best = splits;
+  double best_eff = 0.0;
+  for (int s = splits; s >= 1 && 4 * s > 3 * splits; --s) {       // candidates in (3/4 * splits, splits], ties -> larger
+    const double q = (double)(tiles * s) / 256.0;
+    const double eff = q / (double)((tiles * s + 255) / 256);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+  }
+  return best;
+}
+
 // Tile / slice / split choice.  PRN_CONV_FORCE="tm,tn,bk,splits" overrides it (tuning sweeps: tools/conv_bench.py).
 FwdPlan plan_fwd(int M, int64_t N, int K) {
   static int forced[4] = {-1, 0, 0, 0};
@@ -539,18 +571,19 @@ FwdPlan plan_fwd(int M, int64_t N, int K) {
   FwdPlan p;
   if (forced[0] > 0) {
     p.tm = forced[0]; p.tn = forced[1]; p.bk = 16; p.splits = forced[3];
+    if (p.tm != p.tn) { p.tm = 1; p.tn = 1; }
   } else {
-    // Rule fitted to the sweep of tools/conv_sweep.py over the PlaneRecNet shapes (profiles/r01_conv_sweep.txt):
-    // 16-deep slices always; 128x128 tiles only for wide-M, deep-K layers with enough tiles; otherwise 64x128, or 64x64
-    // when even that leaves CUs idle; then split K until ~4 workgroups per CU exist (latency hiding on small-N layers).
+    // Rule fitted to the sweep of tools/conv_sweep.py over the PlaneRecNet shapes (profiles/r01_conv_sweep.txt, re-run after
+    // the buffer-load rewrite): 16-deep slices always; 128x128 tiles only for wide-M, deep-K layers with enough tiles,
+    // otherwise 64x64 (64x128 never won a shape); then split K until ~4 workgroups per CU exist (small-N layers).
     auto tiles = [&](int tm, int tn) { return (int64_t)cdiv(M, 64 * tm) * cdiv(N, 64 * tn); };
     p.bk = 16;
     if (M >= 128 && K >= 1152 && tiles(2, 2) >= 512) { p.tm = 2; p.tn = 2; }
-    else if (tiles(1, 2) >= 256) { p.tm = 1; p.tn = 2; }
     else { p.tm = 1; p.tn = 1; }
     const int64_t t = tiles(p.tm, p.tn);
     p.splits = t < 1024 ? (int)((1024 + t - 1) / t) : 1;
     if (p.splits > 8) p.splits = 8;
+    p.splits = quantise_splits(t, p.splits);
   }
   const int kt = cdiv(K, p.bk);
   if (p.splits > kt / 4) p.splits = kt / 4;        // at least 4 K slices per split
@@ -570,7 +603,6 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
     const bool vec = a.stride == 1 && a.pad == 0 && (a.HW & 3) == 0 && a.HW == a.HoWo && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
     if (vec) {
       if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 2, 2, 16, true>), grid, block, 0, st, a);
-      else if (p.tm == 1 && p.tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 1, 2, 16, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 1, 1, 16, true>), grid, block, 0, st, a);
       return 0;
     }
@@ -578,7 +610,6 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
 #define PRN_LAUNCH(TM_, TN_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, TM_, TN_, BK_>), grid, block, 0, st, a)
   // (deeper slices were measured slower on every shape -- only BK = 16 is instantiated)
   if (p.tm == 2 && p.tn == 2) PRN_LAUNCH(2, 2, 16);
-  else if (p.tm == 1 && p.tn == 2) PRN_LAUNCH(1, 2, 16);
   else PRN_LAUNCH(1, 1, 16);
 #undef PRN_LAUNCH
   return 0;
@@ -593,18 +624,35 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
   p.tilesJ = cdiv(K, 64 * p.tj);
   p.chunks = cdiv(N, 16);
   const int tiles = p.tilesM * p.tilesJ;
-  // Splits: the kernel hides its gather latency only with several workgroups per CU, so aim for ~8 per CU, but bound
-  // the workspace round trip (2 * splits * M*K*4 bytes) to a fraction of the MFMA time: splits <= 0.0035 * pixels
-  // (fit to the PRN_WGRAD_TARGET sweep in profiles/r01_conv_sweep.txt).
+  // Splits.  Every workgroup of a wgrad launch is resident at once when tiles * splits <= 256 CUs * R (R = workgroups a
+  // CU holds: 3 for the 128x128 tile at 152 VGPRs, 4 / 6 for the smaller ones), and the launch then lasts as long as its
+  // most loaded CU.  The split sweep (profiles/r01_wgrad_split_sweep.txt) has its minimum where that single round is
+  // exactly full (e.g. 36 tiles x 21 splits = 756 of 768 slots: 131 us, vs 156 us at 28 splits and 154 us at 33), so:
+  // fill one round; when the bounds below cut that short, land on a whole number of workgroups per CU instead.
+  // Bounds: the workspace round trip (2 * splits * M*K*4 bytes) stays a fraction of the MFMA time (splits <= 0.0035 *
+  // pixels) and every split keeps at least 128 pixels.  Layers with more tiles than slots only split to ~2048 workgroups.
   static int target = -1;          // PRN_WGRAD_TARGET overrides (tuning sweeps)
   if (target < 0) { const char* e = getenv("PRN_WGRAD_TARGET"); target = e ? atoi(e) : 2048; }
-  int s = cdiv(target, tiles);
+  static int forced = -1;          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
+  if (forced < 0) { const char* e = getenv("PRN_WGRAD_SPLITS"); forced = e ? atoi(e) : 0; }
+  const int R = (p.tm == 2 && p.tj == 2) ? 3 : (p.tm + p.tj == 3 ? 4 : 6);
+  const int slots = 256 * R;
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;
-  if (s > sbw) s = sbw;
   const int smax = p.chunks / 8 > 0 ? p.chunks / 8 : 1;   // at least 128 pixels per split
-  if (s > smax) s = smax;
-  if (s > 256) s = 256;
+  int cap = sbw < smax ? sbw : smax;
+  if (cap > 256) cap = 256;
+  int s;
+  if (tiles < slots) {
+    s = (R == 3 ? 1 : 2) * slots / tiles;       // the smaller tiles ran ~3 % faster with two rounds (deconv4: 2198 -> 2141 us)
+    if (s > cap) s = quantise_splits(tiles, cap);
+  } else {
+    s = target / tiles;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    s = quantise_splits(tiles, s);
+  }
   if (s < 1) s = 1;
+  if (forced > 0) s = forced < smax ? forced : smax;
   p.splits = s;
   return p;
 }
@@ -713,7 +761,7 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
   PRN_CHECK_LAUNCH("prn_conv2d_wgrad");
   if (p.splits > 1) {
     const int64_t n = (int64_t)a.M * a.K;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
     PRN_CHECK_LAUNCH("prn_conv2d_wgrad/reduce");
   }
   return 0;

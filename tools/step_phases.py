@@ -18,6 +18,8 @@ timer.disable_all()
 
 torch.set_num_threads(int(os.environ.get("HOST_THREADS", "4")))
 dev = torch.device("cuda:0")
+H, W = 480, 640
+PB = int(os.environ.get("PHASE_B", "8"))   # PHASE_B=1 exposes the pure host cost (the GPU then finishes long before the host)
 set_cfg("PlaneRecNet_101_config")
 torch.manual_seed(0)
 net = PlaneRecNet(cfg)
@@ -25,9 +27,9 @@ net.init_head_weights()
 net = net.to(dev).train()
 crit = PlaneRecNetLoss().to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
-images, inst, depths = bench.synth_batch(8, 480, 640, 1000, dev)
+images, inst, depths = bench.synth_batch(PB, H, W, 1000, dev)
 pf = TargetPrefetcher(crit)
-pf.submit(inst, (480, 640))
+pf.submit(inst, (H, W))
 acc = {}
 
 
@@ -37,7 +39,7 @@ def mark(name, t0):
 
 def step():
     t0 = time.perf_counter(); opt.zero_grad(set_to_none=True); ft, fv = pf.pending; h = ft.result(); h["vnl"] = fv.result(); mark("wait_worker", t0)
-    t0 = time.perf_counter(); pf.pending = None; targets = crit.upload(h, depths, dev); pf.submit(inst, (480, 640)); mark("upload", t0)
+    t0 = time.perf_counter(); pf.pending = None; targets = crit.upload(h, depths, dev); pf.submit(inst, (H, W)); mark("upload", t0)
     t0 = time.perf_counter(); out = net(images); mark("net_fwd", t0)
     t0 = time.perf_counter(); losses = crit(net, *out, inst, depths, targets=targets); loss = sum(losses.values()).sum(); mark("loss_fwd", t0)
     t0 = time.perf_counter(); loss.backward(); mark("backward", t0)
