@@ -80,8 +80,9 @@ int prn_channel_sum(const float* x, float* out, double* ws, int B, int C, int HW
 int prn_dcn_sample(const float* x, const float* om, float* cols, int B, int C, int H, int W, int Ho, int Wo,
                    int stride, float max_offset, void* stream);
 /* backward of prn_dcn_sample: dx and d_om from dcols (both fully overwritten).  d_om is reduced from fixed-order channel
- * partials in `ws` (prn_dcn_sample_bwd_ws_bytes); dx is scattered in LDS-private channel planes (no global atomics). */
-int64_t prn_dcn_sample_bwd_ws_bytes(int B, int C, int Ho, int Wo);
+ * partials; dx is gathered through a CSR inversion of the sampling pattern built per call (no float atomics).  Both live
+ * in `ws` (prn_dcn_sample_bwd_ws_bytes, -1 on invalid sizes). */
+int64_t prn_dcn_sample_bwd_ws_bytes(int B, int C, int H, int W, int Ho, int Wo);
 int prn_dcn_sample_bwd(const float* x, const float* om, const float* dcols, float* dx, float* d_om, void* ws,
                        int B, int C, int H, int W, int Ho, int Wo, int stride, float max_offset, void* stream);
 

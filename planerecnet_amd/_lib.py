@@ -35,7 +35,7 @@ SIGNATURES = {
     "prn_pad_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_channel_sum": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "prn_dcn_sample": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
-    "prn_dcn_sample_bwd_ws_bytes": (c_i64, [c_int] * 4),
+    "prn_dcn_sample_bwd_ws_bytes": (c_i64, [c_int] * 6),
     "prn_dcn_sample_bwd": (c_int, [P, P, P, P, P, P] + [c_int] * 7 + [c_float, P]),
     "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "prn_bn_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

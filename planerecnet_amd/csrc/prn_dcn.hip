@@ -3,6 +3,7 @@
 // validity are computed once and reused for every input channel; the channel loop streams x planes with the
 // wave's 64 consecutive wo positions touching neighbouring addresses, and writes the column tensor fully
 // coalesced.  HBM-bound (no contraction here; the [Cout x 9Cin] GEMM runs on the MFMA conv kernel).
+#include <stdlib.h>
 #include "prn_common.h"
 
 namespace {
@@ -112,63 +113,136 @@ __global__ void dcn_dom_final_kernel(const float* __restrict__ part, float* __re
   d_om[i] = s;
 }
 
-// backward, part 2: d-input.  The scatter of every sampling point onto its four corners is privatised in LDS: a block
-// owns CG whole channel planes of one image (CG*H*W floats of LDS), walks all 9*Ho*Wo sampling points, accumulates with
-// LDS atomics and finally streams the planes out with plain coalesced stores -- no global atomics, no zero-fill of dx.
-// 1024 threads per block and all CG column loads issued before the first atomic keep enough global loads in flight.
-template <int CG>
-__global__ __launch_bounds__(1024) void dcn_dx_lds_kernel(const float* __restrict__ om, const float* __restrict__ dcols,
-                                                          float* __restrict__ dx, int B, int C, int H, int W, int Ho, int Wo,
-                                                          int stride, float maxoff) {
-  extern __shared__ float planes[];                  // [CG][H*W]
-  const int HW = H * W;
-  const int64_t plane = (int64_t)Ho * Wo;
-  const int groups = (C + CG - 1) / CG;
-  const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * CG;
-  const int cg = min(CG, C - c0);
-  for (int i = threadIdx.x; i < CG * HW; i += 1024) planes[i] = 0.f;
-  __syncthreads();
-  const int ntap = 9 * (int)plane;
-  for (int tix = threadIdx.x; tix < ntap; tix += 1024) {
-    const int k = tix / (int)plane, pix = tix - k * (int)plane;
-    const int ho = pix / Wo, wo = pix - ho * Wo;
-    const float* dp = dcols + (((size_t)b * C + c0) * 9 + k) * plane + pix;
-    float g[CG];
-#pragma unroll
-    for (int cc = 0; cc < CG; ++cc) g[cc] = dp[(size_t)(cc < cg ? cc : 0) * 9 * plane];
-    const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, false);
-#pragma unroll
-    for (int cc = 0; cc < CG; ++cc) {
-      const float gm = (cc < cg) ? g[cc] * t.mod : 0.f;
-      float* pl = planes + cc * HW;
-      atomicAdd(pl + t.i00, gm * t.w00);             // invalid corners carry weight 0 and index 0: harmless adds
-      atomicAdd(pl + t.i01, gm * t.w01);
-      atomicAdd(pl + t.i10, gm * t.w10);
-      atomicAdd(pl + t.i11, gm * t.w11);
-    }
-  }
-  __syncthreads();
-  float* out = dx + ((size_t)b * C + c0) * HW;
-  for (int i = threadIdx.x; i < cg * HW; i += 1024) out[i] = planes[i];
+// backward, part 2: d-input as a GATHER.  Every sampling point (b, tap k, output pixel p) spreads its column gradient onto
+// up to four input pixels with weights that do not depend on the channel, so the scatter pattern is inverted once per call
+// into a CSR structure -- bins (b, k, q) over input pixels q, entries (source column index k*P + p, modulator * corner
+// weight) -- and dx is then accumulated in registers, channel by channel, by a thread that owns (b, q, CH channels):
+// no atomics on floats, no LDS-sized limit on the plane, dx written exactly once with coalesced stores.  (The first
+// version privatised the scatter in LDS; ds_add_f32 retires about one lane per clock per CU, which made that kernel
+// 415 us on the 30x40 stage -- more than the GEMMs of the whole block.)  Binning by tap and walking the taps in lock
+// step keeps a wave's gathers inside one column plane and within a few pixels of each other (two or three cache lines);
+// a pixel-major bin order with one flat entry loop per pixel was measured 40 % slower for exactly that reason.
+// Entry order inside a bin follows the atomic cursor, i.e. the fp32 summation order is not fixed (neither is
+// torchvision's atomicAdd backward); d_om stays deterministic.
+struct CsrEntry { int src; float w; };
+
+__global__ __launch_bounds__(256) void dcn_csr_count_kernel(const float* __restrict__ om, int* __restrict__ counts, int B, int H, int W,
+                                                            int Ho, int Wo, int stride, float maxoff) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int plane = Ho * Wo;
+  if (gid >= (int64_t)B * 9 * plane) return;
+  const int pix = gid % plane, k = (gid / plane) % 9, b = gid / (9 * plane);
+  const int ho = pix / Wo, wo = pix - ho * Wo;
+  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, false);
+  int* cb = counts + (size_t)(b * 9 + k) * H * W;
+  if (t.w00 != 0.f) atomicAdd(cb + t.i00, 1);
+  if (t.w01 != 0.f) atomicAdd(cb + t.i01, 1);
+  if (t.w10 != 0.f) atomicAdd(cb + t.i10, 1);
+  if (t.w11 != 0.f) atomicAdd(cb + t.i11, 1);
 }
 
-template <int CG>
-void launch_dx(const float* om, const float* dcols, float* dx, int B, int C, int H, int W, int Ho, int Wo, int stride, float maxoff,
-               hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_dx_lds_kernel<CG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+// exclusive scan of the bin counts in two launches: per-block totals (2048 bins per block), then every block adds the
+// totals of the blocks before it to its own in-block scan.  The counts are reset to zero for use as fill cursors.
+constexpr int SCAN_PER_THREAD = 8, SCAN_PER_BLOCK = 256 * SCAN_PER_THREAD;
+
+__device__ __forceinline__ int block_sum_256(int v, int* sm) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int t = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void dcn_csr_block_sums_kernel(const int* __restrict__ counts, int* __restrict__ bsum, int n) {
+  __shared__ int sm[4];
+  const int base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  int v = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; ++i) v += (base + i < n) ? counts[base + i] : 0;
+  const int t = block_sum_256(v, sm);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void dcn_csr_scan_kernel(int* __restrict__ counts, int* __restrict__ starts, const int* __restrict__ bsum,
+                                                           int n) {
+  __shared__ int sm[4];
+  __shared__ int wave_tot[4];
+  int pre = 0;                                          // total of all earlier blocks
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) pre += bsum[i];
+  pre = block_sum_256(pre, sm);
+  const int base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  int c[SCAN_PER_THREAD], mine = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; ++i) { c[i] = (base + i < n) ? counts[base + i] : 0; mine += c[i]; }
+  // exclusive scan of `mine` across the block: wave scan + wave totals
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = pre + incl - mine;
+  for (int w = 0; w < wv; ++w) off += wave_tot[w];
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; ++i)
+    if (base + i < n) { starts[base + i] = off; off += c[i]; counts[base + i] = 0; }
+}
+
+__global__ __launch_bounds__(256) void dcn_csr_fill_kernel(const float* __restrict__ om, const int* __restrict__ starts, int* __restrict__ cursor,
+                                                           CsrEntry* __restrict__ entries, int B, int H, int W, int Ho, int Wo, int stride,
+                                                           float maxoff) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int plane = Ho * Wo;
+  if (gid >= (int64_t)B * 9 * plane) return;
+  const int pix = gid % plane, k = (gid / plane) % 9, b = gid / (9 * plane);
+  const int ho = pix / Wo, wo = pix - ho * Wo;
+  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, false);
+  const size_t bb = (size_t)(b * 9 + k) * H * W;
+  const int src = k * plane + pix;
+  auto put = [&](int idx, float w) {
+    if (w != 0.f) {
+      const int pos = starts[bb + idx] + atomicAdd(cursor + bb + idx, 1);
+      entries[pos] = CsrEntry{src, w * t.mod};
+    }
+  };
+  put(t.i00, t.w00); put(t.i01, t.w01); put(t.i10, t.w10); put(t.i11, t.w11);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void dcn_dx_gather_kernel(const float* __restrict__ dcols, const int* __restrict__ starts,
+                                                            const int* __restrict__ counts, const CsrEntry* __restrict__ entries,
+                                                            float* __restrict__ dx, int C, int HW, int plane) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= HW) return;
+  const int b = blockIdx.z, c0 = blockIdx.y * CH;
+  const size_t cstride = (size_t)9 * plane;
+  const float* __restrict__ dp = dcols + ((size_t)b * C + c0) * cstride;
+  float acc[CH];
+#pragma unroll
+  for (int cc = 0; cc < CH; ++cc) acc[cc] = 0.f;
+  for (int k = 0; k < 9; ++k) {
+    const size_t bin = (size_t)(b * 9 + k) * HW + q;
+    const int s = starts[bin], n = counts[bin];
+    for (int e = s; e < s + n; ++e) {
+      const CsrEntry en = entries[e];
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) acc[cc] += en.w * dp[cc * cstride + en.src];
+    }
   }
-  hipLaunchKernelGGL((dcn_dx_lds_kernel<CG>), dim3(B * cdiv(C, CG)), dim3(1024), (size_t)CG * H * W * 4, st, om, dcols, dx, B, C, H, W, Ho, Wo,
-                     stride, maxoff);
+  float* out = dx + ((size_t)b * C + c0) * HW + q;
+#pragma unroll
+  for (int cc = 0; cc < CH; ++cc)
+    if (c0 + cc < C) out[(size_t)cc * HW] = acc[cc];
 }
 
 }  // namespace
 
 static int channel_groups(int C, int64_t threads) {
+  static int cap = -1;                                  // PRN_DCN_GROUPS overrides the cap (tuning)
+  if (cap < 0) { const char* e = getenv("PRN_DCN_GROUPS"); cap = e ? atoi(e) : 8; }
   int g = (int)(1 + (256 * 8 * 256) / (threads > 0 ? threads : 1));     // aim for ~8 blocks of 256 threads per CU
-  if (g > 8) g = 8;
+  if (cap > 8) g = cap;
+  if (g > cap) g = cap;
   while (g > 1 && C % g) --g;
   return g < 1 ? 1 : g;
 }
@@ -184,30 +258,64 @@ extern "C" int prn_dcn_sample(const float* x, const float* om, float* cols, int 
   return 0;
 }
 
-extern "C" int64_t prn_dcn_sample_bwd_ws_bytes(int B, int C, int Ho, int Wo) {
-  return (int64_t)channel_groups(C, (int64_t)B * 9 * Ho * Wo) * B * 27 * Ho * Wo * 4;
+namespace {
+struct BwdWs { int64_t part, counts, starts, bsum, entries, total; int nbins, nblocks; };
+BwdWs bwd_ws_layout(int B, int C, int H, int W, int Ho, int Wo) {
+  auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+  BwdWs l;
+  l.nbins = B * 9 * H * W;
+  l.nblocks = cdiv(l.nbins, SCAN_PER_BLOCK);
+  l.part = 0;
+  l.counts = up((int64_t)channel_groups(C, (int64_t)B * 9 * Ho * Wo) * B * 27 * Ho * Wo * 4);
+  l.starts = l.counts + up((int64_t)l.nbins * 4);
+  l.bsum = l.starts + up((int64_t)l.nbins * 4);
+  l.entries = l.bsum + up((int64_t)l.nblocks * 4);
+  l.total = l.entries + (int64_t)B * 9 * Ho * Wo * 4 * sizeof(CsrEntry);
+  return l;
+}
+}  // namespace
+
+extern "C" int64_t prn_dcn_sample_bwd_ws_bytes(int B, int C, int H, int W, int Ho, int Wo) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || (int64_t)B * 9 * H * W >= (1LL << 31)) return -1;
+  return bwd_ws_layout(B, C, H, W, Ho, Wo).total;
 }
 
 extern "C" int prn_dcn_sample_bwd(const float* x, const float* om, const float* dcols, float* dx, float* d_om, void* ws,
                                   int B, int C, int H, int W, int Ho, int Wo, int stride, float max_offset, void* stream) {
   PRN_REQUIRE(x && om && dcols && dx && d_om && ws && B > 0 && C > 0, "prn_dcn_sample_bwd: bad arguments");
+  PRN_REQUIRE((int64_t)B * 9 * H * W < (1LL << 31) && (int64_t)B * 36 * Ho * Wo < (1LL << 31), "prn_dcn_sample_bwd: map too large");
   hipStream_t st = (hipStream_t)stream;
+  const BwdWs l = bwd_ws_layout(B, C, H, W, Ho, Wo);
+  char* wsb = (char*)ws;
   const int64_t n = (int64_t)B * 9 * Ho * Wo;
   const int G = channel_groups(C, n);
-  hipLaunchKernelGGL(dcn_dom_partial_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, x, om, dcols, (float*)ws, B, C, H, W, Ho, Wo, stride, max_offset);
+  hipLaunchKernelGGL(dcn_dom_partial_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, x, om, dcols, (float*)(wsb + l.part), B, C, H, W, Ho, Wo,
+                     stride, max_offset);
   PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/d_om partial");
   const int64_t nom = (int64_t)B * 27 * Ho * Wo;
-  hipLaunchKernelGGL(dcn_dom_final_kernel, dim3(cdiv(nom, 256)), dim3(256), 0, st, (const float*)ws, d_om, nom, G);
+  hipLaunchKernelGGL(dcn_dom_final_kernel, dim3(cdiv(nom, 256)), dim3(256), 0, st, (const float*)(wsb + l.part), d_om, nom, G);
   PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/d_om final");
-  // channel planes per block: the largest power of two <= 16 that fits 64 KB of LDS
+  // d-input: invert the scatter into CSR bins, then gather
+  int* counts = (int*)(wsb + l.counts);
+  int* starts = (int*)(wsb + l.starts);
+  int* bsum = (int*)(wsb + l.bsum);
+  CsrEntry* entries = (CsrEntry*)(wsb + l.entries);
+  if (hipMemsetAsync(counts, 0, (size_t)l.nbins * 4, st) != hipSuccess) { prn_set_error("prn_dcn_sample_bwd: memset failed"); return 1; }
+  hipLaunchKernelGGL(dcn_csr_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, om, counts, B, H, W, Ho, Wo, stride, max_offset);
+  hipLaunchKernelGGL(dcn_csr_block_sums_kernel, dim3(l.nblocks), dim3(256), 0, st, (const int*)counts, bsum, l.nbins);
+  hipLaunchKernelGGL(dcn_csr_scan_kernel, dim3(l.nblocks), dim3(256), 0, st, counts, starts, (const int*)bsum, l.nbins);
+  hipLaunchKernelGGL(dcn_csr_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, om, (const int*)starts, counts, entries, B, H, W, Ho, Wo, stride,
+                     max_offset);
+  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/csr");
   const int HW = H * W;
-  PRN_REQUIRE((int64_t)HW * 4 <= 150 * 1024, "prn_dcn_sample_bwd: a %dx%d plane does not fit LDS", H, W);
-  const int fit = (64 * 1024) / (HW * 4);
-  if (fit >= 16) launch_dx<16>(om, dcols, dx, B, C, H, W, Ho, Wo, stride, max_offset, st);
-  else if (fit >= 8) launch_dx<8>(om, dcols, dx, B, C, H, W, Ho, Wo, stride, max_offset, st);
-  else if (fit >= 4) launch_dx<4>(om, dcols, dx, B, C, H, W, Ho, Wo, stride, max_offset, st);
-  else if (fit >= 2) launch_dx<2>(om, dcols, dx, B, C, H, W, Ho, Wo, stride, max_offset, st);
-  else launch_dx<1>(om, dcols, dx, B, C, H, W, Ho, Wo, stride, max_offset, st);
-  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/dx");
+  // channels per thread: 8, or 4 when that leaves fewer than ~4 blocks per CU
+  const int64_t blocks8 = (int64_t)cdiv(HW, 256) * cdiv(C, 8) * B;
+  if (blocks8 >= 1024)
+    hipLaunchKernelGGL((dcn_dx_gather_kernel<8>), dim3(cdiv(HW, 256), cdiv(C, 8), B), dim3(256), 0, st, dcols, (const int*)starts, (const int*)counts,
+                       (const CsrEntry*)entries, dx, C, HW, Ho * Wo);
+  else
+    hipLaunchKernelGGL((dcn_dx_gather_kernel<4>), dim3(cdiv(HW, 256), cdiv(C, 4), B), dim3(256), 0, st, dcols, (const int*)starts, (const int*)counts,
+                       (const CsrEntry*)entries, dx, C, HW, Ho * Wo);
+  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/dx gather");
   return 0;
 }

@@ -185,6 +185,20 @@ def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE,
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
+_DCN_WS = {}
+
+
+def _dcn_ws_bytes(B, C, H, W, Ho, Wo):
+    key = (B, C, H, W, Ho, Wo)
+    n = _DCN_WS.get(key)
+    if n is None:
+        n = lib.prn_dcn_sample_bwd_ws_bytes(B, C, H, W, Ho, Wo)
+        if n < 0:
+            raise RuntimeError("prn_dcn_sample_bwd_ws_bytes: map too large")
+        _DCN_WS[key] = n
+    return n
+
+
 class _DeformConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, om, w, bias, stride, max_offset):
@@ -216,7 +230,7 @@ class _DeformConv(torch.autograd.Function):
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[3]) else None
         dx = torch.empty_like(x)
         dom = torch.empty_like(om)
-        ws = torch.empty(lib.prn_dcn_sample_bwd_ws_bytes(B, C, Ho, Wo) // 4, device=x.device, dtype=torch.float32)
+        ws = torch.empty(_dcn_ws_bytes(B, C, H, W, Ho, Wo) // 4, device=x.device, dtype=torch.float32)
         with profiling.span("dcn_sample_bwd_kernel", "hbm", 4.0 * (2 * x.numel() + 2 * om.numel() + dcols.numel())):
             check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), _p(ws), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
                   "prn_dcn_sample_bwd")

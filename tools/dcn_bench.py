@@ -26,7 +26,7 @@ for name, C, H, W, s in SHAPES:
     tf = timeit(lambda: check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, s, max(H, W) / 4.0, _stream()), "f"))
     dcols = torch.randn_like(cols)
     dx, dom = torch.empty_like(x), torch.empty_like(om)
-    ws = torch.empty(lib.prn_dcn_sample_bwd_ws_bytes(B, C, Ho, Wo) // 4, device=dev)
+    ws = torch.empty(lib.prn_dcn_sample_bwd_ws_bytes(B, C, H, W, Ho, Wo) // 4, device=dev)
     tb = timeit(lambda: check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), _p(ws), B, C, H, W, Ho, Wo, s, max(H, W) / 4.0, _stream()), "b"))
     bf = 4.0 * (x.numel() + om.numel() + cols.numel())
     bb = 4.0 * (2 * x.numel() + 2 * om.numel() + cols.numel())
