@@ -59,6 +59,17 @@ int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const
 /* wt[c][m][KH-1-r][KW-1-s] = w[m][c][r][s]   (operand layout for dgrad-as-forward) */
 int prn_weight_flip_transpose(const float* w, float* wt, int M, int C, int KH, int KW, void* stream);
 
+/* The same permutation for a list of weight tensors in ONE launch (all conv weights of a model, once per training step).
+ * `items_dev` is a DEVICE array of n_items descriptors; `first` is the running sum of M*C*KH*KW over the preceding items
+ * and total_elements the sum over all of them. */
+typedef struct prn_flip_item {
+  const float* src;   /* [M][C][KH][KW] */
+  float* dst;         /* [C][M][KH][KW], flipped */
+  int M, C, KH, KW;
+  int64_t first;
+} prn_flip_item;
+int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_items, int64_t total_elements, void* stream);
+
 /* dw[m, c*KH*KW + r*KW + s] = sum_{b,oh,ow} dy[b,m,oh,ow] * gather(x)[b,c,oh*stride-pad+r,ow*stride-pad+s]
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
 int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);

@@ -36,7 +36,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = _bn(self.bn1, ops.conv2d(x, self.conv1.weight), relu=True)
+        if self.downsample is None:
+            out, x = ops.conv2d_fork(x, self.conv1.weight)      # x's two gradients (conv1, identity) meet in conv1's dgrad epilogue
+        else:
+            out = ops.conv2d(x, self.conv1.weight)
+        out = _bn(self.bn1, out, relu=True)
         if isinstance(self.conv2, DeformableConv2d):
             out = self.conv2(out)
         else:

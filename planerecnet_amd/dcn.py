@@ -29,5 +29,4 @@ class DeformableConv2d(nn.Module):
         h, w = x.shape[2:]
         w27 = torch.cat([self.offset_conv.weight, self.modulator_conv.weight], 0)
         b27 = torch.cat([self.offset_conv.bias, self.modulator_conv.bias], 0)
-        om = ops.conv2d(x, w27, b27, stride=self.stride, pad=1)
-        return ops.deform_conv2d(x, om, self.regular_conv.weight, self.regular_conv.bias, self.stride, max(h, w) / 4.0)
+        return ops.deform_conv_block(x, w27, b27, self.regular_conv.weight, self.regular_conv.bias, self.stride, max(h, w) / 4.0)

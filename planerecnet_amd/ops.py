@@ -104,10 +104,56 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
 
 
 def flip_transpose(w):
+    e = _FLIPPED.get(w.data_ptr())
+    if e is not None and e[0]._version == e[1] and e[2].shape[1] == w.shape[0]:
+        return e[2]                                         # flipped by FlippedWeights.refresh() since the last weight update
     M, C, KH, KW = w.shape
     wt = torch.empty(C, M, KH, KW, device=w.device, dtype=torch.float32)
     check(lib.prn_weight_flip_transpose(_p(w), _p(wt), M, C, KH, KW, _stream()), "prn_weight_flip_transpose")
     return wt
+
+
+_FLIPPED = {}       # weight data_ptr -> (weight, version at flip time, flipped tensor)
+
+
+class FlippedWeights:
+    """All dgrad operand layouts (include/prn.h: prn_weight_flip_transpose) of a model's conv weights, refreshed with ONE
+    launch per training step instead of one launch per conv per backward (180 launches for PlaneRecNet_101).
+    `weights` is a list of (parameter, (M, C, KH, KW)) -- the shape the dgrad sees (a DCN weight is [M, C*9, 1, 1])."""
+
+    def __init__(self, weights):
+        self.weights = [(w, tuple(int(v) for v in shp)) for w, shp in weights]
+        self.ptrs = None
+
+    def _build(self):
+        import numpy as np
+        dev = self.weights[0][0].device
+        total = sum(M * C * KH * KW for _, (M, C, KH, KW) in self.weights)
+        self.flat = torch.empty(total, device=dev, dtype=torch.float32)
+        items = np.zeros(len(self.weights), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("M", "i4"), ("C", "i4"), ("KH", "i4"), ("KW", "i4"),
+                                                             ("first", "i8")]))
+        self.views, first = [], 0
+        for i, (w, (M, C, KH, KW)) in enumerate(self.weights):
+            assert w.is_contiguous() and w.numel() == M * C * KH * KW and w.dtype == torch.float32
+            v = self.flat[first:first + w.numel()].view(C, M, KH, KW)
+            items[i] = (w.data_ptr(), v.data_ptr(), M, C, KH, KW, first)
+            self.views.append(v)
+            first += w.numel()
+        self.items = torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.total = total
+        self.ptrs = [w.data_ptr() for w, _ in self.weights]
+
+    def refresh(self):
+        """Call after the weights changed (once per step, before backward)."""
+        if not self.weights:
+            return
+        if self.ptrs is None or any(w.data_ptr() != p for (w, _), p in zip(self.weights, self.ptrs)):
+            for p in (self.ptrs or []):
+                _FLIPPED.pop(p, None)
+            self._build()
+        check(lib.prn_weight_flip_transpose_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_weight_flip_transpose_batched")
+        for (w, _), v in zip(self.weights, self.views):
+            _FLIPPED[w.data_ptr()] = (w, w._version, v)
 
 
 def channel_sum(g):
@@ -118,8 +164,9 @@ def channel_sum(g):
     return out
 
 
-def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode):
-    """Gradient w.r.t. the conv input: the same implicit-GEMM kernel run over dy with flipped/transposed weights."""
+def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
+    """Gradient w.r.t. the conv input: the same implicit-GEMM kernel run over dy with flipped/transposed weights.
+    `addend` (another gradient of the same input, e.g. the residual branch) is summed in the kernel epilogue."""
     B, C, H, W = x_shape
     M, _, K, _ = w.shape
     wt = flip_transpose(w)                                  # [C, M, K, K]
@@ -128,19 +175,20 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode):
         dp = conv_fwd_raw(dy, wt, None, None, C, K, 1, 2, Hv + 2, Wv + 2)       # grad of the virtual padded tensor
         dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
         check(lib.prn_pad_fold(_p(dp), _p(dx), B, C, H, W, 1 if mode == IN_UP2_REFLECT else 0, _stream()), "prn_pad_fold")
-        return dx
+        return dx if addend is None else dx + addend
     if stride == 1:
-        return conv_fwd_raw(dy, wt, None, None, C, K, 1, K - 1 - pad, H, W)
+        return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W)
     if stride != 2:
         raise RuntimeError("conv dgrad: stride %d not implemented" % stride)
-    return conv_fwd_raw(dy, wt, None, None, C, K, 1, K - 1 - pad, H, W, IN_DILATED, 2)
+    return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W, IN_DILATED, 2)
 
 
 # ------------------------------------------------------------------------------------------ conv2d
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi):
+    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi, fork=False):
         _dev(x, w, bias, addend)
+        x0 = x
         x, w, bias, addend = _c(x), _c(w), _c(bias), _c(addend)
         M, C, K, _ = w.shape
         assert x.shape[1] == C, (x.shape, w.shape)
@@ -148,13 +196,22 @@ class _Conv2d(torch.autograd.Function):
         y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
         ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
+        ctx.fork = fork
+        if fork:
+            # second output = the input itself: whatever else consumes x (the residual add) takes it from here, so both
+            # gradients of x reach THIS node and are summed in the dgrad epilogue instead of by a separate add kernel
+            ctx.set_materialize_grads(False)
+            return y, x0
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dfork=None):
         x, w, y = ctx.saved_tensors
         stride, pad, mode, epi, has_bias, has_add = ctx.cfg
+        if dy is None:                                      # only the forked identity was used
+            return (dfork,) + (None,) * 8
         dy = _c(dy)
+        dfork = _c(dfork)
         if epi == EPI_RELU:
             dy = dy * (y > 0)
         elif epi == EPI_SIGMOID:
@@ -172,16 +229,26 @@ class _Conv2d(torch.autograd.Function):
             main.wait_stream(side)
             dw.record_stream(main)
         else:
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode) if ctx.needs_input_grad[0] else None
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
+            dfork = None
             dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode) if ctx.needs_input_grad[1] else None
+        if dfork is not None and dx is not None:
+            dx = dx + dfork
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[2]) else None
         da = dy if (has_add and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, da, None, None, None, None
+        return dx, dw, db, da, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
     """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list)."""
     return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue)
+
+
+def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
+    """conv2d that also hands its input back: `y, x_id = conv2d_fork(x, w)`.  Use x_id wherever else x is consumed
+    (the identity branch of a residual block): the two gradients of x are then summed inside the input-gradient GEMM's
+    epilogue rather than by autograd's separate accumulation kernel (one full-tensor read-read-write pass per block)."""
+    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, True)
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
@@ -235,6 +302,55 @@ class _DeformConv(torch.autograd.Function):
             check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), _p(ws), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
                   "prn_dcn_sample_bwd")
         return dx, dom, dw, db, None, None
+
+
+class _DeformConvBlock(torch.autograd.Function):
+    """27-channel offset/modulator conv + DCNv2 as one node: x feeds both, so its two gradients (through the sampler and
+    through the offset conv) are summed in the offset conv's input-gradient epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w27, b27, w, bias, stride, max_offset):
+        _dev(x, w27, b27, w, bias)
+        x, w27, b27, w, bias = _c(x), _c(w27), _c(b27), _c(w), _c(bias)
+        B, C, H, W = x.shape
+        M = w.shape[0]
+        Ho, Wo = _out_hw(H, W, 3, stride, 1, IN_ZERO)
+        om = conv_fwd_raw(x, w27, b27, None, 27, 3, stride, 1, Ho, Wo)
+        cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
+        with profiling.span("dcn_sample_kernel", "hbm", 4.0 * (x.numel() + om.numel() + cols.numel())):
+            check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
+        y = conv_fwd_raw(cols, w, bias, None, M, 1, 1, 0, Ho, Wo)
+        ctx.save_for_backward(x, om, w27, w, cols)
+        ctx.cfg = (stride, float(max_offset), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, om, w27, w, cols = ctx.saved_tensors
+        stride, max_offset, has_bias = ctx.cfg
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        M = w.shape[0]
+        Ho, Wo = om.shape[2:]
+        w1 = w.view(M, C * 9, 1, 1)
+        dcols = conv_dgrad_raw(dy, w1, cols.shape, 1, 0, IN_ZERO)
+        dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[3] else None
+        db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[4]) else None
+        dx1 = torch.empty_like(x)
+        dom = torch.empty_like(om)
+        ws = torch.empty(_dcn_ws_bytes(B, C, H, W, Ho, Wo) // 4, device=x.device, dtype=torch.float32)
+        with profiling.span("dcn_sample_bwd_kernel", "hbm", 4.0 * (2 * x.numel() + 2 * om.numel() + dcols.numel())):
+            check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx1), _p(dom), _p(ws), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
+                  "prn_dcn_sample_bwd")
+        dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if ctx.needs_input_grad[1] else None
+        db27 = channel_sum(dom) if ctx.needs_input_grad[2] else None
+        dx = conv_dgrad_raw(dom, w27, x.shape, stride, 1, IN_ZERO, dx1) if ctx.needs_input_grad[0] else None
+        return dx, dw27, db27, dw, db, None, None
+
+
+def deform_conv_block(x, w27, b27, weight, bias, stride, max_offset):
+    """models/dcn.py:52-67 in one node: om = conv3x3(x; [offset | modulator] weights), y = deform_conv2d(x, om, weight)."""
+    return _DeformConvBlock.apply(x, w27, b27, weight, bias, stride, max_offset)
 
 
 def deform_conv2d(x, om_raw, weight, bias, stride, max_offset):

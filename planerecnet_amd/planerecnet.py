@@ -62,7 +62,23 @@ class PlaneRecNet(nn.Module):
         self.inst_head = SOLOv2InsHead(cfg, [cfg.fpn.num_features] * len(s.instance_in_features))
         self.mask_head = SOLOv2MaskHead(cfg, [cfg.fpn.num_features] * len(s.masks_in_features))
 
+    def _refresh_dgrad_weights(self):
+        """One launch that lays every conv weight out for its input-gradient GEMM (ops.FlippedWeights)."""
+        fw = self.__dict__.get("_flipped")
+        if fw is None:
+            from .dcn import DeformableConv2d
+            dcn_w = {id(m.regular_conv.weight) for m in self.modules() if isinstance(m, DeformableConv2d)}
+            items = []
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d) and m.weight.requires_grad and m.weight.is_cuda:
+                    M, C, KH, KW = m.weight.shape
+                    items.append((m.weight, (M, C * KH * KW, 1, 1) if id(m.weight) in dcn_w else (M, C, KH, KW)))
+            fw = self.__dict__["_flipped"] = ops.FlippedWeights(items)
+        fw.refresh()
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled() and x.is_cuda:
+            self._refresh_dgrad_weights()
         with timer.env("backbone"):
             enc = self.backbone(x)
         with timer.env("fpn"):

@@ -127,6 +127,76 @@ def test_deform_conv_fwd_bwd(B, C, H, W, M, stride):
         close(g1, g0, "dcn " + n, rtol=5e-4)
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_deform_conv_block_matches_unfused(stride):
+    """offset conv + DCNv2 as one autograd node (x's two gradients summed in the dgrad epilogue) vs the two separate ops
+    vs the fp64 oracle."""
+    from planerecnet_amd import ops
+    from oracle.dcn_ref import deform_conv2d_ref
+    B, C, H, W, M = 2, 32, 14, 18, 40
+    maxoff = max(H, W) / 4.0
+    x = rnd(B, C, H, W, seed=1)
+    w27 = rnd(27, C, 3, 3, seed=2, scale=0.4 * (9 * C) ** -0.5)
+    b27 = rnd(27, seed=3, scale=0.3) + 0.137
+    w = rnd(M, C, 3, 3, seed=4, scale=(9 * C) ** -0.5)
+    b = rnd(M, seed=5)
+    ts = [t.clone().requires_grad_(True) for t in (x, w27, b27, w, b)]
+    om = F.conv2d(ts[0], ts[1], ts[2], stride=stride, padding=1)
+    yr = deform_conv2d_ref(ts[0], om[:, :18].clamp(-maxoff, maxoff), 2 * torch.sigmoid(om[:, 18:]), ts[3], ts[4], stride, 1)
+    go = rnd(*yr.shape, seed=6)
+    gr = torch.autograd.grad(yr, ts, go)
+    d = dev()
+    xs = [t.detach().float().to(d).requires_grad_(True) for t in (x, w27, b27, w, b)]
+    yd = ops.deform_conv_block(*xs, stride, maxoff)
+    close(yd, yr, "dcn block fwd")
+    gd = torch.autograd.grad(yd, xs, go.float().to(d))
+    for n, g1, g0 in zip(["dx", "dw27", "db27", "dw", "db"], gd, gr):
+        close(g1, g0, "dcn block " + n, rtol=5e-4)
+
+
+def test_conv_fork_sums_both_input_gradients():
+    """y, x_id = conv2d_fork(x, w); loss uses both: dx = dgrad(dy) + d(x_id), summed inside the dgrad epilogue."""
+    from planerecnet_amd import ops
+    x = rnd(2, 48, 11, 14, seed=1)
+    w = rnd(32, 48, 1, 1, seed=2, scale=48 ** -0.5)
+    g1, g2 = rnd(2, 32, 11, 14, seed=3), rnd(2, 48, 11, 14, seed=4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ((F.conv2d(xr, wr) * g1).sum() + (xr * g2).sum()).backward()
+    d = dev()
+    xd, wd = x.float().to(d).requires_grad_(True), w.float().to(d).requires_grad_(True)
+    y, xid = ops.conv2d_fork(xd, wd)
+    assert xid.data_ptr() == xd.data_ptr()
+    ((y * g1.float().to(d)).sum() + (xid * g2.float().to(d)).sum()).backward()
+    close(xd.grad, xr.grad, "fork dx")
+    close(wd.grad, wr.grad, "fork dw")
+    # identity branch only / conv branch only
+    xd2 = x.float().to(d).requires_grad_(True)
+    y, xid = ops.conv2d_fork(xd2, wd)
+    (xid * g2.float().to(d)).sum().backward()
+    close(xd2.grad, g2, "fork identity-only")
+    xd3 = x.float().to(d).requires_grad_(True)
+    y, xid = ops.conv2d_fork(xd3, wd)
+    (y * g1.float().to(d)).sum().backward()
+    close(xd3.grad, torch.autograd.grad((F.conv2d(xr, wr) * g1).sum(), xr)[0], "fork conv-only")
+
+
+def test_flipped_weights_batched_matches_single():
+    from planerecnet_amd import ops
+    d = dev()
+    ws = [rnd(24, 16, 3, 3, seed=1).float().to(d), rnd(8, 40, 1, 1, seed=2).float().to(d), rnd(5, 3, 7, 7, seed=3).float().to(d),
+          rnd(12, 4, 3, 3, seed=4).float().to(d)]
+    fw = ops.FlippedWeights([(ws[0], ws[0].shape), (ws[1], ws[1].shape), (ws[2], ws[2].shape), (ws[3], (12, 36, 1, 1))])
+    fw.refresh()
+    for w, v in zip(ws[:3], fw.views[:3]):
+        assert torch.equal(v, w.flip(2, 3).transpose(0, 1).contiguous())
+    assert torch.equal(fw.views[3].view(36, 12), ws[3].view(12, 36).t())
+    assert ops.flip_transpose(ws[0]) is fw.views[0]                  # cache hit while the version is unchanged
+    ws[0].mul_(2.0)
+    assert ops.flip_transpose(ws[0]) is not fw.views[0]             # stale after an in-place update -> per-call flip
+    fw.refresh()
+    assert torch.equal(ops.flip_transpose(ws[0]), ws[0].flip(2, 3).transpose(0, 1).contiguous())
+
+
 def test_deform_conv_zero_offsets_equals_conv():
     from planerecnet_amd import ops
     d = dev()
