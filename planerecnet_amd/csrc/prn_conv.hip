@@ -77,25 +77,29 @@ __device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W)
 // workspace that reduce_epilogue_kernel sums in fixed order before bias / addend / activation).
 // VEC (1x1, stride 1, no padding, H*W % 4 == 0): the im2col operand is the activation matrix itself, staged with float4
 // loads along the pixel axis and 128-bit LDS stores.
-template <int KS, int MODE, int TM, int TN, int BK, bool VEC = false>
-__global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel(ConvArgs a) {   // 128x128: cap at 128 VGPRs -> 4 waves/SIMD (+7..15 %)
+// WM = waves along M (2: the 2x2 wave grid; 1: all four waves side by side along the pixels, a 32 x 128 tile for layers
+// with <= 32 output channels -- the 27-channel offset/modulator conv of every DCN block wasted 58 % of a 64-row tile).
+template <int KS, int MODE, int TM, int TN, int BK, bool VEC = false, int WM = 2, int WN = 4 / WM>
+__global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel(ConvArgs a) {   // 128x128: cap at 128 VGPRs -> 4 waves/SIMD (+7..15 %)
   static_assert(!VEC || (KS == 1 && MODE == PRN_IN_ZERO), "vector staging is the plain-GEMM case");
-  constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BK + 1;
-  constexpr int KSTEP = 256 / BN;  // K rows covered by one sweep of the block
+  constexpr int NT = 64 * WM * WN;               // threads per workgroup
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BK + 1;
+  constexpr int KSTEP = NT / BN;   // K rows covered by one sweep of the block
   constexpr int NB = BK / KSTEP;   // gathered elements per thread per K slice
   constexpr int AQ = BK / 4;       // float4 groups per A row
-  constexpr int AROWS = 256 / AQ;  // A rows covered by one sweep
-  constexpr int NA = BM / AROWS;   // float4 loads per thread per K slice
+  constexpr int AROWS = NT / AQ;   // A rows covered by one sweep
+  constexpr int NA = BM >= AROWS ? BM / AROWS : 1;   // float4 loads per thread per K slice
+  constexpr bool AALL = BM >= AROWS;                 // every thread stages A (otherwise only those with arow < BM)
   constexpr int KK = KS * KS;
   constexpr int VG = BN / 4;       // VEC: float4 pixel groups per K row
-  constexpr int VROWS = 256 / VG;  // VEC: K rows per sweep
+  constexpr int VROWS = NT / VG;   // VEC: K rows per sweep
   constexpr int NBV = BK / VROWS;  // VEC: float4 loads per thread per K slice
   __shared__ float As[2][BM * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
   __shared__ unsigned taps[KS > 1 ? KK * BN : 1];   // per-pixel tap byte offsets (or OOB), built once per workgroup
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
   const int m0 = (id % a.tilesM) * BM, n0 = (id / a.tilesM) * BN;
 
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel
 
   // pixel owned by this thread in the B (im2col) operand; its K rows are wave-uniform
   const int nl = tid % BN;
-  const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
+  // K row of this thread inside a sweep: wave-uniform (-> SGPR address math) when a wave spans one row of the tile
+  const int krow0 = (BN >= 64) ? __builtin_amdgcn_readfirstlane(tid / BN) : tid / BN;
   const int n = n0 + nl;
   const bool nvalid = n < a.N;
   int b = 0, oh = 0, ow = 0;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int m = m0 + arow + AROWS * i;
-    abase[i] = m < a.M ? (unsigned)(m * a.K + akq) * 4u : OOB;
+    abase[i] = (m < a.M && (AALL || arow < BM)) ? (unsigned)(m * a.K + akq) * 4u : OOB;
   }
 
   // VEC staging: this thread's group of 4 consecutive pixels, K row vrow0 (+ VROWS * i)
@@ -189,18 +194,21 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel
       } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform
+          const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform when BN >= 64
           const int c = kr / KK, rs = kr - c * KK;
           const unsigned off = (KS == 1) ? off1 : taps[rs * BN + nl];
-          rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off : OOB, c * a.HW * 4);
+          if (BN >= 64) rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off : OOB, c * a.HW * 4);
+          else rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off + (unsigned)(c * a.HW * 4) : OOB, 0);   // (OOB + channel offset stays >= 2^31)
         }
       }
     };
     auto store_tile = [&](int buf) {
+      if (AALL || arow < BM) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
+          for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
+      }
       if (VEC) {
 #pragma unroll
         for (int i = 0; i < NBV; ++i) *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = rv[i];
@@ -280,14 +288,15 @@ struct WgArgs {
   int xbytes, dybytes;
 };
 
-template <int KS, int MODE, int TM, int TJ>
+template <int KS, int MODE, int TM, int TJ, int WM = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
-  constexpr int BM = 64 * TM, BJ = 64 * TJ, LD = 17, KK = KS * KS;
+  constexpr int WJ = 4 / WM;                     // WM = 1: 32 x 128 tile for <= 32 output channels (see conv_igemm_kernel)
+  constexpr int BM = 32 * WM * TM, BJ = 32 * WJ * TJ, LD = 17, KK = KS * KS;
   constexpr int NBJ = BJ / 16;
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wj = wave & 1;
+  const int wm = wave / WJ, wj = wave % WJ;
   const int m0 = (blockIdx.x % a.tilesM) * BM, j0 = (blockIdx.x / a.tilesM) * BJ;
   const int split = blockIdx.y;
   const int cbeg = (int)((int64_t)split * a.chunks / a.splits), cend = (int)((int64_t)(split + 1) * a.chunks / a.splits);
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
   bool mok[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) mok[i] = m0 + arow + 64 * i < a.M;
+  for (int i = 0; i < TM; ++i) mok[i] = (m0 + arow + 64 * i < a.M) && (arow + 64 * i < BM);
 
   float ra[TM][4], rb[NBJ];
   f32x16 acc[TM][TJ];
@@ -377,8 +386,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     auto store_chunk = [&](int buf) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
+        if (BM >= 64 || arow < BM) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) As[buf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
+          for (int q = 0; q < 4; ++q) As[buf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
+        }
 #pragma unroll
       for (int i = 0; i < NBJ; ++i) Bs[buf][(jrow + 16 * i) * LD + nl] = rb[i];
     };
@@ -561,7 +572,7 @@ __global__ void channel_sum_final_kernel(const double* __restrict__ ws, float* _
   out[c] = (float)t;
 }
 
-struct FwdPlan { int tm, tn, bk, splits; };
+struct FwdPlan { int tm, tn, bk, splits, wm, wn; };   // block tile = (32*wm*tm) x (32*wn*tn), 64*wm*wn threads
 
 // All workgroups of these launches are resident at once, so the launch lasts as long as its most loaded CU: 528 workgroups
 // (16 CUs with 3, the rest with 2) ran 27 % longer than 512.  Round the split count down so that tiles * splits lands on
@@ -579,13 +590,14 @@ int quantise_splits(int64_t tiles, int splits) {
 }
 
 // Tile / slice / split choice.  PRN_CONV_FORCE="tm,tn,bk,splits" overrides it (tuning sweeps: tools/conv_bench.py).
-FwdPlan plan_fwd(int M, int64_t N, int K) {
+FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false) {
   static int forced[4] = {-1, 0, 0, 0};
   if (forced[0] == -1) {
     forced[0] = 0;
     if (const char* e = getenv("PRN_CONV_FORCE")) sscanf(e, "%d,%d,%d,%d", &forced[0], &forced[1], &forced[2], &forced[3]);
   }
   FwdPlan p;
+  p.wm = 2; p.wn = 2;
   if (forced[0] > 0) {
     p.tm = forced[0]; p.tn = forced[1]; p.bk = 16; p.splits = forced[3];
     if (p.tm != p.tn) { p.tm = 1; p.tn = 1; }
@@ -597,7 +609,8 @@ FwdPlan plan_fwd(int M, int64_t N, int K) {
     p.bk = 16;
     if (M >= 128 && K >= 1152 && tiles(2, 2) >= 512) { p.tm = 2; p.tn = 2; }
     else { p.tm = 1; p.tn = 1; }
-    const int64_t t = tiles(p.tm, p.tn);
+    int64_t t = tiles(p.tm, p.tn);
+    if (M <= 32 && narrow_ok) { p.wm = 1; p.wn = 4; t = cdiv(N, 128); }        // 32 x 128 tile
     p.splits = t < 1024 ? (int)((1024 + t - 1) / t) : 1;
     if (p.splits > 8) p.splits = 8;
     p.splits = quantise_splits(t, p.splits);
@@ -609,13 +622,24 @@ FwdPlan plan_fwd(int M, int64_t N, int K) {
   return p;
 }
 
+// (kernel size, input mode) pairs that have the 32 x 128 instance
+constexpr bool narrow_available(int ks, int mode) {
+  return (ks == 3 && (mode == PRN_IN_ZERO || mode == PRN_IN_REFLECT)) || (ks == 1 && mode == PRN_IN_ZERO);
+}
+
 template <int KS, int MODE>
 int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
   ConvArgs a = a0;
-  a.tilesM = cdiv(a.M, 64 * p.tm);
-  a.nblocks = a.tilesM * cdiv(a.N, 64 * p.tn);
+  a.tilesM = cdiv(a.M, 32 * p.wm * p.tm);
+  a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
   a.splits = p.splits;
-  dim3 grid(a.nblocks, p.splits), block(256);
+  dim3 grid(a.nblocks, p.splits), block(64 * p.wm * p.wn);
+  if constexpr (narrow_available(KS, MODE)) {
+    if (p.wm == 1) {
+      hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, 1, 1, 16, false, 1>), grid, block, 0, st, a);
+      return 0;
+    }
+  }
   if constexpr (KS == 1 && MODE == PRN_IN_ZERO) {
     const bool vec = a.stride == 1 && a.pad == 0 && (a.HW & 3) == 0 && a.HW == a.HoWo && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
     if (vec) {
@@ -625,20 +649,24 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
     }
   }
 #define PRN_LAUNCH(TM_, TN_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, TM_, TN_, BK_>), grid, block, 0, st, a)
-  // (deeper slices were measured slower on every shape -- only BK = 16 is instantiated)
+  // Measured and NOT instantiated (profiles/r01_conv_sweep_bufferloads.txt and the sweeps after it): 32-deep K slices
+  // (slower or equal on every shape), 64 x 128 tiles (never the best), and a two-wave 64 x 32 tile meant to replace the
+  // K split on the 9600-pixel stages (64 -> 71 us on 1x1 1024->256, 144 -> 193 us on 3x3 256: the split is cheaper).
   if (p.tm == 2 && p.tn == 2) PRN_LAUNCH(2, 2, 16);
   else PRN_LAUNCH(1, 1, 16);
 #undef PRN_LAUNCH
   return 0;
 }
 
-struct WgPlan { int tm, tj, tilesM, tilesJ, splits, chunks; };
+struct WgPlan { int tm, tj, tilesM, tilesJ, splits, chunks, wm; };
 WgPlan plan_wgrad(int M, int K, int64_t N) {
   WgPlan p;
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
-  p.tilesM = cdiv(M, 64 * p.tm);
-  p.tilesJ = cdiv(K, 64 * p.tj);
+  p.wm = 2;
+  if (M <= 32 && K > 64) { p.wm = 1; p.tm = 1; p.tj = 1; }          // 32 x 128 tile
+  p.tilesM = cdiv(M, 32 * p.wm * p.tm);
+  p.tilesJ = cdiv(K, 32 * (4 / p.wm) * p.tj);
   p.chunks = cdiv(N, 16);
   const int tiles = p.tilesM * p.tilesJ;
   // Splits.  Every workgroup of a wgrad launch is resident at once when tiles * splits <= 256 CUs * R (R = workgroups a
@@ -652,7 +680,7 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
   if (target < 0) { const char* e = getenv("PRN_WGRAD_TARGET"); target = e ? atoi(e) : 2048; }
   static int forced = -1;          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
   if (forced < 0) { const char* e = getenv("PRN_WGRAD_SPLITS"); forced = e ? atoi(e) : 0; }
-  const int R = (p.tm == 2 && p.tj == 2) ? 3 : (p.tm + p.tj == 3 ? 4 : 6);
+  const int R = (p.tm == 2 && p.tj == 2) ? 3 : ((p.tm + p.tj == 3 || p.wm == 1) ? 4 : 6);
   const int slots = 256 * R;
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;
   const int smax = p.chunks / 8 > 0 ? p.chunks / 8 : 1;   // at least 128 pixels per split
@@ -677,7 +705,8 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
 template <int KS, int MODE>
 int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st) {
   dim3 grid(p.tilesM * p.tilesJ, p.splits), block(256);
-  if (p.tm == 2 && p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 2>), grid, block, 0, st, a);
+  if (p.wm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1, 1>), grid, block, 0, st, a);
+  else if (p.tm == 2 && p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 2>), grid, block, 0, st, a);
   else if (p.tm == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 1>), grid, block, 0, st, a);
   else if (p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1>), grid, block, 0, st, a);
@@ -703,7 +732,7 @@ int check_desc(const prn_conv_desc* d, const char* who) {
 
 extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
-  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * d->Ho * d->Wo, d->C * d->KH * d->KW);
+  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * d->Ho * d->Wo, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode));
   return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
 
@@ -717,7 +746,7 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
   a.Ho = d->Ho; a.Wo = d->Wo; a.epi = d->epilogue;
   a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
   a.xbytes = d->B * d->C * d->H * d->W * 4; a.wbytes = d->M * a.K * 4;
-  const FwdPlan p = plan_fwd(a.M, a.N, a.K);
+  const FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode));
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
   const int mode = d->in_mode;

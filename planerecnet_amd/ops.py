@@ -9,13 +9,15 @@ CPU path in the product.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib, profiling
 from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
-OVERLAP_WGRAD = False         # (measured: no gain at B=8 -- 119.1 vs 116.6 ms/step -- the extra stream traffic costs host time) backward: weight-gradient kernels on a side stream, concurrent with the data-gradient kernel
+OVERLAP_WGRAD = bool(int(os.environ.get("PRN_OVERLAP_WGRAD", "0")))         # (measured: no gain at B=8 -- 119.1 vs 116.6 ms/step -- the extra stream traffic costs host time) backward: weight-gradient kernels on a side stream, concurrent with the data-gradient kernel
 _SIDE = {}
 
 
@@ -225,7 +227,8 @@ class _Conv2d(torch.autograd.Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode)
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode)
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork)
+            dfork = None
             main.wait_stream(side)
             dw.record_stream(main)
         else:
