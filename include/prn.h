@@ -33,19 +33,26 @@ const char* prn_last_error(void);
  *   PRN_IN_REFLECT  ReflectionPad2d(1) then conv                  (planerecnet.py:516,522,528,534,579,570)
  *   PRN_IN_UP2_REFLECT  Upsample(x2, nearest) -> ReflectionPad2d(1) -> conv   (planerecnet.py:540-566)
  *   PRN_IN_DILATED  input holds every `dil`-th sample of a zero-dilated tensor (dgrad of a strided conv)
+ *   PRN_IN_UP2_PHASE  the SAME operator as PRN_IN_UP2_REFLECT in its sub-pixel form (2.25x fewer multiply-adds): output
+ *                   pixel (2i+py, 2j+px) only sees the 2x2 source window at (i+py-1, j+px-1) (replicate border), through
+ *                   the phase's own [M, C*2*2] matrix -- sums of the 3x3 taps, built by prn_up2_phase_weights.  KH = KW = 2,
+ *                   w = [4][M][C][2][2], Ho = 2H, Wo = 2W; the four phases run as one launch.  For wgrad, dy is phase-major
+ *                   [4][B][M][H][W] (prn_space_to_depth2) and dw is [4][M][C][2][2] (prn_up2_wgrad_combine maps it to 3x3).
  */
-enum { PRN_IN_ZERO = 0, PRN_IN_REFLECT = 1, PRN_IN_UP2_REFLECT = 2, PRN_IN_DILATED = 3 };
+enum { PRN_IN_ZERO = 0, PRN_IN_REFLECT = 1, PRN_IN_UP2_REFLECT = 2, PRN_IN_DILATED = 3, PRN_IN_UP2_PHASE = 4 };
 enum { PRN_EPI_NONE = 0, PRN_EPI_RELU = 1, PRN_EPI_SIGMOID = 2 };
 
 typedef struct prn_conv_desc {
   int32_t B, C, H, W;      /* input tensor [B,C,H,W] as stored                                        */
   int32_t M;               /* output channels                                                          */
-  int32_t KH, KW;          /* 1x1, 3x3 or 7x7                                                          */
+  int32_t KH, KW;          /* 1x1, 3x3, 7x7; 2x2 (PRN_IN_UP2_PHASE), 4x4 (zero padding; its input gradient)  */
   int32_t stride, pad;     /* pad is ignored (==1) for the reflect modes                               */
   int32_t Ho, Wo;          /* output spatial size                                                      */
   int32_t in_mode;         /* PRN_IN_*                                                                 */
   int32_t dil;             /* PRN_IN_DILATED: dilation factor of the virtual input                     */
   int32_t epilogue;        /* PRN_EPI_* (fwd only)                                                     */
+  int32_t ystride;         /* 0/1: dense output.  2 (fwd only): output pixel (oh,ow) is stored at (2*oh, 2*ow) of  */
+  int32_t yH, yW;          /*    a caller-zeroed [B,M,yH,yW] tensor (input gradient of a stride-2 1x1 conv)    */
 } prn_conv_desc;
 
 /* y[b,m,oh,ow] = epi( sum_{c,r,s} w[m,c,r,s] * gather(x)[b,c,oh*stride-pad+r, ow*stride-pad+s] + bias[m] + addend[b,m,oh,ow] )
@@ -74,6 +81,18 @@ int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_item
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
 int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream);
+
+/* --- sub-pixel form of Upsample(x2, nearest) -> ReflectionPad2d(1) -> Conv3x3 (planerecnet.py:540-566), see PRN_IN_UP2_PHASE.
+ * wp [4][M][C][2][2]: per-phase sums of the 3x3 taps of w [M][C][3][3]. */
+int prn_up2_phase_weights(const float* w, float* wp, int M, int C, void* stream);
+/* kd [C][M][4][4]: operand of the input gradient, which is conv(dy [B,M,2H,2W], kd, 4x4, stride 2, zero pad 3) -> [B,C,H+2,W+2]
+ * (gradient w.r.t. the replicate-padded source), folded onto [B,C,H,W] by prn_replicate_fold. */
+int prn_up2_dgrad_weights(const float* w, float* kd, int M, int C, void* stream);
+int prn_replicate_fold(const float* dp, float* dx, int B, int C, int H, int W, void* stream);
+/* out [4][B][C][H][W] = the four sub-pixel phases of in [B][C][2H][2W] (dy layout for the PRN_IN_UP2_PHASE wgrad). */
+int prn_space_to_depth2(const float* in, float* out, int B, int C, int H, int W, void* stream);
+/* dw [M][C][3][3] from the per-phase weight gradients dwp [4][M][C][2][2]. */
+int prn_up2_wgrad_combine(const float* dwp, float* dw, int M, int C, void* stream);
 
 /* adjoint of the PRN_IN_REFLECT / PRN_IN_UP2_REFLECT gather: folds dP [B,C,Hv+2,Wv+2] (gradient w.r.t. the
  * virtual padded tensor, Hv = H or 2H) back onto dx [B,C,H,W]. */

@@ -15,10 +15,10 @@ c_int, c_float, c_void_p, c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
 class ConvDesc(ctypes.Structure):
     """mirror of prn_conv_desc"""
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("B", "C", "H", "W", "M", "KH", "KW", "stride", "pad", "Ho", "Wo", "in_mode", "dil", "epilogue")]
+                ("B", "C", "H", "W", "M", "KH", "KW", "stride", "pad", "Ho", "Wo", "in_mode", "dil", "epilogue", "ystride", "yH", "yW")]
 
 
-IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED = 0, 1, 2, 3
+IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE = 0, 1, 2, 3, 4
 EPI_NONE, EPI_RELU, EPI_SIGMOID = 0, 1, 2
 BN_SPLITS = 32
 
@@ -34,6 +34,11 @@ SIGNATURES = {
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),
     "prn_pad_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_up2_phase_weights": (c_int, [P, P, c_int, c_int, P]),
+    "prn_up2_dgrad_weights": (c_int, [P, P, c_int, c_int, P]),
+    "prn_up2_wgrad_combine": (c_int, [P, P, c_int, c_int, P]),
+    "prn_space_to_depth2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_replicate_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_channel_sum": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "prn_dcn_sample": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
     "prn_dcn_sample_bwd_ws_bytes": (c_i64, [c_int] * 6),

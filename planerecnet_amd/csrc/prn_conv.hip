@@ -23,6 +23,7 @@ struct ConvArgs {
   int B, C, H, W, M, stride, pad, Ho, Wo, epi;
   int K, N, HoWo, HW, tilesM, nblocks, splits;
   int xbytes, wbytes;
+  int ystride, yW, yHW;     // output map: GEMM pixel (oh, ow) is stored at (oh*ystride + phase_y, ow*ystride + phase_x) of a yHW plane
   float* ws;
 };
 
@@ -63,6 +64,9 @@ __device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W)
   } else if (MODE == PRN_IN_UP2_REFLECT) {
     ih = reflect_idx(ih, 2 * H) >> 1;
     iw = reflect_idx(iw, 2 * W) >> 1;
+  } else if (MODE == PRN_IN_UP2_PHASE) {   // replicate border (one sub-pixel phase of nearest-x2 + reflect-pad + 3x3)
+    ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+    iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
   } else {  // PRN_IN_DILATED (factor 2): only even virtual coordinates carry data
     ok = ok && ih >= 0 && iw >= 0 && ((ih | iw) & 1) == 0;
     ih >>= 1;
@@ -103,7 +107,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
   const int m0 = (id % a.tilesM) * BM, n0 = (id / a.tilesM) * BN;
 
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), wr = make_rsrc(a.w, a.wbytes);
+  // PRN_IN_UP2_PHASE: blockIdx.z = output phase (py, px); each phase has its own [M x 4C] weight matrix, reads the 2x2
+  // source window starting at (i + py - 1, j + px - 1) and stores to (2i + py, 2j + px)
+  const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
+  const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
+  const float* wz = (MODE == PRN_IN_UP2_PHASE) ? a.w + (size_t)blockIdx.z * a.M * a.K : a.w;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), wr = make_rsrc(wz, a.wbytes);
 
   // pixel owned by this thread in the B (im2col) operand; its K rows are wave-uniform
   const int nl = tid % BN;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
     oh = p / a.Wo;
     ow = p - oh * a.Wo;
   }
-  const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+  const int ih0 = oh * a.stride - pad_y, iw0 = ow * a.stride - pad_x;
   const int pix0 = b * a.C * a.HW;                      // element offset of this pixel's image
   unsigned off1 = OOB;                                   // byte offsets (or OOB) relative to a.x, channel 0
   if (KS == 1) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
 
   // A (weight) operand: NA float4 groups per thread; rows beyond M fall outside the descriptor by themselves
   const int arow = tid / AQ, akq = (tid % AQ) * 4;
-  const bool k4 = ((a.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0);
+  const bool k4 = ((a.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(wz) & 15) == 0);
   unsigned abase[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -260,7 +269,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
     const int nn = n0 + wn * TN * 32 + j * 32 + (lane & 31);
     if (!interior && nn >= a.N) continue;
     const int bb = nn / a.HoWo, p = nn - bb * a.HoWo;
-    const size_t base = (size_t)bb * a.M * a.HoWo + p;
+    size_t base = (size_t)bb * a.M * a.HoWo + p;
+    size_t mstride = a.HoWo;
+    if (a.ystride != 1) {                               // strided / phase-interleaved output plane (never with a K split)
+      const int qh = p / a.Wo, qw = p - qh * a.Wo;
+      mstride = a.yHW;
+      base = (size_t)bb * a.M * a.yHW + (size_t)(qh * a.ystride + py) * a.yW + qw * a.ystride + px;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         if (!interior && m >= a.M) continue;
-        const size_t idx = base + (size_t)m * a.HoWo;
+        const size_t idx = base + (size_t)m * mstride;
         float v = acc[i][j][r];
         if (has_bias) v += a.bias[m];
         if (has_add) v += a.addend[idx];
@@ -285,7 +300,7 @@ struct WgArgs {
   const float* x; const float* dy; float* out;
   int B, C, H, W, M, stride, pad, Ho, Wo;
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
-  int xbytes, dybytes;
+  int xbytes, dybytes;       // dybytes: one phase of dy
 };
 
 template <int KS, int MODE, int TM, int TJ, int WM = 2>
@@ -301,9 +316,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   const int split = blockIdx.y;
   const int cbeg = (int)((int64_t)split * a.chunks / a.splits), cend = (int)((int64_t)(split + 1) * a.chunks / a.splits);
 
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(a.dy, a.dybytes);
+  // PRN_IN_UP2_PHASE: blockIdx.z = phase; dy is phase-major [4][B][M][H][W] (prn_space_to_depth2), out is [4][M][4C]
+  const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
+  const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
+  const float* dyz = a.dy + (size_t)blockIdx.z * (a.dybytes / 4);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
   const int arow = tid >> 2, anq = (tid & 3) * 4;
-  const bool n4 = ((a.HoWo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dy) & 15) == 0);
+  const bool n4 = ((a.HoWo & 3) == 0) && ((reinterpret_cast<uintptr_t>(dyz) & 15) == 0);
   const int nl = tid & 15, jrow = tid >> 4;
   int jcoff[NBJ], jr[NBJ], js[NBJ];
   bool jok[NBJ];
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
       }
       {  // im2col rows
         const bool ok = ch * 16 + nl < a.N;
-        const int ih0 = g_oh * a.stride - a.pad, iw0 = g_ow * a.stride - a.pad;
+        const int ih0 = g_oh * a.stride - pad_y, iw0 = g_ow * a.stride - pad_x;
         const int pix0 = g_b * a.C * a.HW;
 #pragma unroll
         for (int i = 0; i < NBJ; ++i) {
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   };
   if (n4) run(std::true_type{}); else run(std::false_type{});
 
-  float* out = a.out + (size_t)split * a.M * a.K;
+  float* out = a.out + ((size_t)split * gridDim.z + blockIdx.z) * a.M * a.K;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int jj = j0 + wj * TJ * 32 + j * 32 + (lane & 31);
@@ -590,7 +609,7 @@ int quantise_splits(int64_t tiles, int splits) {
 }
 
 // Tile / slice / split choice.  PRN_CONV_FORCE="tm,tn,bk,splits" overrides it (tuning sweeps: tools/conv_bench.py).
-FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false) {
+FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false, int phases = 1, bool nosplit = false) {
   static int forced[4] = {-1, 0, 0, 0};
   if (forced[0] == -1) {
     forced[0] = 0;
@@ -611,6 +630,7 @@ FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false) {
     else { p.tm = 1; p.tn = 1; }
     int64_t t = tiles(p.tm, p.tn);
     if (M <= 32 && narrow_ok) { p.wm = 1; p.wn = 4; t = cdiv(N, 128); }        // 32 x 128 tile
+    t *= phases;
     p.splits = t < 1024 ? (int)((1024 + t - 1) / t) : 1;
     if (p.splits > 8) p.splits = 8;
     p.splits = quantise_splits(t, p.splits);
@@ -618,7 +638,7 @@ FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false) {
   const int kt = cdiv(K, p.bk);
   if (p.splits > kt / 4) p.splits = kt / 4;        // at least 4 K slices per split
   if (p.splits > 16) p.splits = 16;
-  if (p.splits < 1) p.splits = 1;
+  if (p.splits < 1 || nosplit) p.splits = 1;
   return p;
 }
 
@@ -628,12 +648,12 @@ constexpr bool narrow_available(int ks, int mode) {
 }
 
 template <int KS, int MODE>
-int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
+int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases = 1) {
   ConvArgs a = a0;
   a.tilesM = cdiv(a.M, 32 * p.wm * p.tm);
   a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
   a.splits = p.splits;
-  dim3 grid(a.nblocks, p.splits), block(64 * p.wm * p.wn);
+  dim3 grid(a.nblocks, p.splits, phases), block(64 * p.wm * p.wn);
   if constexpr (narrow_available(KS, MODE)) {
     if (p.wm == 1) {
       hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, 1, 1, 16, false, 1>), grid, block, 0, st, a);
@@ -659,7 +679,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st) {
 }
 
 struct WgPlan { int tm, tj, tilesM, tilesJ, splits, chunks, wm; };
-WgPlan plan_wgrad(int M, int K, int64_t N) {
+WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1) {
   WgPlan p;
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
@@ -668,7 +688,7 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
   p.tilesM = cdiv(M, 32 * p.wm * p.tm);
   p.tilesJ = cdiv(K, 32 * (4 / p.wm) * p.tj);
   p.chunks = cdiv(N, 16);
-  const int tiles = p.tilesM * p.tilesJ;
+  const int tiles = p.tilesM * p.tilesJ * phases;
   // Splits.  Every workgroup of a wgrad launch is resident at once when tiles * splits <= 256 CUs * R (R = workgroups a
   // CU holds: 3 for the 128x128 tile at 152 VGPRs, 4 / 6 for the smaller ones), and the launch then lasts as long as its
   // most loaded CU.  The split sweep (profiles/r01_wgrad_split_sweep.txt) has its minimum where that single round is
@@ -703,8 +723,8 @@ WgPlan plan_wgrad(int M, int K, int64_t N) {
 }
 
 template <int KS, int MODE>
-int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st) {
-  dim3 grid(p.tilesM * p.tilesJ, p.splits), block(256);
+int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st, int phases = 1) {
+  dim3 grid(p.tilesM * p.tilesJ, p.splits, phases), block(256);
   if (p.wm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1, 1>), grid, block, 0, st, a);
   else if (p.tm == 2 && p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 2>), grid, block, 0, st, a);
   else if (p.tm == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 1>), grid, block, 0, st, a);
@@ -715,24 +735,44 @@ int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st) {
 
 int check_desc(const prn_conv_desc* d, const char* who) {
   PRN_REQUIRE(d != nullptr, "%s: null descriptor", who);
-  PRN_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 7), "%s: kernel %dx%d unsupported (1,3,7 square)", who, d->KH, d->KW);
+  PRN_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 2 || d->KH == 3 || d->KH == 4 || d->KH == 7), "%s: kernel %dx%d unsupported (1,2,3,4,7 square)", who,
+              d->KH, d->KW);
   PRN_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->M > 0 && d->Ho > 0 && d->Wo > 0, "%s: empty dimension", who);
-  PRN_REQUIRE(d->in_mode >= 0 && d->in_mode <= 3, "%s: bad in_mode %d", who, d->in_mode);
+  PRN_REQUIRE(d->in_mode >= 0 && d->in_mode <= 4, "%s: bad in_mode %d", who, d->in_mode);
+  PRN_REQUIRE((d->in_mode == PRN_IN_UP2_PHASE) == (d->KH == 2), "%s: 2x2 kernels are the sub-pixel phases of PRN_IN_UP2_PHASE (and only that)", who);
+  PRN_REQUIRE(d->in_mode != PRN_IN_UP2_PHASE || (d->Ho == 2 * d->H && d->Wo == 2 * d->W && d->stride == 1 && d->ystride <= 1),
+              "%s: PRN_IN_UP2_PHASE maps [H,W] to [2H,2W]", who);
+  PRN_REQUIRE(d->KH != 4 || d->in_mode == PRN_IN_ZERO, "%s: 4x4 kernels only with zero padding", who);
+  PRN_REQUIRE(d->ystride == 0 || d->ystride == 1 || (d->ystride == 2 && d->yH >= 2 * d->Ho - 1 && d->yW >= 2 * d->Wo - 1),
+              "%s: ystride 2 needs a [yH,yW] plane that holds the strided output", who);
   PRN_REQUIRE(d->in_mode != PRN_IN_DILATED || d->dil == 2, "%s: only dilation 2 is implemented", who);
   PRN_REQUIRE((d->in_mode != PRN_IN_REFLECT && d->in_mode != PRN_IN_UP2_REFLECT) || (d->pad == 1 && d->stride == 1 && d->KH == 3),
               "%s: reflect modes need a 3x3 stride-1 pad-1 conv", who);
   PRN_REQUIRE(d->KH != 7 || d->in_mode == PRN_IN_ZERO || d->in_mode == PRN_IN_DILATED, "%s: 7x7 kernels only with zero padding", who);
   // operands are addressed through buffer descriptors with 31-bit byte offsets
   PRN_REQUIRE((int64_t)d->B * d->C * d->H * d->W < (1LL << 29) && (int64_t)d->B * d->M * d->Ho * d->Wo < (1LL << 29) &&
-              ((int64_t)d->M + 128) * d->C * d->KH * d->KW < (1LL << 29), "%s: tensor larger than 2 GiB", who);
+              ((int64_t)d->M + 128) * d->C * d->KH * d->KW < (1LL << 29) && (int64_t)d->B * d->M * (d->yH > 0 ? d->yH : 1) * (d->yW > 0 ? d->yW : 1) < (1LL << 29),
+              "%s: tensor larger than 2 GiB", who);
   return 0;
+}
+
+// GEMM-side geometry of a descriptor: the pixel grid the N dimension runs over, phases, and whether K may be split
+struct Geo { int gH, gW, phases; bool nosplit; };
+Geo geo_of(const prn_conv_desc* d) {
+  Geo g;
+  g.phases = d->in_mode == PRN_IN_UP2_PHASE ? 4 : 1;
+  g.gH = g.phases == 4 ? d->H : d->Ho;
+  g.gW = g.phases == 4 ? d->W : d->Wo;
+  g.nosplit = g.phases == 4 || d->ystride == 2;      // the split workspace holds dense [B,M,Ho,Wo] partials only
+  return g;
 }
 
 }  // namespace
 
 extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
-  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * d->Ho * d->Wo, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode));
+  const Geo g = geo_of(d);
+  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit);
   return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
 
@@ -743,21 +783,29 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
   ConvArgs a;
   a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.y = y; a.ws = (float*)ws;
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
-  a.Ho = d->Ho; a.Wo = d->Wo; a.epi = d->epilogue;
-  a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
+  const Geo g = geo_of(d);
+  a.Ho = g.gH; a.Wo = g.gW; a.epi = d->epilogue;
+  a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
   a.xbytes = d->B * d->C * d->H * d->W * 4; a.wbytes = d->M * a.K * 4;
-  const FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode));
+  a.ystride = 1; a.yW = g.gW; a.yHW = a.HoWo;
+  if (g.phases == 4) { a.ystride = 2; a.yW = d->Wo; a.yHW = d->Ho * d->Wo; }
+  else if (d->ystride == 2) { a.ystride = 2; a.yW = d->yW; a.yHW = d->yH * d->yW; }
+  const FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit);
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
   const int mode = d->in_mode;
   if (d->KH == 1) {
     PRN_REQUIRE(mode == PRN_IN_ZERO || mode == PRN_IN_DILATED, "prn_conv2d_fwd: 1x1 kernels take zero or dilated input mode");
     if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st); else launch_fwd<1, PRN_IN_DILATED>(a, p, st);
+  } else if (d->KH == 2) {
+    launch_fwd<2, PRN_IN_UP2_PHASE>(a, p, st, 4);
   } else if (d->KH == 3) {
     if (mode == PRN_IN_ZERO) launch_fwd<3, PRN_IN_ZERO>(a, p, st);
     else if (mode == PRN_IN_REFLECT) launch_fwd<3, PRN_IN_REFLECT>(a, p, st);
     else if (mode == PRN_IN_UP2_REFLECT) launch_fwd<3, PRN_IN_UP2_REFLECT>(a, p, st);
     else launch_fwd<3, PRN_IN_DILATED>(a, p, st);
+  } else if (d->KH == 4) {
+    launch_fwd<4, PRN_IN_ZERO>(a, p, st);
   } else {
     if (mode == PRN_IN_ZERO) launch_fwd<7, PRN_IN_ZERO>(a, p, st); else launch_fwd<7, PRN_IN_DILATED>(a, p, st);
   }
@@ -774,21 +822,23 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
 extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_wgrad_ws_bytes")) return -1;
   const int K = d->C * d->KH * d->KW;
-  WgPlan p = plan_wgrad(d->M, K, (int64_t)d->B * d->Ho * d->Wo);
-  return p.splits > 1 ? (int64_t)p.splits * d->M * K * 4 : 0;
+  const Geo g = geo_of(d);
+  WgPlan p = plan_wgrad(d->M, K, (int64_t)d->B * g.gH * g.gW, g.phases);
+  return p.splits > 1 ? (int64_t)p.splits * g.phases * d->M * K * 4 : 0;
 }
 
 extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream) {
   if (int e = check_desc(d, "prn_conv2d_wgrad")) return e;
-  PRN_REQUIRE(d->in_mode != PRN_IN_DILATED, "prn_conv2d_wgrad: dilated input mode is a dgrad-only mode");
+  PRN_REQUIRE(d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->ystride <= 1, "prn_conv2d_wgrad: dgrad-only descriptor (dilated input, 4x4, strided output)");
   PRN_REQUIRE(x && dy && dw, "prn_conv2d_wgrad: null tensor");
   WgArgs a;
   a.x = x; a.dy = dy;
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
-  a.Ho = d->Ho; a.Wo = d->Wo;
-  a.K = d->C * d->KH * d->KW; a.N = d->B * d->Ho * d->Wo; a.HoWo = d->Ho * d->Wo; a.HW = d->H * d->W;
-  a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * d->Ho * d->Wo * 4;
-  WgPlan p = plan_wgrad(a.M, a.K, a.N);
+  const Geo g = geo_of(d);
+  a.Ho = g.gH; a.Wo = g.gW;
+  a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
+  a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * a.HoWo * 4;
+  WgPlan p = plan_wgrad(a.M, a.K, a.N, g.phases);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;
@@ -797,6 +847,8 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
   if (d->KH == 1) {
     PRN_REQUIRE(mode == PRN_IN_ZERO, "prn_conv2d_wgrad: 1x1 kernels take zero input mode");
     launch_wgrad<1, PRN_IN_ZERO>(a, p, st);
+  } else if (d->KH == 2) {
+    launch_wgrad<2, PRN_IN_UP2_PHASE>(a, p, st, 4);
   } else if (d->KH == 3) {
     if (mode == PRN_IN_ZERO) launch_wgrad<3, PRN_IN_ZERO>(a, p, st);
     else if (mode == PRN_IN_REFLECT) launch_wgrad<3, PRN_IN_REFLECT>(a, p, st);
@@ -806,7 +858,7 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
   }
   PRN_CHECK_LAUNCH("prn_conv2d_wgrad");
   if (p.splits > 1) {
-    const int64_t n = (int64_t)a.M * a.K;
+    const int64_t n = (int64_t)g.phases * a.M * a.K;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
     PRN_CHECK_LAUNCH("prn_conv2d_wgrad/reduce");
   }

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib, profiling
-from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
+from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
 OVERLAP_WGRAD = bool(int(os.environ.get("PRN_OVERLAP_WGRAD", "0")))         # (measured: no gain at B=8 -- 119.1 vs 116.6 ms/step -- the extra stream traffic costs host time) backward: weight-gradient kernels on a side stream, concurrent with the data-gradient kernel
@@ -53,14 +53,14 @@ def _c(t):
 _DESC = {}        # (shape key) -> (ConvDesc, byref, fwd workspace bytes, wgrad workspace bytes): built once per distinct launch shape
 
 
-def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE):
-    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, ystride=0, yH=0, yW=0):
+    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW)
     e = _DESC.get(key)
     if e is None:
-        d = ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi)
+        d = ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW)
         ref = ctypes.byref(d)
         fb = lib.prn_conv2d_fwd_ws_bytes(ref)
-        wb = lib.prn_conv2d_wgrad_ws_bytes(ref) if mode != IN_DILATED else 0
+        wb = lib.prn_conv2d_wgrad_ws_bytes(ref) if (mode != IN_DILATED and K != 4 and ystride <= 1) else 0
         if fb < 0 or wb < 0:
             raise RuntimeError(lib.prn_last_error().decode())
         e = _DESC[key] = (d, ref, fb, wb)
@@ -76,10 +76,15 @@ def _out_hw(H, W, K, stride, pad, mode):
 
 
 # ------------------------------------------------------------------------------------------ raw launches
-def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE):
+def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None):
+    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor."""
     B, C, H, W = x.shape
-    y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
-    _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+    if scatter2 is None:
+        y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
+        _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+    else:
+        y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
+        _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
@@ -93,10 +98,14 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
 
 def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     B, C, H, W = x.shape
-    Ho, Wo = dy.shape[2:]
+    if mode == IN_UP2_PHASE:                                 # dy: phase-major [4, B, M, H, W]; dw: [4, M, C, 2, 2]
+        Ho, Wo = 2 * H, 2 * W
+        dw = torch.empty(4, M, C, 2, 2, device=x.device, dtype=torch.float32)
+    else:
+        Ho, Wo = dy.shape[2:]
+        dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
     _, ref, _, nbytes = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-    dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
     if profiling._enabled:
         with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo):
             check(lib.prn_conv2d_wgrad(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
@@ -182,6 +191,10 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
         return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W)
     if stride != 2:
         raise RuntimeError("conv dgrad: stride %d not implemented" % stride)
+    if K == 1 and pad == 0 and addend is None:
+        # only the even positions of dx are non-zero: run the GEMM over dy's own pixel grid and scatter (4x fewer MACs
+        # than gathering through the zero-dilated view)
+        return conv_fwd_raw(dy, wt, None, None, C, 1, 1, 0, dy.shape[2], dy.shape[3], scatter2=(H, W))
     return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W, IN_DILATED, 2)
 
 
@@ -242,8 +255,56 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, da, None, None, None, None, None
 
 
+class _ConvUp2(torch.autograd.Function):
+    """Upsample(x2, nearest) -> ReflectionPad2d(1) -> Conv3x3 in its sub-pixel form (include/prn.h: PRN_IN_UP2_PHASE):
+    four 2x2 convolutions of the source map instead of one 3x3 convolution of the upsampled one (2.25x fewer MACs in
+    forward, input gradient and weight gradient alike)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _dev(x, w, bias)
+        x, w, bias = _c(x), _c(w), _c(bias)
+        B, C, H, W = x.shape
+        M = w.shape[0]
+        assert w.shape[1:] == (C, 3, 3), (x.shape, w.shape)
+        wp = torch.empty(4, M, C, 2, 2, device=x.device, dtype=torch.float32)
+        check(lib.prn_up2_phase_weights(_p(w), _p(wp), M, C, _stream()), "prn_up2_phase_weights")
+        y = conv_fwd_raw(x, wp, bias, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        B, C, H, W = x.shape
+        M = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            kd = torch.empty(C, M, 4, 4, device=x.device, dtype=torch.float32)
+            check(lib.prn_up2_dgrad_weights(_p(w), _p(kd), M, C, _stream()), "prn_up2_dgrad_weights")
+            dp = conv_fwd_raw(dy, kd, None, None, C, 4, 2, 3, H + 2, W + 2)           # gradient of the replicate-padded source
+            dx = torch.empty_like(x)
+            check(lib.prn_replicate_fold(_p(dp), _p(dx), B, C, H, W, _stream()), "prn_replicate_fold")
+        if ctx.needs_input_grad[1]:
+            dyp = torch.empty(4, B, M, H, W, device=x.device, dtype=torch.float32)
+            check(lib.prn_space_to_depth2(_p(dy), _p(dyp), B, M, H, W, _stream()), "prn_space_to_depth2")
+            dwp = conv_wgrad_raw(x, dyp, M, 2, 1, 0, IN_UP2_PHASE)
+            dw = torch.empty_like(w)
+            check(lib.prn_up2_wgrad_combine(_p(dwp), _p(dw), M, C, _stream()), "prn_up2_wgrad_combine")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = channel_sum(dy)
+        return dx, dw, db
+
+
+UP2_SUBPIXEL = bool(int(os.environ.get("PRN_UP2_SUBPIXEL", "1")))      # 0: the PRN_IN_UP2_REFLECT gather at output resolution
+
+
 def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
     """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list)."""
+    if in_mode == IN_UP2_REFLECT and UP2_SUBPIXEL and epilogue == EPI_NONE and addend is None and x.shape[2] > 1 and x.shape[3] > 1:
+        return _ConvUp2.apply(x, w, bias)
     return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue)
 
 

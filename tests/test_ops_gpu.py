@@ -59,6 +59,9 @@ CONV_CASES = [
     (2, 20, 10, 14, 27, 3, 1, 1, 0, True, True, 0),
     (1, 128, 12, 16, 300, 1, 1, 0, 0, True, False, 2),
     (1, 64, 24, 32, 1, 3, 1, 1, 1, True, False, 0),
+    (2, 24, 15, 21, 40, 1, 2, 0, 0, False, False, 0),        # stride-2 1x1 on odd sizes (scatter-form input gradient)
+    (2, 130, 9, 13, 70, 3, 1, 1, 2, True, False, 0),         # nearest-x2 + reflect + 3x3, sub-pixel form, ragged tiles
+    (1, 16, 2, 2, 8, 3, 1, 1, 2, False, False, 0),           # ... smallest map it accepts
 ]
 
 
@@ -86,6 +89,28 @@ def test_conv2d_fwd_bwd(case):
     names = ["dx", "dw"] + (["db"] if has_b else []) + (["dadd"] if has_a else [])
     for name, g1, g0 in zip(names, gd, gr):
         close(g1, g0, "conv " + name)
+
+
+def test_up2_subpixel_form_matches_gather_form():
+    """PRN_IN_UP2_PHASE (four 2x2 phase convolutions of the source) against PRN_IN_UP2_REFLECT (3x3 gather on the upsampled
+    map): same operator, both in fp32 on the GPU -- forward and all three gradients."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, 48, 11, 14, seed=1).float().to(d)
+    w = rnd(36, 48, 3, 3, seed=2, scale=(48 * 9) ** -0.5).float().to(d)
+    b = rnd(36, seed=3).float().to(d)
+    go = rnd(2, 36, 22, 28, seed=4).float().to(d)
+    outs = []
+    for sub in (True, False):
+        ops.UP2_SUBPIXEL = sub
+        try:
+            ts = [t.clone().requires_grad_(True) for t in (x, w, b)]
+            y = ops.conv2d(ts[0], ts[1], ts[2], 1, 1, ops.IN_UP2_REFLECT)
+            outs.append([y] + list(torch.autograd.grad(y, ts, go)))
+        finally:
+            ops.UP2_SUBPIXEL = True
+    for name, a, r in zip(["y", "dx", "dw", "db"], outs[0], outs[1]):
+        close(a, r.double().cpu(), "up2 subpixel vs gather " + name, rtol=2e-5)
 
 
 def test_conv2d_is_transpose_safe():
