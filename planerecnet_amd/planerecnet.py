@@ -12,6 +12,8 @@ arithmetic goes through planerecnet_amd.ops (HIP).  Differences in *how* (never 
     linear per pixel, the resize weights sum to one and all inputs are detached.  The [B,3728,120,160] tensor
     (286 MB/image) is never formed; see DESIGN.md for the accounting of executed vs reference FLOPs.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -85,7 +87,7 @@ class PlaneRecNet(nn.Module):
             feats = self.fpn([enc[i] for i in self.fpn_indices])
         with timer.env("instance head"):
             ins_feats = self.split_feats([feats[f] for f in range(len(self.instance_in_features))])
-            cate_pred, kernel_pred = self.inst_head(ins_feats)
+            cate_pred, kernel_pred = self.inst_head(ins_feats)            # five levels on five streams (ops.run_branches)
         with timer.env("mask head"):
             mask_pred = self.mask_head([feats[f] for f in range(len(self.mask_in_features))])
         with timer.env("depth_decoder"):
@@ -227,18 +229,26 @@ class SOLOv2InsHead(nn.Module):
             x = _conv_gn_relu(x, mods[i], mods[i + 1])
         return x
 
+    def _level(self, idx, feat):
+        kf = torch.cat([feat, _coord_channels(feat)], 1)
+        g = self.num_grids[idx]
+        kf = ops.resize_bilinear(kf, (g, g))
+        cf = kf[:, :-2]
+        kf = self._tower(self.kernel_tower, kf)
+        kp = ops.conv2d(kf, self.kernel_pred.weight, self.kernel_pred.bias, pad=1)
+        cf = self._tower(self.cate_tower, cf)
+        return ops.conv2d(cf, self.cate_pred.weight, self.cate_pred.bias, pad=1), kp
+
+    def branches(self, features):
+        """One closure per level (independent chains; see ops.run_branches)."""
+        return [lambda i=i, f=f: self._level(i, f) for i, f in enumerate(features)]
+
+    @staticmethod
+    def gather(outs):
+        return [o[0] for o in outs], [o[1] for o in outs]
+
     def forward(self, features):
-        cate_pred, kernel_pred = [], []
-        for idx, feat in enumerate(features):
-            kf = torch.cat([feat, _coord_channels(feat)], 1)
-            g = self.num_grids[idx]
-            kf = ops.resize_bilinear(kf, (g, g))
-            cf = kf[:, :-2]
-            kf = self._tower(self.kernel_tower, kf)
-            kernel_pred.append(ops.conv2d(kf, self.kernel_pred.weight, self.kernel_pred.bias, pad=1))
-            cf = self._tower(self.cate_tower, cf)
-            cate_pred.append(ops.conv2d(cf, self.cate_pred.weight, self.cate_pred.bias, pad=1))
-        return cate_pred, kernel_pred
+        return self.gather(ops.run_branches(self.branches(features)))
 
 
 class SOLOv2MaskHead(nn.Module):
@@ -275,15 +285,25 @@ class SOLOv2MaskHead(nn.Module):
                 x = ops.resize_bilinear(x, (2 * x.shape[2], 2 * x.shape[3]))
         return x
 
-    def forward(self, features):
+    def _branch(self, i, f):
+        if i == 3:
+            f = torch.cat([f, _coord_channels(f)], 1)
+        return self._level(i, f)
+
+    def branches(self, features):
         assert len(features) == self.num_levels
-        acc = self._level(0, features[0])
-        for i in range(1, self.num_levels):
-            f = features[i]
-            if i == 3:
-                f = torch.cat([f, _coord_channels(f)], 1)
-            acc = acc + self._level(i, f)
+        return [lambda i=i, f=f: self._branch(i, f) for i, f in enumerate(features)]
+
+    def gather(self, levels):
+        acc = levels[0]
+        for l in levels[1:]:
+            acc = acc + l
         return _conv_gn_relu(acc, self.conv_pred[0], self.conv_pred[1])
+
+    def forward(self, features):
+        # (sequential on purpose: putting these four chains, or the decoder's lateral branches, on streams of their own
+        # next to the instance head's measured no gain -- 85.7 off / 84.9 instance head only / 85.7 with these too)
+        return self.gather([b() for b in self.branches(features)])
 
 
 class DepthDecoder_FPN(nn.Module):
@@ -344,14 +364,22 @@ class DepthDecoder_FPN(nn.Module):
         c = self.conv1x1[0]
         return ops.conv2d(pooled, c.weight, c.bias)
 
-    def forward(self, feature_maps, seg_preds, kernel_preds):
-        prior = self.plane_prior(seg_preds, kernel_preds)
+    def branches(self, feature_maps):
+        """The parts of the decoder that only read backbone features: the deepest chain up to deconv1 and the three
+        lateral -> conv branches."""
         c2, c3, c4, c5 = feature_maps
         lat = lambda m, f: ops.conv2d(f, m.weight, m.bias)
-        x = self._cbr(self.deconv1, self._cbr(self.conv1, lat(self.latlayer1, c5)))
+        return [lambda: self._cbr(self.deconv1, self._cbr(self.conv1, lat(self.latlayer1, c5))),
+                lambda: self._cbr(self.conv2, lat(self.latlayer2, c4)),
+                lambda: self._cbr(self.conv3, lat(self.latlayer3, c3)),
+                lambda: self._cbr(self.conv4, lat(self.latlayer4, c2))]
+
+    def forward(self, feature_maps, seg_preds, kernel_preds):
+        prior = self.plane_prior(seg_preds, kernel_preds)
+        x, l2, l3, l4 = [b() for b in self.branches(feature_maps)]
         x = self._cbr(self.refine_conv, torch.cat([x, x * prior], 1))
-        x = self._cbr(self.deconv2, torch.cat([self._cbr(self.conv2, lat(self.latlayer2, c4)), x], 1))
-        x = self._cbr(self.deconv3, torch.cat([self._cbr(self.conv3, lat(self.latlayer3, c3)), x], 1))
-        x = self._cbr(self.deconv4, torch.cat([self._cbr(self.conv4, lat(self.latlayer4, c2)), x], 1))
+        x = self._cbr(self.deconv2, torch.cat([l2, x], 1))
+        x = self._cbr(self.deconv3, torch.cat([l3, x], 1))
+        x = self._cbr(self.deconv4, torch.cat([l4, x], 1))
         c = self.depth_pred[1]
         return F.softplus(ops.conv2d(x, c.weight, c.bias, pad=1, in_mode=ops.IN_REFLECT))
