@@ -131,8 +131,9 @@ int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const flo
                      float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps, float momentum,
                      int relu, void* stream);
 /* backward (training statistics). g = dy * (y>0 if relu). Outputs dx, dgamma, dbeta and, if dres != NULL, dres = g.
- * ws: 2*C*PRN_BN_SPLITS doubles. */
-int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+ * y may be NULL for a ReLU layer WITHOUT residual: the sign of the forward output is then recomputed from x, the statistics
+ * and gamma / beta (same fused multiply-add as the forward), which saves reading y in both passes.  ws: 2*C*PRN_BN_SPLITS doubles. */
+int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma, const float* beta,
                float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
                int B, int C, int HW, int relu, int frozen, void* stream);
 

@@ -457,7 +457,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
-// y = epi( sum_s ws[s] + bias[m] + addend ) for split-K launches (fixed summation order)
+// y = epi( sum_s ws[s] + bias[m] + addend ) for split-K launches (fixed summation order).
+// (Folding this into the GEMM kernel -- last workgroup to arrive at a per-tile counter sums the partials -- was tried and is
+// 4x SLOWER on MI355X: the release/acquire pair it needs is a device-scope __threadfence(), which writes back and
+// invalidates the XCD's whole L2 because the eight L2s are not coherent with each other; 57 -> 257 us on 1x1 1024->256.)
 __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                const float* __restrict__ addend, float* __restrict__ y, int64_t total,
                                                                int M, int HoWo, int splits, int epi) {

@@ -119,14 +119,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     float4* yp = reinterpret_cast<float4*>(y + base);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
       float4 v = xp[i];
-      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
       if (rp) { const float4 r = rp[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       yp[i] = v;
     }
   } else {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
-      float v = x[base + i] * sc + sh;
+      float v = fmaf(x[base + i], sc, sh);
       if (res) v += res[base + i];
       if (relu) v = fmaxf(v, 0.f);
       y[base + i] = v;
@@ -137,12 +137,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // partial sums of g and g*xhat, g = dy * (y > 0 if relu)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y, const float* __restrict__ stats,
-                                                             double* __restrict__ ws, int B, int C, int HW, int relu) {
+                                                             double* __restrict__ ws, int B, int C, int HW, int relu, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta) {
+  // relu: 0 none | 1 mask = (y > 0) read from the forward output | 2 mask recomputed as fmaf(x, sc, sh) > 0 (the forward's
+  // own expression; BN + ReLU without a residual), which saves the y read in both backward passes
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const bool vec = (HW & 3) == 0;
   int beg, end;
   slice_bounds(HW, s, S, vec, beg, end);
   const float mean = stats[c], istd = stats[C + c];
+  const float sc = relu == 2 ? istd * gamma[c] : 0.f, sh = relu == 2 ? beta[c] - mean * sc : 0.f;
   float s1 = 0.f, s2 = 0.f;
   for (int b = 0; b < B; ++b) {
     const size_t base = ((size_t)b * C + c) * HW;
@@ -150,9 +154,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       for (int p = beg + threadIdx.x * 4; p < end; p += 1024) {
         float4 g = *reinterpret_cast<const float4*>(dy + base + p);
         const float4 xv = *reinterpret_cast<const float4*>(x + base + p);
-        if (relu) {
+        if (relu == 1) {
           const float4 yv = *reinterpret_cast<const float4*>(y + base + p);
           g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        } else if (relu == 2) {
+          g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+          g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
         }
         s1 += (g.x + g.y) + (g.z + g.w);
         s2 += (g.x * (xv.x - mean) + g.y * (xv.y - mean)) + (g.z * (xv.z - mean) + g.w * (xv.w - mean));
@@ -160,7 +167,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     } else {
       for (int p = beg + threadIdx.x; p < end; p += 256) {
         float g = dy[base + p];
-        if (relu && !(y[base + p] > 0.f)) g = 0.f;
+        if (relu == 1 && !(y[base + p] > 0.f)) g = 0.f;
+        if (relu == 2 && !(fmaf(x[base + p], sc, sh) > 0.f)) g = 0.f;
         s1 += g; s2 += g * (x[base + p] - mean);
       }
     }
@@ -178,9 +186,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const double* __restrict__ ws,
                                                            float* __restrict__ dx, float* __restrict__ dres, int C, int HW,
                                                            int S, float inv_count, int relu, int frozen, int have_partials,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           const float* __restrict__ beta) {
   const int bc = blockIdx.y, c = bc % C;
   const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
+  const float sc = relu == 2 ? gi : 0.f, sh = relu == 2 ? beta[c] - mean * sc : 0.f;     // (see bn_bwd_partial_kernel)
   double t1 = 0.0, t2 = 0.0;                      // every block sums its channel's fixed-order partials (no finalize launch)
   if (have_partials)
     for (int s = 0; s < S; ++s) { t1 += ws[((size_t)c * S + s) * 2]; t2 += ws[((size_t)c * S + s) * 2 + 1]; }
@@ -196,9 +206,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
       float4 g = reinterpret_cast<const float4*>(dy + base)[i];
       const float4 xv = reinterpret_cast<const float4*>(x + base)[i];
-      if (relu) {
+      if (relu == 1) {
         const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      } else if (relu == 2) {
+        g.x = fmaf(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sc, sh) > 0.f ? g.w : 0.f;
       }
       if (dres) reinterpret_cast<float4*>(dres + base)[i] = g;
       float4 o;
@@ -210,7 +223,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     float g = dy[base + i];
-    if (relu && !(y[base + i] > 0.f)) g = 0.f;
+    if (relu == 1 && !(y[base + i] > 0.f)) g = 0.f;
+    if (relu == 2 && !(fmaf(x[base + i], sc, sh) > 0.f)) g = 0.f;
     if (dres) dres[base + i] = g;
     const float xh = (x[base + i] - mean) * istd;
     dx[base + i] = gi * (g - m1 - xh * m2);
@@ -333,23 +347,24 @@ extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma
   return 0;
 }
 
-extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma, const float* beta,
                           float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
                           int B, int C, int HW, int relu, int frozen, void* stream) {
   PRN_REQUIRE(dy && x && stats && gamma && dx && ws && B > 0 && C > 0 && HW > 0, "prn_bn_bwd: bad arguments");
-  PRN_REQUIRE(!relu || y, "prn_bn_bwd: relu needs the forward output");
+  PRN_REQUIRE(!relu || y || (beta && !dres), "prn_bn_bwd: relu needs the forward output, or beta (and no residual) to recompute its sign");
+  if (relu) relu = y ? 1 : 2;
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_bwd: B*C too large for grid.y");
   hipStream_t st = (hipStream_t)stream;
   const int S = bn_splits(B, HW);
   const int have = (!frozen || dgamma || dbeta) ? 1 : 0;
   if (have) {
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu, gamma, beta);
     PRN_CHECK_LAUNCH("prn_bn_bwd/partial");
   }
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, st, dy, x, y, stats, gamma, (const double*)ws, dx, dres, C, HW,
-                     S, 1.f / ((float)B * HW), relu, frozen, have, dgamma, dbeta);
+                     S, 1.f / ((float)B * HW), relu, frozen, have, dgamma, dbeta, beta);
   PRN_CHECK_LAUNCH("prn_bn_bwd/apply");
   return 0;
 }

@@ -484,13 +484,14 @@ class _BatchNorm(torch.autograd.Function):
             stats = torch.cat([rmean, torch.rsqrt(rvar + eps)])
             with profiling.span("bn_apply", "hbm", 4.0 * x.numel() * (3 if residual is not None else 2)):
                 check(lib.prn_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), B, C, HW, int(relu), _stream()), "prn_bn_apply")
-        ctx.save_for_backward(x, y if relu else None, stats, gamma)
+        # the ReLU mask is re-derived from x in the backward unless a residual was added (then the output's sign is needed)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, stats, gamma, beta)
         ctx.cfg = (training, relu, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, stats, gamma = ctx.saved_tensors
+        x, y, stats, gamma, beta = ctx.saved_tensors
         training, relu, has_res = ctx.cfg
         dy = _c(dy)
         B, C, H, W = x.shape
@@ -501,7 +502,7 @@ class _BatchNorm(torch.autograd.Function):
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
         with profiling.span("bn_bwd", "hbm", 4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
-            check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
+            check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
                                  B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
         return dx, dg, db, None, None, dres, None, None, None, None
 
