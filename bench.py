@@ -193,11 +193,13 @@ def main():
     if rank == 0 and not args.no_roofline:
         if graphed:
             raise SystemExit("bench.py: the roofline leg needs eagerly issued launches; combine --graph with --no-roofline")
+        branch_streams, ops.BRANCH_STREAMS = ops.BRANCH_STREAMS, False      # one stream: an event pair then times one launch, not its neighbours
         profiling.enable()
         step()
         torch.cuda.synchronize()
         fams = profiling.summary()
         profiling.disable()
+        ops.BRANCH_STREAMS = branch_streams
         kernels = fams
         dom = max((f for f in fams if f["bound"] == "mfma"), key=lambda f: f["time_ms"])
         roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -62,6 +62,10 @@ typedef struct prn_conv_desc {
 int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
+/* The same call issued in parts, so that a profiler can bracket the GEMM launch and the split-K reduction separately:
+ * phase 0 = everything (== prn_conv2d_fwd), 1 = GEMM launch only, 2 = reduction + epilogue only (no-op without a K split). */
+int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
+                         const float* addend, float* y, void* ws, void* stream, int phase);
 
 /* wt[c][m][KH-1-r][KW-1-s] = w[m][c][r][s]   (operand layout for dgrad-as-forward) */
 int prn_weight_flip_transpose(const float* w, float* wt, int M, int C, int KH, int KW, void* stream);
@@ -81,6 +85,7 @@ int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_item
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
 int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream);
+int prn_conv2d_wgrad_phase(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase);
 
 /* --- sub-pixel form of Upsample(x2, nearest) -> ReflectionPad2d(1) -> Conv3x3 (planerecnet.py:540-566), see PRN_IN_UP2_PHASE.
  * wp [4][M][C][2][2]: per-phase sums of the 3x3 taps of w [M][C][3][3]. */

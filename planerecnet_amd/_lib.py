@@ -29,6 +29,8 @@ SIGNATURES = {
     "prn_last_error": (ctypes.c_char_p, []),
     "prn_conv2d_fwd_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_fwd": (c_int, [_DP, P, P, P, P, P, P, P]),
+    "prn_conv2d_fwd_phase": (c_int, [_DP, P, P, P, P, P, P, P, c_int]),
+    "prn_conv2d_wgrad_phase": (c_int, [_DP, P, P, P, P, P, c_int]),
     "prn_weight_flip_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_weight_flip_transpose_batched": (c_int, [P, c_int, c_i64, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),

@@ -687,6 +687,9 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1) {
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
   p.wm = 2;
+  static int ftm = -1, ftj = 0;            // PRN_WGRAD_TILE="tm,tj" overrides the tile (tuning sweeps)
+  if (ftm < 0) { ftm = 0; if (const char* e = getenv("PRN_WGRAD_TILE")) sscanf(e, "%d,%d", &ftm, &ftj); }
+  if (ftm > 0) { p.tm = M > 32 ? ftm : 1; p.tj = K > 32 ? ftj : 1; }
   if (M <= 32 && K > 64) { p.wm = 1; p.tm = 1; p.tj = 1; }          // 32 x 128 tile
   p.tilesM = cdiv(M, 32 * p.wm * p.tm);
   p.tilesJ = cdiv(K, 32 * (4 / p.wm) * p.tj);
@@ -781,6 +784,11 @@ extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
 
 extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* addend, float* y, void* ws, void* stream) {
+  return prn_conv2d_fwd_phase(d, x, w, bias, addend, y, ws, stream, 0);
+}
+
+extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
+                                    const float* addend, float* y, void* ws, void* stream, int phase) {
   if (int e = check_desc(d, "prn_conv2d_fwd")) return e;
   PRN_REQUIRE(x && w && y, "prn_conv2d_fwd: null tensor");
   ConvArgs a;
@@ -797,6 +805,7 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
   const int mode = d->in_mode;
+  if (phase == 2) goto reduce_only;
   if (d->KH == 1) {
     PRN_REQUIRE(mode == PRN_IN_ZERO || mode == PRN_IN_DILATED, "prn_conv2d_fwd: 1x1 kernels take zero or dilated input mode");
     if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st); else launch_fwd<1, PRN_IN_DILATED>(a, p, st);
@@ -813,6 +822,8 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
     if (mode == PRN_IN_ZERO) launch_fwd<7, PRN_IN_ZERO>(a, p, st); else launch_fwd<7, PRN_IN_DILATED>(a, p, st);
   }
   PRN_CHECK_LAUNCH("prn_conv2d_fwd");
+  if (phase == 1) return 0;
+reduce_only:
   if (p.splits > 1) {
     const int64_t total = (int64_t)a.B * a.M * a.HoWo;
     hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, (const float*)ws, bias, addend, y, total, a.M, a.HoWo,
@@ -831,6 +842,10 @@ extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
 }
 
 extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream) {
+  return prn_conv2d_wgrad_phase(d, x, dy, dw, ws, stream, 0);
+}
+
+extern "C" int prn_conv2d_wgrad_phase(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase) {
   if (int e = check_desc(d, "prn_conv2d_wgrad")) return e;
   PRN_REQUIRE(d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->ystride <= 1, "prn_conv2d_wgrad: dgrad-only descriptor (dilated input, 4x4, strided output)");
   PRN_REQUIRE(x && dy && dw, "prn_conv2d_wgrad: null tensor");
@@ -847,6 +862,7 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
   a.out = p.splits > 1 ? (float*)ws : dw;
   hipStream_t st = (hipStream_t)stream;
   const int mode = d->in_mode;
+  if (phase == 2) goto reduce_only;
   if (d->KH == 1) {
     PRN_REQUIRE(mode == PRN_IN_ZERO, "prn_conv2d_wgrad: 1x1 kernels take zero input mode");
     launch_wgrad<1, PRN_IN_ZERO>(a, p, st);
@@ -860,6 +876,8 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
     launch_wgrad<7, PRN_IN_ZERO>(a, p, st);
   }
   PRN_CHECK_LAUNCH("prn_conv2d_wgrad");
+  if (phase == 1) return 0;
+reduce_only:
   if (p.splits > 1) {
     const int64_t n = (int64_t)g.phases * a.M * a.K;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);

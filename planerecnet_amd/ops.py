@@ -128,7 +128,10 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
         # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
         with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)):
-            check(lib.prn_conv2d_fwd(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
+            check(lib.prn_conv2d_fwd_phase(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream(), 1), "prn_conv2d_fwd")
+        if nbytes:
+            with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
+                check(lib.prn_conv2d_fwd_phase(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream(), 2), "prn_conv2d_fwd")
     else:
         check(lib.prn_conv2d_fwd(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
     return y
@@ -146,7 +149,10 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     if profiling._enabled:
         with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo):
-            check(lib.prn_conv2d_wgrad(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
+            check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_conv2d_wgrad")
+        if nbytes:
+            with profiling.span("reduce_splits_kernel", "hbm", float(nbytes) + 4.0 * dw.numel()):
+                check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 2), "prn_conv2d_wgrad")
     else:
         check(lib.prn_conv2d_wgrad(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
     return dw
