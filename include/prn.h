@@ -62,6 +62,21 @@ typedef struct prn_conv_desc {
 int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
+/* Ragged batch: `nseg` dense tensors [B, C, H[s], W[s]] stored back to back, convolved with the SAME weights as one
+ * GEMM over all their pixels (SOLOv2 applies its instance-head towers to five grid sizes, planerecnet.py:337-360).  Output
+ * and addend are packed the same way with M channels.  Stride-1 "same" 1x1 / 3x3 convolutions with zero padding; desc->H,
+ * W, Ho, Wo are ignored.  Every segment must hold a multiple of 64 pixels (B*H*W) for the forward / input-gradient call and
+ * a multiple of 16 (and H*W % 4 == 0) for the weight gradient; otherwise the call fails and the caller loops over segments. */
+typedef struct prn_ragged {
+  int32_t nseg;            /* 1..6 */
+  int32_t H[6], W[6];
+} prn_ragged;
+int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias,
+                          const float* addend, float* y, void* stream);
+int64_t prn_conv2d_wgrad_ragged_ws_bytes(const prn_conv_desc* d, const prn_ragged* rg);
+int prn_conv2d_wgrad_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws,
+                            void* stream);
+
 /* The same call issued in parts, so that a profiler can bracket the GEMM launch and the split-K reduction separately:
  * phase 0 = everything (== prn_conv2d_fwd), 1 = GEMM launch only, 2 = reduction + epilogue only (no-op without a K split). */
 int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -149,6 +164,13 @@ int prn_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float
 int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
                     float* dx, float* dgamma_part /*[B*C]*/, float* dbeta_part /*[B*C]*/,
                     int B, int C, int HW, int G, void* stream);
+/* The same on a ragged batch: nseg dense [B, C, hw[s]] tensors stored back to back (see prn_ragged); statistics are per
+ * (segment, image, group): stats [nseg][B][G][2], dgamma_part / dbeta_part [nseg][B][C]. */
+int prn_gn_relu_fwd_ragged(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                           int B, int C, int nseg, const int* hw, int G, float eps, void* stream);
+int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+                           float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int nseg, const int* hw, int G,
+                           void* stream);
 
 /* ---- resampling ---------------------------------------------------------------------------------------------------
  * bilinear, align_corners=False (F.interpolate / nn.Upsample): models/fpn.py:54 ; planerecnet.py:115,381,439,453,594 ;

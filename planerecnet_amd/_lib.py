@@ -18,6 +18,11 @@ class ConvDesc(ctypes.Structure):
                 ("B", "C", "H", "W", "M", "KH", "KW", "stride", "pad", "Ho", "Wo", "in_mode", "dil", "epilogue", "ystride", "yH", "yW")]
 
 
+class Ragged(ctypes.Structure):
+    """mirror of prn_ragged"""
+    _fields_ = [("nseg", ctypes.c_int32), ("H", ctypes.c_int32 * 6), ("W", ctypes.c_int32 * 6)]
+
+
 IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE = 0, 1, 2, 3, 4
 EPI_NONE, EPI_RELU, EPI_SIGMOID = 0, 1, 2
 BN_SPLITS = 32
@@ -29,6 +34,11 @@ SIGNATURES = {
     "prn_last_error": (ctypes.c_char_p, []),
     "prn_conv2d_fwd_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_fwd": (c_int, [_DP, P, P, P, P, P, P, P]),
+    "prn_conv2d_fwd_ragged": (c_int, [_DP, P, P, P, P, P, P, P]),
+    "prn_conv2d_wgrad_ragged_ws_bytes": (c_i64, [_DP, P]),
+    "prn_conv2d_wgrad_ragged": (c_int, [_DP, P, P, P, P, P, P]),
+    "prn_gn_relu_fwd_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, c_int, c_float, P]),
+    "prn_gn_relu_bwd_ragged": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P]),
     "prn_conv2d_fwd_phase": (c_int, [_DP, P, P, P, P, P, P, P, c_int]),
     "prn_conv2d_wgrad_phase": (c_int, [_DP, P, P, P, P, P, c_int]),
     "prn_weight_flip_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -10,6 +10,7 @@
 // through LDS in 16-deep K slices, double buffered, with the next slice's global loads in flight during the
 // MFMA loop.  LDS rows that are read "down a column" by the MFMA operand pattern use a 17-float pitch, which
 // makes the 32-lane-group reads conflict-free.
+#include <stddef.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "prn_common.h"
@@ -18,6 +19,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// Ragged batches: up to 6 segments, each a dense [B, C, H_s, W_s] tensor, stored back to back (the five SOLO grid levels
+// run through the same weights).  The GEMM's pixel axis is the concatenation of all segments' pixels; a tile / pixel chunk
+// never straddles two segments (host-side alignment check), so a workgroup looks its segment up once (scalar code) and then
+// works on plain dense geometry.
+constexpr int MAX_SEG = 6;
+struct Seg {
+  int nseg;                 // 0: dense tensor
+  int n0[MAX_SEG + 1];      // first pixel of segment s on the GEMM's pixel axis; n0[nseg] = total
+  int H[MAX_SEG], W[MAX_SEG];
+  int x0[MAX_SEG], y0[MAX_SEG];   // element offsets of the segment inside the packed input / output tensor
+};
+__device__ __forceinline__ int seg_find(const Seg& g, int n) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < MAX_SEG; ++t)
+    if (t < g.nseg && n >= g.n0[t]) s = t;
+  return s;
+}
+// Entry `s` of one of the table's arrays, read straight from the kernel-argument segment with a scalar load (the table is
+// the last member of the single by-value kernel argument).  Indexing the by-value copy dynamically, or overwriting fields
+// of it, made hipcc spill the whole argument struct to scratch and wrap the gathers in waterfall loops (84 -> 117 ms/step).
+template <class Args>
+__device__ __forceinline__ int seg_read(size_t member_offset, int s) {
+  typedef __attribute__((address_space(4))) const int* kptr;
+  kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  return base[(offsetof(Args, seg) + member_offset) / 4 + s];
+}
+#define SEG_READ(Args, member, s) seg_read<Args>(offsetof(Seg, member), s)
+
 struct ConvArgs {
   const float* x; const float* w; const float* bias; const float* addend; float* y;
   int B, C, H, W, M, stride, pad, Ho, Wo, epi;
@@ -25,6 +55,7 @@ struct ConvArgs {
   int xbytes, wbytes;
   int ystride, yW, yHW;     // output map: GEMM pixel (oh, ow) is stored at (oh*ystride + phase_y, ow*ystride + phase_x) of a yHW plane
   float* ws;
+  Seg seg;
 };
 
 // Operand fetches go through buffer descriptors: a lane whose element does not exist (padding, tile tails) carries the
@@ -105,38 +136,58 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
-  const int m0 = (id % a.tilesM) * BM, n0 = (id / a.tilesM) * BN;
+  const int m0 = (id % a.tilesM) * BM;
+  int n0 = (id / a.tilesM) * BN;
+  // geometry of the tensor this workgroup works on: the descriptor's, or its segment's in a ragged batch
+  int H_ = a.H, W_ = a.W, HW_ = a.HW, Ho_ = a.Ho, Wo_ = a.Wo, HoWo_ = a.HoWo, N_ = a.N, xbytes_ = a.xbytes;
+  const float* x_ = a.x;
+  const float* add_ = a.addend;
+  float* y_ = a.y;
+  if (a.seg.nseg > 0) {
+    const int sg = seg_find(a.seg, n0);
+    H_ = Ho_ = SEG_READ(ConvArgs, H, sg);
+    W_ = Wo_ = SEG_READ(ConvArgs, W, sg);
+    HW_ = HoWo_ = H_ * W_;
+    const int yo = SEG_READ(ConvArgs, y0, sg);
+    x_ += SEG_READ(ConvArgs, x0, sg);
+    y_ += yo;
+    if (add_) add_ += yo;
+    xbytes_ = a.B * a.C * HW_ * 4;
+    N_ = a.B * HoWo_;
+    n0 -= SEG_READ(ConvArgs, n0, sg);
+  }
+  (void)Ho_;
 
   // PRN_IN_UP2_PHASE: blockIdx.z = output phase (py, px); each phase has its own [M x 4C] weight matrix, reads the 2x2
   // source window starting at (i + py - 1, j + px - 1) and stores to (2i + py, 2j + px)
   const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
   const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
   const float* wz = (MODE == PRN_IN_UP2_PHASE) ? a.w + (size_t)blockIdx.z * a.M * a.K : a.w;
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), wr = make_rsrc(wz, a.wbytes);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(x_, xbytes_), wr = make_rsrc(wz, a.wbytes);
 
   // pixel owned by this thread in the B (im2col) operand; its K rows are wave-uniform
   const int nl = tid % BN;
   // K row of this thread inside a sweep: wave-uniform (-> SGPR address math) when a wave spans one row of the tile
   const int krow0 = (BN >= 64) ? __builtin_amdgcn_readfirstlane(tid / BN) : tid / BN;
   const int n = n0 + nl;
-  const bool nvalid = n < a.N;
+  const bool nvalid = n < N_;
   int b = 0, oh = 0, ow = 0;
   if (nvalid) {
-    b = n / a.HoWo;
-    const int p = n - b * a.HoWo;
-    oh = p / a.Wo;
-    ow = p - oh * a.Wo;
+    b = n / HoWo_;
+    const int p = n - b * HoWo_;
+    oh = p / Wo_;
+    ow = p - oh * Wo_;
   }
   const int ih0 = oh * a.stride - pad_y, iw0 = ow * a.stride - pad_x;
-  const int pix0 = b * a.C * a.HW;                      // element offset of this pixel's image
-  unsigned off1 = OOB;                                   // byte offsets (or OOB) relative to a.x, channel 0
+  const int pix0 = b * a.C * HW_;                      // element offset of this pixel's image
+  unsigned off1 = OOB;                                   // byte offsets (or OOB) relative to x_, channel 0
   if (KS == 1) {
-    const int o = tap_offset<MODE>(ih0, iw0, nvalid, a.H, a.W);
+    const int o = tap_offset<MODE>(ih0, iw0, nvalid, H_, W_);
     off1 = o >= 0 ? (unsigned)(pix0 + o) * 4u : OOB;
   } else {
     for (int t = krow0; t < KK; t += KSTEP) {
       const int r = t / KS, s = t - r * KS;
-      const int o = tap_offset<MODE>(ih0 + r, iw0 + s, nvalid, a.H, a.W);
+      const int o = tap_offset<MODE>(ih0 + r, iw0 + s, nvalid, H_, W_);
       taps[t * BN + nl] = o >= 0 ? (unsigned)(pix0 + o) * 4u : OOB;
     }
     __syncthreads();
@@ -157,9 +208,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   unsigned vbase = OOB;
   if (VEC) {
     const int nv = n0 + vg * 4;
-    if (nv < a.N) {
-      const int bv = nv / a.HoWo;
-      vbase = (unsigned)((bv * a.C + vrow0) * a.HW + (nv - bv * a.HoWo)) * 4u;
+    if (nv < N_) {
+      const int bv = nv / HoWo_;
+      vbase = (unsigned)((bv * a.C + vrow0) * HW_ + (nv - bv * HoWo_)) * 4u;
     }
   }
 
@@ -198,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
 #pragma unroll
         for (int i = 0; i < NBV; ++i) {
           const int kr = k0 + i * VROWS;                         // + vrow0 is folded into vbase
-          rv[i] = bload4(xr, (kr + vrow0 < a.K) ? vbase : OOB, kr * a.HW * 4);
+          rv[i] = bload4(xr, (kr + vrow0 < a.K) ? vbase : OOB, kr * HW_ * 4);
         }
       } else {
 #pragma unroll
@@ -206,8 +257,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
           const int kr = k0 + krow0 + i * KSTEP;               // wave-uniform when BN >= 64
           const int c = kr / KK, rs = kr - c * KK;
           const unsigned off = (KS == 1) ? off1 : taps[rs * BN + nl];
-          if (BN >= 64) rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off : OOB, c * a.HW * 4);
-          else rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off + (unsigned)(c * a.HW * 4) : OOB, 0);   // (OOB + channel offset stays >= 2^31)
+          if (BN >= 64) rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off : OOB, c * HW_ * 4);
+          else rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off + (unsigned)(c * HW_ * 4) : OOB, 0);   // (OOB + channel offset stays >= 2^31)
         }
       }
     };
@@ -260,19 +311,19 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   // epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel).
   // Uniform decisions (split partial / bias / addend / activation / interior tile) are hoisted out of the element loops.
   const bool partial = a.splits > 1;
-  float* __restrict__ outp = partial ? a.ws + (size_t)blockIdx.y * a.B * a.M * a.HoWo : a.y;
-  const bool has_bias = !partial && a.bias != nullptr, has_add = !partial && a.addend != nullptr;
+  float* __restrict__ outp = partial ? a.ws + (size_t)blockIdx.y * a.B * a.M * HoWo_ : y_;
+  const bool has_bias = !partial && a.bias != nullptr, has_add = !partial && add_ != nullptr;
   const int epi = partial ? PRN_EPI_NONE : a.epi;
-  const bool interior = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  const bool interior = (m0 + BM <= a.M) && (n0 + BN <= N_);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nn = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    if (!interior && nn >= a.N) continue;
-    const int bb = nn / a.HoWo, p = nn - bb * a.HoWo;
-    size_t base = (size_t)bb * a.M * a.HoWo + p;
-    size_t mstride = a.HoWo;
+    if (!interior && nn >= N_) continue;
+    const int bb = nn / HoWo_, p = nn - bb * HoWo_;
+    size_t base = (size_t)bb * a.M * HoWo_ + p;
+    size_t mstride = HoWo_;
     if (a.ystride != 1) {                               // strided / phase-interleaved output plane (never with a K split)
-      const int qh = p / a.Wo, qw = p - qh * a.Wo;
+      const int qh = p / Wo_, qw = p - qh * Wo_;
       mstride = a.yHW;
       base = (size_t)bb * a.M * a.yHW + (size_t)(qh * a.ystride + py) * a.yW + qw * a.ystride + px;
     }
@@ -286,7 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
         const size_t idx = base + (size_t)m * mstride;
         float v = acc[i][j][r];
         if (has_bias) v += a.bias[m];
-        if (has_add) v += a.addend[idx];
+        if (has_add) v += add_[idx];
         if (epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
         else if (epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + __expf(-v));
         outp[idx] = v;
@@ -301,10 +352,11 @@ struct WgArgs {
   int B, C, H, W, M, stride, pad, Ho, Wo;
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
   int xbytes, dybytes;       // dybytes: one phase of dy
+  Seg seg;
 };
 
-template <int KS, int MODE, int TM, int TJ, int WM = 2>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+template <int KS, int MODE, int TM, int TJ, int WM = 2, bool RAG = false>      // RAG: ragged-batch instance (keeps the dense ones at 152 VGPRs)
+__global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad_kernel(WgArgs a) {
   constexpr int WJ = 4 / WM;                     // WM = 1: 32 x 128 tile for <= 32 output channels (see conv_igemm_kernel)
   constexpr int BM = 32 * WM * TM, BJ = 32 * WJ * TJ, LD = 17, KK = KS * KS;
   constexpr int NBJ = BJ / 16;
@@ -320,9 +372,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
   const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
   const float* dyz = a.dy + (size_t)blockIdx.z * (a.dybytes / 4);
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
+  int H_ = a.H, W_ = a.W, HW_ = a.HW, Ho_ = a.Ho, Wo_ = a.Wo, HoWo_ = a.HoWo, N_ = a.N;     // current segment's geometry (ragged) / the tensor's
+  __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
   const int arow = tid >> 2, anq = (tid & 3) * 4;
-  const bool n4 = ((a.HoWo & 3) == 0) && ((reinterpret_cast<uintptr_t>(dyz) & 15) == 0);
+  const bool n4 = ((HoWo_ & 3) == 0 || a.seg.nseg > 0) && ((reinterpret_cast<uintptr_t>(dyz) & 15) == 0);   // (ragged: host checked every segment)
   const int nl = tid & 15, jrow = tid >> 4;
   int jcoff[NBJ], jr[NBJ], js[NBJ];
   bool jok[NBJ];
@@ -331,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const int j = j0 + jrow + 16 * i;
     const int c = j / KK, rs = j - c * KK;
     jok[i] = j < a.K;
-    jcoff[i] = jok[i] ? c * a.HW : 0;
+    jcoff[i] = jok[i] ? c * HW_ : 0;
     jr[i] = rs / KS;
     js[i] = rs - jr[i] * KS;
   }
@@ -350,56 +403,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 
   // pixel cursors of this thread (dY column group and im2col pixel), advanced by 16 pixels per chunk -- no divisions in the loop
   int a_b, a_p, g_b, g_oh, g_ow;
-  {
-    const int n = cbeg * 16 + anq;
-    a_b = n / a.HoWo; a_p = n - a_b * a.HoWo;
-    const int g = cbeg * 16 + nl;
-    g_b = g / a.HoWo;
-    const int p = g - g_b * a.HoWo;
-    g_oh = p / a.Wo; g_ow = p - g_oh * a.Wo;
-  }
+  int nbase = 0, nend = N_;                              // pixel range of the current segment on the GEMM's pixel axis
+  auto enter = [&](int ch) {                              // (re)initialise geometry and cursors at chunk `ch`
+    if (RAG) {
+      const int sg = seg_find(a.seg, ch * 16);
+      H_ = Ho_ = SEG_READ(WgArgs, H, sg);
+      W_ = Wo_ = SEG_READ(WgArgs, W, sg);
+      HW_ = HoWo_ = H_ * W_;
+      nbase = SEG_READ(WgArgs, n0, sg);
+      N_ = a.B * HoWo_;
+      nend = nbase + N_;
+      xr = make_rsrc(a.x + SEG_READ(WgArgs, x0, sg), a.B * a.C * HW_ * 4);
+      dyr = make_rsrc(dyz + SEG_READ(WgArgs, y0, sg), a.B * a.M * HoWo_ * 4);
+#pragma unroll
+      for (int i = 0; i < NBJ; ++i) jcoff[i] = jok[i] ? ((j0 + jrow + 16 * i) / KK) * HW_ : 0;
+    }
+    const int n = ch * 16 - nbase + anq;
+    a_b = n / HoWo_; a_p = n - a_b * HoWo_;
+    const int g = ch * 16 - nbase + nl;
+    g_b = g / HoWo_;
+    const int p = g - g_b * HoWo_;
+    g_oh = p / Wo_; g_ow = p - g_oh * Wo_;
+  };
+  enter(cbeg);
   // every fetch is a buffer load whose offset is OOB (-> 0.0) for elements that do not exist; nothing depends on the
   // loaded values until store_chunk, so the loads overlap the MFMA loop of the previous chunk.  N4 is a compile-time
   // tag and the last chunk is peeled (branch-free loop body, see conv_igemm_kernel).
   auto run = [&](auto n4tag) {
     constexpr bool N4 = decltype(n4tag)::value;
     auto load_chunk = [&](int ch) {
+      if (RAG && ch * 16 >= nend) enter(ch);              // ragged batch: next segment (uniform, a handful of times per workgroup)
       {  // dY rows: 4 consecutive pixels of one output channel
-        const int n = ch * 16 + anq;
+        const int n = ch * 16 - nbase + anq;
         if (N4) {
-          const bool ok = n < a.N;
-          const unsigned base = (unsigned)((a_b * a.M + m0 + arow) * a.HoWo + a_p) * 4u;
+          const bool ok = n < N_;
+          const unsigned base = (unsigned)((a_b * a.M + m0 + arow) * HoWo_ + a_p) * 4u;
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const float4 v = bload4(dyr, (ok && mok[i]) ? base : OOB, i * 64 * a.HoWo * 4);
+            const float4 v = bload4(dyr, (ok && mok[i]) ? base : OOB, i * 64 * HoWo_ * 4);
             ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
           }
         } else {
           int qb = a_b, qp = a_p;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const bool ok = n + q < a.N;
-            const unsigned base = (unsigned)((qb * a.M + m0 + arow) * a.HoWo + qp) * 4u;
+            const bool ok = n + q < N_;
+            const unsigned base = (unsigned)((qb * a.M + m0 + arow) * HoWo_ + qp) * 4u;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) ra[i][q] = bload(dyr, (ok && mok[i]) ? base : OOB, i * 64 * a.HoWo * 4);
-            if (++qp >= a.HoWo) { qp = 0; ++qb; }
+            for (int i = 0; i < TM; ++i) ra[i][q] = bload(dyr, (ok && mok[i]) ? base : OOB, i * 64 * HoWo_ * 4);
+            if (++qp >= HoWo_) { qp = 0; ++qb; }
           }
         }
         a_p += 16;
-        while (a_p >= a.HoWo) { a_p -= a.HoWo; ++a_b; }
+        while (a_p >= HoWo_) { a_p -= HoWo_; ++a_b; }
       }
       {  // im2col rows
-        const bool ok = ch * 16 + nl < a.N;
+        const bool ok = ch * 16 - nbase + nl < N_;
         const int ih0 = g_oh * a.stride - pad_y, iw0 = g_ow * a.stride - pad_x;
-        const int pix0 = g_b * a.C * a.HW;
+        const int pix0 = g_b * a.C * HW_;
 #pragma unroll
         for (int i = 0; i < NBJ; ++i) {
-          const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], ok && jok[i], a.H, a.W);
+          const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], ok && jok[i], H_, W_);
           rb[i] = bload(xr, off >= 0 ? (unsigned)(pix0 + jcoff[i] + off) * 4u : OOB, 0);
         }
         g_ow += 16;
-        while (g_ow >= a.Wo) { g_ow -= a.Wo; ++g_oh; }
-        while (g_oh >= a.Ho) { g_oh -= a.Ho; ++g_b; }
+        while (g_ow >= Wo_) { g_ow -= Wo_; ++g_oh; }
+        while (g_oh >= Ho_) { g_oh -= Ho_; ++g_b; }
       }
     };
     auto store_chunk = [&](int buf) {
@@ -664,7 +733,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
     }
   }
   if constexpr (KS == 1 && MODE == PRN_IN_ZERO) {
-    const bool vec = a.stride == 1 && a.pad == 0 && (a.HW & 3) == 0 && a.HW == a.HoWo && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+    const bool vec = a.seg.nseg == 0 && a.stride == 1 && a.pad == 0 && (a.HW & 3) == 0 && a.HW == a.HoWo && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
     if (vec) {
       if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 2, 2, 16, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 1, 1, 16, true>), grid, block, 0, st, a);
@@ -682,7 +751,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
 }
 
 struct WgPlan { int tm, tj, tilesM, tilesJ, splits, chunks, wm; };
-WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1) {
+WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false) {
   WgPlan p;
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
@@ -691,6 +760,9 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1) {
   if (ftm < 0) { ftm = 0; if (const char* e = getenv("PRN_WGRAD_TILE")) sscanf(e, "%d,%d", &ftm, &ftj); }
   if (ftm > 0) { p.tm = M > 32 ? ftm : 1; p.tj = K > 32 ? ftj : 1; }
   if (M <= 32 && K > 64) { p.wm = 1; p.tm = 1; p.tj = 1; }          // 32 x 128 tile
+  if (ragged) {                                                      // ragged batches: the two instantiated tiles only
+    if (M <= 32) { p.wm = 1; p.tm = 1; p.tj = 1; } else { p.wm = 2; p.tm = 2; p.tj = 2; }
+  }
   p.tilesM = cdiv(M, 32 * p.wm * p.tm);
   p.tilesJ = cdiv(K, 32 * (4 / p.wm) * p.tj);
   p.chunks = cdiv(N, 16);
@@ -731,6 +803,13 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1) {
 template <int KS, int MODE>
 int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st, int phases = 1) {
   dim3 grid(p.tilesM * p.tilesJ, p.splits, phases), block(256);
+  if constexpr ((KS == 1 || KS == 3) && MODE == PRN_IN_ZERO) {
+    if (a.seg.nseg > 0) {                                  // plan_wgrad(..., ragged) only hands out these two tiles
+      if (p.wm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1, 1, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 2, 2, true>), grid, block, 0, st, a);
+      return 0;
+    }
+  }
   if (p.wm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1, 1>), grid, block, 0, st, a);
   else if (p.tm == 2 && p.tj == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 2>), grid, block, 0, st, a);
   else if (p.tm == 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 2, 1>), grid, block, 0, st, a);
@@ -787,8 +866,58 @@ extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const floa
   return prn_conv2d_fwd_phase(d, x, w, bias, addend, y, ws, stream, 0);
 }
 
+namespace {
+// Segment table of a ragged batch (nullptr / nseg 0: dense).  `align` = pixels per tile / chunk that must not straddle segments.
+int fill_seg(Seg& sg, const prn_ragged* rg, const prn_conv_desc* d, int align, const char* who) {
+  sg.nseg = 0;
+  if (rg == nullptr) return 0;
+  PRN_REQUIRE(rg->nseg >= 1 && rg->nseg <= MAX_SEG, "%s: 1..%d segments", who, MAX_SEG);
+  PRN_REQUIRE(d->in_mode == PRN_IN_ZERO && d->stride == 1 && (d->KH == 1 || d->KH == 3) && d->pad == (d->KH - 1) / 2 && d->ystride <= 1,
+              "%s: ragged batches take stride-1 'same' 1x1 / 3x3 convolutions with zero padding", who);
+  int64_t n = 0, xo = 0, yo = 0;
+  for (int s = 0; s < rg->nseg; ++s) {
+    const int H = rg->H[s], W = rg->W[s];
+    PRN_REQUIRE(H > 0 && W > 0, "%s: empty segment", who);
+    PRN_REQUIRE(n % align == 0, "%s: segment %d starts at pixel %lld, not a multiple of %d", who, s, (long long)n, align);
+    sg.n0[s] = (int)n; sg.H[s] = H; sg.W[s] = W; sg.x0[s] = (int)xo; sg.y0[s] = (int)yo;
+    n += (int64_t)d->B * H * W;
+    xo += (int64_t)d->B * d->C * H * W;
+    yo += (int64_t)d->B * d->M * H * W;
+  }
+  PRN_REQUIRE(n % align == 0 && n < (1LL << 31) && xo < (1LL << 29) && yo < (1LL << 29), "%s: ragged batch too large or unaligned", who);
+  for (int s = rg->nseg; s <= MAX_SEG; ++s) sg.n0[s] = (int)n;
+  sg.nseg = rg->nseg;
+  return 0;
+}
+int64_t seg_pixels(const prn_ragged* rg, int B) {
+  int64_t n = 0;
+  for (int s = 0; s < rg->nseg; ++s) n += (int64_t)B * rg->H[s] * rg->W[s];
+  return n;
+}
+int conv_fwd_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias, const float* addend, float* y,
+                  void* ws, void* stream, int phase);
+int conv_wgrad_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase);
+}  // namespace
+
 extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                                     const float* addend, float* y, void* ws, void* stream, int phase) {
+  return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase);
+}
+
+extern "C" int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias,
+                                     const float* addend, float* y, void* stream) {
+  PRN_REQUIRE(rg != nullptr, "prn_conv2d_fwd_ragged: null segment list");
+  return conv_fwd_impl(d, rg, x, w, bias, addend, y, nullptr, stream, 0);
+}
+
+namespace {
+int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x, const float* w, const float* bias, const float* addend, float* y,
+                  void* ws, void* stream, int phase) {
+  prn_conv_desc dd;
+  const prn_conv_desc* d = d0;
+  if (rg && d0) {                                       // geometry fields of the descriptor are per segment: validate with the first one
+    dd = *d0; dd.H = dd.Ho = rg->H[0]; dd.W = dd.Wo = rg->W[0]; d = &dd;
+  }
   if (int e = check_desc(d, "prn_conv2d_fwd")) return e;
   PRN_REQUIRE(x && w && y, "prn_conv2d_fwd: null tensor");
   ConvArgs a;
@@ -801,7 +930,18 @@ extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, cons
   a.ystride = 1; a.yW = g.gW; a.yHW = a.HoWo;
   if (g.phases == 4) { a.ystride = 2; a.yW = d->Wo; a.yHW = d->Ho * d->Wo; }
   else if (d->ystride == 2) { a.ystride = 2; a.yW = d->yW; a.yHW = d->yH * d->yW; }
-  const FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit);
+  if (rg) a.N = (int)seg_pixels(rg, d->B);
+  FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit || rg != nullptr);
+  if (rg) {                                             // tiles must not straddle segments: fall back from 128 to 64 pixels per tile
+    int bn = 32 * p.wn * p.tn;
+    bool ok = true;
+    int64_t n = 0;
+    for (int sI = 0; sI < rg->nseg; ++sI) { ok = ok && n % bn == 0; n += (int64_t)d->B * rg->H[sI] * rg->W[sI]; }
+    if (!(ok && n % bn == 0) && !(p.tm == 1 && p.tn == 1 && p.wm == 2)) { p.tm = 1; p.tn = 1; p.wm = 2; p.wn = 2; }
+    if (int e = fill_seg(a.seg, rg, d, 32 * p.wn * p.tn, "prn_conv2d_fwd_ragged")) return e;
+  } else {
+    a.seg.nseg = 0;
+  }
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
   const int mode = d->in_mode;
@@ -832,6 +972,7 @@ reduce_only:
   }
   return 0;
 }
+}  // namespace
 
 extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_wgrad_ws_bytes")) return -1;
@@ -846,6 +987,27 @@ extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const fl
 }
 
 extern "C" int prn_conv2d_wgrad_phase(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase) {
+  return conv_wgrad_impl(d, nullptr, x, dy, dw, ws, stream, phase);
+}
+
+extern "C" int64_t prn_conv2d_wgrad_ragged_ws_bytes(const prn_conv_desc* d, const prn_ragged* rg) {
+  if (d == nullptr || rg == nullptr || rg->nseg < 1 || rg->nseg > MAX_SEG) return -1;
+  const int K = d->C * d->KH * d->KW;
+  WgPlan p = plan_wgrad(d->M, K, seg_pixels(rg, d->B), 1, true);
+  return p.splits > 1 ? (int64_t)p.splits * d->M * K * 4 : 0;
+}
+
+extern "C" int prn_conv2d_wgrad_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws,
+                                       void* stream) {
+  PRN_REQUIRE(rg != nullptr, "prn_conv2d_wgrad_ragged: null segment list");
+  return conv_wgrad_impl(d, rg, x, dy, dw, ws, stream, 0);
+}
+
+namespace {
+int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase) {
+  prn_conv_desc dd;
+  const prn_conv_desc* d = d0;
+  if (rg && d0) { dd = *d0; dd.H = dd.Ho = rg->H[0]; dd.W = dd.Wo = rg->W[0]; d = &dd; }
   if (int e = check_desc(d, "prn_conv2d_wgrad")) return e;
   PRN_REQUIRE(d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->ystride <= 1, "prn_conv2d_wgrad: dgrad-only descriptor (dilated input, 4x4, strided output)");
   PRN_REQUIRE(x && dy && dw, "prn_conv2d_wgrad: null tensor");
@@ -856,7 +1018,13 @@ extern "C" int prn_conv2d_wgrad_phase(const prn_conv_desc* d, const float* x, co
   a.Ho = g.gH; a.Wo = g.gW;
   a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
   a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * a.HoWo * 4;
-  WgPlan p = plan_wgrad(a.M, a.K, a.N, g.phases);
+  a.seg.nseg = 0;
+  if (rg) {
+    a.N = (int)seg_pixels(rg, d->B);
+    if (int e = fill_seg(a.seg, rg, d, 16, "prn_conv2d_wgrad_ragged")) return e;
+    for (int sI = 0; sI < rg->nseg; ++sI) PRN_REQUIRE((rg->H[sI] * rg->W[sI]) % 4 == 0, "prn_conv2d_wgrad_ragged: segment planes must be multiples of 4 pixels");
+  }
+  WgPlan p = plan_wgrad(a.M, a.K, a.N, g.phases, rg != nullptr);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;
@@ -885,6 +1053,7 @@ reduce_only:
   }
   return 0;
 }
+}  // namespace
 
 extern "C" int prn_weight_flip_transpose(const float* w, float* wt, int M, int C, int KH, int KW, void* stream) {
   PRN_REQUIRE(w && wt && M > 0 && C > 0 && KH > 0 && KW > 0, "prn_weight_flip_transpose: bad arguments");

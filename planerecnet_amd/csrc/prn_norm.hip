@@ -233,10 +233,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------- GroupNorm
 // one block per (b, group): pass 1 statistics, pass 2 normalise + affine + ReLU (second read is L2-resident)
+// Ragged batch (nseg > 0): segment s is a dense [B, C, hw[s]] tensor at element offset off[s]; block -> (segment, image, group)
+struct GnSeg { int nseg; int hw[6]; int off[6]; };
+__device__ __forceinline__ int gn_seg_get(const int (&v)[6], int s) {
+  int r = v[0];
+#pragma unroll
+  for (int t = 1; t < 6; ++t)
+    if (s == t) r = v[t];
+  return r;
+}
+
 __global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
-                                                          float* __restrict__ stats, int C, int HW, int G, float eps) {
-  const int bg = blockIdx.x, g = bg % G, cpg = C / G;
+                                                          float* __restrict__ stats, int C, int HW, int G, float eps, int BG, GnSeg sg) {
+  int bg = blockIdx.x;
+  if (sg.nseg > 0) {
+    const int sI = bg / BG;
+    bg -= sI * BG;
+    HW = gn_seg_get(sg.hw, sI);
+    const int off = gn_seg_get(sg.off, sI);
+    x += off; y += off; stats += (size_t)sI * BG * 2;
+  }
+  const int g = bg % G, cpg = C / G;
   const int b = bg / G;
   const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
   const int n = cpg * HW;
@@ -260,8 +278,18 @@ __global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ y, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, float* __restrict__ dx,
-                                                          float* __restrict__ dgp, float* __restrict__ dbp, int C, int HW, int G) {
-  const int bg = blockIdx.x, g = bg % G, cpg = C / G, b = bg / G;
+                                                          float* __restrict__ dgp, float* __restrict__ dbp, int C, int HW, int G, int BG,
+                                                          GnSeg sg) {
+  int bg = blockIdx.x;
+  if (sg.nseg > 0) {
+    const int sI = bg / BG;
+    bg -= sI * BG;
+    HW = gn_seg_get(sg.hw, sI);
+    const int off = gn_seg_get(sg.off, sI);
+    dy += off; x += off; y += off; dx += off; stats += (size_t)sI * BG * 2;
+    dgp += (size_t)sI * (BG / G) * C; dbp += (size_t)sI * (BG / G) * C;
+  }
+  const int g = bg % G, cpg = C / G, b = bg / G;
   const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
   const float mu = stats[bg * 2], istd = stats[bg * 2 + 1];
   __shared__ double sm[16];
@@ -372,15 +400,53 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
 extern "C" int prn_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                                int B, int C, int HW, int G, float eps, void* stream) {
   PRN_REQUIRE(x && gamma && beta && y && stats && B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "prn_gn_relu_fwd: bad arguments");
-  hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, y, stats, C, HW, G, eps);
+  GnSeg sg; sg.nseg = 0;
+  hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, y, stats, C, HW, G, eps, B * G, sg);
   PRN_CHECK_LAUNCH("prn_gn_relu_fwd");
+  return 0;
+}
+
+static int gn_fill_seg(GnSeg& sg, int B, int C, int nseg, const int* hw) {
+  PRN_REQUIRE(nseg >= 1 && nseg <= 6 && hw, "prn_gn_relu_*_ragged: 1..6 segments");
+  int64_t off = 0;
+  for (int s = 0; s < nseg; ++s) {
+    PRN_REQUIRE(hw[s] > 0, "prn_gn_relu_*_ragged: empty segment");
+    sg.hw[s] = hw[s]; sg.off[s] = (int)off;
+    off += (int64_t)B * C * hw[s];
+  }
+  PRN_REQUIRE(off < (1LL << 31), "prn_gn_relu_*_ragged: batch too large");
+  sg.nseg = nseg;
+  return 0;
+}
+
+extern "C" int prn_gn_relu_fwd_ragged(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                      int B, int C, int nseg, const int* hw, int G, float eps, void* stream) {
+  PRN_REQUIRE(x && gamma && beta && y && stats && B > 0 && C > 0 && G > 0 && C % G == 0, "prn_gn_relu_fwd_ragged: bad arguments");
+  GnSeg sg;
+  if (int e = gn_fill_seg(sg, B, C, nseg, hw)) return e;
+  hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(nseg * B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, y, stats, C, 0, G, eps, B * G, sg);
+  PRN_CHECK_LAUNCH("prn_gn_relu_fwd_ragged");
   return 0;
 }
 
 extern "C" int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
                                float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int HW, int G, void* stream) {
   PRN_REQUIRE(dy && x && y && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd: bad arguments");
-  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, y, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G);
+  GnSeg sg; sg.nseg = 0;
+  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, y, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G,
+                     B * G, sg);
   PRN_CHECK_LAUNCH("prn_gn_relu_bwd");
+  return 0;
+}
+
+extern "C" int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+                                      float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int nseg, const int* hw, int G,
+                                      void* stream) {
+  PRN_REQUIRE(dy && x && y && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd_ragged: bad arguments");
+  GnSeg sg;
+  if (int e = gn_fill_seg(sg, B, C, nseg, hw)) return e;
+  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(nseg * B * G), dim3(512), 0, (hipStream_t)stream, dy, x, y, stats, gamma, dx, dgamma_part, dbeta_part, C, 0,
+                     G, B * G, sg);
+  PRN_CHECK_LAUNCH("prn_gn_relu_bwd_ragged");
   return 0;
 }

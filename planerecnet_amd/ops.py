@@ -552,6 +552,132 @@ def group_norm_relu(x, gamma, beta, groups=32, eps=1e-5):
     return _GroupNormReLU.apply(x, gamma, beta, groups, eps)
 
 
+# ------------------------------------------------------------------------------------------ ragged batches
+class RaggedShape:
+    """Geometry of a ragged batch: segments [B, C, H_s, W_s] stored back to back in one flat tensor (include/prn.h: prn_ragged)."""
+
+    def __init__(self, B, sizes):
+        self.B, self.sizes = int(B), [(int(h), int(w)) for h, w in sizes]
+        self.c = _lib.Ragged(len(self.sizes), (ctypes.c_int32 * 6)(*[h for h, _ in self.sizes]), (ctypes.c_int32 * 6)(*[w for _, w in self.sizes]))
+        self.ref = ctypes.byref(self.c)
+        self.hw = (ctypes.c_int32 * 6)(*[h * w for h, w in self.sizes])
+        self.pixels = sum(self.B * h * w for h, w in self.sizes)
+        self.key = (self.B, tuple(self.sizes))
+
+    def supported(self):
+        """The HIP path needs whole 64-pixel tiles / 16-pixel chunks per segment (see prn_ragged)."""
+        return len(self.sizes) <= 6 and all((self.B * h * w) % 64 == 0 and (h * w) % 4 == 0 for h, w in self.sizes)
+
+    def pack(self, tensors):
+        return torch.cat([t.reshape(-1) for t in tensors])
+
+    def unpack(self, flat, C):
+        out, o = [], 0
+        for h, w in self.sizes:
+            n = self.B * C * h * w
+            out.append(flat[o:o + n].view(self.B, C, h, w))
+            o += n
+        return out
+
+
+_RDESC = {}
+
+
+def _rdesc(rs, C, M, K, epi=EPI_NONE):
+    key = (rs.key, C, M, K, epi)
+    e = _RDESC.get(key)
+    if e is None:
+        h, w = rs.sizes[0]
+        d = ConvDesc(rs.B, C, h, w, M, K, K, 1, (K - 1) // 2, h, w, IN_ZERO, 1, epi, 0, 0, 0)
+        ref = ctypes.byref(d)
+        wb = lib.prn_conv2d_wgrad_ragged_ws_bytes(ref, rs.ref)
+        if wb < 0:
+            raise RuntimeError("prn_conv2d_wgrad_ragged_ws_bytes failed")
+        e = _RDESC[key] = (d, ref, wb)
+    return e
+
+
+def _ragged_conv_raw(xp, w, bias, addend, rs, C, M, K, epi=EPI_NONE):
+    y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
+    _, ref, _ = _rdesc(rs, C, M, K, epi)
+    with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * rs.pixels):
+        check(lib.prn_conv2d_fwd_ragged(ref, rs.ref, _p(xp), _p(w), _p(bias), _p(addend), _p(y), _stream()), "prn_conv2d_fwd_ragged")
+    return y
+
+
+class _RaggedConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, w, bias, rs):
+        _dev(xp, w, bias)
+        xp, w, bias = _c(xp), _c(w), _c(bias)
+        M, C, K, _ = w.shape
+        assert xp.numel() == rs.pixels * C, (xp.shape, w.shape, rs.sizes)
+        y = _ragged_conv_raw(xp, w, bias, None, rs, C, M, K)
+        ctx.save_for_backward(xp, w)
+        ctx.rs, ctx.has_bias = rs, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        rs = ctx.rs
+        dy = _c(dy)
+        M, C, K, _ = w.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _ragged_conv_raw(dy, flip_transpose(w), None, None, rs, M, C, K)
+        if ctx.needs_input_grad[1]:
+            _, ref, nbytes = _rdesc(rs, C, M, K)
+            ws = torch.empty(max(nbytes // 4, 1), device=xp.device, dtype=torch.float32)
+            dw = torch.empty_like(w)
+            with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * rs.pixels):
+                check(lib.prn_conv2d_wgrad_ragged(ref, rs.ref, _p(xp), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad_ragged")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.stack([t.sum((0, 2, 3)) for t in rs.unpack(dy, M)]).sum(0)
+        return dx, dw, db, None
+
+
+def ragged_conv2d(xp, w, bias, rs):
+    """Stride-1 'same' conv of every segment of the packed batch `xp` with the same weights, as ONE implicit GEMM."""
+    return _RaggedConv.apply(xp, w, bias, rs)
+
+
+class _RaggedGNReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, gamma, beta, groups, eps, rs):
+        _dev(xp, gamma, beta)
+        xp = _c(xp)
+        C = gamma.numel()
+        n = len(rs.sizes)
+        y = torch.empty_like(xp)
+        stats = torch.empty(n * rs.B * groups * 2, device=xp.device, dtype=torch.float32)
+        with profiling.span("gn_relu_fwd", "hbm", 4.0 * xp.numel() * 2):
+            check(lib.prn_gn_relu_fwd_ragged(_p(xp), _p(gamma), _p(beta), _p(y), _p(stats), rs.B, C, n, rs.hw, groups, eps, _stream()),
+                  "prn_gn_relu_fwd_ragged")
+        ctx.save_for_backward(xp, y, stats, gamma)
+        ctx.cfg = (groups, rs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, y, stats, gamma = ctx.saved_tensors
+        groups, rs = ctx.cfg
+        dy = _c(dy)
+        C = gamma.numel()
+        n = len(rs.sizes)
+        dx = torch.empty_like(xp)
+        dgp = torch.empty(n * rs.B, C, device=xp.device, dtype=torch.float32)
+        dbp = torch.empty(n * rs.B, C, device=xp.device, dtype=torch.float32)
+        with profiling.span("gn_relu_bwd", "hbm", 4.0 * xp.numel() * 4):
+            check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(y), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), rs.B, C, n, rs.hw, groups,
+                                             _stream()), "prn_gn_relu_bwd_ragged")
+        return dx, dgp.sum(0), dbp.sum(0), None, None, None
+
+
+def ragged_group_norm_relu(xp, gamma, beta, groups, eps, rs):
+    return _RaggedGNReLU.apply(xp, gamma, beta, groups, eps, rs)
+
+
 # ------------------------------------------------------------------------------------------ resampling
 class _Resize(torch.autograd.Function):
     @staticmethod

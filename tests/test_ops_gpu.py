@@ -113,6 +113,54 @@ def test_up2_subpixel_form_matches_gather_form():
         close(a, r.double().cpu(), "up2 subpixel vs gather " + name, rtol=2e-5)
 
 
+@pytest.mark.parametrize("K,C,M,bias", [(3, 40, 72, False), (3, 258, 256, False), (3, 64, 2, True), (1, 48, 40, True)])
+def test_ragged_conv_and_group_norm_match_per_segment_ops(K, C, M, bias):
+    """One GEMM over the pixels of five differently sized maps (shared weights) == the five dense convolutions; same for the
+    GroupNorm+ReLU that follows.  Forward, input gradient, weight / affine gradients."""
+    from planerecnet_amd import ops
+    d = dev()
+    B, sizes = 8, [(12, 12), (8, 8), (6, 4), (4, 4), (4, 2)]
+    rs = ops.RaggedShape(B, sizes)
+    assert rs.supported()
+    xs = [rnd(B, C, h, w, seed=10 + i).float().to(d) for i, (h, w) in enumerate(sizes)]
+    w = rnd(M, C, K, K, seed=2, scale=(C * K * K) ** -0.5).float().to(d)
+    b = rnd(M, seed=3).float().to(d) if bias else None
+    G = 2 if M % 2 == 0 else 1
+    gam, bet = (rnd(M, seed=4).float() + 1.5).to(d), rnd(M, seed=5).float().to(d)
+    gos = [rnd(B, M, h, w_, seed=20 + i).float().to(d) for i, (h, w_) in enumerate(sizes)]
+
+    def run(ragged):
+        leaves = [t.clone().requires_grad_(True) for t in xs] + [t.clone().requires_grad_(True) for t in ([w, gam, bet] + ([b] if bias else []))]
+        xl, (wl, gl, bl) = leaves[:5], leaves[5:8]
+        bb = leaves[8] if bias else None
+        # (a bias in front of a GroupNorm has a mathematically zero gradient: the biased cases test the conv alone)
+        if ragged:
+            y = ops.ragged_conv2d(rs.pack(xl), wl, bb, rs)
+            if not bias:
+                y = ops.ragged_group_norm_relu(y, gl, bl, G, 1e-5, rs)
+            loss = (y * rs.pack(gos)).sum() + 0.0 * (gl.sum() + bl.sum())
+            ys = rs.unpack(y, M)
+        else:
+            ys = [ops.conv2d(x, wl, bb, 1, (K - 1) // 2) for x in xl]
+            if not bias:
+                ys = [ops.group_norm_relu(y, gl, bl, G, 1e-5) for y in ys]
+            loss = sum((y * g).sum() for y, g in zip(ys, gos)) + 0.0 * (gl.sum() + bl.sum())
+        return ys, torch.autograd.grad(loss, leaves)
+
+    ya, ga = run(True)
+    yb, gb = run(False)
+    for i, (a, r) in enumerate(zip(ya, yb)):
+        close(a, r.double().cpu(), "ragged y[%d]" % i, rtol=2e-5)
+    for i, (a, r) in enumerate(zip(ga, gb)):
+        close(a, r.double().cpu(), "ragged grad[%d]" % i, rtol=1e-4)
+
+
+def test_ragged_shape_rejects_unaligned_segments():
+    from planerecnet_amd import ops
+    assert not ops.RaggedShape(1, [(36, 36), (24, 24)]).supported()       # 1296 pixels: not a whole number of 64-pixel tiles
+    assert ops.RaggedShape(8, [(40, 40), (36, 36), (24, 24), (16, 16), (12, 12)]).supported()
+
+
 def test_conv2d_is_transpose_safe():
     """A = I style check with asymmetric data: 1x1 conv with a permutation weight must permute channels."""
     from planerecnet_amd import ops
