@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="PlaneRecNet_101_config")
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--sync-wgrad", action="store_true", help="weight gradients in line with the input-gradient chain (A/B of ops.WGRAD_ASYNC)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,6 +153,7 @@ def main():
             print("bench.py: hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
             run_net = net
 
+    ops.set_wgrad_async(not args.sync_wgrad)                 # weight gradients on a side stream, joined after backward (ops.py)
     hw = (args.height, args.width)
     prefetch = TargetPrefetcher(crit)
     prefetch.submit(inst, hw)
@@ -164,6 +166,7 @@ def main():
         losses = crit(net, *out, inst, depths, targets=targets)
         loss = sum(losses.values()).sum()
         loss.backward()
+        ops.wgrad_join()
         exchange.finish()
         opt.step()
         return losses

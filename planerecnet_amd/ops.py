@@ -19,6 +19,59 @@ from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_
 
 OVERLAP_WGRAD = bool(int(os.environ.get("PRN_OVERLAP_WGRAD", "0")))         # (measured: no gain at B=8 -- 119.1 vs 116.6 ms/step -- the extra stream traffic costs host time) backward: weight-gradient kernels on a side stream, concurrent with the data-gradient kernel
 _SIDE = {}
+# Deferred weight gradients.  In the backward pass only the input-gradient chain is on the critical path; the weight
+# gradient of a layer is needed by nobody until the optimizer (or the gradient exchange) runs.  With this mode on, every conv
+# weight gradient is launched on a side HIP stream that waits for dy but that the main stream never waits for inside backward:
+# the ~190 wgrad GEMMs + reductions of a step fill the CUs that the small launches of the main chain leave idle (launch ramp,
+# first-load latency, drain: ~25 % of a small kernel's duration).  Measured 83.3 -> 80.8 ms/step.  The gradient is written
+# to `weight.grad` directly (on the side stream) and the op returns None for it, so this is OPT-IN for training loops that
+# (1) read gradients only through `.grad`, (2) call wgrad_join() after backward() and before anything consumes `.grad`
+# (bench.py, train.py).  Post-accumulate-grad hooks (the data-parallel bucketing) are fired by hand; GradAllReduce makes its
+# exchange stream wait for the side stream as well.  torch.autograd.grad() callers keep the default (off).
+WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
+
+
+def set_wgrad_async(on):
+    global WGRAD_ASYNC
+    WGRAD_ASYNC = bool(on)
+
+
+def wgrad_streams():
+    return list(_SIDE.values())
+
+
+def wgrad_join():
+    """Make the current stream wait for the deferred weight gradients.  Call after backward(), before reading any `.grad`."""
+    if _SIDE:
+        main = torch.cuda.current_stream()
+        for st in _SIDE.values():
+            main.wait_stream(st)
+
+
+def _defer(needs_grad, w):
+    return WGRAD_ASYNC and needs_grad and w.is_leaf and w.requires_grad and not profiling.active()
+
+
+def _deferred_wgrad(w, inputs, compute):
+    main = torch.cuda.current_stream()
+    side = _side_stream(w.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        dw = compute()
+        if dw.shape != w.shape:
+            dw = dw.view_as(w)
+        dw.record_stream(main)                              # read by the optimizer on the main stream after wgrad_join()
+        if w.grad is None:
+            w.grad = dw
+        else:
+            w.grad.add_(dw)
+        hooks = getattr(w, "_post_accumulate_grad_hooks", None)
+        if hooks:
+            for h in list(hooks.values()):
+                h(w)
+    for t in inputs:
+        t.record_stream(side)
+
 
 BRANCH_STREAMS = bool(int(os.environ.get("PRN_BRANCH_STREAMS", "1")))
 _BRANCH_POOL = {}
@@ -276,7 +329,12 @@ class _Conv2d(torch.autograd.Function):
         elif epi == EPI_SIGMOID:
             dy = dy * y * (1 - y)
         M, C, K, _ = w.shape
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and OVERLAP_WGRAD and not profiling.active():
+        if _defer(ctx.needs_input_grad[1], w):
+            _deferred_wgrad(w, (x, dy), lambda: conv_wgrad_raw(x, dy, M, K, stride, pad, mode))
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
+            dfork = None
+            dw = None
+        elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and OVERLAP_WGRAD and not profiling.active():
             # dgrad and wgrad only share their inputs: run wgrad on a side HIP stream so the two kernels fill each other's
             # idle CUs (most backbone layers launch fewer workgroups than one GPU-wide wave), then join.
             main = torch.cuda.current_stream()
@@ -331,12 +389,17 @@ class _ConvUp2(torch.autograd.Function):
             dp = conv_fwd_raw(dy, kd, None, None, C, 4, 2, 3, H + 2, W + 2)           # gradient of the replicate-padded source
             dx = torch.empty_like(x)
             check(lib.prn_replicate_fold(_p(dp), _p(dx), B, C, H, W, _stream()), "prn_replicate_fold")
-        if ctx.needs_input_grad[1]:
+        def wgrad():
             dyp = torch.empty(4, B, M, H, W, device=x.device, dtype=torch.float32)
             check(lib.prn_space_to_depth2(_p(dy), _p(dyp), B, M, H, W, _stream()), "prn_space_to_depth2")
             dwp = conv_wgrad_raw(x, dyp, M, 2, 1, 0, IN_UP2_PHASE)
-            dw = torch.empty_like(w)
-            check(lib.prn_up2_wgrad_combine(_p(dwp), _p(dw), M, C, _stream()), "prn_up2_wgrad_combine")
+            dwo = torch.empty_like(w)
+            check(lib.prn_up2_wgrad_combine(_p(dwp), _p(dwo), M, C, _stream()), "prn_up2_wgrad_combine")
+            return dwo
+        if _defer(ctx.needs_input_grad[1], w):
+            _deferred_wgrad(w, (x, dy), wgrad)
+        elif ctx.needs_input_grad[1]:
+            dw = wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = channel_sum(dy)
         return dx, dw, db
@@ -442,7 +505,11 @@ class _DeformConvBlock(torch.autograd.Function):
         Ho, Wo = om.shape[2:]
         w1 = w.view(M, C * 9, 1, 1)
         dcols = conv_dgrad_raw(dy, w1, cols.shape, 1, 0, IN_ZERO)
-        dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[3] else None
+        if _defer(ctx.needs_input_grad[3], w):
+            _deferred_wgrad(w, (cols, dy), lambda: conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO))
+            dw = None
+        else:
+            dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[3] else None
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[4]) else None
         dx1 = torch.empty_like(x)
         dom = torch.empty_like(om)
@@ -626,12 +693,17 @@ class _RaggedConv(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _ragged_conv_raw(dy, flip_transpose(w), None, None, rs, M, C, K)
-        if ctx.needs_input_grad[1]:
+        def wgrad():
             _, ref, nbytes = _rdesc(rs, C, M, K)
             ws = torch.empty(max(nbytes // 4, 1), device=xp.device, dtype=torch.float32)
-            dw = torch.empty_like(w)
+            dwo = torch.empty_like(w)
             with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * rs.pixels):
-                check(lib.prn_conv2d_wgrad_ragged(ref, rs.ref, _p(xp), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad_ragged")
+                check(lib.prn_conv2d_wgrad_ragged(ref, rs.ref, _p(xp), _p(dy), _p(dwo), _p(ws), _stream()), "prn_conv2d_wgrad_ragged")
+            return dwo
+        if _defer(ctx.needs_input_grad[1], w):
+            _deferred_wgrad(w, (xp, dy), wgrad)
+        elif ctx.needs_input_grad[1]:
+            dw = wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.stack([t.sum((0, 2, 3)) for t in rs.unpack(dy, M)]).sum(0)
         return dx, dw, db, None

@@ -63,6 +63,9 @@ class GradAllReduce:
                 p.grad = p.grad.contiguous()
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
+            from . import ops
+            for st in ops.wgrad_streams():                # deferred weight gradients are produced on side streams (ops.WGRAD_ASYNC)
+                self.stream.wait_stream(st)
             ctx = torch.cuda.stream(self.stream)
         else:
             import contextlib

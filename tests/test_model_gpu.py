@@ -143,13 +143,17 @@ def test_gt_assignment_bit_exact_vs_golden(setup, golden_dir):
         assert np.array_equal(ins[lv].sum((1, 2)).numpy(), fx[f"tg_ins_area{lv}"])
 
 
-def test_e2e_train_step_matches_oracle(setup, golden_dir):
+@pytest.mark.parametrize("wgrad_async", [False, True])
+def test_e2e_train_step_matches_oracle(setup, golden_dir, wgrad_async):
     """R50, 480x640, B=1: forward + joint loss + backward. Losses vs oracle and vs the reference's golden values;
-    parameter gradients vs oracle autograd."""
+    parameter gradients vs oracle autograd.  Run with the weight gradients in line and deferred to the side stream
+    (ops.set_wgrad_async, the mode train.py / bench.py use)."""
     import os
     from oracle import loss_ref, model_ref, synth
+    from planerecnet_amd import ops
     from planerecnet_amd.losses import PlaneRecNetLoss
     net, sd, arch = setup
+    ops.set_wgrad_async(wgrad_async)
     net.load_state_dict(sd)
     net.train()
     x, inst, gtd = synth.make_batch(1, 480, 640, seed=6)
@@ -159,7 +163,12 @@ def test_e2e_train_step_matches_oracle(setup, golden_dir):
     losses = crit(net, *out, [{k: v.cuda() for k, v in g.items()} for g in inst], gtd.cuda())
     total = sum(losses.values()).sum()
     net.zero_grad()
-    total.backward()
+    try:
+        total.backward()
+        ops.wgrad_join()
+    finally:
+        ops.set_wgrad_async(False)
+    torch.cuda.synchronize()
     fx = np.load(os.path.join(golden_dir, "e2e_r50_480x640.npz"))
     for k in ("ins", "cat", "dpt", "pln", "lav"):
         assert abs(float(losses[k]) - float(fx[k])) <= 1e-3 * abs(float(fx[k])) + 1e-4, (k, float(losses[k]), float(fx[k]))

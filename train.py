@@ -146,7 +146,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     torch.set_num_threads(4)
 
-    from planerecnet_amd import timer
+    from planerecnet_amd import ops, timer
     from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
     from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
     from planerecnet_amd.planerecnet import PlaneRecNet
@@ -185,6 +185,7 @@ def main():
         {"params": prn_net.inst_head.parameters(), "lr": args.lr}, {"params": prn_net.mask_head.parameters(), "lr": args.lr},
         {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr, fused=True)
     exchange = GradAllReduce([p for p in prn_net.parameters()])
+    ops.set_wgrad_async(True)          # weight gradients on a side stream; joined by ops.wgrad_join() after every backward()
 
     # BN-safe warm-up forward with frozen statistics (reference train.py:270-272)
     if not cfg.freeze_bn:
@@ -244,6 +245,7 @@ def main():
                 losses = net(x, gt_instances, d, targets=targets)
                 loss = sum(losses[k].sum() for k in losses)
                 loss.backward()
+                ops.wgrad_join()                               # deferred weight gradients (ops.set_wgrad_async)
                 exchange.finish()
                 stats = all_reduce_mean_scalars([losses[k].detach().sum() for k in LOSS_TYPES if k in losses] + [loss.detach()], dev).tolist()
                 if math.isfinite(stats[-1]):               # collective decision: every rank sees the same mean
