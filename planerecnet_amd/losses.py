@@ -17,6 +17,8 @@ structure is different:
     single segmented sort for the "drop the best 25 %" rule.
   * lava: sum(up4(s) * g) is evaluated as sum(s * up4^T(g)); the adjoint-resized gradient map depends only on the GT.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -34,6 +36,9 @@ def _pin(x):
 class Targets:
     """Device-resident, GT-only inputs of one loss evaluation (built by PlaneRecNetLoss.prepare)."""
     __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum")
+
+
+LOSS_STREAMS = bool(int(os.environ.get("PRN_LOSS_STREAMS", "1")))
 
 
 class PlaneRecNetLoss(nn.Module):
@@ -158,40 +163,52 @@ class PlaneRecNetLoss(nn.Module):
         fh, fw = mask_preds.shape[-2:]
         t = targets if targets is not None else self.prepare(gt_instances, gt_depths, dev, (fh, fw))
         E = kernel_preds[0].shape[1]
+
+        def instance_terms():
+            out = {}
+            # ---- ins (Dice) -- losses.py:69-118 : one dynamic conv per image over all of its positive cells
+            flat_k = torch.cat([k.reshape(B, E, -1) for k in kernel_preds], 2)                          # [B, E, 3728]
+            preds = []
+            for b in range(B):
+                if t.n_pos[b] == 0:
+                    continue
+                w = flat_k[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
+                preds.append(ops.conv2d(mask_preds[b:b + 1], w).view(t.n_pos[b], fh, fw))
+            ins_sig = torch.sigmoid(torch.cat(preds, 0))                                                # [sum n_pos, fh, fw]
+            out["ins"] = dice_loss(ins_sig, t.ins_labels).mean() * self.ins_loss_weight
+            # ---- lav -- losses.py:169-197 : sum(up(s) * g) / (sum(g) * n)  ==  sum(s * up^T(g)) / (sum(g) * n)
+            if cfg.use_lava_loss:
+                seg, npos = t.pos_img, t.n_pos_dev
+                num = torch.zeros(B, device=dev, dtype=ins_sig.dtype).index_add_(0, seg, (ins_sig * t.lava_adj[seg, 0]).flatten(1).sum(1))
+                ok = (t.lava_gsum > 0) & (npos > 0)
+                per_img = torch.where(ok, num / (t.lava_gsum * npos).clamp(min=1e-30), torch.zeros_like(num))
+                # mean over qualifying images; 0 when none qualifies (the reference then returns a [1]-shaped zero, quirk Q4)
+                out["lav"] = per_img.sum() / ok.sum().clamp(min=1) * self.lava_loss_weight
+            return out
+
+        def category_term():
+            # ---- cat (sigmoid focal, sum / (num_pos + 1)) -- losses.py:121-138
+            flat_pred = torch.cat([c.permute(0, 2, 3, 1).reshape(-1, self.num_classes) for c in cate_preds])
+            onehot = F.one_hot(t.cate_labels, self.num_classes + 1)[:, : self.num_classes].to(flat_pred.dtype)
+            return {"cat": self.conf_loss_weight * sigmoid_focal_sum(flat_pred, onehot, self.focal_loss_alpha, self.focal_loss_gamma) / (t.num_ins + 1)}
+
+        def depth_terms():
+            # ---- dpt (RMSE-log at full resolution) -- losses.py:142-147 (the clamp there is discarded: quirk Q2)
+            dp = ops.resize_bilinear(depth_preds, (2 * depth_preds.shape[2], 2 * depth_preds.shape[3]))
+            out = {"dpt": self.depth_loss_weight * rmse_log(dp, gt_depths, gt_depths > cfg.dataset.min_depth)}
+            # ---- pln (virtual normals) -- losses.py:151-165
+            if cfg.use_plane_loss:
+                out["pln"] = self.vnl.batched(dp, gt_depths, t.vnl).mean() * self.pln_loss_weight
+            return out
+
+        # three independent chains of small launches (the backward replays on the same streams): ops.run_branches
+        parts = ops.run_branches([instance_terms, category_term, depth_terms]) if (LOSS_STREAMS and mask_preds.is_cuda) else \
+            [instance_terms(), category_term(), depth_terms()]
         losses = {}
-
-        # ---- ins (Dice) -- losses.py:69-118 : one dynamic conv per image over all of its positive cells
-        flat_k = torch.cat([k.reshape(B, E, -1) for k in kernel_preds], 2)                          # [B, E, 3728]
-        preds = []
-        for b in range(B):
-            if t.n_pos[b] == 0:
-                continue
-            w = flat_k[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
-            preds.append(ops.conv2d(mask_preds[b:b + 1], w).view(t.n_pos[b], fh, fw))
-        ins_sig = torch.sigmoid(torch.cat(preds, 0))                                                # [sum n_pos, fh, fw]
-        losses["ins"] = dice_loss(ins_sig, t.ins_labels).mean() * self.ins_loss_weight
-
-        # ---- cat (sigmoid focal, sum / (num_pos + 1)) -- losses.py:121-138
-        flat_pred = torch.cat([c.permute(0, 2, 3, 1).reshape(-1, self.num_classes) for c in cate_preds])
-        onehot = F.one_hot(t.cate_labels, self.num_classes + 1)[:, : self.num_classes].to(flat_pred.dtype)
-        losses["cat"] = self.conf_loss_weight * sigmoid_focal_sum(flat_pred, onehot, self.focal_loss_alpha, self.focal_loss_gamma) / (t.num_ins + 1)
-
-        # ---- dpt (RMSE-log at full resolution) -- losses.py:142-147 (the clamp there is discarded: quirk Q2)
-        dp = ops.resize_bilinear(depth_preds, (2 * depth_preds.shape[2], 2 * depth_preds.shape[3]))
-        losses["dpt"] = self.depth_loss_weight * rmse_log(dp, gt_depths, gt_depths > cfg.dataset.min_depth)
-
-        # ---- pln (virtual normals) -- losses.py:151-165
-        if cfg.use_plane_loss:
-            losses["pln"] = self.vnl.batched(dp, gt_depths, t.vnl).mean() * self.pln_loss_weight
-
-        # ---- lav -- losses.py:169-197 : sum(up(s) * g) / (sum(g) * n)  ==  sum(s * up^T(g)) / (sum(g) * n)
-        if cfg.use_lava_loss:
-            seg, npos = t.pos_img, t.n_pos_dev
-            num = torch.zeros(B, device=dev, dtype=ins_sig.dtype).index_add_(0, seg, (ins_sig * t.lava_adj[seg, 0]).flatten(1).sum(1))
-            ok = (t.lava_gsum > 0) & (npos > 0)
-            per_img = torch.where(ok, num / (t.lava_gsum * npos).clamp(min=1e-30), torch.zeros_like(num))
-            # mean over qualifying images; 0 when none qualifies (the reference then returns a [1]-shaped zero, quirk Q4)
-            losses["lav"] = per_img.sum() / ok.sum().clamp(min=1) * self.lava_loss_weight
+        for part in parts:
+            losses.update(part)
+        if all(k in losses for k in ("ins", "cat", "dpt", "pln", "lav")):
+            losses = {k: losses[k] for k in ("ins", "cat", "dpt", "pln", "lav")}      # reference order (logging)
         return losses
 
 

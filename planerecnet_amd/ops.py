@@ -28,6 +28,8 @@ _SIDE = {}
 # (1) read gradients only through `.grad`, (2) call wgrad_join() after backward() and before anything consumes `.grad`
 # (bench.py, train.py).  Post-accumulate-grad hooks (the data-parallel bucketing) are fired by hand; GradAllReduce makes its
 # exchange stream wait for the side stream as well.  torch.autograd.grad() callers keep the default (off).
+# (Also tried on the side stream and dropped: the bias gradients -- no change -- and the once-per-step batched weight flip,
+# whose per-layer event waits cost 1.5 ms/step more than the 0.5 ms it hides.)
 WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
 
 
@@ -82,6 +84,9 @@ def _tensors(o):
         yield o
     elif isinstance(o, (list, tuple)):
         for v in o:
+            yield from _tensors(v)
+    elif isinstance(o, dict):
+        for v in o.values():
             yield from _tensors(v)
 
 
