@@ -26,8 +26,8 @@ _SIDE = {}
 # first-load latency, drain: ~25 % of a small kernel's duration).  Measured 83.3 -> 80.8 ms/step.  The gradient is written
 # to `weight.grad` directly (on the side stream) and the op returns None for it, so this is OPT-IN for training loops that
 # (1) read gradients only through `.grad`, (2) call wgrad_join() after backward() and before anything consumes `.grad`
-# (bench.py, train.py).  Post-accumulate-grad hooks (the data-parallel bucketing) are fired by hand; GradAllReduce makes its
-# exchange stream wait for the side stream as well.  torch.autograd.grad() callers keep the default (off).
+# (bench.py, train.py).  Post-accumulate-grad hooks (the data-parallel bucketing) keep firing from the autograd engine;
+# GradAllReduce makes its exchange stream wait for the side stream as well.  torch.autograd.grad() callers keep the default (off).
 # (Also tried on the side stream and dropped: the bias gradients -- no change -- and the once-per-step batched weight flip,
 # whose per-layer event waits cost 1.5 ms/step more than the 0.5 ms it hides.)
 WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
@@ -67,10 +67,8 @@ def _deferred_wgrad(w, inputs, compute):
             w.grad = dw
         else:
             w.grad.add_(dw)
-        hooks = getattr(w, "_post_accumulate_grad_hooks", None)
-        if hooks:
-            for h in list(hooks.values()):
-                h(w)
+        # (post-accumulate-grad hooks still fire: the engine runs the parameter's AccumulateGrad node -- a no-op for the
+        # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
     for t in inputs:
         t.record_stream(side)
 

@@ -32,6 +32,7 @@ class GradAllReduce:
         dev = self.params[0].device
         self.on_gpu = dev.type == "cuda"
         self.stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
+        self.main = torch.cuda.current_stream(dev) if self.on_gpu else None      # the stream forward / backward are issued on
         cur, size = [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -62,9 +63,12 @@ class GradAllReduce:
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
         if self.on_gpu:
+            # gradients of one bucket come from the backward's own stream AND (deferred weight gradients, ops.WGRAD_ASYNC)
+            # from the side streams; the hook that completes a bucket may run under either
             self.stream.wait_stream(torch.cuda.current_stream())
+            self.stream.wait_stream(self.main)
             from . import ops
-            for st in ops.wgrad_streams():                # deferred weight gradients are produced on side streams (ops.WGRAD_ASYNC)
+            for st in ops.wgrad_streams():
                 self.stream.wait_stream(st)
             ctx = torch.cuda.stream(self.stream)
         else:

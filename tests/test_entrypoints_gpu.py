@@ -53,7 +53,7 @@ sys.path.insert(0, %r)
 from planerecnet_amd.config import cfg, set_cfg
 from planerecnet_amd.planerecnet import PlaneRecNet
 from planerecnet_amd.parallel import GradAllReduce
-from planerecnet_amd import timer
+from planerecnet_amd import ops, timer
 timer.disable_all()
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -67,13 +67,17 @@ def grads(ex):
         if isinstance(m, torch.nn.BatchNorm2d): m.eval()          # keep running stats fixed between the two runs
     mask, cate, kern, depth = net(x)
     (mask.square().mean() + depth.mean() + sum(c.mean() for c in cate) + sum(k.square().mean() for k in kern)).backward()
+    ops.wgrad_join()
     if ex is not None: ex.finish()
     torch.cuda.synchronize()
     return [p.grad.clone() for p in net.parameters() if p.grad is not None]
 g0 = grads(None)
 ex = GradAllReduce(list(net.parameters()), bucket_bytes=8 << 20, force=True)
 assert ex.active and len(ex.buckets) > 3
-g1 = grads(ex); g2 = grads(ex)
+g1 = grads(ex)
+ops.set_wgrad_async(True)                                       # deferred weight gradients (side stream) feeding the same buckets
+g2 = grads(ex)
+ops.set_wgrad_async(False)
 assert len(g0) == len(g1) == len(g2)
 for a, b, c in zip(g0, g1, g2):
     # (not bit-equal: the DCN d-input scatter uses LDS atomics, whose order varies run to run)
