@@ -681,7 +681,7 @@ int quantise_splits(int64_t tiles, int splits) {
 }
 
 // Tile / slice / split choice.  PRN_CONV_FORCE="tm,tn,bk,splits" overrides it (tuning sweeps: tools/conv_bench.py).
-FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false, int phases = 1, bool nosplit = false) {
+FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false, int phases = 1, bool nosplit = false, int ks = 0) {
   static int forced[4] = {-1, 0, 0, 0};
   if (forced[0] == -1) {
     forced[0] = 0;
@@ -691,14 +691,19 @@ FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false, int phases = 1
   p.wm = 2; p.wn = 2;
   if (forced[0] > 0) {
     p.tm = forced[0]; p.tn = forced[1]; p.bk = 16; p.splits = forced[3];
-    if (p.tm != p.tn) { p.tm = 1; p.tn = 1; }
+    if (p.tm != p.tn && !(p.tm == 2 && p.tn == 1 && ks != 0)) { p.tm = 1; p.tn = 1; }
   } else {
     // Rule fitted to the sweep of tools/conv_sweep.py over the PlaneRecNet shapes (profiles/r01_conv_sweep.txt, re-run after
     // the buffer-load rewrite): 16-deep slices always; 128x128 tiles only for wide-M, deep-K layers with enough tiles,
     // otherwise 64x64 (64x128 never won a shape); then split K until ~4 workgroups per CU exist (small-N layers).
     auto tiles = [&](int tm, int tn) { return (int64_t)cdiv(M, 64 * tm) * cdiv(N, 64 * tn); };
     p.bk = 16;
-    if (M >= 128 && K >= 1152 && tiles(2, 2) >= 512) { p.tm = 2; p.tn = 2; }
+    // 128 x 64 tiles (ks = 1 / 3 with zero padding only, else ks == 0): every 3x3 layer with >= 8192 pixels that is too
+    // small for 128 x 128 tiles, and the channel-expanding 1x1 layers (M >= 4 C), gain 5-10 % (profiles/r01_conv_sweep_128x64.txt)
+    const bool wide = ks != 0 && M >= 128 && cdiv(N, 64) >= 128 && tiles(2, 1) >= 256 && (ks == 3 || M >= 4 * K);
+    if (M >= 128 && K >= 1152 && tiles(2, 2) >= 1024) { p.tm = 2; p.tn = 2; }
+    else if (wide) { p.tm = 2; p.tn = 1; }
+    else if (M >= 128 && K >= 1152 && tiles(2, 2) >= 512) { p.tm = 2; p.tn = 2; }
     else { p.tm = 1; p.tn = 1; }
     int64_t t = tiles(p.tm, p.tn);
     if (M <= 32 && narrow_ok) { p.wm = 1; p.wn = 4; t = cdiv(N, 128); }        // 32 x 128 tile
@@ -713,6 +718,9 @@ FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false, int phases = 1
   if (p.splits < 1 || nosplit) p.splits = 1;
   return p;
 }
+
+// kernel size if (kernel size, input mode) has the 128 x 64 instance, else 0
+constexpr int wide_ks(int ks, int mode) { return (mode == PRN_IN_ZERO && (ks == 1 || ks == 3)) ? ks : 0; }
 
 // (kernel size, input mode) pairs that have the 32 x 128 instance
 constexpr bool narrow_available(int ks, int mode) {
@@ -736,6 +744,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
     const bool vec = a.seg.nseg == 0 && a.stride == 1 && a.pad == 0 && (a.HW & 3) == 0 && a.HW == a.HoWo && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
     if (vec) {
       if (p.tm == 2 && p.tn == 2) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 2, 2, 16, true>), grid, block, 0, st, a);
+      else if (p.tm == 2 && p.tn == 1) hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 2, 1, 16, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((conv_igemm_kernel<1, PRN_IN_ZERO, 1, 1, 16, true>), grid, block, 0, st, a);
       return 0;
     }
@@ -744,6 +753,9 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
   // Measured and NOT instantiated (profiles/r01_conv_sweep_bufferloads.txt and the sweeps after it): 32-deep K slices
   // (slower or equal on every shape), 64 x 128 tiles (never the best), and a two-wave 64 x 32 tile meant to replace the
   // K split on the 9600-pixel stages (64 -> 71 us on 1x1 1024->256, 144 -> 193 us on 3x3 256: the split is cheaper).
+  if constexpr (wide_ks(KS, MODE) != 0) {
+    if (p.tm == 2 && p.tn == 1) { PRN_LAUNCH(2, 1, 16); return 0; }
+  }
   if (p.tm == 2 && p.tn == 2) PRN_LAUNCH(2, 2, 16);
   else PRN_LAUNCH(1, 1, 16);
 #undef PRN_LAUNCH
@@ -857,7 +869,8 @@ Geo geo_of(const prn_conv_desc* d) {
 extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
   const Geo g = geo_of(d);
-  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit);
+  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
+                             wide_ks(d->KH, d->in_mode));
   return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
 
@@ -931,7 +944,7 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
   if (g.phases == 4) { a.ystride = 2; a.yW = d->Wo; a.yHW = d->Ho * d->Wo; }
   else if (d->ystride == 2) { a.ystride = 2; a.yW = d->yW; a.yHW = d->yH * d->yW; }
   if (rg) a.N = (int)seg_pixels(rg, d->B);
-  FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit || rg != nullptr);
+  FwdPlan p = plan_fwd(a.M, a.N, a.K, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit || rg != nullptr, wide_ks(d->KH, d->in_mode));
   if (rg) {                                             // tiles must not straddle segments: fall back from 128 to 64 pixels per tile
     int bn = 32 * p.wn * p.tn;
     bool ok = true;
