@@ -86,15 +86,15 @@ int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w,
 int prn_weight_flip_transpose(const float* w, float* wt, int M, int C, int KH, int KW, void* stream);
 
 /* The same permutation for a list of weight tensors in ONE launch (all conv weights of a model, once per training step).
- * `items_dev` is a DEVICE array of n_items descriptors; `first` is the running sum of M*C*KH*KW over the preceding items
- * and total_elements the sum over all of them. */
+ * `items_dev` is a DEVICE array of n_items descriptors.  The launch moves 32 (M) x 32 (C) blocks: `first` is the running sum
+ * of ceil(M/32)*ceil(C/32) over the preceding items and total_blocks the sum over all of them. */
 typedef struct prn_flip_item {
   const float* src;   /* [M][C][KH][KW] */
   float* dst;         /* [C][M][KH][KW], flipped */
   int M, C, KH, KW;
   int64_t first;
 } prn_flip_item;
-int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_items, int64_t total_elements, void* stream);
+int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_items, int64_t total_blocks, void* stream);
 
 /* dw[m, c*KH*KW + r*KW + s] = sum_{b,oh,ow} dy[b,m,oh,ow] * gather(x)[b,c,oh*stride-pad+r,ow*stride-pad+s]
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */

@@ -243,15 +243,16 @@ class FlippedWeights:
         self.flat = torch.empty(total, device=dev, dtype=torch.float32)
         items = np.zeros(len(self.weights), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("M", "i4"), ("C", "i4"), ("KH", "i4"), ("KW", "i4"),
                                                              ("first", "i8")]))
-        self.views, first = [], 0
+        self.views, first, blocks = [], 0, 0
         for i, (w, (M, C, KH, KW)) in enumerate(self.weights):
             assert w.is_contiguous() and w.numel() == M * C * KH * KW and w.dtype == torch.float32
             v = self.flat[first:first + w.numel()].view(C, M, KH, KW)
-            items[i] = (w.data_ptr(), v.data_ptr(), M, C, KH, KW, first)
+            items[i] = (w.data_ptr(), v.data_ptr(), M, C, KH, KW, blocks)       # `first` counts 32x32 (M, C) blocks
             self.views.append(v)
             first += w.numel()
+            blocks += ((M + 31) // 32) * ((C + 31) // 32)
         self.items = torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev)
-        self.total = total
+        self.total = blocks
         self.ptrs = [w.data_ptr() for w, _ in self.weights]
 
     def refresh(self):

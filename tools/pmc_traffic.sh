@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad > /tmp/pmc_$c.log 2>&1
   ls /tmp/pmc_$c | head -5
 done
 python3 - <<'PY'
@@ -20,11 +20,25 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r['Counter_Name'] != c: continue
         k = r['Kernel_Name']
         fam = None
-        for key in ("conv_igemm_kernel", "conv_wgrad_kernel", "reduce_epilogue_kernel", "reduce_splits_kernel", "bn_partial_kernel", "bn_apply_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "dcn_sample_bwd_kernel", "dcn_sample_kernel", "gn_relu_fwd", "gn_relu_bwd", "resize_fwd", "resize_bwd"):
+        for key in ("conv_igemm_kernel", "conv_wgrad_kernel", "reduce_epilogue_kernel", "reduce_splits_kernel", "bn_partial_kernel", "bn_apply_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "dcn_dom_partial_kernel", "dcn_dx_gather_kernel", "dcn_csr_fill_kernel", "dcn_csr_count_kernel", "dcn_sample_kernel", "gn_relu_fwd", "gn_relu_bwd", "resize_fwd", "resize_bwd", "flip_transpose_batched", "space_to_depth2", "replicate_fold"):
             if key in k: fam = key; break
         if fam: acc[fam].append(float(r['Counter_Value']))
     out[c] = {k: {"launches": len(v), "sum_kb": sum(v), "avg_kb": sum(v)/len(v)} for k, v in acc.items()}
-json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+json.dump(out, open(root + "/gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+# the file bench.py reads (copy to profiles/<round>_pmc_traffic.json): bytes per launch with the gfx950 fetch correction
+STEPS = 2
+fams = {}
+for k in set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"]):
+    f, w = out["FETCH_SIZE"].get(k), out["WRITE_SIZE"].get(k)
+    if not f or not w: continue
+    fams[k] = {"launches_per_step": f["launches"] / STEPS, "fetch_kb_avg": f["avg_kb"], "write_kb_avg": w["avg_kb"],
+               "hbm_bytes_per_launch": (2.0 * f["avg_kb"] + w["avg_kb"]) * 1024.0}
+note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) over `bench.py --steps 1 --warmup 1 --sync-wgrad` "
+        "(= 2 steps), tools/pmc_traffic.sh. Units: KB as reported. gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per "
+        "128-B request -> x2 (calibrated in round 1 on bn_apply / bn_partial, whose bytes are known: measured/known = 0.48); WRITE_SIZE as is. "
+        "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024.")
+json.dump({"_note": note, "steps_profiled": STEPS, "families": fams}, open(root + "/gpurun_out/pmc_traffic/pmc_traffic.json", "w"), indent=1)
 for c, d in out.items():
     print(c)
     for k, v in sorted(d.items(), key=lambda kv: -kv[1]["sum_kb"]):
