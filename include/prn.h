@@ -161,14 +161,14 @@ int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* sta
  * replaces ATen group_norm fwd/bwd + ReLU: planerecnet.py:340-342,419-421,436-437,450-451,463-464           */
 int prn_gn_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats /*[B*G*2]*/,
                     int B, int C, int HW, int G, float eps, void* stream);
-int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+int prn_gn_relu_bwd(const float* dy, const float* x, const float* beta, const float* stats, const float* gamma,
                     float* dx, float* dgamma_part /*[B*C]*/, float* dbeta_part /*[B*C]*/,
                     int B, int C, int HW, int G, void* stream);
 /* The same on a ragged batch: nseg dense [B, C, hw[s]] tensors stored back to back (see prn_ragged); statistics are per
  * (segment, image, group): stats [nseg][B][G][2], dgamma_part / dbeta_part [nseg][B][C]. */
 int prn_gn_relu_fwd_ragged(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                            int B, int C, int nseg, const int* hw, int G, float eps, void* stream);
-int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* beta, const float* stats, const float* gamma,
                            float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int nseg, const int* hw, int G,
                            void* stream);
 

@@ -270,13 +270,16 @@ __global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restric
   if (threadIdx.x == 0) { stats[bg * 2] = mu; stats[bg * 2 + 1] = istd; }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int c = g * cpg + i / HW;
-    const float v = (x[base + i] - mu) * istd * gamma[c] + beta[c];
+    const float xh = (x[base + i] - mu) * istd;
+    const float v = xh * gamma[c] + beta[c];               // (the backward re-derives the ReLU mask from this same expression)
     y[base + i] = fmaxf(v, 0.f);
   }
 }
 
+// The ReLU mask is re-derived from x (sign of the forward's own (x - mu) * istd * gamma + beta): the forward output is not
+// read at all (4 instead of 6 activation reads over the two passes).
 __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                          const float* __restrict__ y, const float* __restrict__ stats,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, float* __restrict__ dx,
                                                           float* __restrict__ dgp, float* __restrict__ dbp, int C, int HW, int G, int BG,
                                                           GnSeg sg) {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restric
     bg -= sI * BG;
     HW = gn_seg_get(sg.hw, sI);
     const int off = gn_seg_get(sg.off, sI);
-    dy += off; x += off; y += off; dx += off; stats += (size_t)sI * BG * 2;
+    dy += off; x += off; dx += off; stats += (size_t)sI * BG * 2;
     dgp += (size_t)sI * (BG / G) * C; dbp += (size_t)sI * (BG / G) * C;
   }
   const int g = bg % G, cpg = C / G, b = bg / G;
@@ -299,10 +302,12 @@ __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restric
     const int c = g * cpg + cc;
     const size_t cb = base + (size_t)cc * HW;
     float s1 = 0.f, s2 = 0.f;
+    const float gc = gamma[c], bc = beta[c];
     for (int i = threadIdx.x; i < HW; i += blockDim.x) {
       float gg = dy[cb + i];
-      if (!(y[cb + i] > 0.f)) gg = 0.f;
-      s1 += gg; s2 += gg * (x[cb + i] - mu) * istd;
+      const float xh = (x[cb + i] - mu) * istd;
+      if (!(xh * gc + bc > 0.f)) gg = 0.f;
+      s1 += gg; s2 += gg * xh;
     }
     double d1 = s1, d2 = s2;
     block_sum2(d1, d2, sm);
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restric
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int c = g * cpg + i / HW;
     float gg = dy[base + i];
-    if (!(y[base + i] > 0.f)) gg = 0.f;
     const float xh = (x[base + i] - mu) * istd;
+    if (!(xh * gamma[c] + beta[c] > 0.f)) gg = 0.f;
     dx[base + i] = istd * (gamma[c] * gg - m1 - xh * m2);
   }
   (void)tot;
@@ -429,23 +434,23 @@ extern "C" int prn_gn_relu_fwd_ragged(const float* x, const float* gamma, const 
   return 0;
 }
 
-extern "C" int prn_gn_relu_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+extern "C" int prn_gn_relu_bwd(const float* dy, const float* x, const float* beta, const float* stats, const float* gamma,
                                float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int HW, int G, void* stream) {
-  PRN_REQUIRE(dy && x && y && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd: bad arguments");
+  PRN_REQUIRE(dy && x && beta && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd: bad arguments");
   GnSeg sg; sg.nseg = 0;
-  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, y, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G,
+  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, beta, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G,
                      B * G, sg);
   PRN_CHECK_LAUNCH("prn_gn_relu_bwd");
   return 0;
 }
 
-extern "C" int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* y, const float* stats, const float* gamma,
+extern "C" int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* beta, const float* stats, const float* gamma,
                                       float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int nseg, const int* hw, int G,
                                       void* stream) {
-  PRN_REQUIRE(dy && x && y && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd_ragged: bad arguments");
+  PRN_REQUIRE(dy && x && beta && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd_ragged: bad arguments");
   GnSeg sg;
   if (int e = gn_fill_seg(sg, B, C, nseg, hw)) return e;
-  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(nseg * B * G), dim3(512), 0, (hipStream_t)stream, dy, x, y, stats, gamma, dx, dgamma_part, dbeta_part, C, 0,
+  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(nseg * B * G), dim3(512), 0, (hipStream_t)stream, dy, x, beta, stats, gamma, dx, dgamma_part, dbeta_part, C, 0,
                      G, B * G, sg);
   PRN_CHECK_LAUNCH("prn_gn_relu_bwd_ragged");
   return 0;

@@ -601,20 +601,20 @@ class _GroupNormReLU(torch.autograd.Function):
         stats = torch.empty(B * groups * 2, device=x.device, dtype=torch.float32)
         with profiling.span("gn_relu_fwd", "hbm", 4.0 * x.numel() * 2):
             check(lib.prn_gn_relu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, C, H * W, groups, eps, _stream()), "prn_gn_relu_fwd")
-        ctx.save_for_backward(x, y, stats, gamma)
+        ctx.save_for_backward(x, beta, stats, gamma)       # (the backward re-derives the ReLU mask from x: y is not kept)
         ctx.groups = groups
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, stats, gamma = ctx.saved_tensors
+        x, beta, stats, gamma = ctx.saved_tensors
         dy = _c(dy)
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         dgp = torch.empty(B, C, device=x.device, dtype=torch.float32)
         dbp = torch.empty(B, C, device=x.device, dtype=torch.float32)
         with profiling.span("gn_relu_bwd", "hbm", 4.0 * x.numel() * 4):
-            check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), B, C, H * W, ctx.groups, _stream()),
+            check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(beta), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), B, C, H * W, ctx.groups, _stream()),
                   "prn_gn_relu_bwd")
         return dx, dgp.sum(0), dbp.sum(0), None, None
 
@@ -730,13 +730,13 @@ class _RaggedGNReLU(torch.autograd.Function):
         with profiling.span("gn_relu_fwd", "hbm", 4.0 * xp.numel() * 2):
             check(lib.prn_gn_relu_fwd_ragged(_p(xp), _p(gamma), _p(beta), _p(y), _p(stats), rs.B, C, n, rs.hw, groups, eps, _stream()),
                   "prn_gn_relu_fwd_ragged")
-        ctx.save_for_backward(xp, y, stats, gamma)
+        ctx.save_for_backward(xp, beta, stats, gamma)
         ctx.cfg = (groups, rs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xp, y, stats, gamma = ctx.saved_tensors
+        xp, beta, stats, gamma = ctx.saved_tensors
         groups, rs = ctx.cfg
         dy = _c(dy)
         C = gamma.numel()
@@ -745,7 +745,7 @@ class _RaggedGNReLU(torch.autograd.Function):
         dgp = torch.empty(n * rs.B, C, device=xp.device, dtype=torch.float32)
         dbp = torch.empty(n * rs.B, C, device=xp.device, dtype=torch.float32)
         with profiling.span("gn_relu_bwd", "hbm", 4.0 * xp.numel() * 4):
-            check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(y), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), rs.B, C, n, rs.hw, groups,
+            check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(beta), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), rs.B, C, n, rs.hw, groups,
                                              _stream()), "prn_gn_relu_bwd_ragged")
         return dx, dgp.sum(0), dbp.sum(0), None, None, None
 
