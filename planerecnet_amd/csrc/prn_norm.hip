@@ -1,6 +1,7 @@
 // BatchNorm2d (+residual +ReLU) and GroupNorm(32)+ReLU, forward and backward. HBM-bound: every pass is a
 // float4-vectorised stream over NCHW planes with wave-level (shuffle) reductions; cross-block combines are
 // done in fp64 from fixed-order partials, so results are deterministic.
+#include <stdlib.h>
 #include "prn_common.h"
 
 namespace {
@@ -231,6 +232,118 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------- BatchNorm, one pass
+// Small maps (stages 3-4 of the backbone: 8 x 30x40 / 15x20 pixels per channel): one workgroup owns a whole channel and
+// keeps its <= 12288 values in REGISTERS between the statistics and the normalisation, so the activation is read from HBM
+// once and the layer is one launch instead of two -- for 78 of the 113 BatchNorm layers of PlaneRecNet_101, whose two
+// launches were ~10 us each, i.e. launch-bound.  NV = float4 groups per thread; needs HW % 4 == 0.
+constexpr int BN_SMALL_MAX = 12288;
+
+template <int NV>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
+                                                           float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, int HW, float eps,
+                                                           float momentum, int relu) {
+  const int c = blockIdx.x, n4 = (B * HW) >> 2;
+  float4 v[NV];
+  size_t off[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = threadIdx.x + i * 256;
+    const bool ok = q < n4;
+    const int e = ok ? q * 4 : 0, b = e / HW, p = e - b * HW;
+    off[i] = ((size_t)b * C + c) * HW + p;
+    v[i] = ok ? *reinterpret_cast<const float4*>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  __shared__ double sm[16];
+  double d1 = s1, d2 = s2;
+  block_sum2(d1, d2, sm);
+  const double count = (double)B * HW, mean = d1 / count;
+  double var = d2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mean_f = (float)mean, istd_f = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    stats[c] = mean_f;
+    stats[C + c] = istd_f;
+    if (rmean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean_f;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+  }
+  const float sc = istd_f * gamma[c], sh = beta[c] - mean_f * sc;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (threadIdx.x + i * 256 >= n4) continue;
+    float4 o = v[i];
+    o.x = fmaf(o.x, sc, sh); o.y = fmaf(o.y, sc, sh); o.z = fmaf(o.z, sc, sh); o.w = fmaf(o.w, sc, sh);
+    if (res) { const float4 r = *reinterpret_cast<const float4*>(res + off[i]); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(y + off[i]) = o;
+  }
+}
+
+// relu: 0 none | 1 mask from y | 2 mask from fmaf(x, sc, sh) (no residual)
+template <int NV>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int HW, int relu,
+                                                           int frozen) {
+  const int c = blockIdx.x, n4 = (B * HW) >> 2;
+  const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
+  const float sc = relu == 2 ? gi : 0.f, sh = relu == 2 ? beta[c] - mean * sc : 0.f;
+  float4 g[NV], xv[NV];
+  size_t off[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = threadIdx.x + i * 256;
+    const bool ok = q < n4;
+    const int e = ok ? q * 4 : 0, b = e / HW, p = e - b * HW;
+    off[i] = ((size_t)b * C + c) * HW + p;
+    g[i] = ok ? *reinterpret_cast<const float4*>(dy + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    xv[i] = ok ? *reinterpret_cast<const float4*>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (relu == 1) {
+      const float4 yv = ok ? *reinterpret_cast<const float4*>(y + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      g[i].x = yv.x > 0.f ? g[i].x : 0.f; g[i].y = yv.y > 0.f ? g[i].y : 0.f; g[i].z = yv.z > 0.f ? g[i].z : 0.f; g[i].w = yv.w > 0.f ? g[i].w : 0.f;
+    } else if (relu == 2) {
+      g[i].x = fmaf(xv[i].x, sc, sh) > 0.f ? g[i].x : 0.f; g[i].y = fmaf(xv[i].y, sc, sh) > 0.f ? g[i].y : 0.f;
+      g[i].z = fmaf(xv[i].z, sc, sh) > 0.f ? g[i].z : 0.f; g[i].w = fmaf(xv[i].w, sc, sh) > 0.f ? g[i].w : 0.f;
+    }
+    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+    s2 += (g[i].x * (xv[i].x - mean) + g[i].y * (xv[i].y - mean)) + (g[i].z * (xv[i].z - mean) + g[i].w * (xv[i].w - mean));
+  }
+  s2 *= istd;
+  __shared__ double sm[16];
+  double t1 = s1, t2 = s2;
+  block_sum2(t1, t2, sm);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = (float)t1;
+    if (dgamma) dgamma[c] = (float)t2;
+  }
+  const float inv_count = 1.f / ((float)B * HW);
+  const float m1 = frozen ? 0.f : (float)t1 * inv_count, m2 = frozen ? 0.f : (float)t2 * inv_count;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (threadIdx.x + i * 256 >= n4) continue;
+    if (dres) *reinterpret_cast<float4*>(dres + off[i]) = g[i];
+    float4 o;
+    o.x = gi * (g[i].x - m1 - (xv[i].x - mean) * istd * m2); o.y = gi * (g[i].y - m1 - (xv[i].y - mean) * istd * m2);
+    o.z = gi * (g[i].z - m1 - (xv[i].z - mean) * istd * m2); o.w = gi * (g[i].w - m1 - (xv[i].w - mean) * istd * m2);
+    *reinterpret_cast<float4*>(dx + off[i]) = o;
+  }
+}
+
+bool bn_small_ok(int B, int HW) {
+  static int on = -1;                                   // PRN_BN_SMALL=0 switches the one-pass kernels off (A/B)
+  if (on < 0) { const char* e = getenv("PRN_BN_SMALL"); on = e ? atoi(e) : 1; }
+  return on && (HW & 3) == 0 && (int64_t)B * HW <= BN_SMALL_MAX;
+}
+
 // ------------------------------------------------------------------------------------------- GroupNorm
 // one block per (b, group): pass 1 statistics, pass 2 normalise + affine + ReLU (second read is L2-resident)
 // Ragged batch (nseg > 0): segment s is a dense [B, C, hw[s]] tensor at element offset off[s]; block -> (segment, image, group)
@@ -369,6 +482,15 @@ extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma
   PRN_REQUIRE(x && stats && gamma && beta && y && ws && B > 0 && C > 0 && HW > 0, "prn_bn_train_fwd: bad arguments");
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_train_fwd: B*C too large for grid.y");
   hipStream_t st = (hipStream_t)stream;
+  if (bn_small_ok(B, HW)) {                                // whole channel in one workgroup's registers: one launch, one read
+    const int nv = cdiv(B * HW / 4, 256);
+#define PRN_BN_SMALL_FWD(NV_) hipLaunchKernelGGL((bn_small_fwd_kernel<NV_>), dim3(C), dim3(256), 0, st, x, stats, gamma, beta, residual, y, \
+                                                 running_mean, running_var, B, C, HW, eps, momentum, relu)
+    if (nv <= 3) PRN_BN_SMALL_FWD(3); else if (nv <= 6) PRN_BN_SMALL_FWD(6); else if (nv <= 10) PRN_BN_SMALL_FWD(10); else PRN_BN_SMALL_FWD(12);
+#undef PRN_BN_SMALL_FWD
+    PRN_CHECK_LAUNCH("prn_bn_train_fwd/small");
+    return 0;
+  }
   const int S = bn_splits(B, HW);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
   PRN_CHECK_LAUNCH("prn_bn_train_fwd/partial");
@@ -388,6 +510,15 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
   if (relu) relu = y ? 1 : 2;
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_bwd: B*C too large for grid.y");
   hipStream_t st = (hipStream_t)stream;
+  if (bn_small_ok(B, HW)) {
+    const int nv = cdiv(B * HW / 4, 256);
+#define PRN_BN_SMALL_BWD(NV_) hipLaunchKernelGGL((bn_small_bwd_kernel<NV_>), dim3(C), dim3(256), 0, st, dy, x, y, stats, gamma, beta, dx, dres, dgamma, \
+                                                 dbeta, B, C, HW, relu, frozen)
+    if (nv <= 3) PRN_BN_SMALL_BWD(3); else if (nv <= 6) PRN_BN_SMALL_BWD(6); else if (nv <= 10) PRN_BN_SMALL_BWD(10); else PRN_BN_SMALL_BWD(12);
+#undef PRN_BN_SMALL_BWD
+    PRN_CHECK_LAUNCH("prn_bn_bwd/small");
+    return 0;
+  }
   const int S = bn_splits(B, HW);
   const int have = (!frozen || dgamma || dbeta) ? 1 : 0;
   if (have) {
