@@ -36,10 +36,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if self.downsample is None:
-            out, x = ops.conv2d_fork(x, self.conv1.weight)      # x's two gradients (conv1, identity) meet in conv1's dgrad epilogue
-        else:
-            out = ops.conv2d(x, self.conv1.weight)
+        # x has a second consumer (the identity branch or the downsample conv): hand it on through the fork so that both
+        # gradients of x meet in conv1's input-gradient epilogue instead of in a separate accumulation kernel
+        out, x = ops.conv2d_fork(x, self.conv1.weight)
         out = _bn(self.bn1, out, relu=True)
         if isinstance(self.conv2, DeformableConv2d):
             out = self.conv2(out)

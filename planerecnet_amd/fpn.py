@@ -29,13 +29,18 @@ class FPN(nn.Module):
         if self.interpolation_mode != "bilinear":
             raise NotImplementedError("fpn.interpolation_mode=%r" % self.interpolation_mode)
 
-    def forward(self, inputs):
+    def forward(self, inputs, return_inputs=False):
+        """return_inputs: also hand the (forked) input features back, for the next consumer of the backbone features --
+        their gradient then joins this module's lateral-conv input gradient in the GEMM epilogue (ops.conv2d_fork)."""
         assert len(inputs) == len(self.in_channels)
-        laterals, prev = [], None
+        laterals, prev, idents = [], None, list(inputs)
         for i, lat in enumerate(self.lateral_convs):
             f = inputs[i + self.start_level]
             add = None if prev is None else ops.resize_bilinear(prev, f.shape[2:])
-            prev = ops.conv2d(f, lat.weight, lat.bias, addend=add)
+            if return_inputs:
+                prev, idents[i + self.start_level] = ops.conv2d_fork(f, lat.weight, lat.bias, addend=add)
+            else:
+                prev = ops.conv2d(f, lat.weight, lat.bias, addend=add)
             laterals.append(prev)
         epi = ops.EPI_RELU if self.relu_pred_layers else ops.EPI_NONE
         outs = [ops.conv2d(l, c.weight, c.bias, pad=1, epilogue=epi) for l, c in zip(laterals, self.fpn_convs)]
@@ -45,4 +50,4 @@ class FPN(nn.Module):
             p6 = ops.conv2d(outs[-1], self.downsample_layers[0].weight, self.downsample_layers[0].bias, stride=2, pad=1)
             p7 = ops.conv2d(p6.relu(), self.downsample_layers[1].weight, self.downsample_layers[1].bias, stride=2, pad=1)
             outs += [p6, p7]
-        return outs
+        return (outs, idents) if return_inputs else outs

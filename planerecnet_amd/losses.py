@@ -169,11 +169,13 @@ class PlaneRecNetLoss(nn.Module):
             # ---- ins (Dice) -- losses.py:69-118 : one dynamic conv per image over all of its positive cells
             flat_k = torch.cat([k.reshape(B, E, -1) for k in kernel_preds], 2)                          # [B, E, 3728]
             preds = []
+            per_image = torch.split(mask_preds, 1)          # one backward node (cat) instead of B zero-filled slice gradients + adds
+            flat_kb = flat_k.unbind(0)
             for b in range(B):
                 if t.n_pos[b] == 0:
                     continue
-                w = flat_k[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
-                preds.append(ops.conv2d(mask_preds[b:b + 1], w).view(t.n_pos[b], fh, fw))
+                w = flat_kb[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
+                preds.append(ops.conv2d(per_image[b], w).view(t.n_pos[b], fh, fw))
             ins_sig = torch.sigmoid(torch.cat(preds, 0))                                                # [sum n_pos, fh, fw]
             out["ins"] = dice_loss(ins_sig, t.ins_labels).mean() * self.ins_loss_weight
             # ---- lav -- losses.py:169-197 : sum(up(s) * g) / (sum(g) * n)  ==  sum(s * up^T(g)) / (sum(g) * n)

@@ -643,12 +643,10 @@ class RaggedShape:
         return torch.cat([t.reshape(-1) for t in tensors])
 
     def unpack(self, flat, C):
-        out, o = [], 0
-        for h, w in self.sizes:
-            n = self.B * C * h * w
-            out.append(flat[o:o + n].view(self.B, C, h, w))
-            o += n
-        return out
+        # torch.split: ONE backward node that concatenates the five gradients (five slices would each allocate a zero-filled
+        # full-size gradient and autograd would add them up)
+        parts = torch.split(flat, [self.B * C * h * w for h, w in self.sizes])
+        return [p.view(self.B, C, h, w) for p, (h, w) in zip(parts, self.sizes)]
 
 
 _RDESC = {}

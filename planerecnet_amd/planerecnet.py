@@ -84,7 +84,11 @@ class PlaneRecNet(nn.Module):
         with timer.env("backbone"):
             enc = self.backbone(x)
         with timer.env("fpn"):
-            feats = self.fpn([enc[i] for i in self.fpn_indices])
+            # the decoder reads the same backbone features: it gets them back from the FPN's forked lateral convs
+            feats, fenc = self.fpn([enc[i] for i in self.fpn_indices], return_inputs=True)
+            enc = list(enc)
+            for i, f in zip(self.fpn_indices, fenc):
+                enc[i] = f
         with timer.env("instance head"):
             ins_feats = self.split_feats([feats[f] for f in range(len(self.instance_in_features))])
             cate_pred, kernel_pred = self.inst_head(ins_feats)            # five levels on five streams (ops.run_branches)
