@@ -114,9 +114,13 @@ __device__ __forceinline__ int tap_offset(int ih, int iw, bool ok, int H, int W)
 // loads along the pixel axis and 128-bit LDS stores.
 // WM = waves along M (2: the 2x2 wave grid; 1: all four waves side by side along the pixels, a 32 x 128 tile for layers
 // with <= 32 output channels -- the 27-channel offset/modulator conv of every DCN block wasted 58 % of a 64-row tile).
-template <int KS, int MODE, int TM, int TN, int BK, bool VEC = false, int WM = 2, int WN = 4 / WM>
+// V3 (3x3, stride 1, zero padding 1, W % 4 == 0): the im2col operand is fetched as float4 too -- four consecutive output
+// pixels of one row read four consecutive input pixels for every tap; at the left / right image border the vector is
+// loaded one pixel further in and shifted (with a zero) when it is stored to LDS.  4x fewer gather instructions.
+template <int KS, int MODE, int TM, int TN, int BK, bool VEC = false, int WM = 2, int WN = 4 / WM, bool V3 = false>
 __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_igemm_kernel(ConvArgs a) {   // 128x128: cap at 128 VGPRs -> 4 waves/SIMD (+7..15 %)
   static_assert(!VEC || (KS == 1 && MODE == PRN_IN_ZERO), "vector staging is the plain-GEMM case");
+  static_assert(!V3 || (KS == 3 && MODE == PRN_IN_ZERO && !VEC), "V3 is the 3x3 zero-padded stride-1 case");
   constexpr int NT = 64 * WM * WN;               // threads per workgroup
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, LDA = BK + 1;
   constexpr int KSTEP = NT / BN;   // K rows covered by one sweep of the block
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   __shared__ float As[2][BM * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
   __shared__ unsigned taps[KS > 1 ? KK * BN : 1];   // per-pixel tap byte offsets (or OOB), built once per workgroup
+                                                    // (V3: per 4-pixel group: offset of the vector | border code in bits 0-1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -184,6 +189,24 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   if (KS == 1) {
     const int o = tap_offset<MODE>(ih0, iw0, nvalid, H_, W_);
     off1 = o >= 0 ? (unsigned)(pix0 + o) * 4u : OOB;
+  } else if (V3) {
+    for (int idx = tid; idx < KK * VG; idx += NT) {
+      const int rs = idx / VG, g = idx - rs * VG;
+      const int r = rs / 3, sx = rs - r * 3;
+      const int n4 = n0 + g * 4;                           // first of four pixels in one output row (Wo % 4 == 0)
+      unsigned e = OOB;
+      if (n4 < N_) {
+        const int b4 = n4 / HoWo_, p4 = n4 - b4 * HoWo_, oh4 = p4 / Wo_, ow4 = p4 - oh4 * Wo_;
+        const int ih = oh4 + r - 1, iw = ow4 + sx - 1;
+        if ((unsigned)ih < (unsigned)H_) {
+          const unsigned code = iw < 0 ? 1u : (iw + 3 >= W_ ? 2u : 0u);      // 1: loaded one pixel to the right, 2: one to the left
+          const int iwl = iw < 0 ? iw + 1 : (iw + 3 >= W_ ? iw - 1 : iw);
+          e = ((unsigned)(b4 * a.C * HW_ + ih * W_ + iwl) * 4u) | code;
+        }
+      }
+      taps[idx] = e;
+    }
+    __syncthreads();
   } else {
     for (int t = krow0; t < KK; t += KSTEP) {
       const int r = t / KS, s = t - r * KS;
@@ -215,8 +238,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   }
 
   float ra[NA][4];
-  float rb[VEC ? 1 : NB];
-  float4 rv[VEC ? NBV : 1];
+  float rb[(VEC || V3) ? 1 : NB];
+  float4 rv[(VEC || V3) ? NBV : 1];
+  unsigned rcode = 0;                                      // V3: 2-bit border codes of this slice's vectors
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -251,6 +275,16 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
           const int kr = k0 + i * VROWS;                         // + vrow0 is folded into vbase
           rv[i] = bload4(xr, (kr + vrow0 < a.K) ? vbase : OOB, kr * HW_ * 4);
         }
+      } else if (V3) {
+        rcode = 0;
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+          const int kr = k0 + vrow0 + i * VROWS;
+          const int c = kr / 9, rs = kr - c * 9;
+          const unsigned e = taps[rs * VG + vg];
+          rcode |= (e & 3u) << (2 * i);
+          rv[i] = bload4(xr, (kr < a.K) ? (e & ~3u) + (unsigned)(c * HW_ * 4) : OOB, 0);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -258,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
           const int c = kr / KK, rs = kr - c * KK;
           const unsigned off = (KS == 1) ? off1 : taps[rs * BN + nl];
           if (BN >= 64) rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off : OOB, c * HW_ * 4);
-          else rb[VEC ? 0 : i] = bload(xr, (kr < a.K) ? off + (unsigned)(c * HW_ * 4) : OOB, 0);   // (OOB + channel offset stays >= 2^31)
+          else rb[(VEC || V3) ? 0 : i] = bload(xr, (kr < a.K) ? off + (unsigned)(c * HW_ * 4) : OOB, 0);   // (OOB + channel offset stays >= 2^31)
         }
       }
     };
@@ -272,9 +306,18 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
       if (VEC) {
 #pragma unroll
         for (int i = 0; i < NBV; ++i) *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = rv[i];
+      } else if (V3) {
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+          const unsigned code = (rcode >> (2 * i)) & 3u;
+          float4 v = rv[i];
+          if (code == 1u) v = make_float4(0.f, v.x, v.y, v.z);
+          else if (code == 2u) v = make_float4(v.y, v.z, v.w, 0.f);
+          *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = v;
+        }
       } else {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[VEC ? 0 : i];
+        for (int i = 0; i < NB; ++i) Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[(VEC || V3) ? 0 : i];
       }
     };
     auto mma_tile = [&](int buf) {
@@ -775,6 +818,19 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
   // Measured and NOT instantiated (profiles/r01_conv_sweep_bufferloads.txt and the sweeps after it): 32-deep K slices
   // (slower or equal on every shape), 64 x 128 tiles (never the best), and a two-wave 64 x 32 tile meant to replace the
   // K split on the 9600-pixel stages (64 -> 71 us on 1x1 1024->256, 144 -> 193 us on 3x3 256: the split is cheaper).
+  if constexpr (KS == 3 && MODE == PRN_IN_ZERO) {
+    static int v3on = -1;                                  // PRN_CONV_V3=0 switches the float4 gather off (A/B)
+    if (v3on < 0) { const char* e = getenv("PRN_CONV_V3"); v3on = e ? atoi(e) : 1; }
+    bool v3 = v3on && a.stride == 1 && a.pad == 1 && p.wm == 2 && p.wn == 2;
+    if (a.seg.nseg > 0) { for (int sI = 0; sI < a.seg.nseg; ++sI) v3 = v3 && (a.seg.W[sI] & 3) == 0; }
+    else v3 = v3 && (a.W & 3) == 0 && a.Wo == a.W && a.Ho == a.H;
+    if (v3) {
+#define PRN_LAUNCH_V3(TM_, TN_) hipLaunchKernelGGL((conv_igemm_kernel<3, PRN_IN_ZERO, TM_, TN_, 16, false, 2, 2, true>), grid, block, 0, st, a)
+      if (p.tm == 2 && p.tn == 2) PRN_LAUNCH_V3(2, 2); else if (p.tm == 2 && p.tn == 1) PRN_LAUNCH_V3(2, 1); else PRN_LAUNCH_V3(1, 1);
+#undef PRN_LAUNCH_V3
+      return 0;
+    }
+  }
   if constexpr (wide_ks(KS, MODE) != 0) {
     if (p.tm == 2 && p.tn == 1) { PRN_LAUNCH(2, 1, 16); return 0; }
   }

@@ -46,4 +46,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=50, max_shapes_column_width=60))
 print(prof.key_averages(group_by_stack_n=4).table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=40))
+print("==== callers of fill / zero / add / copy")
+rows = [e for e in prof.key_averages(group_by_stack_n=10) if e.key in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::add", "aten::add_", "aten::copy_", "aten::zeros_like")]
+rows.sort(key=lambda e: -e.count)
+for e in rows[:40]:
+    st = [l for l in e.stack if "planerecnet_amd" in l or "autograd" in l or "bench" in l or "tools" in l][:4]
+    print(e.key, e.count, "%.1f us" % (e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total), " | ".join(s_.strip()[-90:] for s_ in st))
 pf.close()
