@@ -198,6 +198,10 @@ def main():
             raise SystemExit("bench.py: the roofline leg needs eagerly issued launches; combine --graph with --no-roofline")
         branch_streams, ops.BRANCH_STREAMS = ops.BRANCH_STREAMS, False      # one stream: an event pair then times one launch, not its neighbours
         profiling.enable()
+        # Park the stream behind a ~150 ms spin kernel while the host enqueues the bracketed step: with two event records per
+        # launch the host is slower than the GPU, and every event pair would otherwise also time the idle wait for the
+        # kernel's submission (several us per launch, i.e. 5-10 % of the small kernels' durations).
+        torch.cuda._sleep(int(0.15 * 2.4e9))
         step()
         torch.cuda.synchronize()
         fams = profiling.summary()

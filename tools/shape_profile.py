@@ -32,12 +32,12 @@ _f, _w = ops.conv_fwd_raw, ops.conv_wgrad_raw
 recording = False
 
 
-def fwd(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=0, dil=1, epi=0):
+def fwd(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=0, dil=1, epi=0, scatter2=None):
     if not recording:
-        return _f(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+        return _f(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode, dil, epi, scatter2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    y = _f(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+    y = _f(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode, dil, epi, scatter2)
     e.record()
     B, C, H, W = x.shape
     REC.append((("fwd", C, H, W, M, K, stride, mode, dil), 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil), s, e))
