@@ -71,6 +71,56 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   dx[i] = acc;
 }
 
+// ---- exact factor-2 cases (FPN bottom-up path and split_feats: x0.5; mask-head levels and the depth loss: x2).  Same
+// arithmetic, in the same order, as the generic kernels -- every weight is 0.25 / 0.5 / 0.75 / 1 exactly -- without the
+// per-element index search: the generic adjoint ran at 0.7 TB/s on the 8x256x120x160 FPN gradient (285 us).
+__global__ __launch_bounds__(256) void resize_down2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total, int Ho, int Wo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int wo = i % Wo, ho = (i / Wo) % Ho;
+  const int64_t bc = i / ((int64_t)Wo * Ho);
+  const float* p = x + (bc * 2 * Ho + 2 * ho) * (int64_t)(2 * Wo) + 2 * wo;
+  const float2 r0 = *reinterpret_cast<const float2*>(p), r1 = *reinterpret_cast<const float2*>(p + 2 * Wo);
+  y[i] = 0.5f * (0.5f * r0.x + 0.5f * r0.y) + 0.5f * (0.5f * r1.x + 0.5f * r1.y);
+}
+
+__global__ __launch_bounds__(256) void resize_down2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int Ho, int Wo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per PAIR of input pixels (2h', 2wo), (2h', 2wo+1)
+  if (i >= total) return;
+  const int wo = i % Wo, h = (i / Wo) % (2 * Ho);
+  const int64_t bc = i / ((int64_t)Wo * 2 * Ho);
+  const float g = 0.5f * (0.5f * dy[(bc * Ho + (h >> 1)) * (int64_t)Wo + wo]);
+  *reinterpret_cast<float2*>(dx + (bc * 2 * Ho + h) * (int64_t)(2 * Wo) + 2 * wo) = make_float2(g, g);
+}
+
+// adjoint of the x2 upsample: input (i, j) is touched by output rows 2i-1 .. 2i+2 with weights .25 .75 .75 .25 (1.0 where the
+// border clamp folds two of them together), same for columns
+__device__ __forceinline__ float up2_weight(int o, int i, int in) {         // weight of output index o on input index i
+  const int base = o >> 1;                                                   // o = 2*base + a
+  if (o & 1) return (base == i ? 0.75f : 0.f) + ((base + 1 > in - 1 ? in - 1 : base + 1) == i ? 0.25f : 0.f);
+  if (o == 0) return i == 0 ? 1.f : 0.f;                                     // source coordinate clamped to 0
+  return (base - 1 == i ? 0.25f : 0.f) + (base == i ? 0.75f : 0.f);
+}
+
+__global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int H, int W) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int w = i % W, h = (i / W) % H;
+  const int64_t bc = i / ((int64_t)W * H);
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float* p = dy + bc * (int64_t)Ho * Wo;
+  const int olo = max(2 * h - 1, 0), ohi = min(2 * h + 2, Ho - 1), wlo = max(2 * w - 1, 0), whi = min(2 * w + 2, Wo - 1);
+  float acc = 0.f;
+  for (int oh = olo; oh <= ohi; ++oh) {
+    const float wh = up2_weight(oh, h, H);
+    if (wh == 0.f) continue;
+    float row = 0.f;
+    for (int ow = wlo; ow <= whi; ++ow) row += up2_weight(ow, w, W) * p[(int64_t)oh * Wo + ow];
+    acc += wh * row;
+  }
+  dx[i] = acc;
+}
+
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total,
                                                           int H, int W, int Ho, int Wo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -120,6 +170,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 extern "C" int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(x && y && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_fwd: bad arguments");
   const int64_t n = (int64_t)BC * Ho * Wo;
+  if (H == 2 * Ho && W == 2 * Wo && (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
+    hipLaunchKernelGGL(resize_down2_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, Ho, Wo);
+    PRN_CHECK_LAUNCH("prn_resize_bilinear_fwd/down2");
+    return 0;
+  }
   hipLaunchKernelGGL(resize_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
   PRN_CHECK_LAUNCH("prn_resize_bilinear_fwd");
   return 0;
@@ -128,6 +183,16 @@ extern "C" int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, 
 extern "C" int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_bwd: bad arguments");
   const int64_t n = (int64_t)BC * H * W;
+  if (H == 2 * Ho && W == 2 * Wo && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {
+    hipLaunchKernelGGL(resize_down2_bwd_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n / 2, Ho, Wo);
+    PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd/down2");
+    return 0;
+  }
+  if (Ho == 2 * H && Wo == 2 * W) {
+    hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W);
+    PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd/up2");
+    return 0;
+  }
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
   PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd");
   return 0;

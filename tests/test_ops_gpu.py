@@ -329,7 +329,8 @@ def test_group_norm_relu_fwd_bwd(B, C, H, W):
         close(g1, g0, "gn " + n, rtol=5e-4)
 
 
-@pytest.mark.parametrize("H,W,Ho,Wo", [(12, 16, 6, 8), (6, 8, 12, 16), (15, 20, 40, 40), (30, 40, 36, 36), (16, 24, 4, 6), (15, 20, 24, 24)])
+@pytest.mark.parametrize("H,W,Ho,Wo", [(12, 16, 6, 8), (6, 8, 12, 16), (15, 20, 40, 40), (30, 40, 36, 36), (16, 24, 4, 6), (15, 20, 24, 24),
+                                        (2, 2, 4, 4), (4, 6, 2, 3), (3, 5, 6, 10), (1, 1, 2, 2)])
 def test_resize_bilinear_fwd_bwd(H, W, Ho, Wo):
     from planerecnet_amd import ops
     x = rnd(2, 5, H, W, seed=1).requires_grad_(True)
