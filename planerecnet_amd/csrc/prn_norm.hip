@@ -11,10 +11,10 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
   b = wave_sum_d(b);
   const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[8 + w] = b; }
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[nw + w] = b; }           // sm: 2 * (waves per block) doubles
   __syncthreads();
   double ra = 0.0, rb = 0.0;
-  for (int i = 0; i < nw; ++i) { ra += sm[i]; rb += sm[8 + i]; }
+  for (int i = 0; i < nw; ++i) { ra += sm[i]; rb += sm[nw + i]; }
   a = ra; b = rb;
 }
 
@@ -356,7 +356,7 @@ __device__ __forceinline__ int gn_seg_get(const int (&v)[6], int s) {
   return r;
 }
 
-__global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void gn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           float* __restrict__ stats, int C, int HW, int G, float eps, int BG, GnSeg sg) {
   int bg = blockIdx.x;
@@ -371,9 +371,18 @@ __global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restric
   const int b = bg / G;
   const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
   const int n = cpg * HW;
+  const bool vec = (HW & 3) == 0 && (base & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[base + i]; s1 += v; s2 += v * v; }
-  __shared__ double sm[16];
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[base + i]; s1 += v; s2 += v * v; }
+  }
+  __shared__ double sm[32];
   double d1 = s1, d2 = s2;
   block_sum2(d1, d2, sm);
   const double mean = d1 / n;
@@ -381,6 +390,18 @@ __global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restric
   if (var < 0.0) var = 0.0;
   const float mu = (float)mean, istd = (float)(1.0 / sqrt(var + (double)eps));
   if (threadIdx.x == 0) { stats[bg * 2] = mu; stats[bg * 2 + 1] = istd; }
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+      const int c = g * cpg + i / HW;
+      const float gc = gamma[c], bc = beta[c];
+      const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      float4 o;
+      o.x = fmaxf(((v.x - mu) * istd) * gc + bc, 0.f); o.y = fmaxf(((v.y - mu) * istd) * gc + bc, 0.f);
+      o.z = fmaxf(((v.z - mu) * istd) * gc + bc, 0.f); o.w = fmaxf(((v.w - mu) * istd) * gc + bc, 0.f);
+      *reinterpret_cast<float4*>(y + base + i) = o;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int c = g * cpg + i / HW;
     const float xh = (x[base + i] - mu) * istd;
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(512) void gn_relu_fwd_kernel(const float* __restric
 
 // The ReLU mask is re-derived from x (sign of the forward's own (x - mu) * istd * gamma + beta): the forward output is not
 // read at all (4 instead of 6 activation reads over the two passes).
-__global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void gn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, float* __restrict__ dx,
                                                           float* __restrict__ dgp, float* __restrict__ dbp, int C, int HW, int G, int BG,
@@ -408,19 +429,35 @@ __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restric
   const int g = bg % G, cpg = C / G, b = bg / G;
   const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
   const float mu = stats[bg * 2], istd = stats[bg * 2 + 1];
-  __shared__ double sm[16];
+  __shared__ double sm[32];
   __shared__ double tot[2];
+  const bool vec = (HW & 3) == 0 && (base & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
   double ds = 0.0, db = 0.0;       // sum_c gamma_c * sum(g*xhat), sum_c gamma_c * sum(g)
   for (int cc = 0; cc < cpg; ++cc) {
     const int c = g * cpg + cc;
     const size_t cb = base + (size_t)cc * HW;
     float s1 = 0.f, s2 = 0.f;
     const float gc = gamma[c], bc = beta[c];
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      float gg = dy[cb + i];
-      const float xh = (x[cb + i] - mu) * istd;
-      if (!(xh * gc + bc > 0.f)) gg = 0.f;
-      s1 += gg; s2 += gg * xh;
+    if (vec) {
+      for (int i = threadIdx.x * 4; i < HW; i += blockDim.x * 4) {
+        float4 gg = *reinterpret_cast<const float4*>(dy + cb + i);
+        const float4 xv = *reinterpret_cast<const float4*>(x + cb + i);
+        const float h0 = (xv.x - mu) * istd, h1 = (xv.y - mu) * istd, h2 = (xv.z - mu) * istd, h3 = (xv.w - mu) * istd;
+        if (!(h0 * gc + bc > 0.f)) gg.x = 0.f;
+        if (!(h1 * gc + bc > 0.f)) gg.y = 0.f;
+        if (!(h2 * gc + bc > 0.f)) gg.z = 0.f;
+        if (!(h3 * gc + bc > 0.f)) gg.w = 0.f;
+        s1 += (gg.x + gg.y) + (gg.z + gg.w);
+        s2 += (gg.x * h0 + gg.y * h1) + (gg.z * h2 + gg.w * h3);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        float gg = dy[cb + i];
+        const float xh = (x[cb + i] - mu) * istd;
+        if (!(xh * gc + bc > 0.f)) gg = 0.f;
+        s1 += gg; s2 += gg * xh;
+      }
     }
     double d1 = s1, d2 = s2;
     block_sum2(d1, d2, sm);
@@ -430,6 +467,24 @@ __global__ __launch_bounds__(512) void gn_relu_bwd_kernel(const float* __restric
   }
   const int n = cpg * HW;
   const float m1 = (float)(db / n), m2 = (float)(ds / n);
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+      const int c = g * cpg + i / HW;
+      const float gc = gamma[c], bc = beta[c];
+      float4 gg = *reinterpret_cast<const float4*>(dy + base + i);
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+      const float h0 = (xv.x - mu) * istd, h1 = (xv.y - mu) * istd, h2 = (xv.z - mu) * istd, h3 = (xv.w - mu) * istd;
+      if (!(h0 * gc + bc > 0.f)) gg.x = 0.f;
+      if (!(h1 * gc + bc > 0.f)) gg.y = 0.f;
+      if (!(h2 * gc + bc > 0.f)) gg.z = 0.f;
+      if (!(h3 * gc + bc > 0.f)) gg.w = 0.f;
+      float4 o;
+      o.x = istd * (gc * gg.x - m1 - h0 * m2); o.y = istd * (gc * gg.y - m1 - h1 * m2);
+      o.z = istd * (gc * gg.z - m1 - h2 * m2); o.w = istd * (gc * gg.w - m1 - h3 * m2);
+      *reinterpret_cast<float4*>(dx + base + i) = o;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int c = g * cpg + i / HW;
     float gg = dy[base + i];
@@ -537,7 +592,7 @@ extern "C" int prn_gn_relu_fwd(const float* x, const float* gamma, const float* 
                                int B, int C, int HW, int G, float eps, void* stream) {
   PRN_REQUIRE(x && gamma && beta && y && stats && B > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "prn_gn_relu_fwd: bad arguments");
   GnSeg sg; sg.nseg = 0;
-  hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, x, gamma, beta, y, stats, C, HW, G, eps, B * G, sg);
+  hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(B * G), dim3((C / G) * HW >= 32768 ? 1024 : 512), 0, (hipStream_t)stream, x, gamma, beta, y, stats, C, HW, G, eps, B * G, sg);
   PRN_CHECK_LAUNCH("prn_gn_relu_fwd");
   return 0;
 }
@@ -569,7 +624,7 @@ extern "C" int prn_gn_relu_bwd(const float* dy, const float* x, const float* bet
                                float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int HW, int G, void* stream) {
   PRN_REQUIRE(dy && x && beta && stats && gamma && dx && dgamma_part && dbeta_part && C % G == 0, "prn_gn_relu_bwd: bad arguments");
   GnSeg sg; sg.nseg = 0;
-  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3(512), 0, (hipStream_t)stream, dy, x, beta, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G,
+  hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(B * G), dim3((C / G) * HW >= 32768 ? 1024 : 512), 0, (hipStream_t)stream, dy, x, beta, stats, gamma, dx, dgamma_part, dbeta_part, C, HW, G,
                      B * G, sg);
   PRN_CHECK_LAUNCH("prn_gn_relu_bwd");
   return 0;

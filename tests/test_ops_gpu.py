@@ -311,7 +311,7 @@ def test_batch_norm_fwd_bwd(B, C, H, W, res, relu, training):
         close(g1, g0, "bn " + n, rtol=5e-4)
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 256, 16, 16), (2, 128, 30, 40), (1, 128, 9, 7)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 16, 16), (2, 128, 30, 40), (1, 128, 9, 7), (1, 128, 96, 88)])   # last: 1024-thread blocks
 def test_group_norm_relu_fwd_bwd(B, C, H, W):
     from planerecnet_amd import ops
     x = (rnd(B, C, H, W, seed=1) * 2 + 0.5).requires_grad_(True)
