@@ -137,7 +137,7 @@ def main():
     net = net.to(dev).train()
     crit = PlaneRecNetLoss().to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
-    exchange = GradAllReduce(list(net.parameters()))
+    exchange = GradAllReduce(list(net.parameters()), force=bool(os.environ.get("PRN_FORCE_EXCHANGE")))    # force: run the bucket / RCCL path with one rank too (overhead probe)
     images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
     np.random.seed(rank)
 
