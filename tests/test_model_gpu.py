@@ -65,6 +65,50 @@ def test_forward_matches_oracle(setup, mode):
             close(got[k], sd2[k], 2e-3, k)
 
 
+def test_backward_with_ragged_heads_and_deferred_wgrads(setup):
+    """B=4 at 128x160 (the batch sizes for which the SOLO grid levels pack into whole GEMM tiles): the instance head runs as
+    ragged batches, weight gradients are deferred to the side stream, backbone-feature gradients meet in forked epilogues.
+    Outputs and parameter gradients of a scalar test loss against the oracle's autograd."""
+    from oracle import model_ref, synth
+    from planerecnet_amd import ops
+    net, sd, arch = setup
+    net.load_state_dict(sd)
+    net.train()
+    x, _, _ = synth.make_batch(4, 128, 160, seed=5)
+    assert ops.RaggedShape(4, [(g, g) for g in net.inst_head.num_grids]).supported()
+
+    def scalar(mask, cate, kern, depth):
+        return mask.square().mean() + depth.mean() + sum(c.square().mean() for c in cate) + sum(k.square().mean() for k in kern)
+
+    ops.set_wgrad_async(True)
+    try:
+        net.zero_grad(set_to_none=True)
+        out = net(x.cuda())
+        scalar(*out).backward()
+        ops.wgrad_join()
+    finally:
+        ops.set_wgrad_async(False)
+    torch.cuda.synchronize()
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    oo = model_ref.forward(sdg, x, arch, training=True)
+    close(out[0], oo[0], 5e-4, "mask_pred")
+    close(out[3], oo[3], 5e-4, "depth_pred")
+    for i in range(len(oo[1])):
+        close(out[1][i], oo[1][i], 5e-4, f"cate{i}")
+        close(out[2][i], oo[2][i], 5e-4, f"kernel{i}")
+    names = ["backbone.conv1.weight", "backbone.layers.1.0.conv1.weight", "backbone.layers.1.0.downsample.0.weight",
+             "backbone.layers.2.5.conv3.weight", "fpn.lateral_convs.1.weight", "fpn.fpn_convs.0.weight",
+             "inst_head.kernel_tower.0.weight", "inst_head.kernel_tower.4.weight", "inst_head.cate_tower.3.weight",
+             "inst_head.cate_pred.weight", "inst_head.cate_pred.bias", "inst_head.kernel_pred.weight",
+             "mask_head.conv_pred.0.weight", "depth_decoder.latlayer2.weight", "depth_decoder.deconv3.2.weight"]
+    grads = torch.autograd.grad(scalar(*oo), [sdg[n] for n in names])
+    params = dict(net.named_parameters())
+    for n, g in zip(names, grads):
+        got = params[n].grad.detach().double().cpu()
+        l2 = ((got - g.double()).norm() / (g.double().norm() + 1e-30)).item()
+        assert l2 <= 3e-2, f"grad {n}: relative L2 {l2:.2e}"
+
+
 def test_inference_matches_oracle(setup):
     from oracle import model_ref, synth
     net, sd, arch = setup
