@@ -17,7 +17,6 @@ from . import _lib, profiling
 from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
-OVERLAP_WGRAD = bool(int(os.environ.get("PRN_OVERLAP_WGRAD", "0")))         # (measured: no gain at B=8 -- 119.1 vs 116.6 ms/step -- the extra stream traffic costs host time) backward: weight-gradient kernels on a side stream, concurrent with the data-gradient kernel
 _SIDE = {}
 # Deferred weight gradients.  In the backward pass only the input-gradient chain is on the critical path; the weight
 # gradient of a layer is needed by nobody until the optimizer (or the gradient exchange) runs.  With this mode on, every conv
@@ -338,18 +337,6 @@ class _Conv2d(torch.autograd.Function):
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None
-        elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and OVERLAP_WGRAD and not profiling.active():
-            # dgrad and wgrad only share their inputs: run wgrad on a side HIP stream so the two kernels fill each other's
-            # idle CUs (most backbone layers launch fewer workgroups than one GPU-wide wave), then join.
-            main = torch.cuda.current_stream()
-            side = _side_stream(dy.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode)
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork)
-            dfork = None
-            main.wait_stream(side)
-            dw.record_stream(main)
         else:
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None

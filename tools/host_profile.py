@@ -15,7 +15,6 @@ from planerecnet_amd.config import cfg, set_cfg  # noqa: E402
 from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher  # noqa: E402
 from planerecnet_amd.planerecnet import PlaneRecNet  # noqa: E402
 
-ops.OVERLAP_WGRAD = bool(int(os.environ.get("OVERLAP", "0")))
 timer.disable_all()
 torch.set_num_threads(4)
 dev = torch.device("cuda:0")
