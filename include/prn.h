@@ -178,8 +178,10 @@ int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* beta, c
 int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
 int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 /* MaxPool2d(3, stride 2, pad 1): models/backbone.py:104 */
-int prn_maxpool3s2_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
-int prn_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
+int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int H, int W, int Ho, int Wo, void* stream);
+/* arg (may be NULL in the forward): window position r*3+s of every output's maximum, one byte per output; the backward
+ * gathers through it (dx fully written, no atomics). */
+int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,14 +121,17 @@ __global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __rest
   dx[i] = acc;
 }
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total,
-                                                          int H, int W, int Ho, int Wo) {
+// arg (optional): position r*3+s of the maximum inside the window (first maximum in scan order, ATen's
+// max_pool2d_with_indices rule; NaN wins like in ATen), kept as one byte per output for the backward.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ arg,
+                                                          int64_t total, int H, int W, int Ho, int Wo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int wo = i % Wo, ho = (i / Wo) % Ho;
   const int64_t bc = i / ((int64_t)Wo * Ho);
   const float* p = x + bc * (int64_t)H * W;
   float m = -INFINITY;
+  int am = 255;
   for (int r = 0; r < 3; ++r) {
     const int h = ho * 2 - 1 + r;
     if ((unsigned)h >= (unsigned)H) continue;
@@ -136,33 +139,35 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       const int w = wo * 2 - 1 + s;
       if ((unsigned)w >= (unsigned)W) continue;
       const float v = p[h * W + w];
-      if (v > m || v != v) m = v;
+      if (v > m || v != v || am == 255) { m = v; am = r * 3 + s; }
     }
   }
   y[i] = m;
+  if (arg) arg[i] = (unsigned char)am;
 }
 
-// gradient goes to the first maximum in scan order (ATen max_pool2d_with_indices rule)
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// gradient goes to the recorded maximum; GATHER form: input (h, w) lies in at most four windows -- window row ho = (h+1-r)/2
+// for the r in {0,1,2} with the parity of h+1 -- and takes dy of those whose recorded position is (r, s).  No atomics, no
+// zero fill, deterministic (the scatter version: 266 us + a 157 MB fill at the stem).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ arg, const float* __restrict__ dy,
                                                           float* __restrict__ dx, int64_t total, int H, int W, int Ho, int Wo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int wo = i % Wo, ho = (i / Wo) % Ho;
-  const int64_t bc = i / ((int64_t)Wo * Ho);
-  const float* p = x + bc * (int64_t)H * W;
-  float m = -INFINITY;
-  int arg = -1;
-  for (int r = 0; r < 3; ++r) {
-    const int h = ho * 2 - 1 + r;
-    if ((unsigned)h >= (unsigned)H) continue;
-    for (int s = 0; s < 3; ++s) {
-      const int w = wo * 2 - 1 + s;
-      if ((unsigned)w >= (unsigned)W) continue;
-      const float v = p[h * W + w];
-      if (v > m || v != v || arg < 0) { m = v; arg = h * W + w; }
+  const int w = i % W, h = (i / W) % H;
+  const int64_t bc = i / ((int64_t)W * H);
+  const int64_t ob = bc * (int64_t)Ho * Wo;
+  float acc = 0.f;
+  for (int r = (h + 1) & 1; r < 3; r += 2) {
+    const int ho = (h + 1 - r) >> 1;
+    if (ho < 0 || ho >= Ho) continue;
+    for (int s = (w + 1) & 1; s < 3; s += 2) {
+      const int wo = (w + 1 - s) >> 1;
+      if (wo < 0 || wo >= Wo) continue;
+      const int64_t o = ob + (int64_t)ho * Wo + wo;
+      if (arg[o] == r * 3 + s) acc += dy[o];
     }
   }
-  if (arg >= 0) atomicAdd(dx + bc * (int64_t)H * W + arg, dy[i]);
+  dx[i] = acc;
 }
 
 }  // namespace
@@ -198,18 +203,18 @@ extern "C" int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H
   return 0;
 }
 
-extern "C" int prn_maxpool3s2_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
+extern "C" int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(x && y && BC > 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "prn_maxpool3s2_fwd: bad arguments");
   const int64_t n = (int64_t)BC * Ho * Wo;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, arg, n, H, W, Ho, Wo);
   PRN_CHECK_LAUNCH("prn_maxpool3s2_fwd");
   return 0;
 }
 
-extern "C" int prn_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
-  PRN_REQUIRE(x && dy && dx && BC > 0, "prn_maxpool3s2_bwd: bad arguments");
-  const int64_t n = (int64_t)BC * Ho * Wo;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, H, W, Ho, Wo);
+extern "C" int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  PRN_REQUIRE(arg && dy && dx && BC > 0, "prn_maxpool3s2_bwd: bad arguments");
+  const int64_t n = (int64_t)BC * H * W;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, arg, dy, dx, n, H, W, Ho, Wo);
   PRN_CHECK_LAUNCH("prn_maxpool3s2_bwd");
   return 0;
 }

@@ -773,17 +773,19 @@ class _MaxPool(torch.autograd.Function):
         B, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
-        check(lib.prn_maxpool3s2_fwd(_p(x), _p(y), B * C, H, W, Ho, Wo, _stream()), "prn_maxpool3s2_fwd")
-        ctx.save_for_backward(x)
+        arg = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.uint8) if ctx.needs_input_grad[0] else None
+        check(lib.prn_maxpool3s2_fwd(_p(x), _p(y), _p(arg), B * C, H, W, Ho, Wo, _stream()), "prn_maxpool3s2_fwd")
+        ctx.save_for_backward(arg)
+        ctx.in_shape = (B, C, H, W)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        (arg,) = ctx.saved_tensors
         dy = _c(dy)
-        B, C, H, W = x.shape
-        dx = torch.zeros_like(x)
-        check(lib.prn_maxpool3s2_bwd(_p(x), _p(dy), _p(dx), B * C, H, W, dy.shape[2], dy.shape[3], _stream()), "prn_maxpool3s2_bwd")
+        B, C, H, W = ctx.in_shape
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        check(lib.prn_maxpool3s2_bwd(_p(arg), _p(dy), _p(dx), B * C, H, W, dy.shape[2], dy.shape[3], _stream()), "prn_maxpool3s2_bwd")
         return dx
 
 
