@@ -569,6 +569,109 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   }
 }
 
+// ---------------------------------------------------------------------------------------------- direct small kernels
+// 3x3 stride-1 layers with one or two output channels over a large map and few input channels (the depth head: 64 -> 1 at
+// 240x320), and their input gradients (1 -> 64), are HBM-bound streams, not GEMMs: on the 64-row MFMA tile they ran at 2-4
+// TFLOP/s (253 / 183 / 416 us for forward / input gradient / weight gradient).  One thread per pixel instead.
+template <int MODE, int MM>
+__global__ __launch_bounds__(256) void conv3x3_small_m_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ addend, float* __restrict__ y, int B, int C, int H, int W,
+                                                              int pad, int epi) {
+  const int HW = H * W;
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= (int64_t)B * HW) return;
+  const int b = (int)(n / HW), p = (int)(n - (int64_t)b * HW), oh = p / W, ow = p - oh * W;
+  int off[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) off[t] = tap_offset<MODE>(oh - pad + t / 3, ow - pad + t % 3, true, H, W);
+  float acc[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+  const float* xb = x + (size_t)b * C * HW;
+  for (int c = 0; c < C; ++c) {                            // same summation order as the GEMM's K axis (c major, tap minor)
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = off[t] >= 0 ? xb[(size_t)c * HW + off[t]] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[m] += w[((size_t)m * C + c) * 9 + t] * v[t];
+  }
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    const size_t idx = ((size_t)b * MM + m) * HW + p;
+    float r = acc[m];
+    if (bias) r += bias[m];
+    if (addend) r += addend[idx];
+    if (epi == PRN_EPI_RELU) r = fmaxf(r, 0.f);
+    else if (epi == PRN_EPI_SIGMOID) r = 1.f / (1.f + __expf(-r));
+    y[idx] = r;
+  }
+}
+
+// one input channel -> M output channels, zero padding: the 9 taps of a pixel are read once and every output row is a
+// 9-term dot product; the launch is bound by writing y
+__global__ __launch_bounds__(256) void conv3x3_one_c_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ addend, float* __restrict__ y, int B, int H, int W, int M,
+                                                            int pad, int Ho, int Wo, int epi) {
+  const int HoWo = Ho * Wo;
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= (int64_t)B * HoWo) return;
+  const int b = (int)(n / HoWo), p = (int)(n - (int64_t)b * HoWo), oh = p / Wo, ow = p - oh * Wo;
+  const float* xb = x + (size_t)b * H * W;
+  float v[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int o = tap_offset<PRN_IN_ZERO>(oh - pad + t / 3, ow - pad + t % 3, true, H, W);
+    v[t] = o >= 0 ? xb[o] : 0.f;
+  }
+  for (int m = 0; m < M; ++m) {
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) r += w[(size_t)m * 9 + t] * v[t];
+    const size_t idx = ((size_t)b * M + m) * HoWo + p;
+    if (bias) r += bias[m];
+    if (addend) r += addend[idx];
+    if (epi == PRN_EPI_RELU) r = fmaxf(r, 0.f);
+    else if (epi == PRN_EPI_SIGMOID) r = 1.f / (1.f + __expf(-r));
+    y[idx] = r;
+  }
+}
+
+// weight gradient of the one-output-channel layer: block (c, split) reduces its pixel range for the 9 taps of channel c
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_small_m_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
+                                                                    int B, int C, int H, int W, int M, int pad) {
+  const int c = blockIdx.x % C, m = blockIdx.x / C, sp = blockIdx.y, S = gridDim.y;
+  const int HW = H * W;
+  const int64_t N = (int64_t)B * HW, beg = N * sp / S, end = N * (sp + 1) / S;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int64_t n = beg + threadIdx.x; n < end; n += 256) {
+    const int b = (int)(n / HW), p = (int)(n - (int64_t)b * HW), oh = p / W, ow = p - oh * W;
+    const float g = dy[((size_t)b * M + m) * HW + p];
+    const float* xc = x + ((size_t)b * C + c) * HW;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int o = tap_offset<MODE>(oh - pad + t / 3, ow - pad + t % 3, true, H, W);
+      acc[t] += g * (o >= 0 ? xc[o] : 0.f);
+    }
+  }
+  __shared__ float sm[4][9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v = acc[t];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int t = threadIdx.x;
+    out[((size_t)sp * M + m) * C * 9 + (size_t)c * 9 + t] = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+  }
+}
+
 // y = epi( sum_s ws[s] + bias[m] + addend ) for split-K launches (fixed summation order).
 // (Folding this into the GEMM kernel -- last workgroup to arrive at a per-tile counter sums the partials -- was tried and is
 // 4x SLOWER on MI355X: the release/acquire pair it needs is a device-scope __threadfence(), which writes back and
@@ -931,6 +1034,19 @@ int check_desc(const prn_conv_desc* d, const char* who) {
   return 0;
 }
 
+// direct (non-GEMM) paths, see conv3x3_small_m_kernel
+bool direct_small_m(const prn_conv_desc* d) {
+  return d->KH == 3 && d->stride == 1 && d->pad == 1 && d->M <= 2 && d->C <= 112 && (d->in_mode == PRN_IN_ZERO || d->in_mode == PRN_IN_REFLECT) &&
+         d->ystride <= 1 && d->Ho == d->H && d->Wo == d->W && (int64_t)d->B * d->H * d->W >= 65536;
+}
+bool direct_one_c(const prn_conv_desc* d) {
+  return d->KH == 3 && d->stride == 1 && d->C == 1 && d->in_mode == PRN_IN_ZERO && d->ystride <= 1 && (int64_t)d->B * d->Ho * d->Wo >= 65536;
+}
+int direct_wgrad_splits(const prn_conv_desc* d) {
+  int s = 2048 / (d->C * d->M);
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
 // GEMM-side geometry of a descriptor: the pixel grid the N dimension runs over, phases, and whether K may be split
 struct Geo { int gH, gW, phases; bool nosplit; };
 Geo geo_of(const prn_conv_desc* d) {
@@ -946,6 +1062,7 @@ Geo geo_of(const prn_conv_desc* d) {
 
 extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
+  if (direct_small_m(d) || direct_one_c(d)) return 0;
   const Geo g = geo_of(d);
   const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
                              wide_ks(d->KH, d->in_mode));
@@ -1011,6 +1128,23 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
   }
   if (int e = check_desc(d, "prn_conv2d_fwd")) return e;
   PRN_REQUIRE(x && w && y, "prn_conv2d_fwd: null tensor");
+  if (rg == nullptr && (direct_small_m(d) || direct_one_c(d))) {
+    if (phase == 2) return 0;
+    hipStream_t sd = (hipStream_t)stream;
+    if (direct_small_m(d)) {
+      const dim3 grid(cdiv((int64_t)d->B * d->H * d->W, 256)), block(256);
+#define PRN_SMALL_M(MODE_, MM_) hipLaunchKernelGGL((conv3x3_small_m_kernel<MODE_, MM_>), grid, block, 0, sd, x, w, bias, addend, y, d->B, d->C, d->H, d->W, \
+                                                   d->pad, d->epilogue)
+      if (d->in_mode == PRN_IN_ZERO) { if (d->M == 1) PRN_SMALL_M(PRN_IN_ZERO, 1); else PRN_SMALL_M(PRN_IN_ZERO, 2); }
+      else { if (d->M == 1) PRN_SMALL_M(PRN_IN_REFLECT, 1); else PRN_SMALL_M(PRN_IN_REFLECT, 2); }
+#undef PRN_SMALL_M
+    } else {
+      hipLaunchKernelGGL(conv3x3_one_c_kernel, dim3(cdiv((int64_t)d->B * d->Ho * d->Wo, 256)), dim3(256), 0, sd, x, w, bias, addend, y, d->B, d->H, d->W,
+                         d->M, d->pad, d->Ho, d->Wo, d->epilogue);
+    }
+    PRN_CHECK_LAUNCH("prn_conv2d_fwd/direct");
+    return 0;
+  }
   ConvArgs a;
   a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.y = y; a.ws = (float*)ws;
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
@@ -1068,6 +1202,7 @@ reduce_only:
 extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_wgrad_ws_bytes")) return -1;
   const int K = d->C * d->KH * d->KW;
+  if (direct_small_m(d)) return (int64_t)direct_wgrad_splits(d) * d->M * K * 4;
   const Geo g = geo_of(d);
   WgPlan p = plan_wgrad(d->M, K, (int64_t)d->B * g.gH * g.gW, g.phases);
   return p.splits > 1 ? (int64_t)p.splits * g.phases * d->M * K * 4 : 0;
@@ -1102,6 +1237,23 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
   if (int e = check_desc(d, "prn_conv2d_wgrad")) return e;
   PRN_REQUIRE(d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->ystride <= 1, "prn_conv2d_wgrad: dgrad-only descriptor (dilated input, 4x4, strided output)");
   PRN_REQUIRE(x && dy && dw, "prn_conv2d_wgrad: null tensor");
+  if (rg == nullptr && direct_small_m(d)) {
+    PRN_REQUIRE(ws != nullptr, "prn_conv2d_wgrad: workspace required");
+    hipStream_t sd = (hipStream_t)stream;
+    const int S = direct_wgrad_splits(d);
+    const int64_t n = (int64_t)d->M * d->C * 9;
+    if (phase != 2) {
+      const dim3 grid(d->C * d->M, S), block(256);
+      if (d->in_mode == PRN_IN_ZERO) hipLaunchKernelGGL((conv3x3_small_m_wgrad_kernel<PRN_IN_ZERO>), grid, block, 0, sd, x, dy, (float*)ws, d->B, d->C, d->H, d->W, d->M, d->pad);
+      else hipLaunchKernelGGL((conv3x3_small_m_wgrad_kernel<PRN_IN_REFLECT>), grid, block, 0, sd, x, dy, (float*)ws, d->B, d->C, d->H, d->W, d->M, d->pad);
+      PRN_CHECK_LAUNCH("prn_conv2d_wgrad/direct");
+    }
+    if (phase != 1) {
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, sd, (const float*)ws, dw, n, S);
+      PRN_CHECK_LAUNCH("prn_conv2d_wgrad/direct reduce");
+    }
+    return 0;
+  }
   WgArgs a;
   a.x = x; a.dy = dy;
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;

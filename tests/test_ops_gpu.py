@@ -62,6 +62,8 @@ CONV_CASES = [
     (2, 24, 15, 21, 40, 1, 2, 0, 0, False, False, 0),        # stride-2 1x1 on odd sizes (scatter-form input gradient)
     (2, 130, 9, 13, 70, 3, 1, 1, 2, True, False, 0),         # nearest-x2 + reflect + 3x3, sub-pixel form, ragged tiles
     (1, 16, 2, 2, 8, 3, 1, 1, 2, False, False, 0),           # ... smallest map it accepts
+    (2, 24, 160, 208, 1, 3, 1, 1, 1, True, False, 0),        # depth-head shape class: direct (non-GEMM) kernels, reflect padding
+    (1, 40, 256, 260, 2, 3, 1, 1, 0, True, True, 1),         # ... two output channels, zero padding, addend + ReLU
 ]
 
 
