@@ -12,9 +12,10 @@ import bench  # noqa: E402
 from planerecnet_amd.config import cfg, set_cfg  # noqa: E402
 from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher  # noqa: E402
 from planerecnet_amd.planerecnet import PlaneRecNet  # noqa: E402
-from planerecnet_amd import timer  # noqa: E402
+from planerecnet_amd import ops, timer  # noqa: E402
 
 timer.disable_all()
+ops.set_wgrad_async(True)
 
 torch.set_num_threads(int(os.environ.get("HOST_THREADS", "4")))
 dev = torch.device("cuda:0")
@@ -42,7 +43,7 @@ def step():
     t0 = time.perf_counter(); pf.pending = None; targets = crit.upload(h, depths, dev); pf.submit(inst, (H, W)); mark("upload", t0)
     t0 = time.perf_counter(); out = net(images); mark("net_fwd", t0)
     t0 = time.perf_counter(); losses = crit(net, *out, inst, depths, targets=targets); loss = sum(losses.values()).sum(); mark("loss_fwd", t0)
-    t0 = time.perf_counter(); loss.backward(); mark("backward", t0)
+    t0 = time.perf_counter(); loss.backward(); ops.wgrad_join(); mark("backward", t0)
     t0 = time.perf_counter(); opt.step(); mark("adam", t0)
 
 
