@@ -16,6 +16,34 @@ def _bn(m, x, residual=None, relu=False):
     return ops.batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
 
 
+def folded_bn(conv_w, conv_b, m):
+    """Inference only (eval-mode BatchNorm, no autograd): scale the conv weights by gamma/sqrt(var+eps) and fold the shift
+    into a bias, so that conv + BN (+ residual + ReLU) is ONE GEMM launch with a fused epilogue and the BatchNorm kernels
+    disappear from the forward pass.  Cached until any of the five tensors changes (their autograd version counters)."""
+    key = (conv_w._version, None if conv_b is None else conv_b._version, m.weight._version, m.bias._version, m.running_mean._version,
+           m.running_var._version, conv_w.data_ptr())
+    c = m.__dict__.get("_prn_folded")
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            scale = m.weight * torch.rsqrt(m.running_var + m.eps)
+            w = (conv_w * scale.view(-1, 1, 1, 1)).contiguous()
+            b = m.bias - m.running_mean * scale if conv_b is None else (conv_b - m.running_mean) * scale + m.bias
+        c = m.__dict__["_prn_folded"] = (key, w, b.contiguous())
+    return c[1], c[2]
+
+
+def can_fold(m):
+    return (not m.training) and (not torch.is_grad_enabled())
+
+
+def conv_bn(x, conv, m, stride=1, pad=0, relu=False, residual=None, in_mode=ops.IN_ZERO):
+    """conv -> BatchNorm (-> + residual) (-> ReLU): folded into one launch at inference, two ops otherwise."""
+    if can_fold(m):
+        w, b = folded_bn(conv.weight, conv.bias, m)
+        return ops.conv2d(x, w, b, stride, pad, in_mode, ops.EPI_RELU if relu else ops.EPI_NONE, residual)
+    return _bn(m, ops.conv2d(x, conv.weight, conv.bias, stride, pad, in_mode), residual, relu)
+
+
 class Bottleneck(nn.Module):
     """1x1 -> 3x3 (stride here; plain or deformable) -> 1x1, each + BN, residual, ReLU (backbone.py:5-73)."""
     expansion = 4
@@ -36,6 +64,14 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if can_fold(self.bn1):                                 # inference: every conv + BN (+ residual + ReLU) is one launch
+            out = conv_bn(x, self.conv1, self.bn1, relu=True)
+            if isinstance(self.conv2, DeformableConv2d):
+                out = self.conv2(out, fold=self.bn2)
+            else:
+                out = conv_bn(out, self.conv2, self.bn2, self.stride, 1, relu=True)
+            res = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], self.downsample[0].stride[0])
+            return conv_bn(out, self.conv3, self.bn3, relu=True, residual=res)
         # x has a second consumer (the identity branch or the downsample conv): hand it on through the fork so that both
         # gradients of x meet in conv1's input-gradient epilogue instead of in a separate accumulation kernel
         out, x = ops.conv2d_fork(x, self.conv1.weight)
@@ -92,7 +128,7 @@ class ResNetBackbone(nn.Module):
         return layer
 
     def forward(self, x):
-        x = _bn(self.bn1, ops.conv2d(x, self.conv1.weight, stride=2, pad=3), relu=True)
+        x = conv_bn(x, self.conv1, self.bn1, 2, 3, relu=True)
         x = ops.max_pool_3x3_s2(x)
         outs = []
         for layer in self.layers:

@@ -25,8 +25,14 @@ class DeformableConv2d(nn.Module):
             nn.init.zeros_(m.bias)
         self.regular_conv = nn.Conv2d(in_channels, out_channels, 3, stride=stride, padding=1, bias=bias)
 
-    def forward(self, x):
+    def forward(self, x, fold=None):
+        """fold: an eval-mode BatchNorm2d to fold into the contraction (inference; the output is then ReLU'd as well)."""
         h, w = x.shape[2:]
         w27 = torch.cat([self.offset_conv.weight, self.modulator_conv.weight], 0)
         b27 = torch.cat([self.offset_conv.bias, self.modulator_conv.bias], 0)
+        if fold is not None:
+            from .backbone import folded_bn
+            wf, bf = folded_bn(self.regular_conv.weight, self.regular_conv.bias, fold)
+            om = ops.conv2d(x, w27, b27, stride=self.stride, pad=1)
+            return ops.deform_conv2d(x, om, wf, bf, self.stride, max(h, w) / 4.0, relu=True)
         return ops.deform_conv_block(x, w27, b27, self.regular_conv.weight, self.regular_conv.bias, self.stride, max(h, w) / 4.0)

@@ -519,9 +519,19 @@ def deform_conv_block(x, w27, b27, weight, bias, stride, max_offset):
     return _DeformConvBlock.apply(x, w27, b27, weight, bias, stride, max_offset)
 
 
-def deform_conv2d(x, om_raw, weight, bias, stride, max_offset):
+def deform_conv2d(x, om_raw, weight, bias, stride, max_offset, relu=False):
     """torchvision.ops.deform_conv2d replacement with the wrapper's clamp / 2*sigmoid folded in
-    (reference models/dcn.py:52-67). om_raw = raw [offset(18) | modulator(9)] conv output."""
+    (reference models/dcn.py:52-67). om_raw = raw [offset(18) | modulator(9)] conv output.
+    relu=True (inference only, no autograd): ReLU in the contraction's epilogue (BatchNorm folded into weight / bias)."""
+    if relu:
+        assert not torch.is_grad_enabled()
+        x, om_raw, weight, bias = _c(x), _c(om_raw), _c(weight), _c(bias)
+        _dev(x, om_raw, weight, bias)
+        B, C, H, W = x.shape
+        Ho, Wo = om_raw.shape[2:]
+        cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
+        check(lib.prn_dcn_sample(_p(x), _p(om_raw), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
+        return conv_fwd_raw(cols, weight, bias, None, weight.shape[0], 1, 1, 0, Ho, Wo, epi=EPI_RELU)
     return _DeformConv.apply(x, om_raw, weight, bias, stride, max_offset)
 
 
