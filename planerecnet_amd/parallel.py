@@ -49,13 +49,23 @@ class GradAllReduce:
                 self.where[p] = bi
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.arrived = [0] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self.next = 0
 
     # called by autograd on the backward thread, once per parameter per backward
     def _on_grad(self, p):
         bi = self.where[p]
         self.arrived[bi] += 1
         if self.arrived[bi] == len(self.buckets[bi]):
-            self._launch(bi)
+            self.ready[bi] = True
+            self._launch_ready()
+
+    def _launch_ready(self):
+        # Collectives are issued strictly in bucket order, whatever order the gradients arrive in: every rank must post the
+        # same sequence of all-reduces, and arrival order may differ between ranks (a parameter without gradient on one rank)
+        while self.next < len(self.buckets) and self.ready[self.next]:
+            self._launch(self.next)
+            self.next += 1
 
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
@@ -84,12 +94,13 @@ class GradAllReduce:
         """Block the compute stream until every bucket has been reduced and written back. Call after backward()."""
         if not self.active:
             return
-        for bi, n in enumerate(self.arrived):           # parameters that received no gradient this step
-            if 0 < n < len(self.buckets[bi]) or (n == 0 and any(p.grad is not None for p in self.buckets[bi])):
+        for bi in range(self.next, len(self.buckets)):  # buckets held back by a parameter that received no gradient this step
+            if any(p.grad is not None for p in self.buckets[bi]) or self.world > 1:
                 for p in self.buckets[bi]:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
                 self._launch(bi)
+        self.next = len(self.buckets)
         for bi, work in self._pending:
             bucket, flat = self.buckets[bi], self.flat[bi]
             if self.on_gpu:
@@ -103,6 +114,8 @@ class GradAllReduce:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending.clear()
         self.arrived = [0] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self.next = 0
 
     def remove(self):
         for h in self._handles:
