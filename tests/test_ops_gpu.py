@@ -255,6 +255,35 @@ def test_conv_fork_sums_both_input_gradients():
     close(xd3.grad, torch.autograd.grad((F.conv2d(xr, wr) * g1).sum(), xr)[0], "fork conv-only")
 
 
+def test_deferred_weight_gradients_accumulate_like_autograd():
+    """ops.set_wgrad_async: the weight gradient is written to .grad on the side stream; two backward passes accumulate, a weight
+    used twice in one graph gets both contributions, and a non-leaf weight falls back to the autograd path."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, 24, 10, 12, seed=1).float().to(d)
+    w0 = rnd(16, 24, 3, 3, seed=2, scale=0.1).float().to(d)
+    g = rnd(2, 16, 10, 12, seed=3).float().to(d)
+
+    def run(deferred):
+        w = w0.clone().requires_grad_(True)
+        scale = torch.ones((), device=d, requires_grad=True)
+        ops.set_wgrad_async(deferred)
+        try:
+            for _ in range(2):                                            # two backward passes -> accumulation
+                y = ops.conv2d(x, w, None, 1, 1) + ops.conv2d(x.flip(3), w, None, 1, 1)      # the same leaf weight twice
+                y = y + ops.conv2d(x, w * scale, None, 1, 1)            # a non-leaf weight (autograd path even when deferred)
+                (y * g).sum().backward()
+                ops.wgrad_join()
+        finally:
+            ops.set_wgrad_async(False)
+        torch.cuda.synchronize()
+        return w.grad.clone(), scale.grad.clone()
+
+    (wa, sa), (wb, sb) = run(True), run(False)
+    close(wa, wb.double().cpu(), "deferred dw", rtol=1e-5)
+    close(sa, sb.double().cpu(), "deferred d(scale)", rtol=1e-5)
+
+
 def test_flipped_weights_batched_matches_single():
     from planerecnet_amd import ops
     d = dev()
