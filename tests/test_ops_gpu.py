@@ -257,7 +257,8 @@ def test_conv_fork_sums_both_input_gradients():
 
 def test_deferred_weight_gradients_accumulate_like_autograd():
     """ops.set_wgrad_async: the weight gradient is written to .grad on the side stream; two backward passes accumulate, a weight
-    used twice in one graph gets both contributions, and a non-leaf weight falls back to the autograd path."""
+    used twice in one graph gets both contributions, and a non-leaf weight falls back to the autograd path.  (A parameter
+    gets its gradients either all through deferred ops or all through autograd -- never mixed; the model obeys that.)"""
     from planerecnet_amd import ops
     d = dev()
     x = rnd(2, 24, 10, 12, seed=1).float().to(d)
@@ -266,22 +267,24 @@ def test_deferred_weight_gradients_accumulate_like_autograd():
 
     def run(deferred):
         w = w0.clone().requires_grad_(True)
+        w2 = (w0 * 0.5).requires_grad_(True)
         scale = torch.ones((), device=d, requires_grad=True)
         ops.set_wgrad_async(deferred)
         try:
             for _ in range(2):                                            # two backward passes -> accumulation
                 y = ops.conv2d(x, w, None, 1, 1) + ops.conv2d(x.flip(3), w, None, 1, 1)      # the same leaf weight twice
-                y = y + ops.conv2d(x, w * scale, None, 1, 1)            # a non-leaf weight (autograd path even when deferred)
+                y = y + ops.conv2d(x, w2 * scale, None, 1, 1)           # a non-leaf weight (autograd path even when deferred)
                 (y * g).sum().backward()
                 ops.wgrad_join()
         finally:
             ops.set_wgrad_async(False)
         torch.cuda.synchronize()
-        return w.grad.clone(), scale.grad.clone()
+        return w.grad.clone(), scale.grad.clone(), w2.grad.clone()
 
-    (wa, sa), (wb, sb) = run(True), run(False)
+    (wa, sa, va), (wb, sb, vb) = run(True), run(False)
     close(wa, wb.double().cpu(), "deferred dw", rtol=1e-5)
     close(sa, sb.double().cpu(), "deferred d(scale)", rtol=1e-5)
+    close(va, vb.double().cpu(), "autograd-path dw", rtol=1e-5)
 
 
 def test_flipped_weights_batched_matches_single():
