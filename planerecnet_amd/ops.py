@@ -27,6 +27,8 @@ _SIDE = {}
 # (1) read gradients only through `.grad`, (2) call wgrad_join() after backward() and before anything consumes `.grad`
 # (bench.py, train.py).  Post-accumulate-grad hooks (the data-parallel bucketing) keep firing from the autograd engine;
 # GradAllReduce makes its exchange stream wait for the side stream as well.  torch.autograd.grad() callers keep the default (off).
+# A parameter must receive its gradients either all through deferred ops or all through autograd (a leaf weight that is ALSO
+# used through a non-leaf expression would be accumulated by autograd on the main stream while the side stream adds to it).
 # (Also tried on the side stream and dropped: the bias gradients -- no change -- and the once-per-step batched weight flip,
 # whose per-layer event waits cost 1.5 ms/step more than the 0.5 ms it hides.)
 WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
