@@ -238,12 +238,12 @@ __global__ __launch_bounds__(256) void dcn_dx_gather_kernel(const float* __restr
 }  // namespace
 
 static int channel_groups(int C, int64_t threads) {
-  static int cap = -1;                                  // PRN_DCN_GROUPS overrides the cap (tuning)
-  if (cap < 0) { const char* e = getenv("PRN_DCN_GROUPS"); cap = e ? atoi(e) : 8; }
-  int g = (int)(1 + (256 * 8 * 256) / (threads > 0 ? threads : 1));     // aim for ~8 blocks of 256 threads per CU
-  if (cap > 8) g = cap;
-  if (g > cap) g = cap;
-  while (g > 1 && C % g) --g;
+  static int forced = -1;                               // PRN_DCN_GROUPS forces the group count (tuning)
+  if (forced < 0) { const char* e = getenv("PRN_DCN_GROUPS"); forced = e ? atoi(e) : 0; }
+  int g = forced > 0 ? forced : (int)(1 + (256 * 8 * 256) / (threads > 0 ? threads : 1));     // aim for ~8 blocks of 256 threads per CU
+  if (g > 16) g = 16;
+  if (g > C) g = C;
+  while (g < C && C % g) ++g;                           // next divisor of C upwards (rounding down left the 30x40 stage at 4 groups)
   return g < 1 ? 1 : g;
 }
 
