@@ -96,6 +96,33 @@ typedef struct prn_flip_item {
 } prn_flip_item;
 int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_items, int64_t total_blocks, void* stream);
 
+/* --- Winograd F(4x4, 3x3) path for 3x3 / stride 1 / pad 1 convolutions with W % 4 == 0 and H >= 5 (csrc/prn_winograd.hip):
+ *   y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A   per 4x4 output tile; 4x fewer multiplies than the direct form.
+ * Replaces the same reference calls as prn_conv2d_fwd for those shapes (models/backbone.py:49-60 conv2 of Bottleneck,
+ * models/fpn.py:60-66 smoothing convs, planerecnet.py mask / depth heads) and their input gradients.
+ * P = prn_winograd_tiles(B, H, W) = B * ceil(H/4) * (W/4) rounded up to a multiple of 4.
+ *   prn_winograd_input : x [B][C][H][W] -> V [36][C][P]     (in_mode PRN_IN_ZERO or PRN_IN_REFLECT, pad 1)
+ *   prn_gemm_batched   : Y_z [M][P] = U_z [M][C] * V_z [C][P] for z < nb, one launch of the MFMA kernel
+ *   prn_winograd_output: Y' [36][M][P] -> y [B][M][H][W]  (+ bias[m], + addend, epilogue PRN_EPI_NONE / PRN_EPI_RELU)
+ *   prn_conv3x3_winograd: the three in sequence; ws holds 36 * (C + M) * P floats.
+ * U [36][M][C] comes from prn_winograd_weights_batched (u: forward operand, ut [36][C][M]: operand of the input gradient,
+ * i.e. the transform of the 180-degree-rotated taps with the channel roles swapped); either pointer may be NULL.
+ * `first` / total_blocks count 32 x 32 (M, C) blocks exactly as for prn_flip_item. */
+int64_t prn_winograd_tiles(int B, int H, int W);
+typedef struct prn_winograd_item {
+  const float* src;   /* [M][C][3][3] */
+  float* u;           /* [36][M][C] or NULL */
+  float* ut;          /* [36][C][M] or NULL */
+  int M, C;
+  int64_t first;
+} prn_winograd_item;
+int prn_winograd_weights_batched(const prn_winograd_item* items_dev, int n_items, int64_t total_blocks, void* stream);
+int prn_winograd_input(const float* x, float* V, int B, int C, int H, int W, int in_mode, void* stream);
+int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const float* V, float* Y, void* stream);
+int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream);
+int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
+                         int in_mode, int epilogue, void* stream);
+
 /* dw[m, c*KH*KW + r*KW + s] = sum_{b,oh,ow} dy[b,m,oh,ow] * gather(x)[b,c,oh*stride-pad+r,ow*stride-pad+s]
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
 int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);

@@ -43,6 +43,12 @@ SIGNATURES = {
     "prn_conv2d_wgrad_phase": (c_int, [_DP, P, P, P, P, P, c_int]),
     "prn_weight_flip_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_weight_flip_transpose_batched": (c_int, [P, c_int, c_i64, P]),
+    "prn_winograd_tiles": (c_i64, [c_int, c_int, c_int]),
+    "prn_winograd_weights_batched": (c_int, [P, c_int, c_i64, P]),
+    "prn_winograd_input": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_gemm_batched": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    "prn_winograd_output": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),
     "prn_pad_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

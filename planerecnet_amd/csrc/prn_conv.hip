@@ -54,6 +54,7 @@ struct ConvArgs {
   int K, N, HoWo, HW, tilesM, nblocks, splits;
   int xbytes, wbytes;
   int ystride, yW, yHW;     // output map: GEMM pixel (oh, ow) is stored at (oh*ystride + phase_y, ow*ystride + phase_x) of a yHW plane
+  int zx, zw, zy;           // VEC instances: element strides of x / w / y per blockIdx.z (prn_gemm_batched; 0 for a plain conv)
   float* ws;
   Seg seg;
 };
@@ -168,6 +169,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
   const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
   const float* wz = (MODE == PRN_IN_UP2_PHASE) ? a.w + (size_t)blockIdx.z * a.M * a.K : a.w;
+  if (VEC) {                                             // batched GEMM: blockIdx.z selects the (weights, activations, output) triple
+    x_ += (size_t)blockIdx.z * a.zx;
+    wz += (size_t)blockIdx.z * a.zw;
+    y_ += (size_t)blockIdx.z * a.zy;
+  }
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(x_, xbytes_), wr = make_rsrc(wz, a.wbytes);
 
   // pixel owned by this thread in the B (im2col) operand; its K rows are wave-uniform
@@ -1153,6 +1159,7 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
   a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
   a.xbytes = d->B * d->C * d->H * d->W * 4; a.wbytes = d->M * a.K * 4;
   a.ystride = 1; a.yW = g.gW; a.yHW = a.HoWo;
+  a.zx = a.zw = a.zy = 0;
   if (g.phases == 4) { a.ystride = 2; a.yW = d->Wo; a.yHW = d->Ho * d->Wo; }
   else if (d->ystride == 2) { a.ystride = 2; a.yW = d->yW; a.yHW = d->yH * d->yW; }
   if (rg) a.N = (int)seg_pixels(rg, d->B);
@@ -1303,6 +1310,32 @@ extern "C" int prn_weight_flip_transpose(const float* w, float* wt, int M, int C
   const int64_t n = (int64_t)M * C * KH * KW;
   hipLaunchKernelGGL(flip_transpose_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wt, M, C, KH, KW);
   PRN_CHECK_LAUNCH("prn_weight_flip_transpose");
+  return 0;
+}
+
+// nb independent GEMMs Y_z[M x P] = U_z[M x C] * V_z[C x P] in one launch of the 1x1 (VEC) instances: the product step of
+// the Winograd path (prn_winograd.hip), z = one of the 36 transform-domain positions.
+extern "C" int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const float* V, float* Y, void* stream) {
+  PRN_REQUIRE(U && V && Y && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched: bad arguments");
+  PRN_REQUIRE((P & 3) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0, "prn_gemm_batched: P %% 4 == 0 and 16-byte aligned V required (P=%d)", P);
+  PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched: operand larger than a buffer descriptor");
+  ConvArgs a;
+  a.x = V; a.w = U; a.bias = nullptr; a.addend = nullptr; a.y = Y; a.ws = nullptr;
+  a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P; a.epi = PRN_EPI_NONE;
+  a.K = C; a.N = P; a.HoWo = P; a.HW = P; a.xbytes = C * P * 4; a.wbytes = M * C * 4;
+  a.ystride = 1; a.yW = P; a.yHW = P;
+  a.zx = C * P; a.zw = M * C; a.zy = M * P;
+  a.seg.nseg = 0;
+  static int forced[2] = {-1, 0};                       // PRN_WINO_TILE="tm,tn" (tuning)
+  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_WINO_TILE")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  FwdPlan p;
+  p.wm = 2; p.wn = 2; p.bk = 16; p.splits = 1;
+  const int64_t t22 = (int64_t)cdiv(M, 128) * cdiv(P, 128) * nb;
+  if (forced[0] > 0) { p.tm = forced[0]; p.tn = forced[1]; }
+  else if (M >= 128 && t22 >= 4096) { p.tm = 2; p.tn = 2; }      // tools/winograd_bench.py: 64 x 64 tiles win below ~4096 tiles of 128 x 128
+  else { p.tm = 1; p.tn = 1; }
+  launch_fwd<1, PRN_IN_ZERO>(a, p, (hipStream_t)stream, nb);
+  PRN_CHECK_LAUNCH("prn_gemm_batched");
   return 0;
 }
 

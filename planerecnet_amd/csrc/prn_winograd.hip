@@ -1,0 +1,243 @@
+// Winograd F(4x4, 3x3) path for the stride-1, pad-1 3x3 convolutions (reference call sites: the bottleneck conv2 of
+// models/backbone.py, the FPN smoothing convs of models/fpn.py, the mask / depth heads of planerecnet.py) and for their
+// input gradients (same kernel run over dy with the 180-degree-rotated weights).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        d: 6x6 input patch, g: 3x3 taps, Y: 4x4 outputs   (Lavin & Gray 2016)
+//
+// 36 multiplies per 16 outputs instead of 144: the element-wise product summed over input channels is 36 independent GEMMs
+// U_z[M x C] * V_z[C x P] (P = tiles in the batch) that run on the MFMA kernel of prn_conv.hip (prn_gemm_batched); the
+// three transforms here are HBM-bound streaming kernels:
+//   winograd_input_kernel   x [B,C,H,W]        -> V [36][C][P]     reads 1 float4 + 2 scalars per patch row, writes coalesced along P
+//   winograd_output_kernel  Y' [36][M][P]      -> y [B,M,H,W]      (+ bias, + addend, ReLU) float4 rows
+//   winograd_weights_kernel w [M,C,3,3]        -> U [36][M][C] and / or the dgrad operand U' [36][C][M], batched over a model
+// fp32 throughout; the transform constants are exact in binary except the 1/6, 1/12, 1/24 of G (relative error of the
+// result ~1e-6, covered by the parity tests against the direct kernel and the CPU oracle).
+#include "prn_common.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect1(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+
+// o = B^T v
+__device__ __forceinline__ void bt6(const float* v, float* o) {
+  o[0] = 4.f * v[0] - 5.f * v[2] + v[4];
+  o[1] = -4.f * (v[1] + v[2]) + v[3] + v[4];
+  o[2] = 4.f * (v[1] - v[2]) - v[3] + v[4];
+  o[3] = -2.f * v[1] - v[2] + 2.f * v[3] + v[4];
+  o[4] = 2.f * v[1] - v[2] - 2.f * v[3] + v[4];
+  o[5] = 4.f * v[1] - 5.f * v[3] + v[5];
+}
+// o = A^T m
+__device__ __forceinline__ void at6(const float* m, float* o) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+// o = G g
+__device__ __forceinline__ void g6(float g0, float g1, float g2, float* o) {
+  o[0] = 0.25f * g0;
+  o[1] = -(g0 + g1 + g2) * (1.f / 6.f);
+  o[2] = -(g0 - g1 + g2) * (1.f / 6.f);
+  o[3] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+  o[4] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+  o[5] = g2;
+}
+
+// One thread = one 6x6 patch of one channel.  grid (ceil(P/256), C); W % 4 == 0, so the four interior columns of every
+// patch row are one aligned float4 and only the two halo columns are scalar loads (which hit the neighbours' lines).
+template <int MODE>
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int C, int H, int W, int TH, int TW,
+                                                             int P, int P4) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = blockIdx.y;
+  const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
+  const float* xc = x + ((size_t)b * C + c) * H * W;
+  const int w0 = 4 * tx;
+  float d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int ih = 4 * ty - 1 + i;
+    bool ok = true;
+    if (MODE == PRN_IN_REFLECT) ih = reflect1(ih, H); else ok = (unsigned)ih < (unsigned)H;
+    ih = ok ? ih : 0;
+    const float* row = xc + (size_t)ih * W;
+    const float4 q = *reinterpret_cast<const float4*>(row + w0);
+    int il = w0 - 1, ir = w0 + 4;
+    bool okl = il >= 0, okr = ir < W;
+    if (MODE == PRN_IN_REFLECT) { il = okl ? il : 1; ir = okr ? ir : W - 2; okl = okr = true; }
+    const float l = row[okl ? il : 0], r = row[okr ? ir : 0];
+    d[i][0] = (ok && okl) ? l : 0.f;
+    d[i][1] = ok ? q.x : 0.f; d[i][2] = ok ? q.y : 0.f; d[i][3] = ok ? q.z : 0.f; d[i][4] = ok ? q.w : 0.f;
+    d[i][5] = (ok && okr) ? r : 0.f;
+  }
+  float t[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {                 // columns: t = B^T d
+    float v[6], o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = d[i][j];
+    bt6(v, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+  }
+  float* out = V + (size_t)c * P4 + p;
+  const size_t zs = (size_t)C * P4;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {                 // rows: V = t B
+    float o[6];
+    bt6(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * zs] = o[j];
+  }
+}
+
+// One thread = one 4x4 output tile of one channel.  grid (ceil(P/256), M).
+__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Y, const float* __restrict__ bias, const float* __restrict__ addend,
+                                                              float* __restrict__ y, int B, int M, int H, int W, int TH, int TW, int P, int P4, int relu) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int m = blockIdx.y;
+  const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
+  const float* in = Y + (size_t)m * P4 + p;
+  const size_t zs = (size_t)M * P4;
+  float t[4][6];                                // t = A^T Y'  (4 x 6)
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float v[6], o[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = in[(size_t)(i * 6 + j) * zs];
+    at6(v, o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i][j] = o[i];
+  }
+  const float bv = bias ? bias[m] : 0.f;
+  const size_t plane = ((size_t)b * M + m) * H * W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oh = 4 * ty + i;
+    if (oh >= H) break;
+    float o[4];
+    at6(t[i], o);
+    const size_t idx = plane + (size_t)oh * W + 4 * tx;
+    float4 r = make_float4(o[0] + bv, o[1] + bv, o[2] + bv, o[3] + bv);
+    if (addend) {
+      const float4 q = *reinterpret_cast<const float4*>(addend + idx);
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *reinterpret_cast<float4*>(y + idx) = r;
+  }
+}
+
+// One workgroup = one 32 x 32 (m, c) block of one weight tensor (items are located by bisection over `first`, as in
+// flip_transpose_batched_kernel).  Pass A writes U[z][m][c] with c along the lanes; pass B re-reads the same 36 KiB block
+// (L1/L2 hits) with m along the lanes and writes the rotated-tap transform U'[z][c][m] -- both stores coalesced.
+__device__ __forceinline__ void transform_taps(const float* g, bool rot, float* u /*36*/) {
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = rot ? g[8 - i] : g[i];
+  float t[6][3];                                // t = G g   (6 x 3)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float o[6];
+    g6(k[j], k[3 + j], k[6 + j], o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g6(t[i][0], t[i][1], t[i][2], u + i * 6);     // rows: u = t G^T
+}
+
+__global__ __launch_bounds__(256) void winograd_weights_kernel(const prn_winograd_item* __restrict__ items, int n, int64_t total) {
+  const int64_t blk = blockIdx.x;
+  if (blk >= total) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first <= blk) lo = mid; else hi = mid - 1;
+  }
+  const prn_winograd_item it = items[lo];
+  const int tilesC = (it.C + 31) / 32;
+  const int t = (int)(blk - it.first), m0 = (t / tilesC) * 32, c0 = (t % tilesC) * 32;
+  const size_t zs = (size_t)it.M * it.C;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    if (it.u) {
+      const int m = m0 + (i >> 5), c = c0 + (i & 31);
+      if (m < it.M && c < it.C) {
+        float u[36];
+        transform_taps(it.src + ((size_t)m * it.C + c) * 9, false, u);
+#pragma unroll
+        for (int z = 0; z < 36; ++z) it.u[z * zs + (size_t)m * it.C + c] = u[z];
+      }
+    }
+    if (it.ut) {
+      const int c = c0 + (i >> 5), m = m0 + (i & 31);
+      if (m < it.M && c < it.C) {
+        float u[36];
+        transform_taps(it.src + ((size_t)m * it.C + c) * 9, true, u);
+#pragma unroll
+        for (int z = 0; z < 36; ++z) it.ut[z * zs + (size_t)c * it.M + m] = u[z];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static inline int64_t tiles_of(int B, int H, int W) { return (int64_t)B * ((H + 3) / 4) * (W / 4); }
+static inline int64_t pad4(int64_t p) { return (p + 3) & ~(int64_t)3; }
+
+extern "C" int64_t prn_winograd_tiles(int B, int H, int W) {
+  return pad4(tiles_of(B, H, W));
+}
+
+extern "C" int prn_winograd_weights_batched(const prn_winograd_item* items_dev, int n_items, int64_t total_blocks, void* stream) {
+  PRN_REQUIRE(items_dev && n_items > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "prn_winograd_weights_batched: bad arguments");
+  hipLaunchKernelGGL(winograd_weights_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items, total_blocks);
+  PRN_CHECK_LAUNCH("prn_winograd_weights_batched");
+  return 0;
+}
+
+extern "C" int prn_winograd_input(const float* x, float* V, int B, int C, int H, int W, int in_mode, void* stream) {
+  PRN_REQUIRE(x && V && B > 0 && C > 0 && C < 65536 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_winograd_input: W %% 4 == 0 and H >= 5 required (H=%d W=%d)", H, W);
+  PRN_REQUIRE(in_mode == PRN_IN_ZERO || in_mode == PRN_IN_REFLECT, "prn_winograd_input: zero or reflect padding only");
+  PRN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "prn_winograd_input: x must be 16-byte aligned");
+  const int TH = (H + 3) / 4, TW = W / 4;
+  const int64_t P = tiles_of(B, H, W), P4 = pad4(P);
+  PRN_REQUIRE(P < (1LL << 30), "prn_winograd_input: too many tiles");
+  const dim3 grid(cdiv(P, 256), C), block(256);
+  if (in_mode == PRN_IN_ZERO) hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_ZERO>), grid, block, 0, (hipStream_t)stream, x, V, B, C, H, W, TH, TW, (int)P, (int)P4);
+  else hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_REFLECT>), grid, block, 0, (hipStream_t)stream, x, V, B, C, H, W, TH, TW, (int)P, (int)P4);
+  PRN_CHECK_LAUNCH("prn_winograd_input");
+  return 0;
+}
+
+extern "C" int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream) {
+  PRN_REQUIRE(Y && y && B > 0 && M > 0 && M < 65536 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_winograd_output: W %% 4 == 0 and H >= 5 required (H=%d W=%d)", H, W);
+  PRN_REQUIRE(epilogue == PRN_EPI_NONE || epilogue == PRN_EPI_RELU, "prn_winograd_output: epilogue none or ReLU only");
+  PRN_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0, "prn_winograd_output: y / addend must be 16-byte aligned");
+  const int TH = (H + 3) / 4, TW = W / 4;
+  const int64_t P = tiles_of(B, H, W), P4 = pad4(P);
+  hipLaunchKernelGGL(winograd_output_kernel, dim3(cdiv(P, 256), M), dim3(256), 0, (hipStream_t)stream, Y, bias, addend, y, B, M, H, W, TH, TW, (int)P, (int)P4,
+                     epilogue == PRN_EPI_RELU ? 1 : 0);
+  PRN_CHECK_LAUNCH("prn_winograd_output");
+  return 0;
+}
+
+// x -> V -> (36 GEMMs) -> Y' -> y in one call.  ws: 36 * (C + M) * prn_winograd_tiles(B, H, W) floats.
+extern "C" int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
+                                    int in_mode, int epilogue, void* stream) {
+  PRN_REQUIRE(ws && U, "prn_conv3x3_winograd: workspace and transformed weights required");
+  const int64_t P4 = pad4(tiles_of(B, H, W));
+  float* V = (float*)ws;
+  float* Yt = V + 36 * (int64_t)C * P4;
+  if (int e = prn_winograd_input(x, V, B, C, H, W, in_mode, stream)) return e;
+  if (int e = prn_gemm_batched(M, C, (int)P4, 36, U, V, Yt, stream)) return e;
+  return prn_winograd_output(Yt, bias, addend, y, B, M, H, W, epilogue, stream);
+}

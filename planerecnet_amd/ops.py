@@ -10,6 +10,7 @@ CPU path in the product.
 import ctypes
 
 import os
+import weakref
 
 import torch
 
@@ -269,6 +270,110 @@ class FlippedWeights:
             _FLIPPED[w.data_ptr()] = (w, w._version, v)
 
 
+# ------------------------------------------------------------------------------------------ Winograd F(4x4, 3x3)
+WINOGRAD = bool(int(os.environ.get("PRN_WINOGRAD", "1")))       # 0: every 3x3 conv takes the direct implicit-GEMM kernel
+WINOGRAD_MIN_TILES = int(os.environ.get("PRN_WINOGRAD_MIN_TILES", "128"))   # 4x4 output tiles in the batch below which the direct kernel runs
+_WINO = {}          # weight data_ptr -> (weight, version at transform time, U [36,M,C], Ut [36,C,M])
+
+
+def winograd_ok(B, C, H, W, M, K, stride, pad, mode, epi):
+    """Shapes the Winograd path takes (include/prn.h): 3x3 / stride 1 / pad 1, zero or reflect padding, W % 4 == 0, wide
+    enough in channels and tiles that 36 GEMMs of [M x C] x [C x tiles] fill the GPU."""
+    return (WINOGRAD and K == 3 and stride == 1 and pad == 1 and mode in (IN_ZERO, IN_REFLECT) and epi in (EPI_NONE, EPI_RELU)
+            and W % 4 == 0 and H >= 8 and C >= 64 and M >= 64 and B * ((H + 3) // 4) * (W // 4) >= WINOGRAD_MIN_TILES)
+
+
+def _winograd_items(entries, dev):
+    """entries: [(w, M, C, U or None, Ut or None)] -> (device item array, total 32x32 blocks)"""
+    import numpy as np
+    items = np.zeros(len(entries), dtype=np.dtype([("src", "u8"), ("u", "u8"), ("ut", "u8"), ("M", "i4"), ("C", "i4"), ("first", "i8")]))
+    blocks = 0
+    for i, (w, M, C, U, Ut) in enumerate(entries):
+        items[i] = (w.data_ptr(), U.data_ptr() if U is not None else 0, Ut.data_ptr() if Ut is not None else 0, M, C, blocks)
+        blocks += ((M + 31) // 32) * ((C + 31) // 32)
+    return torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev), blocks
+
+
+def winograd_weights(w):
+    """(U, Ut) of a [M, C, 3, 3] weight: from the per-step batch (WinogradWeights.refresh) when current, else computed here."""
+    e = _WINO.get(w.data_ptr())
+    if e is not None and e[0]._version == e[1] and tuple(e[2].shape[1:]) == tuple(w.shape[:2]):
+        return e[2], e[3]
+    M, C = w.shape[:2]
+    U = torch.empty(36, M, C, device=w.device, dtype=torch.float32)
+    Ut = torch.empty(36, C, M, device=w.device, dtype=torch.float32)
+    items, blocks = _winograd_items([(w, M, C, U, Ut)], w.device)
+    check(lib.prn_winograd_weights_batched(_p(items), 1, blocks, _stream()), "prn_winograd_weights_batched")
+    _WINO[w.data_ptr()] = (w, w._version, U, Ut)            # valid until the weight is modified in place (inference: for good)
+    if isinstance(w, torch.nn.Parameter):
+        _WINO_SEEN[w.data_ptr()] = weakref.ref(w)
+    return U, Ut
+
+
+_WINO_SEEN = {}     # data_ptr -> weakref(Parameter): weights the Winograd path was asked for (a model batches these per step)
+
+
+def winograd_seen():
+    return [w for w in (r() for r in _WINO_SEEN.values()) if w is not None]
+
+
+class WinogradWeights:
+    """Transform-domain operands (include/prn.h: prn_winograd_weights_batched) of a model's 3x3 weights, forward and
+    input-gradient form, refreshed with ONE launch per training step."""
+
+    def __init__(self, weights):
+        self.weights = [w for w in weights]
+        self.ptrs = None
+
+    def _build(self):
+        dev = self.weights[0].device
+        total = sum(w.numel() * 4 for w in self.weights)                      # 36 / 9 floats per tap set
+        self.flat_u = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_ut = torch.empty(total, device=dev, dtype=torch.float32)
+        self.views, entries, first = [], [], 0
+        for w in self.weights:
+            M, C = w.shape[:2]
+            assert w.is_contiguous() and tuple(w.shape[2:]) == (3, 3) and w.dtype == torch.float32
+            n = 36 * M * C
+            U, Ut = self.flat_u[first:first + n].view(36, M, C), self.flat_ut[first:first + n].view(36, C, M)
+            self.views.append((U, Ut))
+            entries.append((w, M, C, U, Ut))
+            first += n
+        self.items, self.total = _winograd_items(entries, dev)
+        self.ptrs = [w.data_ptr() for w in self.weights]
+
+    def refresh(self):
+        """Call after the weights changed (once per step, before forward)."""
+        if not self.weights or not WINOGRAD:
+            return
+        if self.ptrs is None or any(w.data_ptr() != p for w, p in zip(self.weights, self.ptrs)):
+            for p in (self.ptrs or []):
+                _WINO.pop(p, None)
+            self._build()
+        check(lib.prn_winograd_weights_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_winograd_weights_batched")
+        for w, (U, Ut) in zip(self.weights, self.views):
+            _WINO[w.data_ptr()] = (w, w._version, U, Ut)
+
+
+def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE):
+    """3x3 / stride 1 / pad 1 convolution of x [B,C,H,W] with transform-domain weights U [36,M,C]."""
+    B, C, H, W = x.shape
+    P = lib.prn_winograd_tiles(B, H, W)
+    y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
+    ws = torch.empty(36 * (C + M) * P, device=x.device, dtype=torch.float32)
+    if profiling._enabled:
+        V, Yt = ws[:36 * C * P], ws[36 * C * P:]
+        with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel()):
+            check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P):
+            check(lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()), "prn_gemm_batched")
+        with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1)):
+            check(lib.prn_winograd_output(_p(Yt), _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
+    else:
+        check(lib.prn_conv3x3_winograd(_p(x), _p(U), _p(bias), _p(addend), _p(y), _p(ws), B, C, H, W, M, mode, epi, _stream()), "prn_conv3x3_winograd")
+    return y
+
+
 def channel_sum(g):
     B, C, H, W = g.shape
     out = torch.empty(C, device=g.device, dtype=torch.float32)
@@ -282,6 +387,8 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
     `addend` (another gradient of the same input, e.g. the residual branch) is summed in the kernel epilogue."""
     B, C, H, W = x_shape
     M, _, K, _ = w.shape
+    if mode == IN_ZERO and winograd_ok(B, M, H, W, C, K, stride, pad, IN_ZERO, EPI_NONE) and tuple(dy.shape[2:]) == (H, W):
+        return conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, addend, C)
     wt = flip_transpose(w)                                  # [C, M, K, K]
     if mode in (IN_REFLECT, IN_UP2_REFLECT):
         Hv, Wv = (2 * H, 2 * W) if mode == IN_UP2_REFLECT else (H, W)
@@ -310,7 +417,10 @@ class _Conv2d(torch.autograd.Function):
         M, C, K, _ = w.shape
         assert x.shape[1] == C, (x.shape, w.shape)
         Ho, Wo = _out_hw(x.shape[2], x.shape[3], K, stride, pad, mode)
-        y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
+        if winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, epi):
+            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi)
+        else:
+            y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
         ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
         ctx.fork = fork

@@ -77,6 +77,16 @@ class PlaneRecNet(nn.Module):
                     items.append((m.weight, (M, C * KH * KW, 1, 1) if id(m.weight) in dcn_w else (M, C, KH, KW)))
             fw = self.__dict__["_flipped"] = ops.FlippedWeights(items)
         fw.refresh()
+        # transform-domain operands of the 3x3 weights the Winograd path asked for in earlier steps (ops.WinogradWeights)
+        mine = self.__dict__.get("_param_ids")
+        if mine is None:
+            mine = self.__dict__["_param_ids"] = {id(p) for p in self.parameters()}
+        seen = [w for w in ops.winograd_seen() if id(w) in mine]
+        ww = self.__dict__.get("_wino")
+        if seen and (ww is None or len(ww.weights) != len(seen)):
+            ww = self.__dict__["_wino"] = ops.WinogradWeights(seen)
+        if ww is not None:
+            ww.refresh()
 
     def forward(self, x):
         if self.training and torch.is_grad_enabled() and x.is_cuda:

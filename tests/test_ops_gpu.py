@@ -409,3 +409,73 @@ def test_ops_reject_cpu_tensors():
     from planerecnet_amd import ops
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 1, 1))
+
+
+WINO_CASES = [
+    # B, C, H, W, M, mode, bias, addend, epi
+    (2, 64, 30, 40, 96, 0, True, False, 0),
+    (2, 64, 30, 40, 96, 1, True, True, 1),
+    (1, 128, 64, 64, 64, 0, False, True, 0),
+    (8, 256, 15, 20, 256, 0, False, False, 0),
+    (3, 70, 17, 48, 130, 0, True, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd_fwd_bwd(case, monkeypatch):
+    """The F(4x4, 3x3) path (include/prn.h: prn_conv3x3_winograd) against torch CPU fp64, forward / input gradient (the
+    rotated-tap transform) / weight gradient (direct kernel), and against the direct kernel it replaces."""
+    from planerecnet_amd import ops
+    B, C, H, W, M, mode, has_b, has_a, epi = case
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    assert ops.winograd_ok(B, C, H, W, M, 3, 1, 1, mode, epi)
+    x, w = rnd(B, C, H, W, seed=1), rnd(M, C, 3, 3, seed=2, scale=(C * 9) ** -0.5)
+    b = rnd(M, seed=3) if has_b else None
+    a = rnd(B, M, H, W, seed=4) if has_a else None
+    g = rnd(B, M, H, W, seed=5)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = ref_conv(xr, wr, b, 1, 1, mode, a, epi)
+    yr.backward(g)
+
+    def run():
+        xd, wd = x.float().to(dev()).requires_grad_(), w.float().to(dev()).requires_grad_()
+        bd = b.float().to(dev()) if has_b else None
+        ad = a.float().to(dev()) if has_a else None
+        y = ops.conv2d(xd, wd, bd, 1, 1, mode, epi, ad)
+        y.backward(g.float().to(dev()))
+        return y, xd.grad, wd.grad
+    y, dx, dw = run()
+    close(y, yr, "winograd fwd")
+    close(dx, xr.grad, "winograd dgrad")
+    close(dw, wr.grad, "wgrad")
+    ops.WINOGRAD = False
+    try:
+        y0, dx0, _ = run()
+    finally:
+        ops.WINOGRAD = True
+    close(y, y0.double().cpu(), "winograd vs direct fwd", rtol=5e-5)
+    close(dx, dx0.double().cpu(), "winograd vs direct dgrad", rtol=5e-5)
+
+
+def test_winograd_weights_batched_refresh():
+    """WinogradWeights.refresh(): one launch for several weights; cached operands are used until the weight changes."""
+    from planerecnet_amd import ops
+    ws = [torch.nn.Parameter(rnd(M, C, 3, 3, seed=M).float().to(dev())) for M, C in ((64, 64), (96, 70), (256, 128))]
+    ww = ops.WinogradWeights(ws)
+    ww.refresh()
+    for w in ws:
+        U, Ut = ops.winograd_weights(w)
+        assert U.data_ptr() == ops._WINO[w.data_ptr()][2].data_ptr()
+        with torch.no_grad():
+            fresh = torch.nn.Parameter(w.detach().clone())
+        U2, Ut2 = ops.winograd_weights(fresh)                 # not registered: computed on the spot
+        assert torch.equal(U, U2) and torch.equal(Ut, Ut2)
+        # U[z, m, c] of the rotated, transposed weight == Ut[z, c, m]
+        U3, _ = ops.winograd_weights(torch.nn.Parameter(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
+        assert torch.equal(U3, Ut)
+    old = ops._WINO[ws[0].data_ptr()][2]
+    old_vals = old.clone()
+    with torch.no_grad():
+        ws[0].mul_(2.0)
+    U = ops.winograd_weights(ws[0])[0]                        # stale entry is not used: recomputed for the new values
+    assert U.data_ptr() != old.data_ptr() and torch.allclose(U, 2.0 * old_vals, rtol=1e-6, atol=0)
