@@ -120,6 +120,19 @@ int prn_winograd_weights_batched(const prn_winograd_item* items_dev, int n_items
 int prn_winograd_input(const float* x, float* V, int B, int C, int H, int W, int in_mode, void* stream);
 int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const float* V, float* Y, void* stream);
 int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream);
+/* Weight gradient on the same path: dw = G^T [ sum over tiles (A dy A^T) .* (B^T x B) ] G.
+ *   prn_winograd_dy    : dy [B][M][H][W] -> dY' [36][M][P]
+ *   prn_gemm_batched_nt: out_z [M][C] = A_z [M][P] * B_z [C][P]^T for z < nb; partial sums [splits][nb][M][C] go to ws
+ *                        (splits = prn_gemm_batched_nt_splits, a fixed function of the shape: deterministic reduction)
+ *   prn_winograd_dw    : partials -> dw [M][C][3][3] (sums the splits in fixed order, then G^T . G)
+ *   prn_conv3x3_winograd_wgrad: all of it; ws of prn_winograd_wgrad_ws_bytes; phase 0 = everything, 1 / 2 / 3 = transforms /
+ *                        products / reduction only (profiler brackets). */
+int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M);
+int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream);
+int prn_gemm_batched_nt_splits(int M, int C, int P, int nb);
+int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, void* stream);
+int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream);
+int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase);
 int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
                          int in_mode, int epilogue, void* stream);
 

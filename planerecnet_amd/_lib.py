@@ -48,6 +48,12 @@ SIGNATURES = {
     "prn_winograd_input": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_gemm_batched": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "prn_winograd_output": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_winograd_wgrad_ws_bytes": (c_i64, [c_int] * 5),
+    "prn_winograd_dy": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_gemm_batched_nt_splits": (c_int, [c_int] * 4),
+    "prn_gemm_batched_nt": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    "prn_winograd_dw": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "prn_conv3x3_winograd_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int]),
     "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),

@@ -401,6 +401,7 @@ struct WgArgs {
   int B, C, H, W, M, stride, pad, Ho, Wo;
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
   int xbytes, dybytes;       // dybytes: one phase of dy
+  int xz;                    // element stride of x per blockIdx.z (prn_gemm_batched_nt; 0 for a convolution)
   Seg seg;
 };
 
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
   const float* dyz = a.dy + (size_t)blockIdx.z * (a.dybytes / 4);
   int H_ = a.H, W_ = a.W, HW_ = a.HW, Ho_ = a.Ho, Wo_ = a.Wo, HoWo_ = a.HoWo, N_ = a.N;     // current segment's geometry (ragged) / the tensor's
-  __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
+  __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (size_t)blockIdx.z * a.xz, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
   const int arow = tid >> 2, anq = (tid & 3) * 4;
   const bool n4 = ((HoWo_ & 3) == 0 || a.seg.nseg > 0) && ((reinterpret_cast<uintptr_t>(dyz) & 15) == 0);   // (ragged: host checked every segment)
   const int nl = tid & 15, jrow = tid >> 4;
@@ -950,7 +951,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
 }
 
 struct WgPlan { int tm, tj, tilesM, tilesJ, splits, chunks, wm; };
-WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false) {
+WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false, bool small = false) {
   WgPlan p;
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
@@ -958,6 +959,7 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false) 
   static int ftm = -1, ftj = 0;            // PRN_WGRAD_TILE="tm,tj" overrides the tile (tuning sweeps)
   if (ftm < 0) { ftm = 0; if (const char* e = getenv("PRN_WGRAD_TILE")) sscanf(e, "%d,%d", &ftm, &ftj); }
   if (ftm > 0) { p.tm = M > 32 ? ftm : 1; p.tj = K > 32 ? ftj : 1; }
+  if (small) { p.tm = 1; p.tj = 1; }
   if (M <= 32 && K > 64) { p.wm = 1; p.tm = 1; p.tj = 1; }          // 32 x 128 tile
   if (ragged) {                                                      // ragged batches: the two instantiated tiles only
     if (M <= 32) { p.wm = 1; p.tm = 1; p.tj = 1; } else { p.wm = 2; p.tm = 2; p.tj = 2; }
@@ -1268,6 +1270,7 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
   a.Ho = g.gH; a.Wo = g.gW;
   a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
   a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * a.HoWo * 4;
+  a.xz = 0;
   a.seg.nseg = 0;
   if (rg) {
     a.N = (int)seg_pixels(rg, d->B);
@@ -1336,6 +1339,36 @@ extern "C" int prn_gemm_batched(int M, int C, int P, int nb, const float* U, con
   else { p.tm = 1; p.tn = 1; }
   launch_fwd<1, PRN_IN_ZERO>(a, p, (hipStream_t)stream, nb);
   PRN_CHECK_LAUNCH("prn_gemm_batched");
+  return 0;
+}
+
+// nb independent products out_z[M x C] = A_z[M x P] * B_z[C x P]^T (reduction over P) on the 1x1 weight-gradient instances:
+// the product step of the Winograd weight gradient.  Partials go to ws as [splits][nb][M][C]; the caller sums them
+// (prn_winograd.hip folds that sum into the G^T . G transform).  Returns the split count through *splits.
+namespace {
+// 64 x 64 tiles when the 128 x 128 plan leaves most of the GPU empty (short reductions cap the split count): 54 -> 39 us for
+// 36 x [256 x 256 x 640] (tools/winograd_bench.py)
+WgPlan plan_batched_nt(int M, int C, int P, int nb) {
+  WgPlan p = plan_wgrad(M, C, P, nb);
+  if (p.tm == 2 && p.tj == 2 && (int64_t)p.tilesM * p.tilesJ * nb * p.splits < 400) p = plan_wgrad(M, C, P, nb, false, true);
+  return p;
+}
+}  // namespace
+extern "C" int prn_gemm_batched_nt_splits(int M, int C, int P, int nb) {
+  return plan_batched_nt(M, C, P, nb).splits;
+}
+extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, void* stream) {
+  PRN_REQUIRE(A && Bm && ws && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched_nt: bad arguments");
+  PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched_nt: operand larger than a buffer descriptor");
+  WgArgs a;
+  a.x = Bm; a.dy = A; a.out = ws;
+  a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P;
+  a.K = C; a.N = P; a.HoWo = P; a.HW = P; a.xbytes = C * P * 4; a.dybytes = M * P * 4; a.xz = C * P;
+  a.seg.nseg = 0;
+  const WgPlan p = plan_batched_nt(M, C, P, nb);
+  a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
+  launch_wgrad<1, PRN_IN_ZERO>(a, p, (hipStream_t)stream, nb);
+  PRN_CHECK_LAUNCH("prn_gemm_batched_nt");
   return 0;
 }
 

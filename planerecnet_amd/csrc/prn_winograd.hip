@@ -188,6 +188,102 @@ __global__ __launch_bounds__(256) void winograd_weights_kernel(const prn_winogra
   }
 }
 
+// o = A v   (4 -> 6): the transpose of at6, used by the weight gradient (dY' = A dy A^T)
+__device__ __forceinline__ void a4(const float* v, float* o) {
+  o[0] = v[0];
+  o[1] = v[0] + v[1] + v[2] + v[3];
+  o[2] = v[0] - v[1] + v[2] - v[3];
+  o[3] = v[0] + 2.f * v[1] + 4.f * v[2] + 8.f * v[3];
+  o[4] = v[0] - 2.f * v[1] + 4.f * v[2] - 8.f * v[3];
+  o[5] = v[3];
+}
+// o = G^T v   (6 -> 3)
+__device__ __forceinline__ void gt6(const float* v, float* o) {
+  const float s12 = v[1] + v[2], s34 = v[3] + v[4];
+  o[0] = 0.25f * v[0] - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
+  o[1] = (v[2] - v[1]) * (1.f / 6.f) + (v[3] - v[4]) * (1.f / 12.f);
+  o[2] = -s12 * (1.f / 6.f) + s34 * (1.f / 6.f) + v[5];
+}
+
+// Weight gradient, step 1: dy [B,M,H,W] -> dY' [36][M][P], dY' = A dy A^T per 4x4 tile (rows beyond H are zero).
+__global__ __launch_bounds__(256) void winograd_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int B, int M, int H, int W, int TH, int TW, int P,
+                                                          int P4) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int m = blockIdx.y;
+  const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
+  const float* src = dy + ((size_t)b * M + m) * H * W + 4 * tx;
+  float d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oh = 4 * ty + i;
+    const bool ok = oh < H;
+    const float4 q = *reinterpret_cast<const float4*>(src + (size_t)(ok ? oh : 0) * W);
+    d[i][0] = ok ? q.x : 0.f; d[i][1] = ok ? q.y : 0.f; d[i][2] = ok ? q.z : 0.f; d[i][3] = ok ? q.w : 0.f;
+  }
+  float t[6][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v[4], o[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = d[i][j];
+    a4(v, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+  }
+  float* out = Y + (size_t)m * P4 + p;
+  const size_t zs = (size_t)M * P4;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float o[6];
+    a4(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * zs] = o[j];
+  }
+}
+
+// Weight gradient, step 3: partial dU [splits][36][M][C] -> dw [M][C][3][3] = G^T (sum over splits) G.
+// A workgroup owns 64 (m, c) pairs; its four waves each sum every fourth split (coalesced along the pairs), the four partial
+// sums meet in LDS in fixed order (deterministic), and wave 0 applies the transform.
+__global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restrict__ part, float* __restrict__ dw, int M, int C, int splits) {
+  __shared__ float sm[3][36][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t MC = (int64_t)M * C, i = (int64_t)blockIdx.x * 64 + lane;
+  float u[36];
+#pragma unroll
+  for (int z = 0; z < 36; ++z) u[z] = 0.f;
+  if (i < MC)
+    for (int k = g; k < splits; k += 4) {
+#pragma unroll
+      for (int z = 0; z < 36; ++z) u[z] += part[((size_t)k * 36 + z) * MC + i];
+    }
+  if (g > 0) {
+#pragma unroll
+    for (int z = 0; z < 36; ++z) sm[g - 1][z][lane] = u[z];
+  }
+  __syncthreads();
+  if (g > 0 || i >= MC) return;
+#pragma unroll
+  for (int z = 0; z < 36; ++z) u[z] = ((u[z] + sm[0][z][lane]) + sm[1][z][lane]) + sm[2][z][lane];
+  float t[3][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float v[6], o[3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = u[a * 6 + j];
+    gt6(v, o);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a][j] = o[a];
+  }
+  float* out = dw + (size_t)i * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float o[3];
+    gt6(t[a], o);
+    out[a * 3 + 0] = o[0]; out[a * 3 + 1] = o[1]; out[a * 3 + 2] = o[2];
+  }
+}
+
 }  // namespace
 
 static inline int64_t tiles_of(int B, int H, int W) { return (int64_t)B * ((H + 3) / 4) * (W / 4); }
@@ -240,4 +336,52 @@ extern "C" int prn_conv3x3_winograd(const float* x, const float* U, const float*
   if (int e = prn_winograd_input(x, V, B, C, H, W, in_mode, stream)) return e;
   if (int e = prn_gemm_batched(M, C, (int)P4, 36, U, V, Yt, stream)) return e;
   return prn_winograd_output(Yt, bias, addend, y, B, M, H, W, epilogue, stream);
+}
+
+/* ---- weight gradient: dw = G^T [ sum_tiles (A dy A^T) .* (B^T x B) ] G */
+extern "C" int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M) {
+  const int64_t P4 = pad4(tiles_of(B, H, W));
+  const int splits = prn_gemm_batched_nt_splits(M, C, (int)P4, 36);
+  return 4 * (36 * (int64_t)(C + M) * P4 + (int64_t)splits * 36 * M * C);
+}
+
+extern "C" int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream) {
+  PRN_REQUIRE(dy && Y && B > 0 && M > 0 && M < 65536 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_winograd_dy: W %% 4 == 0 and H >= 5 required (H=%d W=%d)", H, W);
+  PRN_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, "prn_winograd_dy: dy must be 16-byte aligned");
+  const int TH = (H + 3) / 4, TW = W / 4;
+  const int64_t P = tiles_of(B, H, W), P4 = pad4(P);
+  hipLaunchKernelGGL(winograd_dy_kernel, dim3(cdiv(P, 256), M), dim3(256), 0, (hipStream_t)stream, dy, Y, B, M, H, W, TH, TW, (int)P, (int)P4);
+  PRN_CHECK_LAUNCH("prn_winograd_dy");
+  return 0;
+}
+
+extern "C" int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream) {
+  PRN_REQUIRE(partials && dw && M > 0 && C > 0 && splits > 0, "prn_winograd_dw: bad arguments");
+  hipLaunchKernelGGL(winograd_dw_kernel, dim3(cdiv((int64_t)M * C, 64)), dim3(256), 0, (hipStream_t)stream, partials, dw, M, C, splits);
+  PRN_CHECK_LAUNCH("prn_winograd_dw");
+  return 0;
+}
+
+// phase: 0 = everything, 1 = transforms of x and dy, 2 = the 36 products, 3 = reduction + G^T . G (profilers bracket them separately)
+extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream,
+                                          int phase) {
+  PRN_REQUIRE(ws && x && dy && dw, "prn_conv3x3_winograd_wgrad: null tensor / workspace");
+  const int64_t P4 = pad4(tiles_of(B, H, W)), P = tiles_of(B, H, W);
+  float* V = (float*)ws;
+  float* Yt = V + 36 * (int64_t)C * P4;
+  float* part = Yt + 36 * (int64_t)M * P4;
+  if (phase == 0 || phase == 1) {
+    if (int e = prn_winograd_input(x, V, B, C, H, W, in_mode, stream)) return e;
+    if (int e = prn_winograd_dy(dy, Yt, B, M, H, W, stream)) return e;
+    if (P4 != P) {                                     // the products reduce over P4 columns: the padding must be zero
+      // (at most 3 columns per row: cleared with one strided memset per operand)
+      hipMemset2DAsync(V + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)C, (hipStream_t)stream);
+      hipMemset2DAsync(Yt + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)M, (hipStream_t)stream);
+    }
+  }
+  if (phase == 0 || phase == 2)
+    if (int e = prn_gemm_batched_nt(M, C, (int)P4, 36, Yt, V, part, stream)) return e;
+  if (phase == 0 || phase == 3)
+    return prn_winograd_dw(part, dw, M, C, prn_gemm_batched_nt_splits(M, C, (int)P4, 36), stream);
+  return 0;
 }

@@ -272,6 +272,7 @@ class FlippedWeights:
 
 # ------------------------------------------------------------------------------------------ Winograd F(4x4, 3x3)
 WINOGRAD = bool(int(os.environ.get("PRN_WINOGRAD", "1")))       # 0: every 3x3 conv takes the direct implicit-GEMM kernel
+WINOGRAD_WGRAD = bool(int(os.environ.get("PRN_WINOGRAD_WGRAD", "1")))   # 0: weight gradients stay on the direct kernel
 WINOGRAD_MIN_TILES = int(os.environ.get("PRN_WINOGRAD_MIN_TILES", "128"))   # 4x4 output tiles in the batch below which the direct kernel runs
 _WINO = {}          # weight data_ptr -> (weight, version at transform time, U [36,M,C], Ut [36,C,M])
 
@@ -374,6 +375,32 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE):
     return y
 
 
+_WINO_WG_WS = {}
+
+
+def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO):
+    """Weight gradient [M,C,3,3] of a 3x3 / stride 1 / pad 1 convolution on the Winograd path."""
+    B, C, H, W = x.shape
+    key = (B, C, H, W, M)
+    nbytes = _WINO_WG_WS.get(key)
+    if nbytes is None:
+        nbytes = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
+    args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, mode, _stream())
+    if profiling._enabled:
+        P = lib.prn_winograd_tiles(B, H, W)
+        with profiling.span("winograd_input_kernel", "hbm", 4.0 * (x.numel() + dy.numel()) + 4.0 * 36 * (C + M) * P):
+            check(lib.prn_conv3x3_winograd_wgrad(*args, 1), "prn_conv3x3_winograd_wgrad")
+        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P):
+            check(lib.prn_conv3x3_winograd_wgrad(*args, 2), "prn_conv3x3_winograd_wgrad")
+        with profiling.span("reduce_splits_kernel", "hbm", float(nbytes) - 4.0 * 36 * (C + M) * P + 4.0 * dw.numel()):
+            check(lib.prn_conv3x3_winograd_wgrad(*args, 3), "prn_conv3x3_winograd_wgrad")
+    else:
+        check(lib.prn_conv3x3_winograd_wgrad(*args, 0), "prn_conv3x3_winograd_wgrad")
+    return dw
+
+
 def channel_sum(g):
     B, C, H, W = g.shape
     out = torch.empty(C, device=g.device, dtype=torch.float32)
@@ -444,15 +471,21 @@ class _Conv2d(torch.autograd.Function):
         elif epi == EPI_SIGMOID:
             dy = dy * y * (1 - y)
         M, C, K, _ = w.shape
+        if WINOGRAD_WGRAD and winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, EPI_NONE):
+            def wgrad():
+                return conv3x3_winograd_wgrad_raw(x, dy, M, mode)
+        else:
+            def wgrad():
+                return conv_wgrad_raw(x, dy, M, K, stride, pad, mode)
         if _defer(ctx.needs_input_grad[1], w):
-            _deferred_wgrad(w, (x, dy), lambda: conv_wgrad_raw(x, dy, M, K, stride, pad, mode))
+            _deferred_wgrad(w, (x, dy), wgrad)
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None
         else:
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
-            dw = conv_wgrad_raw(x, dy, M, K, stride, pad, mode) if ctx.needs_input_grad[1] else None
+            dw = wgrad() if ctx.needs_input_grad[1] else None
         if dfork is not None and dx is not None:
             dx = dx + dfork
         db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[2]) else None

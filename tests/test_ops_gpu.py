@@ -418,6 +418,7 @@ WINO_CASES = [
     (1, 128, 64, 64, 64, 0, False, True, 0),
     (8, 256, 15, 20, 256, 0, False, False, 0),
     (3, 70, 17, 48, 130, 0, True, False, 0),
+    (1, 64, 12, 20, 64, 0, False, False, 0),        # 15 tiles: the padded 16th column of the transform-domain operands must not count
 ]
 
 
@@ -447,14 +448,15 @@ def test_conv3x3_winograd_fwd_bwd(case, monkeypatch):
     y, dx, dw = run()
     close(y, yr, "winograd fwd")
     close(dx, xr.grad, "winograd dgrad")
-    close(dw, wr.grad, "wgrad")
+    close(dw, wr.grad, "winograd wgrad")
     ops.WINOGRAD = False
     try:
-        y0, dx0, _ = run()
+        y0, dx0, dw0 = run()
     finally:
         ops.WINOGRAD = True
     close(y, y0.double().cpu(), "winograd vs direct fwd", rtol=5e-5)
     close(dx, dx0.double().cpu(), "winograd vs direct dgrad", rtol=5e-5)
+    close(dw, dw0.double().cpu(), "winograd vs direct wgrad", rtol=5e-5)
 
 
 def test_winograd_weights_batched_refresh():

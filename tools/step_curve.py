@@ -40,6 +40,11 @@ def step():
     opt.step()
 
 
+if os.environ.get("NOGC"):
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 evs, host = [], []

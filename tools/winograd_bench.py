@@ -51,3 +51,28 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def wgrad_main():
+    dev = torch.device("cuda:0")
+    print(f"{'wgrad shape':34s} {'GFLOP':>7s} | {'direct us':>9s} {'TF/s':>6s} | {'wino us':>8s} {'TF/s':>6s} {'x':>5s} | {'xform us':>8s} {'gemm us':>8s} {'TF/s':>6s} {'dw us':>7s} splits")
+    for name, C, H, W, M in SHAPES:
+        x = torch.randn(B, C, H, W, device=dev)
+        dy = torch.randn(B, M, H, W, device=dev)
+        fl = 2.0 * M * C * 9 * B * H * W
+        td = timeit(lambda: ops.conv_wgrad_raw(x, dy, M, 3, 1, 1, 0))
+        tw = timeit(lambda: ops.conv3x3_winograd_wgrad_raw(x, dy, M))
+        P = lib.prn_winograd_tiles(B, H, W)
+        ws = torch.empty(lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M) // 4, device=dev)
+        dw = torch.empty(M, C, 3, 3, device=dev)
+        args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, 0, _stream())
+        t1 = timeit(lambda: lib.prn_conv3x3_winograd_wgrad(*args, 1))
+        t2 = timeit(lambda: lib.prn_conv3x3_winograd_wgrad(*args, 2))
+        t3 = timeit(lambda: lib.prn_conv3x3_winograd_wgrad(*args, 3))
+        gfl = 2.0 * 36 * M * C * P
+        print(f"{name:34s} {fl / 1e9:7.2f} | {td * 1e6:9.1f} {fl / td / 1e12:6.1f} | {tw * 1e6:8.1f} {fl / tw / 1e12:6.1f} {td / tw:5.2f} | "
+              f"{t1 * 1e6:8.1f} {t2 * 1e6:8.1f} {gfl / t2 / 1e12:6.1f} {t3 * 1e6:7.1f} {lib.prn_gemm_batched_nt_splits(M, C, P, 36)}", flush=True)
+
+
+if __name__ == "__main__":
+    wgrad_main()
