@@ -67,9 +67,10 @@ int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const
  * and addend are packed the same way with M channels.  Stride-1 "same" 1x1 / 3x3 convolutions with zero padding; desc->H,
  * W, Ho, Wo are ignored.  Every segment must hold a multiple of 64 pixels (B*H*W) for the forward / input-gradient call and
  * a multiple of 16 (and H*W % 4 == 0) for the weight gradient; otherwise the call fails and the caller loops over segments. */
+#define PRN_MAX_SEGMENTS 6
 typedef struct prn_ragged {
-  int32_t nseg;            /* 1..6 */
-  int32_t H[6], W[6];
+  int32_t nseg;            /* 1..PRN_MAX_SEGMENTS */
+  int32_t H[PRN_MAX_SEGMENTS], W[PRN_MAX_SEGMENTS];
 } prn_ragged;
 int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias,
                           const float* addend, float* y, void* stream);
@@ -133,6 +134,13 @@ int prn_gemm_batched_nt_splits(int M, int C, int P, int nb);
 int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, void* stream);
 int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream);
 int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase);
+/* Ragged batches (prn_ragged; zero padding; every segment with W % 4 == 0, H >= 5): the tiles of all segments share the 36
+ * products, only the transforms look at the segment table.  P = prn_winograd_tiles_ragged(rg, B). */
+int64_t prn_winograd_tiles_ragged(const prn_ragged* rg, int B);
+int prn_conv3x3_winograd_ragged(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B, int C,
+                                int M, int epilogue, void* stream);
+int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M);
+int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M, void* stream);
 int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
                          int in_mode, int epilogue, void* stream);
 

@@ -54,6 +54,10 @@ SIGNATURES = {
     "prn_gemm_batched_nt": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "prn_winograd_dw": (c_int, [P, P, c_int, c_int, c_int, P]),
     "prn_conv3x3_winograd_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int]),
+    "prn_winograd_tiles_ragged": (c_i64, [P, c_int]),
+    "prn_conv3x3_winograd_ragged": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_winograd_wgrad_ragged_ws_bytes": (c_i64, [P, c_int, c_int, c_int]),
+    "prn_conv3x3_winograd_wgrad_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),

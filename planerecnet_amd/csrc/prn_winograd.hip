@@ -21,6 +21,28 @@ __device__ __forceinline__ int reflect1(int i, int n) {
   return i >= n ? 2 * n - 2 - i : i;
 }
 
+// Tile geometry of a (possibly ragged) batch: segment t holds B maps of H[t] x W[t] stored [B][channels][H][W] back to back
+// (include/prn.h: prn_ragged); its 4x4 tiles occupy columns p0[t] .. p0[t+1] of the transform-domain operands and its maps
+// start hw0[t] * B * channels elements into the packed tensor.  A dense tensor is the one-segment case.
+struct WSeg {
+  int nseg, B;
+  int p0[PRN_MAX_SEGMENTS + 1], hw0[PRN_MAX_SEGMENTS], H[PRN_MAX_SEGMENTS], W[PRN_MAX_SEGMENTS];
+};
+struct TilePos { int H, W, b, ty, tx; size_t base; };       // base: element offset of map (b, channel 0) -> add channel * H * W
+// (static indices only: indexing the by-value kernel argument dynamically sends it to scratch, see prn_conv.hip)
+__device__ __forceinline__ TilePos locate(const WSeg& g, int p, int channels) {
+  int H = g.H[0], W = g.W[0], q0 = 0, hw0 = 0;
+#pragma unroll
+  for (int t = 1; t < PRN_MAX_SEGMENTS; ++t)
+    if (t < g.nseg && p >= g.p0[t]) { H = g.H[t]; W = g.W[t]; q0 = g.p0[t]; hw0 = g.hw0[t]; }
+  const int TW = W >> 2, TH = (H + 3) >> 2, q = p - q0;
+  TilePos r;
+  r.H = H; r.W = W;
+  r.tx = q % TW; r.ty = (q / TW) % TH; r.b = q / (TW * TH);
+  r.base = ((size_t)hw0 * g.B + (size_t)r.b * H * W) * channels;
+  return r;
+}
+
 // o = B^T v
 __device__ __forceinline__ void bt6(const float* v, float* o) {
   o[0] = 4.f * v[0] - 5.f * v[2] + v[4];
@@ -51,14 +73,14 @@ __device__ __forceinline__ void g6(float g0, float g1, float g2, float* o) {
 // One thread = one 6x6 patch of one channel.  grid (ceil(P/256), C); W % 4 == 0, so the four interior columns of every
 // patch row are one aligned float4 and only the two halo columns are scalar loads (which hit the neighbours' lines).
 template <int MODE>
-__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int C, int H, int W, int TH, int TW,
-                                                             int P, int P4) {
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int C, int P, int P4, WSeg g) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int c = blockIdx.y;
-  const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
-  const float* xc = x + ((size_t)b * C + c) * H * W;
-  const int w0 = 4 * tx;
+  const TilePos tp = locate(g, p, C);
+  const int H = tp.H, W = tp.W, ty = tp.ty;
+  const float* xc = x + tp.base + (size_t)c * H * W;
+  const int w0 = 4 * tp.tx;
   float d[6][6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -99,11 +121,12 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __rest
 
 // One thread = one 4x4 output tile of one channel.  grid (ceil(P/256), M).
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Y, const float* __restrict__ bias, const float* __restrict__ addend,
-                                                              float* __restrict__ y, int B, int M, int H, int W, int TH, int TW, int P, int P4, int relu) {
+                                                              float* __restrict__ y, int M, int P, int P4, int relu, WSeg g) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int m = blockIdx.y;
-  const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
+  const TilePos tp = locate(g, p, M);
+  const int H = tp.H, W = tp.W, ty = tp.ty, tx = tp.tx;
   const float* in = Y + (size_t)m * P4 + p;
   const size_t zs = (size_t)M * P4;
   float t[4][6];                                // t = A^T Y'  (4 x 6)
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
     for (int i = 0; i < 4; ++i) t[i][j] = o[i];
   }
   const float bv = bias ? bias[m] : 0.f;
-  const size_t plane = ((size_t)b * M + m) * H * W;
+  const size_t plane = tp.base + (size_t)m * H * W;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int oh = 4 * ty + i;
@@ -206,13 +229,13 @@ __device__ __forceinline__ void gt6(const float* v, float* o) {
 }
 
 // Weight gradient, step 1: dy [B,M,H,W] -> dY' [36][M][P], dY' = A dy A^T per 4x4 tile (rows beyond H are zero).
-__global__ __launch_bounds__(256) void winograd_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int B, int M, int H, int W, int TH, int TW, int P,
-                                                          int P4) {
+__global__ __launch_bounds__(256) void winograd_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int M, int P, int P4, WSeg g) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int m = blockIdx.y;
-  const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
-  const float* src = dy + ((size_t)b * M + m) * H * W + 4 * tx;
+  const TilePos tp = locate(g, p, M);
+  const int H = tp.H, W = tp.W, ty = tp.ty;
+  const float* src = dy + tp.base + (size_t)m * H * W + 4 * tp.tx;
   float d[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -286,11 +309,37 @@ __global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restric
 
 }  // namespace
 
-static inline int64_t tiles_of(int B, int H, int W) { return (int64_t)B * ((H + 3) / 4) * (W / 4); }
 static inline int64_t pad4(int64_t p) { return (p + 3) & ~(int64_t)3; }
 
+// Fills the segment table; returns the tile count P (unpadded) or -1 after prn_set_error.
+static int64_t make_seg(WSeg& g, const prn_ragged* rg, int B, int H, int W, const char* who) {
+  prn_ragged one;
+  if (rg == nullptr) { one.nseg = 1; one.H[0] = H; one.W[0] = W; rg = &one; }
+  if (!(rg->nseg >= 1 && rg->nseg <= PRN_MAX_SEGMENTS && B > 0)) { prn_set_error("%s: bad segment table", who); return -1; }
+  g.nseg = rg->nseg; g.B = B;
+  int64_t p = 0, hw = 0;
+  for (int t = 0; t < PRN_MAX_SEGMENTS; ++t) {
+    const bool live = t < rg->nseg;
+    const int h = live ? rg->H[t] : 0, w = live ? rg->W[t] : 0;
+    if (live && !(h >= 5 && w >= 4 && (w & 3) == 0)) { prn_set_error("%s: W %% 4 == 0 and H >= 5 required (segment %d: H=%d W=%d)", who, t, h, w); return -1; }
+    g.p0[t] = (int)p; g.hw0[t] = (int)hw; g.H[t] = h; g.W[t] = w;
+    p += (int64_t)B * ((h + 3) / 4) * (w / 4);
+    hw += (int64_t)h * w;
+    if (live && (p >= (1LL << 30) || hw * B >= (1LL << 30))) { prn_set_error("%s: too many tiles", who); return -1; }
+  }
+  g.p0[PRN_MAX_SEGMENTS] = (int)p;
+  return p;
+}
+
 extern "C" int64_t prn_winograd_tiles(int B, int H, int W) {
-  return pad4(tiles_of(B, H, W));
+  WSeg g;
+  const int64_t P = make_seg(g, nullptr, B, H, W, "prn_winograd_tiles");
+  return P < 0 ? -1 : pad4(P);
+}
+extern "C" int64_t prn_winograd_tiles_ragged(const prn_ragged* rg, int B) {
+  WSeg g;
+  const int64_t P = rg ? make_seg(g, rg, B, 0, 0, "prn_winograd_tiles_ragged") : -1;
+  return P < 0 ? -1 : pad4(P);
 }
 
 extern "C" int prn_winograd_weights_batched(const prn_winograd_item* items_dev, int n_items, int64_t total_blocks, void* stream) {
@@ -300,79 +349,81 @@ extern "C" int prn_winograd_weights_batched(const prn_winograd_item* items_dev, 
   return 0;
 }
 
-extern "C" int prn_winograd_input(const float* x, float* V, int B, int C, int H, int W, int in_mode, void* stream) {
-  PRN_REQUIRE(x && V && B > 0 && C > 0 && C < 65536 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_winograd_input: W %% 4 == 0 and H >= 5 required (H=%d W=%d)", H, W);
+namespace {
+int input_impl(const float* x, float* V, const prn_ragged* rg, int B, int C, int H, int W, int in_mode, void* stream) {
+  PRN_REQUIRE(x && V && C > 0 && C < 65536, "prn_winograd_input: bad arguments");
   PRN_REQUIRE(in_mode == PRN_IN_ZERO || in_mode == PRN_IN_REFLECT, "prn_winograd_input: zero or reflect padding only");
   PRN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "prn_winograd_input: x must be 16-byte aligned");
-  const int TH = (H + 3) / 4, TW = W / 4;
-  const int64_t P = tiles_of(B, H, W), P4 = pad4(P);
-  PRN_REQUIRE(P < (1LL << 30), "prn_winograd_input: too many tiles");
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_winograd_input");
+  if (P < 0) return 2;
   const dim3 grid(cdiv(P, 256), C), block(256);
-  if (in_mode == PRN_IN_ZERO) hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_ZERO>), grid, block, 0, (hipStream_t)stream, x, V, B, C, H, W, TH, TW, (int)P, (int)P4);
-  else hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_REFLECT>), grid, block, 0, (hipStream_t)stream, x, V, B, C, H, W, TH, TW, (int)P, (int)P4);
+  if (in_mode == PRN_IN_ZERO) hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_ZERO>), grid, block, 0, (hipStream_t)stream, x, V, C, (int)P, (int)pad4(P), g);
+  else hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_REFLECT>), grid, block, 0, (hipStream_t)stream, x, V, C, (int)P, (int)pad4(P), g);
   PRN_CHECK_LAUNCH("prn_winograd_input");
   return 0;
 }
 
-extern "C" int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream) {
-  PRN_REQUIRE(Y && y && B > 0 && M > 0 && M < 65536 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_winograd_output: W %% 4 == 0 and H >= 5 required (H=%d W=%d)", H, W);
+int output_impl(const float* Y, const float* bias, const float* addend, float* y, const prn_ragged* rg, int B, int M, int H, int W, int epilogue, void* stream) {
+  PRN_REQUIRE(Y && y && M > 0 && M < 65536, "prn_winograd_output: bad arguments");
   PRN_REQUIRE(epilogue == PRN_EPI_NONE || epilogue == PRN_EPI_RELU, "prn_winograd_output: epilogue none or ReLU only");
   PRN_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0, "prn_winograd_output: y / addend must be 16-byte aligned");
-  const int TH = (H + 3) / 4, TW = W / 4;
-  const int64_t P = tiles_of(B, H, W), P4 = pad4(P);
-  hipLaunchKernelGGL(winograd_output_kernel, dim3(cdiv(P, 256), M), dim3(256), 0, (hipStream_t)stream, Y, bias, addend, y, B, M, H, W, TH, TW, (int)P, (int)P4,
-                     epilogue == PRN_EPI_RELU ? 1 : 0);
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_winograd_output");
+  if (P < 0) return 2;
+  hipLaunchKernelGGL(winograd_output_kernel, dim3(cdiv(P, 256), M), dim3(256), 0, (hipStream_t)stream, Y, bias, addend, y, M, (int)P, (int)pad4(P),
+                     epilogue == PRN_EPI_RELU ? 1 : 0, g);
   PRN_CHECK_LAUNCH("prn_winograd_output");
   return 0;
 }
 
-// x -> V -> (36 GEMMs) -> Y' -> y in one call.  ws: 36 * (C + M) * prn_winograd_tiles(B, H, W) floats.
-extern "C" int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
-                                    int in_mode, int epilogue, void* stream) {
-  PRN_REQUIRE(ws && U, "prn_conv3x3_winograd: workspace and transformed weights required");
-  const int64_t P4 = pad4(tiles_of(B, H, W));
-  float* V = (float*)ws;
-  float* Yt = V + 36 * (int64_t)C * P4;
-  if (int e = prn_winograd_input(x, V, B, C, H, W, in_mode, stream)) return e;
-  if (int e = prn_gemm_batched(M, C, (int)P4, 36, U, V, Yt, stream)) return e;
-  return prn_winograd_output(Yt, bias, addend, y, B, M, H, W, epilogue, stream);
-}
-
-/* ---- weight gradient: dw = G^T [ sum_tiles (A dy A^T) .* (B^T x B) ] G */
-extern "C" int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M) {
-  const int64_t P4 = pad4(tiles_of(B, H, W));
-  const int splits = prn_gemm_batched_nt_splits(M, C, (int)P4, 36);
-  return 4 * (36 * (int64_t)(C + M) * P4 + (int64_t)splits * 36 * M * C);
-}
-
-extern "C" int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream) {
-  PRN_REQUIRE(dy && Y && B > 0 && M > 0 && M < 65536 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_winograd_dy: W %% 4 == 0 and H >= 5 required (H=%d W=%d)", H, W);
+int dy_impl(const float* dy, float* Y, const prn_ragged* rg, int B, int M, int H, int W, void* stream) {
+  PRN_REQUIRE(dy && Y && M > 0 && M < 65536, "prn_winograd_dy: bad arguments");
   PRN_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, "prn_winograd_dy: dy must be 16-byte aligned");
-  const int TH = (H + 3) / 4, TW = W / 4;
-  const int64_t P = tiles_of(B, H, W), P4 = pad4(P);
-  hipLaunchKernelGGL(winograd_dy_kernel, dim3(cdiv(P, 256), M), dim3(256), 0, (hipStream_t)stream, dy, Y, B, M, H, W, TH, TW, (int)P, (int)P4);
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_winograd_dy");
+  if (P < 0) return 2;
+  hipLaunchKernelGGL(winograd_dy_kernel, dim3(cdiv(P, 256), M), dim3(256), 0, (hipStream_t)stream, dy, Y, M, (int)P, (int)pad4(P), g);
   PRN_CHECK_LAUNCH("prn_winograd_dy");
   return 0;
 }
 
-extern "C" int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream) {
-  PRN_REQUIRE(partials && dw && M > 0 && C > 0 && splits > 0, "prn_winograd_dw: bad arguments");
-  hipLaunchKernelGGL(winograd_dw_kernel, dim3(cdiv((int64_t)M * C, 64)), dim3(256), 0, (hipStream_t)stream, partials, dw, M, C, splits);
-  PRN_CHECK_LAUNCH("prn_winograd_dw");
-  return 0;
+int fwd_impl(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M,
+             int in_mode, int epilogue, void* stream) {
+  PRN_REQUIRE(ws && U, "prn_conv3x3_winograd: workspace and transformed weights required");
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_conv3x3_winograd");
+  if (P < 0) return 2;
+  const int64_t P4 = pad4(P);
+  float* V = (float*)ws;
+  float* Yt = V + 36 * (int64_t)C * P4;
+  if (int e = input_impl(x, V, rg, B, C, H, W, in_mode, stream)) return e;
+  if (int e = prn_gemm_batched(M, C, (int)P4, 36, U, V, Yt, stream)) return e;
+  return output_impl(Yt, bias, addend, y, rg, B, M, H, W, epilogue, stream);
+}
+
+int64_t wgrad_ws(const prn_ragged* rg, int B, int C, int H, int W, int M) {
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_winograd_wgrad_ws_bytes");
+  if (P < 0) return -1;
+  const int64_t P4 = pad4(P);
+  const int splits = prn_gemm_batched_nt_splits(M, C, (int)P4, 36);
+  return 4 * (36 * (int64_t)(C + M) * P4 + (int64_t)splits * 36 * M * C);
 }
 
 // phase: 0 = everything, 1 = transforms of x and dy, 2 = the 36 products, 3 = reduction + G^T . G (profilers bracket them separately)
-extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream,
-                                          int phase) {
+int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase) {
   PRN_REQUIRE(ws && x && dy && dw, "prn_conv3x3_winograd_wgrad: null tensor / workspace");
-  const int64_t P4 = pad4(tiles_of(B, H, W)), P = tiles_of(B, H, W);
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_conv3x3_winograd_wgrad");
+  if (P < 0) return 2;
+  const int64_t P4 = pad4(P);
   float* V = (float*)ws;
   float* Yt = V + 36 * (int64_t)C * P4;
   float* part = Yt + 36 * (int64_t)M * P4;
   if (phase == 0 || phase == 1) {
-    if (int e = prn_winograd_input(x, V, B, C, H, W, in_mode, stream)) return e;
-    if (int e = prn_winograd_dy(dy, Yt, B, M, H, W, stream)) return e;
+    if (int e = input_impl(x, V, rg, B, C, H, W, in_mode, stream)) return e;
+    if (int e = dy_impl(dy, Yt, rg, B, M, H, W, stream)) return e;
     if (P4 != P) {                                     // the products reduce over P4 columns: the padding must be zero
       // (at most 3 columns per row: cleared with one strided memset per operand)
       hipMemset2DAsync(V + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)C, (hipStream_t)stream);
@@ -384,4 +435,45 @@ extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float
   if (phase == 0 || phase == 3)
     return prn_winograd_dw(part, dw, M, C, prn_gemm_batched_nt_splits(M, C, (int)P4, 36), stream);
   return 0;
+}
+}  // namespace
+
+extern "C" int prn_winograd_input(const float* x, float* V, int B, int C, int H, int W, int in_mode, void* stream) {
+  return input_impl(x, V, nullptr, B, C, H, W, in_mode, stream);
+}
+extern "C" int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream) {
+  return output_impl(Y, bias, addend, y, nullptr, B, M, H, W, epilogue, stream);
+}
+extern "C" int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream) {
+  return dy_impl(dy, Y, nullptr, B, M, H, W, stream);
+}
+extern "C" int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream) {
+  PRN_REQUIRE(partials && dw && M > 0 && C > 0 && splits > 0, "prn_winograd_dw: bad arguments");
+  hipLaunchKernelGGL(winograd_dw_kernel, dim3(cdiv((int64_t)M * C, 64)), dim3(256), 0, (hipStream_t)stream, partials, dw, M, C, splits);
+  PRN_CHECK_LAUNCH("prn_winograd_dw");
+  return 0;
+}
+
+// x -> V -> (36 GEMMs) -> Y' -> y in one call.  ws: 36 * (C + M) * prn_winograd_tiles(B, H, W) floats.
+extern "C" int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
+                                    int in_mode, int epilogue, void* stream) {
+  return fwd_impl(x, U, bias, addend, y, ws, nullptr, B, C, H, W, M, in_mode, epilogue, stream);
+}
+// The same over a ragged batch (prn_ragged: every segment convolved with the same weights; zero padding).
+extern "C" int prn_conv3x3_winograd_ragged(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B,
+                                           int C, int M, int epilogue, void* stream) {
+  PRN_REQUIRE(rg, "prn_conv3x3_winograd_ragged: null segment table");
+  return fwd_impl(x, U, bias, addend, y, ws, rg, B, C, 0, 0, M, PRN_IN_ZERO, epilogue, stream);
+}
+
+/* ---- weight gradient: dw = G^T [ sum_tiles (A dy A^T) .* (B^T x B) ] G */
+extern "C" int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M) { return wgrad_ws(nullptr, B, C, H, W, M); }
+extern "C" int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M) { return rg ? wgrad_ws(rg, B, C, 0, 0, M) : -1; }
+extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream,
+                                          int phase) {
+  return wgrad_impl(x, dy, dw, ws, nullptr, B, C, H, W, M, in_mode, stream, phase);
+}
+extern "C" int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M, void* stream) {
+  PRN_REQUIRE(rg, "prn_conv3x3_winograd_wgrad_ragged: null segment table");
+  return wgrad_impl(x, dy, dw, ws, rg, B, C, 0, 0, M, PRN_IN_ZERO, stream, 0);
 }

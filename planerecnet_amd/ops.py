@@ -781,6 +781,15 @@ class RaggedShape:
         """The HIP path needs whole 64-pixel tiles / 16-pixel chunks per segment (see prn_ragged)."""
         return len(self.sizes) <= 6 and all((self.B * h * w) % 64 == 0 and (h * w) % 4 == 0 for h, w in self.sizes)
 
+    def winograd(self, C, M, K):
+        """Ragged 3x3 convs take the Winograd path when every segment has W % 4 == 0 (include/prn.h: prn_conv3x3_winograd_ragged)."""
+        if not (WINOGRAD and K == 3 and C >= 64 and M >= 64 and all(w % 4 == 0 and h >= 8 for h, w in self.sizes)):
+            return 0
+        P = self.__dict__.get("_tiles")
+        if P is None:
+            P = self._tiles = lib.prn_winograd_tiles_ragged(self.ref, self.B)
+        return P if P >= WINOGRAD_MIN_TILES else 0
+
     def pack(self, tensors):
         return torch.cat([t.reshape(-1) for t in tensors])
 
@@ -808,6 +817,15 @@ def _rdesc(rs, C, M, K, epi=EPI_NONE):
     return e
 
 
+def _ragged_winograd_raw(xp, U, bias, addend, rs, C, M, P, epi=EPI_NONE):
+    y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
+    ws = torch.empty(36 * (C + M) * P, device=xp.device, dtype=torch.float32)
+    with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P):          # (transforms included in the bracket)
+        check(lib.prn_conv3x3_winograd_ragged(_p(xp), _p(U), _p(bias), _p(addend), _p(y), _p(ws), rs.ref, rs.B, C, M, epi, _stream()),
+              "prn_conv3x3_winograd_ragged")
+    return y
+
+
 def _ragged_conv_raw(xp, w, bias, addend, rs, C, M, K, epi=EPI_NONE):
     y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
     _, ref, _ = _rdesc(rs, C, M, K, epi)
@@ -823,7 +841,8 @@ class _RaggedConv(torch.autograd.Function):
         xp, w, bias = _c(xp), _c(w), _c(bias)
         M, C, K, _ = w.shape
         assert xp.numel() == rs.pixels * C, (xp.shape, w.shape, rs.sizes)
-        y = _ragged_conv_raw(xp, w, bias, None, rs, C, M, K)
+        P = rs.winograd(C, M, K)
+        y = _ragged_winograd_raw(xp, winograd_weights(w)[0], bias, None, rs, C, M, P) if P else _ragged_conv_raw(xp, w, bias, None, rs, C, M, K)
         ctx.save_for_backward(xp, w)
         ctx.rs, ctx.has_bias = rs, bias is not None
         return y
@@ -835,9 +854,20 @@ class _RaggedConv(torch.autograd.Function):
         dy = _c(dy)
         M, C, K, _ = w.shape
         dx = dw = db = None
+        P = rs.winograd(C, M, K)
         if ctx.needs_input_grad[0]:
-            dx = _ragged_conv_raw(dy, flip_transpose(w), None, None, rs, M, C, K)
+            dx = _ragged_winograd_raw(dy, winograd_weights(w)[1], None, None, rs, M, C, P) if P else _ragged_conv_raw(dy, flip_transpose(w), None, None, rs, M, C, K)
         def wgrad():
+            if P and WINOGRAD_WGRAD:
+                key = (rs.key, C, M)
+                nb = _WINO_WG_WS.get(key)
+                if nb is None:
+                    nb = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ragged_ws_bytes(rs.ref, rs.B, C, M)
+                ws = torch.empty(nb // 4, device=xp.device, dtype=torch.float32)
+                dwo = torch.empty_like(w)
+                with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P):
+                    check(lib.prn_conv3x3_winograd_wgrad_ragged(_p(xp), _p(dy), _p(dwo), _p(ws), rs.ref, rs.B, C, M, _stream()), "prn_conv3x3_winograd_wgrad_ragged")
+                return dwo
             _, ref, nbytes = _rdesc(rs, C, M, K)
             ws = torch.empty(max(nbytes // 4, 1), device=xp.device, dtype=torch.float32)
             dwo = torch.empty_like(w)

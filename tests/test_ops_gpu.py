@@ -481,3 +481,31 @@ def test_winograd_weights_batched_refresh():
         ws[0].mul_(2.0)
     U = ops.winograd_weights(ws[0])[0]                        # stale entry is not used: recomputed for the new values
     assert U.data_ptr() != old.data_ptr() and torch.allclose(U, 2.0 * old_vals, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("C,M", [(66, 64), (128, 96)])
+def test_ragged_winograd_matches_direct_ragged_kernel(C, M, monkeypatch):
+    """Ragged batch (the instance head's five grids, shared weights) on the Winograd path == the direct ragged GEMM and the
+    per-segment dense convs: forward, input gradient, weight gradient."""
+    from planerecnet_amd import ops
+    d = dev()
+    B, sizes = 8, [(40, 40), (36, 36), (24, 24), (16, 16), (12, 12)]
+    xs = [rnd(B, C, h, w, seed=10 + i).float().to(d) for i, (h, w) in enumerate(sizes)]
+    w = rnd(M, C, 3, 3, seed=2, scale=(C * 9) ** -0.5).float().to(d)
+    gos = [rnd(B, M, h, w_, seed=20 + i).float().to(d) for i, (h, w_) in enumerate(sizes)]
+
+    def run(wino):
+        monkeypatch.setattr(ops, "WINOGRAD", wino)
+        rs = ops.RaggedShape(B, sizes)
+        assert rs.supported() and bool(rs.winograd(C, M, 3)) == wino
+        xl = [t.clone().requires_grad_(True) for t in xs]
+        wl = w.clone().requires_grad_(True)
+        y = ops.ragged_conv2d(rs.pack(xl), wl, None, rs)
+        return rs.unpack(y, M), torch.autograd.grad((y * rs.pack(gos)).sum(), xl + [wl])
+    ya, ga = run(True)
+    yb, gb = run(False)
+    for i, (a, r) in enumerate(zip(ya, yb)):
+        close(a, r.double().cpu(), "ragged winograd y[%d]" % i, rtol=5e-5)
+        close(a, F.conv2d(xs[i].double().cpu(), w.double().cpu(), padding=1), "ragged winograd y[%d] vs torch" % i)
+    for i, (a, r) in enumerate(zip(ga, gb)):
+        close(a, r.double().cpu(), "ragged winograd grad[%d]" % i, rtol=1e-4)
