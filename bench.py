@@ -56,7 +56,11 @@ def synth_batch(B, H, W, seed, device):
         K = np.array([[577.0, 0, W / 2], [0, 577.0, H / 2], [0, 0, 1]], np.float64)
         inst.append({"masks": torch.from_numpy(masks), "boxes": torch.from_numpy(boxes), "classes": torch.zeros(n, dtype=torch.int64),
                      "plane_paras": torch.from_numpy(paras), "k_matrix": torch.from_numpy(K)})
-    # annotations stay on the host (the loss's GT-only preparation runs there); images and GT depth live in HBM
+    # annotations stay on the host (the loss's GT-only preparation runs there, in worker processes: shared memory, so a
+    # batch is handed over as handles the way a DataLoader worker's batch is); images and GT depth live in HBM
+    for g_ in inst:
+        for v in g_.values():
+            v.share_memory_()
     return images.to(device), inst, depths.to(device)
 
 
@@ -156,12 +160,13 @@ def main():
     ops.set_wgrad_async(not args.sync_wgrad)                 # weight gradients on a side stream, joined after backward (ops.py)
     hw = (args.height, args.width)
     prefetch = TargetPrefetcher(crit)
+    prefetch.submit(inst, hw)                                # two batches in flight: the workers never wait for the trainer
     prefetch.submit(inst, hw)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared on the worker thread) + async uploads
-        prefetch.submit(inst, hw)                           # next step's targets: recomputed every step, overlapping this step's GPU work
+        targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared by the worker processes) + async uploads
+        prefetch.submit(inst, hw)                           # targets two steps ahead: recomputed every step, overlapping the GPU work
         out = run_net(images)
         losses = crit(net, *out, inst, depths, targets=targets)
         loss = sum(losses.values()).sum()

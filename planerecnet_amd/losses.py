@@ -17,6 +17,7 @@ structure is different:
     single segmented sort for the "drop the best 25 %" rule.
   * lava: sum(up4(s) * g) is evaluated as sum(s * up4^T(g)); the adjoint-resized gradient map depends only on the GT.
 """
+import collections
 import os
 
 import numpy as np
@@ -103,7 +104,7 @@ class PlaneRecNetLoss(nn.Module):
 
     # ------------------------------------------------------------------ GT-only work, before the forward
     @torch.no_grad()
-    def prepare_host(self, gt_instances, hw, mask_feat_size=None, with_vnl=True):
+    def prepare_host(self, gt_instances, hw, mask_feat_size=None, with_vnl=True, pin=True):
         """Pure host part (numpy / CPU torch; safe to run on a worker thread -- see TargetPrefetcher): SOLOv2 targets and
         the virtual-normal triplet indices for a list of per-image GT dicts."""
         H, W = hw
@@ -120,7 +121,7 @@ class PlaneRecNetLoss(nn.Module):
             num_ins += sum(int(i.sum()) for i in ind_l)
             for lv in range(L):
                 cate_rows[lv].append(cate_l[lv].flatten())
-        pin = _pin if torch.cuda.is_available() else (lambda x: x)       # page-locked staging: the later H2D copies are truly async
+        pin = _pin if (pin and torch.cuda.is_available()) else (lambda x: x)       # page-locked staging: the later H2D copies are truly async
         return {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
                 "cell_ids": pin(torch.from_numpy(np.concatenate(cell_ids))), "pos_img": pin(torch.from_numpy(np.repeat(np.arange(B), n_pos))),
                 "ins_labels": pin(torch.cat(ins_labels, 0)),
@@ -293,7 +294,7 @@ class VNL_Loss(nn.Module):
         return out
 
     @torch.no_grad()
-    def prepare_host(self, host_instances, hw):
+    def prepare_host(self, host_instances, hw, pin=True):
         """Host: pixel ids of every sampled triplet (global over the batch) + segment bookkeeping, as CPU tensors."""
         H, W = hw
         gids, seg_len, seg_img, seg_plane, normals, N_per, fx, fy = [], [], [], [], [], [], [], []
@@ -318,7 +319,7 @@ class VNL_Loss(nn.Module):
                 normals.append(planes[r] if r < N else np.zeros(3))
         seg_len = np.asarray(seg_len, dtype=np.int64)
         n_seg = len(seg_len)
-        pin = _pin if torch.cuda.is_available() else (lambda x: x)
+        pin = _pin if (pin and torch.cuda.is_available()) else (lambda x: x)
         return {"B": len(host_instances), "n_seg": n_seg, "n_tot": int(seg_len.sum()),
                 "N": torch.as_tensor(N_per, dtype=torch.float64), "fx": torch.as_tensor(np.asarray(fx), dtype=torch.float64),
                 "fy": torch.as_tensor(np.asarray(fy), dtype=torch.float64),
@@ -441,35 +442,110 @@ class VNL_Loss(nn.Module):
         return self.batched(pred_depth.unsqueeze(0), gt_depth.unsqueeze(0), t)[0]
 
 
-class TargetPrefetcher:
-    """Runs the GT-only host work for the NEXT batch on worker threads while the GPU executes the current step (the role
-    the reference gives to its DataLoader workers + the host part of its loss).  Two jobs per batch -- SOLOv2 targets
-    (CPU torch ops) and virtual-normal triplet draws (numpy) -- run side by side; each kind is processed one batch at a
-    time in submission order, so the numpy RNG stream of the sampling stays deterministic."""
+_WORKER = {}
 
-    def __init__(self, criterion):
+
+def _worker_init(cfg_blob, rng_state):
+    """Runs once in each prefetch worker process: the parent's active config and numpy RNG state (the virtual-normal draws
+    use numpy's global generator, vnl.py:43-55, so the worker continues the parent's sequence)."""
+    import pickle
+    torch.set_num_threads(2)
+    cfg.replace(pickle.loads(cfg_blob))
+    np.random.set_state(rng_state)
+    _WORKER["crit"] = PlaneRecNetLoss()
+
+
+def _worker_targets(gt_instances, hw, mask_feat_size):
+    return _WORKER["crit"].prepare_host(gt_instances, hw, mask_feat_size, False, pin=False)
+
+
+def _worker_vnl(host, hw):
+    return _WORKER["crit"].vnl.prepare_host(host, hw, pin=False)
+
+
+def _pin_tree(o):
+    if torch.is_tensor(o):
+        return _pin(o) if o.numel() >= 4096 else o            # the large index / label arrays only
+    if isinstance(o, dict):
+        return {k: _pin_tree(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_pin_tree(v) for v in o)
+    return o
+
+
+class TargetPrefetcher:
+    """Runs the GT-only host work for the NEXT batch on workers while the GPU executes the current step (the role the
+    reference gives to its DataLoader workers + the host part of its loss).  Two jobs per batch -- SOLOv2 targets (CPU torch
+    ops) and virtual-normal triplet draws (numpy) -- run side by side; each kind is processed one batch at a time in
+    submission order, so the numpy RNG stream of the sampling stays deterministic.
+
+    workers="process" (default on a GPU box): two spawned worker PROCESSES.  The per-instance Python loops of the target
+    assignment hold the GIL; on threads they slowed the trainer's own enqueue work from ~30 to ~65 ms per step (B=8), which
+    made the step host-bound (tools/host_vs_gpu.py).  GT tensors should live in shared memory (DataLoader workers put
+    them there; bench.py calls share_memory_()) so that submitting a batch sends handles, not pixels.
+    workers="thread": in-process threads (no start-up cost; tests and short runs)."""
+
+    def __init__(self, criterion, workers=None):
         from concurrent.futures import ThreadPoolExecutor
         self.criterion = criterion
-        self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
-        self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
-        self.pending = None
+        self.workers = workers or os.environ.get("PRN_PREFETCH_WORKERS") or ("process" if torch.cuda.is_available() else "thread")
+        if self.workers == "process":
+            import pickle
+            import torch.multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            import sys
+            ctx = mp.get_context("spawn")
+            init = (pickle.dumps(cfg), np.random.get_state())
+            # The workers need this module only.  A spawned child normally re-imports the parent's __main__ script first
+            # (a training script without an `if __name__ == "__main__"` guard would run again inside every worker): hide
+            # the script from multiprocessing while the two workers start, and start them now rather than at first use.
+            main = sys.modules.get("__main__")
+            saved = {a: getattr(main, a) for a in ("__file__", "__spec__") if hasattr(main, a)}
+            try:
+                if "__file__" in saved:
+                    del main.__file__
+                if main is not None:
+                    main.__spec__ = None
+                self.pool_t = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
+                self.pool_v = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
+                for f in [self.pool_t.submit(int), self.pool_v.submit(int)]:
+                    f.result()
+            finally:
+                for a, v in saved.items():
+                    setattr(main, a, v)
+        else:
+            self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
+            self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
+        self.queue = collections.deque()                      # FIFO: submit() batches ahead of time, get() returns the oldest
+
+    @property
+    def pending(self):
+        return self.queue[0] if self.queue else None
 
     def submit(self, gt_instances, hw, mask_feat_size=None):
-        ft = self.pool_t.submit(self.criterion.prepare_host, gt_instances, hw, mask_feat_size, False)
+        proc = self.workers == "process"
+        if proc:
+            gt_instances = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in g.items()} for g in gt_instances]
+            ft = self.pool_t.submit(_worker_targets, gt_instances, hw, mask_feat_size)
+        else:
+            ft = self.pool_t.submit(self.criterion.prepare_host, gt_instances, hw, mask_feat_size, False)
         fv = None
         if cfg.use_plane_loss:
             host = [{k: g[k].cpu() for k in ("masks", "plane_paras", "k_matrix")} for g in gt_instances]
-            fv = self.pool_v.submit(self.criterion.vnl.prepare_host, host, hw)
-        self.pending = (ft, fv)
+            fv = self.pool_v.submit(_worker_vnl, host, hw) if proc else self.pool_v.submit(self.criterion.vnl.prepare_host, host, hw)
+        self.queue.append((ft, fv))
 
     def get(self, gt_depths, device):
-        """Targets of the batch submitted last (blocks only if a worker has not finished yet)."""
-        ft, fv = self.pending
+        """Targets of the OLDEST submitted batch (blocks only if a worker has not finished yet).  Keeping two batches in
+        flight hides the workers' latency (~40 ms per batch of 8 next to a ~60 ms step) completely."""
+        ft, fv = self.queue.popleft()
         h = ft.result()
         h["vnl"] = fv.result() if fv is not None else None
-        self.pending = None
+        if self.workers == "process" and torch.cuda.is_available():
+            h = _pin_tree(h)                                  # (page-locked staging cannot cross the process boundary)
         return self.criterion.upload(h, gt_depths, device)
 
     def close(self):
-        self.pool_t.shutdown(wait=False, cancel_futures=True)
-        self.pool_v.shutdown(wait=False, cancel_futures=True)
+        wait = self.workers == "process"                     # (worker processes are joined: nothing left behind at exit)
+        self.pool_t.shutdown(wait=wait, cancel_futures=True)
+        self.pool_v.shutdown(wait=wait, cancel_futures=True)

@@ -46,6 +46,7 @@ def wgrad_streams():
 
 def wgrad_join():
     """Make the current stream wait for the deferred weight gradients.  Call after backward(), before reading any `.grad`."""
+    wgrad_flush()
     if _SIDE:
         main = torch.cuda.current_stream()
         for st in _SIDE.values():
@@ -56,23 +57,53 @@ def _defer(needs_grad, w):
     return WGRAD_ASYNC and needs_grad and w.is_leaf and w.requires_grad and not profiling.active()
 
 
+# Deferred weight gradients are queued per originating stream and moved to the side stream a few at a time: the stream
+# switch, the event pair of wait_stream and the record_stream calls cost ~25 us of host time per layer when done one by one
+# (128 layers per step on the autograd thread).  Anything that reads `.grad` (wgrad_join, the gradient exchange) flushes first.
+WGRAD_BATCH = int(os.environ.get("PRN_WGRAD_BATCH", "6"))
+_PENDING = {}       # raw stream handle -> (stream object, [(weight, inputs, compute)])
+
+
 def _deferred_wgrad(w, inputs, compute):
     main = torch.cuda.current_stream()
-    side = _side_stream(w.device)
+    e = _PENDING.get(main.cuda_stream)
+    if e is None:
+        e = _PENDING[main.cuda_stream] = (main, [])
+    e[1].append((w, inputs, compute))
+    if len(e[1]) >= WGRAD_BATCH:
+        _flush_one(e)
+
+
+def _flush_one(e):
+    main, items = e
+    if not items:
+        return
+    todo = items[:]
+    del items[:]
+    side = _side_stream(todo[0][0].device, main)          # (keyed by the originating stream)
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
-        dw = compute()
-        if dw.shape != w.shape:
-            dw = dw.view_as(w)
-        dw.record_stream(main)                              # read by the optimizer on the main stream after wgrad_join()
-        if w.grad is None:
-            w.grad = dw
-        else:
-            w.grad.add_(dw)
-        # (post-accumulate-grad hooks still fire: the engine runs the parameter's AccumulateGrad node -- a no-op for the
-        # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
-    for t in inputs:
-        t.record_stream(side)
+        for w, _, compute in todo:
+            dw = compute()
+            if dw.shape != w.shape:
+                dw = dw.view_as(w)
+            dw.record_stream(main)                          # read by the optimizer on the main stream after wgrad_join()
+            if w.grad is None:
+                w.grad = dw
+            else:
+                w.grad.add_(dw)
+            # (post-accumulate-grad hooks still fire: the engine runs the parameter's AccumulateGrad node -- a no-op for the
+            # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
+    for _, inputs, _ in todo:
+        for t in inputs:
+            t.record_stream(side)
+
+
+def wgrad_flush():
+    """Launch every queued weight gradient (on its side stream).  Called by wgrad_join() and by the gradient exchange
+    before it reads a bucket's gradients."""
+    for e in list(_PENDING.values()):
+        _flush_one(e)
 
 
 BRANCH_STREAMS = bool(int(os.environ.get("PRN_BRANCH_STREAMS", "1")))
@@ -117,8 +148,8 @@ def run_branches(fns):
     return outs
 
 
-def _side_stream(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+def _side_stream(device, main=None):
+    key = (device.index, (main if main is not None else torch.cuda.current_stream(device)).cuda_stream)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]

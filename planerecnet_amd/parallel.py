@@ -69,6 +69,9 @@ class GradAllReduce:
 
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
+        if self.on_gpu:
+            from . import ops
+            ops.wgrad_flush()                             # queued deferred weight gradients of this bucket must be in flight
         for p in bucket:                                  # the pack / unpack below work on flat VIEWS of the gradients
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Is the training step bound by the host or by the GPU?  Each measured step is enqueued while the GPU is parked behind a
+spin kernel: H = host time to enqueue the whole step with an idle-waiting GPU (no back-pressure), G = GPU time to drain it
+once released (no host dependency).  S = the ordinary free-running step time for comparison."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from planerecnet_amd import ops, timer  # noqa: E402
+from planerecnet_amd.config import cfg, set_cfg  # noqa: E402
+from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher  # noqa: E402
+from planerecnet_amd.planerecnet import PlaneRecNet  # noqa: E402
+
+timer.disable_all()
+torch.set_num_threads(4)
+dev = torch.device("cuda:0")
+B = int(os.environ.get("BATCH", "8"))
+set_cfg("PlaneRecNet_101_config")
+torch.manual_seed(0)
+net = PlaneRecNet(cfg)
+net.init_head_weights()
+net = net.to(dev).train()
+crit = PlaneRecNetLoss().to(dev)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+images, inst, depths = bench.synth_batch(B, 480, 640, 1000, dev)
+pf = TargetPrefetcher(crit)
+pf.submit(inst, (480, 640))
+pf.submit(inst, (480, 640))
+ops.set_wgrad_async(True)
+
+
+FIXED = [None]
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    if os.environ.get("FIXED_TARGETS"):                 # targets computed once: no worker thread competing for the GIL
+        if FIXED[0] is None:
+            FIXED[0] = pf.get(depths, dev)
+        t = FIXED[0]
+    else:
+        t = pf.get(depths, dev)
+        pf.submit(inst, (480, 640))
+    out = net(images)
+    losses = crit(net, *out, inst, depths, targets=t)
+    sum(losses.values()).sum().backward()
+    ops.wgrad_join()
+    opt.step()
+
+
+for _ in range(6):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    step()
+torch.cuda.synchronize()
+S = (time.perf_counter() - t0) / 10 * 1e3
+Hs, Gs = [], []
+for _ in range(6):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(0.25 * 2.4e9))            # ~250 ms at 2.4 GHz... clock-dependent: only has to outlast the enqueue
+    e0.record()
+    t0 = time.perf_counter()
+    step()
+    Hs.append((time.perf_counter() - t0) * 1e3)
+    e1.record()
+    torch.cuda.synchronize()
+    Gs.append(e0.elapsed_time(e1))
+print("free-running step S = %.1f ms" % S)
+print("host enqueue H (GPU parked): " + " ".join("%.1f" % h for h in Hs))
+print("GPU drain    G (no host dep): " + " ".join("%.1f" % g for g in Gs))
+pf.close()

@@ -26,6 +26,7 @@ opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
 images, inst, depths = bench.synth_batch(8, 480, 640, 1000, dev)
 pf = TargetPrefetcher(crit)
 pf.submit(inst, (480, 640))
+pf.submit(inst, (480, 640))
 ops.set_wgrad_async(True)
 
 

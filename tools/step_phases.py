@@ -31,6 +31,7 @@ opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
 images, inst, depths = bench.synth_batch(PB, H, W, 1000, dev)
 pf = TargetPrefetcher(crit)
 pf.submit(inst, (H, W))
+pf.submit(inst, (H, W))
 acc = {}
 
 
@@ -39,8 +40,13 @@ def mark(name, t0):
 
 
 def step():
-    t0 = time.perf_counter(); opt.zero_grad(set_to_none=True); ft, fv = pf.pending; h = ft.result(); h["vnl"] = fv.result(); mark("wait_worker", t0)
-    t0 = time.perf_counter(); pf.pending = None; targets = crit.upload(h, depths, dev); pf.submit(inst, (H, W)); mark("upload", t0)
+    t0 = time.perf_counter(); opt.zero_grad(set_to_none=True); ft, fv = pf.queue.popleft(); h = ft.result(); h["vnl"] = fv.result(); mark("wait_worker", t0)
+    t0 = time.perf_counter()
+    if pf.workers == "process":
+        from planerecnet_amd.losses import _pin_tree
+        h = _pin_tree(h)
+    mark("pin", t0)
+    t0 = time.perf_counter(); targets = crit.upload(h, depths, dev); pf.submit(inst, (H, W)); mark("upload", t0)
     t0 = time.perf_counter(); out = net(images); mark("net_fwd", t0)
     t0 = time.perf_counter(); losses = crit(net, *out, inst, depths, targets=targets); loss = sum(losses.values()).sum(); mark("loss_fwd", t0)
     t0 = time.perf_counter(); loss.backward(); ops.wgrad_join(); mark("backward", t0)

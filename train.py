@@ -9,13 +9,14 @@ What differs is the machinery underneath:
     are mean-all-reduced over RCCL on a side stream overlapped with backward (planerecnet_amd/parallel.py), the loss that
     is logged is the mean over ranks (reference train.py:348), and the "skip the step on a non-finite loss" decision
     (train.py:353) is taken collectively so ranks cannot diverge;
-  * GT-only loss preparation for batch k+1 runs on a worker thread while the GPU executes batch k (losses.TargetPrefetcher);
+  * GT-only loss preparation runs in worker processes two batches ahead of the GPU (losses.TargetPrefetcher);
   * `--dataset synthetic` (the default when the annotated datasets are not on disk) feeds seeded synthetic batches with the
     reference's batch contract (data/datasets.py:54-57,250-273) -- the ScanNet / NYU readers need cv2 + pycocotools and are
     outside this hot-path build.
 """
 import argparse
 import datetime
+import collections
 import math
 import os
 import random
@@ -215,9 +216,13 @@ def main():
             if sampler is not None:
                 sampler.set_epoch(epoch)
             it = iter(loader)
-            nxt = next(it, None)
-            if nxt is not None:
-                prefetch.submit(nxt[1], tuple(nxt[0][0].shape[-2:]))
+            ahead = collections.deque()                    # batches whose GT-only targets are being prepared (two in flight)
+            for _ in range(2):
+                b_ = next(it, None)
+                if b_ is not None:
+                    ahead.append(b_)
+                    prefetch.submit(b_[1], tuple(b_[0][0].shape[-2:]))
+            nxt = ahead[0] if ahead else None
             while nxt is not None:
                 images, gt_instances, gt_depths = nxt
                 if iteration == (epoch + 1) * epoch_size or iteration == cfg.max_iter:
@@ -239,9 +244,12 @@ def main():
                 x = torch.stack(images).to(dev, non_blocking=True)
                 d = torch.stack(gt_depths).to(dev, non_blocking=True)
                 targets = prefetch.get(d, dev)
-                nxt = next(it, None)                       # fetch + start preparing the next batch while this one runs
-                if nxt is not None:
-                    prefetch.submit(nxt[1], tuple(nxt[0][0].shape[-2:]))
+                ahead.popleft()
+                b_ = next(it, None)                        # fetch + start preparing a later batch while this one runs
+                if b_ is not None:
+                    ahead.append(b_)
+                    prefetch.submit(b_[1], tuple(b_[0][0].shape[-2:]))
+                nxt = ahead[0] if ahead else None
                 losses = net(x, gt_instances, d, targets=targets)
                 loss = sum(losses[k].sum() for k in losses)
                 loss.backward()
