@@ -134,6 +134,9 @@ int prn_gemm_batched_nt_splits(int M, int C, int P, int nb);
 int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, void* stream);
 int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream);
 int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase);
+/* The same with V = B^T x B supplied by the caller: the first 36 * C * P floats of the workspace of the forward call of the
+ * same layer, kept alive until the backward pass (same ws size as above; its V part is then unused). */
+int prn_conv3x3_winograd_wgrad_v(const float* V, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, void* stream);
 /* Ragged batches (prn_ragged; zero padding; every segment with W % 4 == 0, H >= 5): the tiles of all segments share the 36
  * products, only the transforms look at the segment table.  P = prn_winograd_tiles_ragged(rg, B). */
 int64_t prn_winograd_tiles_ragged(const prn_ragged* rg, int B);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "prn_conv3x3_winograd_ragged": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "prn_winograd_wgrad_ragged_ws_bytes": (c_i64, [P, c_int, c_int, c_int]),
     "prn_conv3x3_winograd_wgrad_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "prn_conv3x3_winograd_wgrad_v": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),

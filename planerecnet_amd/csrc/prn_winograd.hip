@@ -412,20 +412,23 @@ int64_t wgrad_ws(const prn_ragged* rg, int B, int C, int H, int W, int M) {
 }
 
 // phase: 0 = everything, 1 = transforms of x and dy, 2 = the 36 products, 3 = reduction + G^T . G (profilers bracket them separately)
-int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase) {
-  PRN_REQUIRE(ws && x && dy && dw, "prn_conv3x3_winograd_wgrad: null tensor / workspace");
+int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase,
+               const float* V_in = nullptr) {
+  PRN_REQUIRE(ws && (x || V_in) && dy && dw, "prn_conv3x3_winograd_wgrad: null tensor / workspace");
   WSeg g;
   const int64_t P = make_seg(g, rg, B, H, W, "prn_conv3x3_winograd_wgrad");
   if (P < 0) return 2;
   const int64_t P4 = pad4(P);
-  float* V = (float*)ws;
-  float* Yt = V + 36 * (int64_t)C * P4;
+  float* V = V_in ? const_cast<float*>(V_in) : (float*)ws;      // V_in: B^T x B kept from the forward pass of the same layer
+  float* Yt = (float*)ws + 36 * (int64_t)C * P4;
   float* part = Yt + 36 * (int64_t)M * P4;
   if (phase == 0 || phase == 1) {
-    if (int e = input_impl(x, V, rg, B, C, H, W, in_mode, stream)) return e;
+    if (!V_in)
+      if (int e = input_impl(x, V, rg, B, C, H, W, in_mode, stream)) return e;
     if (int e = dy_impl(dy, Yt, rg, B, M, H, W, stream)) return e;
     if (P4 != P) {                                     // the products reduce over P4 columns: the padding must be zero
-      // (at most 3 columns per row: cleared with one strided memset per operand)
+      // (at most 3 columns per row: cleared with one strided memset per operand; a kept V has finite padding only
+      // if its producer cleared it, so it is cleared here as well)
       hipMemset2DAsync(V + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)C, (hipStream_t)stream);
       hipMemset2DAsync(Yt + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)M, (hipStream_t)stream);
     }
@@ -472,6 +475,12 @@ extern "C" int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int 
 extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream,
                                           int phase) {
   return wgrad_impl(x, dy, dw, ws, nullptr, B, C, H, W, M, in_mode, stream, phase);
+}
+// The same with V = B^T x B supplied by the caller (the first 36 * C * P floats of the forward call's workspace, kept alive):
+// the input transform is skipped.
+extern "C" int prn_conv3x3_winograd_wgrad_v(const float* V, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, void* stream) {
+  PRN_REQUIRE(V, "prn_conv3x3_winograd_wgrad_v: null V");
+  return wgrad_impl(nullptr, dy, dw, ws, nullptr, B, C, H, W, M, PRN_IN_ZERO, stream, 0, V);
 }
 extern "C" int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M, void* stream) {
   PRN_REQUIRE(rg, "prn_conv3x3_winograd_wgrad_ragged: null segment table");

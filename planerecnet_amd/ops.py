@@ -387,8 +387,12 @@ class WinogradWeights:
             _WINO[w.data_ptr()] = (w, w._version, U, Ut)
 
 
-def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE):
-    """3x3 / stride 1 / pad 1 convolution of x [B,C,H,W] with transform-domain weights U [36,M,C]."""
+WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
+
+
+def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep=None):
+    """3x3 / stride 1 / pad 1 convolution of x [B,C,H,W] with transform-domain weights U [36,M,C].
+    keep: a list that receives the workspace (whose head is V = B^T x B) for conv3x3_winograd_wgrad_raw(..., V=...)."""
     B, C, H, W = x.shape
     P = lib.prn_winograd_tiles(B, H, W)
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
@@ -403,14 +407,17 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE):
             check(lib.prn_winograd_output(_p(Yt), _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
     else:
         check(lib.prn_conv3x3_winograd(_p(x), _p(U), _p(bias), _p(addend), _p(y), _p(ws), B, C, H, W, M, mode, epi, _stream()), "prn_conv3x3_winograd")
+    if keep is not None and mode == IN_ZERO and 4 * 36 * C * P <= WINOGRAD_KEEP_V:
+        keep.append(ws)
     return y
 
 
 _WINO_WG_WS = {}
 
 
-def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO):
-    """Weight gradient [M,C,3,3] of a 3x3 / stride 1 / pad 1 convolution on the Winograd path."""
+def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
+    """Weight gradient [M,C,3,3] of a 3x3 / stride 1 / pad 1 convolution on the Winograd path.  V: the forward call's kept
+    workspace (see conv3x3_winograd_raw) -- the input transform is then not recomputed."""
     B, C, H, W = x.shape
     key = (B, C, H, W, M)
     nbytes = _WINO_WG_WS.get(key)
@@ -418,6 +425,9 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO):
         nbytes = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
+    if V is not None and not profiling._enabled:
+        check(lib.prn_conv3x3_winograd_wgrad_v(_p(V), _p(dy), _p(dw), _p(ws), B, C, H, W, M, _stream()), "prn_conv3x3_winograd_wgrad_v")
+        return dw
     args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, mode, _stream())
     if profiling._enabled:
         P = lib.prn_winograd_tiles(B, H, W)
@@ -475,8 +485,12 @@ class _Conv2d(torch.autograd.Function):
         M, C, K, _ = w.shape
         assert x.shape[1] == C, (x.shape, w.shape)
         Ho, Wo = _out_hw(x.shape[2], x.shape[3], K, stride, pad, mode)
+        ctx.wino_v = None
         if winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, epi):
-            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi)
+            keep = [] if (WINOGRAD_WGRAD and ctx.needs_input_grad[1]) else None
+            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi, keep)
+            if keep:
+                ctx.wino_v = keep[0]
         else:
             y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
@@ -503,8 +517,10 @@ class _Conv2d(torch.autograd.Function):
             dy = dy * y * (1 - y)
         M, C, K, _ = w.shape
         if WINOGRAD_WGRAD and winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, EPI_NONE):
+            V = ctx.wino_v
+
             def wgrad():
-                return conv3x3_winograd_wgrad_raw(x, dy, M, mode)
+                return conv3x3_winograd_wgrad_raw(x, dy, M, mode, V)
         else:
             def wgrad():
                 return conv_wgrad_raw(x, dy, M, K, stride, pad, mode)
