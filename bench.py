@@ -58,9 +58,12 @@ def synth_batch(B, H, W, seed, device):
                      "plane_paras": torch.from_numpy(paras), "k_matrix": torch.from_numpy(K)})
     # annotations stay on the host (the loss's GT-only preparation runs there, in worker processes: shared memory, so a
     # batch is handed over as handles the way a DataLoader worker's batch is); images and GT depth live in HBM
-    for g_ in inst:
-        for v in g_.values():
-            v.share_memory_()
+    try:
+        for g_ in inst:
+            for v in g_.values():
+                v.share_memory_()
+    except RuntimeError:                                     # no shared-memory segment available: the batch is pickled by value
+        pass
     return images.to(device), inst, depths.to(device)
 
 

@@ -490,33 +490,41 @@ class TargetPrefetcher:
         self.criterion = criterion
         self.workers = workers or os.environ.get("PRN_PREFETCH_WORKERS") or ("process" if torch.cuda.is_available() else "thread")
         if self.workers == "process":
-            import pickle
-            import torch.multiprocessing as mp
-            from concurrent.futures import ProcessPoolExecutor
-            import sys
-            ctx = mp.get_context("spawn")
-            init = (pickle.dumps(cfg), np.random.get_state())
-            # The workers need this module only.  A spawned child normally re-imports the parent's __main__ script first
-            # (a training script without an `if __name__ == "__main__"` guard would run again inside every worker): hide
-            # the script from multiprocessing while the two workers start, and start them now rather than at first use.
-            main = sys.modules.get("__main__")
-            saved = {a: getattr(main, a) for a in ("__file__", "__spec__") if hasattr(main, a)}
             try:
-                if "__file__" in saved:
-                    del main.__file__
-                if main is not None:
-                    main.__spec__ = None
-                self.pool_t = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
-                self.pool_v = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
-                for f in [self.pool_t.submit(int), self.pool_v.submit(int)]:
-                    f.result()
-            finally:
-                for a, v in saved.items():
-                    setattr(main, a, v)
-        else:
+                self._start_processes()
+            except Exception as e:                            # noqa: BLE001  (no /dev/shm, no semaphores, ...): same results from threads, slower trainer
+                import sys
+                print("TargetPrefetcher: worker processes unavailable (%s: %s); using threads" % (type(e).__name__, e), file=sys.stderr)
+                self.workers = "thread"
+        if self.workers != "process":
             self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
             self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
         self.queue = collections.deque()                      # FIFO: submit() batches ahead of time, get() returns the oldest
+
+    def _start_processes(self):
+        import pickle
+        import torch.multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        import sys
+        ctx = mp.get_context("spawn")
+        init = (pickle.dumps(cfg), np.random.get_state())
+        # The workers need this module only.  A spawned child normally re-imports the parent's __main__ script first
+        # (a training script without an `if __name__ == "__main__"` guard would run again inside every worker): hide
+        # the script from multiprocessing while the two workers start, and start them now rather than at first use.
+        main = sys.modules.get("__main__")
+        saved = {a: getattr(main, a) for a in ("__file__", "__spec__") if hasattr(main, a)}
+        try:
+            if "__file__" in saved:
+                del main.__file__
+            if main is not None:
+                main.__spec__ = None
+            self.pool_t = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
+            self.pool_v = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
+            for f in [self.pool_t.submit(int), self.pool_v.submit(int)]:
+                f.result()
+        finally:
+            for a, v in saved.items():
+                setattr(main, a, v)
 
     @property
     def pending(self):
