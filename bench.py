@@ -166,17 +166,28 @@ def main():
     prefetch.submit(inst, hw)                                # two batches in flight: the workers never wait for the trainer
     prefetch.submit(inst, hw)
 
+    ph = {}
+
     def step():
+        t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared by the worker processes) + async uploads
+        t1 = time.perf_counter()
         prefetch.submit(inst, hw)                           # targets two steps ahead: recomputed every step, overlapping the GPU work
+        t2 = time.perf_counter()
         out = run_net(images)
+        t3 = time.perf_counter()
         losses = crit(net, *out, inst, depths, targets=targets)
         loss = sum(losses.values()).sum()
+        t4 = time.perf_counter()
         loss.backward()
         ops.wgrad_join()
         exchange.finish()
+        t5 = time.perf_counter()
         opt.step()
+        t6 = time.perf_counter()
+        for k, v in (("get", t1 - t0), ("submit", t2 - t1), ("fwd", t3 - t2), ("loss", t4 - t3), ("bwd", t5 - t4), ("adam", t6 - t5)):
+            ph[k] = ph.get(k, 0.0) + v
         return losses
 
     def fence():
@@ -193,6 +204,8 @@ def main():
         losses = step()
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PRN_BENCH_PHASES"):
+        print({k: round(v / (args.steps + args.warmup) * 1e3, 2) for k, v in ph.items()}, file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -463,14 +463,126 @@ def _worker_vnl(host, hw):
     return _WORKER["crit"].vnl.prepare_host(host, hw, pin=False)
 
 
-def _pin_tree(o):
-    if torch.is_tensor(o):
-        return _pin(o) if o.numel() >= 4096 else o            # the large index / label arrays only
-    if isinstance(o, dict):
-        return {k: _pin_tree(v) for k, v in o.items()}
-    if isinstance(o, (list, tuple)):
-        return type(o)(_pin_tree(v) for v in o)
-    return o
+def _worker_loop(conn, cfg_blob, rng_state, role, sharing):
+    """Main of a prefetch worker process: one request at a time over the pipe, results go back in submission order."""
+    import traceback
+    import torch.multiprocessing as mp
+    try:
+        mp.set_sharing_strategy(sharing)
+        _worker_init(cfg_blob, rng_state)
+        fn = _worker_targets if role == "targets" else _worker_vnl
+        conn.send("ready")
+    except Exception:                                         # noqa: BLE001
+        conn.send(("error", traceback.format_exc()))
+        return
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            return
+        if msg is None:
+            return
+        try:
+            conn.send(("ok", _pack_tree(fn(*msg))))
+        except Exception:                                     # noqa: BLE001
+            conn.send(("error", traceback.format_exc()))
+
+
+def _pack_tree(o):
+    """All tensors of a (nested dict / list) result as ONE byte tensor + a skeleton with (offset, dtype, shape) leaves: a
+    tensor costs ~0.5 ms to hand over between processes whatever its size, a batch's targets are ~15 of them."""
+    chunks, off = [], [0]
+
+    def walk(v):
+        if torch.is_tensor(v):
+            b = v.contiguous().reshape(-1).view(torch.uint8)
+            spec = ("__t__", off[0], v.dtype, tuple(v.shape))
+            chunks.append(b)
+            pad = (-b.numel()) % 16
+            if pad:
+                chunks.append(torch.zeros(pad, dtype=torch.uint8))
+            off[0] += b.numel() + pad
+            return spec
+        if isinstance(v, dict):
+            return {k: walk(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return type(v)(walk(x) for x in v)
+        return v
+    skel = walk(o)
+    return skel, (torch.cat(chunks) if chunks else torch.zeros(0, dtype=torch.uint8))
+
+
+def _unpack_tree(skel, blob):
+    def walk(v):
+        if isinstance(v, tuple) and len(v) == 4 and v[0] == "__t__":
+            _, o, dt, shp = v
+            n = 1
+            for d in shp:
+                n *= d
+            return blob[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(shp)
+        if isinstance(v, dict):
+            return {k: walk(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return type(v)(walk(x) for x in v)
+        return v
+    return walk(skel)
+
+
+class _PipeWorker:
+    """One worker process behind a pipe.  Unlike concurrent.futures.ProcessPoolExecutor there is NO helper thread in the
+    trainer process: requests are sent and results received by the calling thread itself, at submit() / result() time.
+    (The executor's manager thread unpickles results whenever they arrive -- in the middle of the forward pass -- and every
+    such wake-up takes the GIL from the trainer: 22 -> 10 ms for the forward's enqueue work, tools/host_ops_profile.py.)"""
+
+    def __init__(self, ctx, role, init, sharing):
+        self.conn, child = ctx.Pipe()
+        self.proc = ctx.Process(target=_worker_loop, args=(child,) + init + (role, sharing), daemon=True)
+        self.proc.start()
+        child.close()
+        self.sent = self.received = 0
+        self.results = {}
+        self._check(self.conn.recv())
+
+    @staticmethod
+    def _check(r):
+        if isinstance(r, tuple) and r and r[0] == "error":
+            raise RuntimeError("prefetch worker failed:\n" + r[1])
+        return r
+
+    def submit(self, fn_unused, *args):
+        self.conn.send(args)
+        self.sent += 1
+        return _PipeFuture(self, self.sent - 1)
+
+    def result(self, index):
+        while index not in self.results:
+            r = self._check(self.conn.recv())
+            skel, blob = r[1]
+            if torch.cuda.is_available():
+                blob = _pin(blob)                             # page-locked staging (cannot cross the process boundary): one copy
+            self.results[self.received] = _unpack_tree(skel, blob)
+            self.received += 1
+        return self.results.pop(index)
+
+    def shutdown(self, wait=True, cancel_futures=True):
+        try:
+            self.conn.send(None)
+        except (OSError, ValueError):
+            pass
+        self.proc.join(5 if wait else 0)
+        if self.proc.is_alive():
+            self.proc.terminate()
+        self.conn.close()
+
+
+class _PipeFuture:
+    def __init__(self, worker, index):
+        self.worker, self.index, self.value = worker, index, None
+
+    def result(self):
+        if self.worker is not None:
+            self.value, self.worker = self.worker.result(self.index), None
+        return self.value
 
 
 class TargetPrefetcher:
@@ -503,14 +615,19 @@ class TargetPrefetcher:
 
     def _start_processes(self):
         import pickle
-        import torch.multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor
         import sys
+        import torch.multiprocessing as mp
         ctx = mp.get_context("spawn")
+        # "file_system" sharing: a shared-memory tensor travels as a file name.  (The default strategy passes file
+        # descriptors, which the sender serves from a background thread -- one more GIL customer in the trainer.)
+        sharing = os.environ.get("PRN_PREFETCH_SHARING", "file_system")
+        if sharing in mp.get_all_sharing_strategies():
+            mp.set_sharing_strategy(sharing)
+        sharing = mp.get_sharing_strategy()
         init = (pickle.dumps(cfg), np.random.get_state())
         # The workers need this module only.  A spawned child normally re-imports the parent's __main__ script first
         # (a training script without an `if __name__ == "__main__"` guard would run again inside every worker): hide
-        # the script from multiprocessing while the two workers start, and start them now rather than at first use.
+        # the script from multiprocessing while the two workers start.
         main = sys.modules.get("__main__")
         saved = {a: getattr(main, a) for a in ("__file__", "__spec__") if hasattr(main, a)}
         try:
@@ -518,10 +635,8 @@ class TargetPrefetcher:
                 del main.__file__
             if main is not None:
                 main.__spec__ = None
-            self.pool_t = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
-            self.pool_v = ProcessPoolExecutor(max_workers=1, mp_context=ctx, initializer=_worker_init, initargs=init)
-            for f in [self.pool_t.submit(int), self.pool_v.submit(int)]:
-                f.result()
+            self.pool_t = _PipeWorker(ctx, "targets", init, sharing)
+            self.pool_v = _PipeWorker(ctx, "vnl", init, sharing)
         finally:
             for a, v in saved.items():
                 setattr(main, a, v)
@@ -549,8 +664,6 @@ class TargetPrefetcher:
         ft, fv = self.queue.popleft()
         h = ft.result()
         h["vnl"] = fv.result() if fv is not None else None
-        if self.workers == "process" and torch.cuda.is_available():
-            h = _pin_tree(h)                                  # (page-locked staging cannot cross the process boundary)
         return self.criterion.upload(h, gt_depths, device)
 
     def close(self):

@@ -42,9 +42,6 @@ def mark(name, t0):
 def step():
     t0 = time.perf_counter(); opt.zero_grad(set_to_none=True); ft, fv = pf.queue.popleft(); h = ft.result(); h["vnl"] = fv.result(); mark("wait_worker", t0)
     t0 = time.perf_counter()
-    if pf.workers == "process":
-        from planerecnet_amd.losses import _pin_tree
-        h = _pin_tree(h)
     mark("pin", t0)
     t0 = time.perf_counter(); targets = crit.upload(h, depths, dev); pf.submit(inst, (H, W)); mark("upload", t0)
     t0 = time.perf_counter(); out = net(images); mark("net_fwd", t0)
