@@ -186,6 +186,7 @@ def main():
         t5 = time.perf_counter()
         opt.step()
         t6 = time.perf_counter()
+        ph.setdefault("get_ms_per_step", []).append(round((t1 - t0) * 1e3, 1))
         for k, v in (("get", t1 - t0), ("submit", t2 - t1), ("fwd", t3 - t2), ("loss", t4 - t3), ("bwd", t5 - t4), ("adam", t6 - t5)):
             ph[k] = ph.get(k, 0.0) + v
         return losses
@@ -205,7 +206,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if os.environ.get("PRN_BENCH_PHASES"):
-        print({k: round(v / (args.steps + args.warmup) * 1e3, 2) for k, v in ph.items()}, file=sys.stderr)
+        print({k: (v if isinstance(v, list) else round(v / (args.steps + args.warmup) * 1e3, 2)) for k, v in ph.items()}, file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,6 +234,18 @@ def main():
         roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["kernel"]), "launches": dom["launches"],
                 "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"]}
+        # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation).  The Winograd launches
+        # execute a quarter of the multiply-adds of the convolution they evaluate, so the same step is also summarised the
+        # other way round: FLOPs of the REFERENCE convolutions (2*M*C*KH*KW per output pixel, forward + input gradient +
+        # weight gradient) over the time of every kernel of the convolution family, transforms and reductions included.
+        conv = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "reduce_epilogue_kernel", "winograd_input_kernel", "winograd_output_kernel",
+                                                    "conv3x3_winograd_ragged", "conv_wgrad_kernel", "reduce_splits_kernel", "winograd_wgrad_transforms",
+                                                    "winograd_dw_kernel", "conv3x3_winograd_wgrad_ragged")]
+        ref_flops = sum(f["ref_work"] for f in conv if f["bound"] == "mfma")
+        conv_ms = sum(f["time_ms"] for f in conv)
+        roof["reference_operator_view"] = {"families": [f["kernel"] for f in conv], "reference_flops_per_step": ref_flops, "time_ms": conv_ms,
+                                           "achieved": ref_flops / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                           "frac": ref_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -399,11 +399,11 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
     ws = torch.empty(36 * (C + M) * P, device=x.device, dtype=torch.float32)
     if profiling._enabled:
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
-        with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel()):
+        with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
             check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P):
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W):
             check(lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()), "prn_gemm_batched")
-        with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1)):
+        with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1), 0.0):
             check(lib.prn_winograd_output(_p(Yt), _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
     else:
         check(lib.prn_conv3x3_winograd(_p(x), _p(U), _p(bias), _p(addend), _p(y), _p(ws), B, C, H, W, M, mode, epi, _stream()), "prn_conv3x3_winograd")
@@ -431,11 +431,11 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
     args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, mode, _stream())
     if profiling._enabled:
         P = lib.prn_winograd_tiles(B, H, W)
-        with profiling.span("winograd_input_kernel", "hbm", 4.0 * (x.numel() + dy.numel()) + 4.0 * 36 * (C + M) * P):
+        with profiling.span("winograd_wgrad_transforms", "hbm", 4.0 * (x.numel() + dy.numel()) + 4.0 * 36 * (C + M) * P, 0.0):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 1), "prn_conv3x3_winograd_wgrad")
-        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P):
+        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 2), "prn_conv3x3_winograd_wgrad")
-        with profiling.span("reduce_splits_kernel", "hbm", float(nbytes) - 4.0 * 36 * (C + M) * P + 4.0 * dw.numel()):
+        with profiling.span("winograd_dw_kernel", "hbm", float(nbytes) - 4.0 * 36 * (C + M) * P + 4.0 * dw.numel(), 0.0):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 3), "prn_conv3x3_winograd_wgrad")
     else:
         check(lib.prn_conv3x3_winograd_wgrad(*args, 0), "prn_conv3x3_winograd_wgrad")
@@ -867,7 +867,7 @@ def _rdesc(rs, C, M, K, epi=EPI_NONE):
 def _ragged_winograd_raw(xp, U, bias, addend, rs, C, M, P, epi=EPI_NONE):
     y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
     ws = torch.empty(36 * (C + M) * P, device=xp.device, dtype=torch.float32)
-    with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P):          # (transforms included in the bracket)
+    with profiling.span("conv3x3_winograd_ragged", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * rs.pixels):   # (three launches in one bracket)
         check(lib.prn_conv3x3_winograd_ragged(_p(xp), _p(U), _p(bias), _p(addend), _p(y), _p(ws), rs.ref, rs.B, C, M, epi, _stream()),
               "prn_conv3x3_winograd_ragged")
     return y
@@ -912,7 +912,7 @@ class _RaggedConv(torch.autograd.Function):
                     nb = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ragged_ws_bytes(rs.ref, rs.B, C, M)
                 ws = torch.empty(nb // 4, device=xp.device, dtype=torch.float32)
                 dwo = torch.empty_like(w)
-                with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P):
+                with profiling.span("conv3x3_winograd_wgrad_ragged", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * rs.pixels):
                     check(lib.prn_conv3x3_winograd_wgrad_ragged(_p(xp), _p(dy), _p(dwo), _p(ws), rs.ref, rs.B, C, M, _stream()), "prn_conv3x3_winograd_wgrad_ragged")
                 return dwo
             _, ref, nbytes = _rdesc(rs, C, M, K)

@@ -2,14 +2,15 @@
 
 When enabled, ops.py brackets every HIP launch of the heavy kernel families with a pair of HIP events recorded on the
 stream the kernel is launched on (torch's current stream -- the same handle that is passed to the C ABI), and logs the
-launch's ALGORITHMIC work: FLOPs for the MFMA contraction kernels (2*M*K*N of the reference convolution, whatever the
-kernel really executes, e.g. the zero taps of a strided dgrad are not credited), bytes for the HBM-bound families
-(4 B x elements the reference op must read + write).  Disabled (the default) it costs one attribute test per launch.
+launch's work: FLOPs for the MFMA contraction kernels (2*M*K*N of the GEMM the launch evaluates; the zero taps of a
+strided dgrad are not credited), bytes for the HBM-bound families (4 B x elements the op must read + write), plus -- where
+it differs, i.e. on the Winograd path -- the FLOPs of the reference convolution the launch stands for (`ref`).
+Disabled (the default) it costs one attribute test per launch.
 """
 import torch
 
 _enabled = False
-_records = []          # (family, bound, work, start_event, end_event)
+_records = []          # (family, bound, work, start_event, end_event, reference-operator work)
 
 
 def enable():
@@ -28,11 +29,14 @@ def active():
 
 
 class span:
-    """with span(family, bound, work): <launch>"""
-    __slots__ = ("family", "bound", "work", "s", "e")
+    """with span(family, bound, work): <launch>
+    work: what the launch EXECUTES (FLOPs / bytes) -- the basis of the family's `achieved` rate, i.e. a utilisation.
+    ref:  FLOPs of the reference operator the launch stands for, when that differs (a Winograd product executes a quarter of
+          the direct convolution's multiply-adds; its transform kernels execute none): summed into `ref_work`."""
+    __slots__ = ("family", "bound", "work", "ref", "s", "e")
 
-    def __init__(self, family, bound, work):
-        self.family, self.bound, self.work = family, bound, work
+    def __init__(self, family, bound, work, ref=None):
+        self.family, self.bound, self.work, self.ref = family, bound, work, (work if ref is None else ref)
 
     def __enter__(self):
         if _enabled:
@@ -43,17 +47,18 @@ class span:
     def __exit__(self, *exc):
         if _enabled:
             self.e.record()
-            _records.append((self.family, self.bound, self.work, self.s, self.e))
+            _records.append((self.family, self.bound, self.work, self.s, self.e, self.ref))
 
 
 def summary():
     """-> list of {kernel, bound, launches, time_ms, work, achieved, unit} sorted by time (call after a device sync)."""
     fams = {}
-    for fam, bound, work, s, e in _records:
-        f = fams.setdefault(fam, {"kernel": fam, "bound": bound, "launches": 0, "time_ms": 0.0, "work": 0.0})
+    for fam, bound, work, s, e, ref in _records:
+        f = fams.setdefault(fam, {"kernel": fam, "bound": bound, "launches": 0, "time_ms": 0.0, "work": 0.0, "ref_work": 0.0})
         f["launches"] += 1
         f["time_ms"] += s.elapsed_time(e)
         f["work"] += float(work)
+        f["ref_work"] += float(ref)
     out = []
     for f in fams.values():
         if f["bound"] == "mfma":
