@@ -189,7 +189,9 @@ def main():
         ph.setdefault("get_ms_per_step", []).append(round((t1 - t0) * 1e3, 1))
         for k, v in (("get", t1 - t0), ("submit", t2 - t1), ("fwd", t3 - t2), ("loss", t4 - t3), ("bwd", t5 - t4), ("adam", t6 - t5)):
             ph[k] = ph.get(k, 0.0) + v
-        return losses
+        # (values only: a loss tensor returned with its graph would keep the whole step's autograd nodes -- and the buffers
+        # the operators attach to them -- alive until the NEXT step has finished: +5 ms/step, 65.5 vs 60.5 ms)
+        return {k: v.detach() for k, v in losses.items()}
 
     def fence():
         torch.cuda.synchronize()

@@ -517,15 +517,19 @@ class _Conv2d(torch.autograd.Function):
             dy = dy * y * (1 - y)
         M, C, K, _ = w.shape
         if WINOGRAD_WGRAD and winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, EPI_NONE):
-            V = ctx.wino_v
+            V, ctx.wino_v = ctx.wino_v, None                # (attributes of ctx are not released by autograd after backward)
 
             def wgrad():
                 return conv3x3_winograd_wgrad_raw(x, dy, M, mode, V)
         else:
+            V = None
+
             def wgrad():
                 return conv_wgrad_raw(x, dy, M, K, stride, pad, mode)
         if _defer(ctx.needs_input_grad[1], w):
-            _deferred_wgrad(w, (x, dy), wgrad)
+            # every buffer the deferred launch reads must be listed: it is released here, on the main stream, possibly before
+            # the side stream has run (a kept Winograd operand is one of them)
+            _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad)
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None
