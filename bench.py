@@ -187,6 +187,11 @@ def main():
         opt.step()
         t6 = time.perf_counter()
         ph.setdefault("get_ms_per_step", []).append(round((t1 - t0) * 1e3, 1))
+        ph.setdefault("host_ms_per_step", []).append(round((t6 - t0) * 1e3, 1))
+        if os.environ.get("PRN_BENCH_PHASES"):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            ph.setdefault("_events", []).append(ev)
         for k, v in (("get", t1 - t0), ("submit", t2 - t1), ("fwd", t3 - t2), ("loss", t4 - t3), ("bwd", t5 - t4), ("adam", t6 - t5)):
             ph[k] = ph.get(k, 0.0) + v
         # (values only: a loss tensor returned with its graph would keep the whole step's autograd nodes -- and the buffers
@@ -208,6 +213,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if os.environ.get("PRN_BENCH_PHASES"):
+        evs = ph.pop("_events")
+        ph["gpu_ms_per_step"] = [round(a.elapsed_time(b), 1) for a, b in zip(evs[:-1], evs[1:])]
         print({k: (v if isinstance(v, list) else round(v / (args.steps + args.warmup) * 1e3, 2)) for k, v in ph.items()}, file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
