@@ -39,7 +39,7 @@ class Targets:
     __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum")
 
 
-LOSS_STREAMS = bool(int(os.environ.get("PRN_LOSS_STREAMS", "1")))
+LOSS_STREAMS = bool(int(os.environ.get("PRN_LOSS_STREAMS", "0")))        # off by default: see ops.BRANCH_STREAMS
 
 
 class PlaneRecNetLoss(nn.Module):

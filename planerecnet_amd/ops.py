@@ -106,7 +106,11 @@ def wgrad_flush():
         _flush_one(e)
 
 
-BRANCH_STREAMS = bool(int(os.environ.get("PRN_BRANCH_STREAMS", "1")))
+# Off by default.  With the extra streams on, the SAME binary ran either 60.5 or 65.7 ms/step (bimodal between runs, minutes
+# apart on one box; kernel-time sums identical, i.e. idle gaps): HIP multiplexes all streams of a process onto 4 hardware
+# queues, and whether a branch stream shares a queue with the main chain or with the weight-gradient stream is not under our
+# control.  With main + weight-gradient stream only: 61.1-61.4 ms in every run (a 0.6 ms best-case gain against a 5 ms risk).
+BRANCH_STREAMS = bool(int(os.environ.get("PRN_BRANCH_STREAMS", "0")))
 _BRANCH_POOL = {}
 
 
