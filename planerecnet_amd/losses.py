@@ -666,6 +666,14 @@ class TargetPrefetcher:
         h["vnl"] = fv.result() if fv is not None else None
         return self.criterion.upload(h, gt_depths, device)
 
+    def discard(self):
+        """Drop every batch that was submitted but not fetched (end of an epoch, early exit from a loop)."""
+        while self.queue:
+            ft, fv = self.queue.popleft()
+            ft.result()
+            if fv is not None:
+                fv.result()
+
     def close(self):
         wait = self.workers == "process"                     # (worker processes are joined: nothing left behind at exit)
         self.pool_t.shutdown(wait=wait, cancel_futures=True)

@@ -45,3 +45,32 @@ def test_process_prefetcher_matches_thread_prefetcher():
         assert _same(ta, tb), "SOLOv2 targets differ between worker process and worker thread"
         assert _same(va, vb), "virtual-normal triplets differ: RNG stream not continued in the worker process"
     assert not _same(pr[0][1]["gid"], pr[1][1]["gid"])       # consecutive batches draw different triplets
+
+
+def test_prefetcher_is_fifo_and_discard_resynchronises():
+    """get() order == submit() order with several batches in flight; discard() leaves no stale batch behind."""
+    set_cfg("PlaneRecNet_50_config")
+    crit = PlaneRecNetLoss()
+    batches = [bench.synth_batch(1, 480, 640, 1000 + i, torch.device("cpu"))[1] for i in range(3)]
+    for workers in ("thread", "process"):
+        pf = TargetPrefetcher(crit, workers=workers)
+        try:
+            want = [crit.prepare_host(b, (480, 640), None, False, pin=False)["ins_labels"] for b in batches]
+            for b in batches:
+                pf.submit(b, (480, 640))
+            got = []
+            while pf.queue:
+                ft, fv = pf.queue.popleft()
+                got.append(ft.result()["ins_labels"])
+                fv.result()
+            assert all(torch.equal(a, b) for a, b in zip(got, want)), workers
+            pf.submit(batches[0], (480, 640))
+            pf.submit(batches[1], (480, 640))
+            pf.discard()
+            assert not pf.queue
+            pf.submit(batches[2], (480, 640))
+            ft, fv = pf.queue.popleft()
+            assert torch.equal(ft.result()["ins_labels"], want[2]), workers
+            fv.result()
+        finally:
+            pf.close()

@@ -51,9 +51,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 evs, host = [], []
 e0 = torch.cuda.Event(enable_timing=True)
 e0.record()
+allocs = []
 for i in range(n):                                   # no synchronisation inside the loop: one event per step on the GPU timeline
     t0 = time.perf_counter()
     step()
+    ms_ = torch.cuda.memory_stats()
+    allocs.append((ms_.get("num_device_alloc", 0), ms_.get("num_device_free", 0)))
     host.append((time.perf_counter() - t0) * 1e3)
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -65,5 +68,6 @@ for e in evs:
     prev = e
 print("gpu  ms/step:", " ".join("%.1f" % t for t in ts))
 print("host ms/step:", " ".join("%.1f" % t for t in host))
+print("device mallocs/frees after steps 5, 10, 20, last:", [allocs[i] for i in (5, 10, 20, len(allocs) - 1) if i < len(allocs)])
 print("reserved MB", torch.cuda.memory_reserved() >> 20, "alloc retries", torch.cuda.memory_stats().get("num_alloc_retries"), "segments", torch.cuda.memory_stats().get("segment.all.current"))
 pf.close()

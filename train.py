@@ -216,6 +216,7 @@ def main():
             if sampler is not None:
                 sampler.set_epoch(epoch)
             it = iter(loader)
+            prefetch.discard()                             # (batches of the previous epoch that were prepared but not used)
             ahead = collections.deque()                    # batches whose GT-only targets are being prepared (two in flight)
             for _ in range(2):
                 b_ = next(it, None)
