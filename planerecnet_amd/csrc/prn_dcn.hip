@@ -63,8 +63,24 @@ __global__ __launch_bounds__(256) void dcn_sample_kernel(const float* __restrict
   const size_t HW = (size_t)H * W;
   const float* xp = x + ((size_t)b * C + c0) * HW;
   float* cp = cols + (((size_t)b * C + c0) * 9 + k) * plane + pix;
-#pragma unroll 4
-  for (int c = c0; c < c1; ++c) {
+  // Loads of UN channels are issued together, then consumed: written as a plain unrolled loop hipcc emitted one
+  // global_load + s_waitcnt vmcnt(0) per corner (one memory round trip per FMA); sched_barrier keeps the two groups apart.
+  constexpr int UN = 8;
+  int c = c0;
+  for (; c + UN <= c1; c += UN) {
+    float a00[UN], a01[UN], a10[UN], a11[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float* q = xp + (size_t)u * HW;
+      a00[u] = q[t.i00]; a01[u] = q[t.i01]; a10[u] = q[t.i10]; a11[u] = q[t.i11];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) cp[(size_t)u * 9 * plane] = t.mod * (t.w00 * a00[u] + t.w01 * a01[u] + t.w10 * a10[u] + t.w11 * a11[u]);
+    xp += (size_t)UN * HW;
+    cp += (size_t)UN * 9 * plane;
+  }
+  for (; c < c1; ++c) {
     const float v = t.w00 * xp[t.i00] + t.w01 * xp[t.i01] + t.w10 * xp[t.i10] + t.w11 * xp[t.i11];
     *cp = t.mod * v;
     xp += HW;
@@ -89,8 +105,27 @@ __global__ __launch_bounds__(256) void dcn_dom_partial_kernel(const float* __res
   const float* xp = x + ((size_t)b * C + c0) * HW;
   const float* dp = dcols + (((size_t)b * C + c0) * 9 + k) * plane + pix;
   float gy = 0.f, gx = 0.f, gm = 0.f;
-#pragma unroll 4
-  for (int c = c0; c < c1; ++c) {
+  constexpr int UN = 8;                                    // (same load grouping as dcn_sample_kernel)
+  int c = c0;
+  for (; c + UN <= c1; c += UN) {
+    float g[UN], a00[UN], a01[UN], a10[UN], a11[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float* q = xp + (size_t)u * HW;
+      g[u] = dp[(size_t)u * 9 * plane];
+      a00[u] = q[t.i00]; a01[u] = q[t.i01]; a10[u] = q[t.i10]; a11[u] = q[t.i11];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      gm += g[u] * (t.w00 * a00[u] + t.w01 * a01[u] + t.w10 * a10[u] + t.w11 * a11[u]);
+      gy += g[u] * (t.gy00 * a00[u] + t.gy01 * a01[u] + t.gy10 * a10[u] + t.gy11 * a11[u]);
+      gx += g[u] * (t.gx00 * a00[u] + t.gx01 * a01[u] + t.gx10 * a10[u] + t.gx11 * a11[u]);
+    }
+    xp += (size_t)UN * HW;
+    dp += (size_t)UN * 9 * plane;
+  }
+  for (; c < c1; ++c) {
     const float g = *dp;
     const float x00 = xp[t.i00], x01 = xp[t.i01], x10 = xp[t.i10], x11 = xp[t.i11];
     gm += g * (t.w00 * x00 + t.w01 * x01 + t.w10 * x10 + t.w11 * x11);
@@ -220,11 +255,24 @@ __global__ __launch_bounds__(256) void dcn_dx_gather_kernel(const float* __restr
   float acc[CH];
 #pragma unroll
   for (int cc = 0; cc < CH; ++cc) acc[cc] = 0.f;
+  // The walk is a dependent chain (bin -> entry -> CH gathers).  The nine bins are read up front and the next entry is
+  // fetched while the gathers of the current one are in flight, so a step of the chain costs one memory round trip, not two.
+  int st[9], cn[9];
+#pragma unroll
   for (int k = 0; k < 9; ++k) {
     const size_t bin = (size_t)(b * 9 + k) * HW + q;
-    const int s = starts[bin], n = counts[bin];
+    st[k] = starts[bin];
+    cn[k] = counts[bin];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int s = st[k], n = cn[k];
+    CsrEntry nxt;
+    nxt.src = 0; nxt.w = 0.f;
+    if (n > 0) nxt = entries[s];
     for (int e = s; e < s + n; ++e) {
-      const CsrEntry en = entries[e];
+      const CsrEntry en = nxt;
+      if (e + 1 < s + n) nxt = entries[e + 1];
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) acc[cc] += en.w * dp[cc * cstride + en.src];
     }
