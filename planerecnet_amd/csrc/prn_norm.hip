@@ -245,16 +245,24 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
                                                            float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, int HW, float eps,
                                                            float momentum, int relu) {
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
+  // All NV loads are issued before anything is consumed: they are UNCONDITIONAL (a lane past the end re-reads element 0 and
+  // zeroes it afterwards).  With "ok ? load : 0" hipcc wrapped every load in an exec-masked branch and waited for it
+  // (s_waitcnt vmcnt(0)) before the next one: NV dependent memory round trips per thread (bn_small_bwd: 19.7 us per launch).
   float4 v[NV];
   size_t off[NV];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int q = threadIdx.x + i * 256;
-    const bool ok = q < n4;
-    const int e = ok ? q * 4 : 0, b = e / HW, p = e - b * HW;
+    const int e = q < n4 ? q * 4 : 0, b = e / HW, p = e - b * HW;
     off[i] = ((size_t)b * C + c) * HW + p;
-    v[i] = ok ? *reinterpret_cast<const float4*>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(x + off[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (threadIdx.x + i * 256 >= n4) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
   }
@@ -275,12 +283,20 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     }
   }
   const float sc = istd_f * gamma[c], sh = beta[c] - mean_f * sc;
+  float4 r[NV];
+  if (res) {                                               // (uniform) residual: again all loads first
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const float4*>(res + off[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     if (threadIdx.x + i * 256 >= n4) continue;
     float4 o = v[i];
-    o.x = fmaf(o.x, sc, sh); o.y = fmaf(o.y, sc, sh); o.z = fmaf(o.z, sc, sh); o.w = fmaf(o.w, sc, sh);
-    if (res) { const float4 r = *reinterpret_cast<const float4*>(res + off[i]); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    o.x = fmaf(o.x, sc, sh) + r[i].x; o.y = fmaf(o.y, sc, sh) + r[i].y; o.z = fmaf(o.z, sc, sh) + r[i].z; o.w = fmaf(o.w, sc, sh) + r[i].w;
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     *reinterpret_cast<float4*>(y + off[i]) = o;
   }
@@ -302,18 +318,36 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int q = threadIdx.x + i * 256;
-    const bool ok = q < n4;
-    const int e = ok ? q * 4 : 0, b = e / HW, p = e - b * HW;
+    const int e = q < n4 ? q * 4 : 0, b = e / HW, p = e - b * HW;
     off[i] = ((size_t)b * C + c) * HW + p;
-    g[i] = ok ? *reinterpret_cast<const float4*>(dy + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    xv[i] = ok ? *reinterpret_cast<const float4*>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (relu == 1) {
-      const float4 yv = ok ? *reinterpret_cast<const float4*>(y + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      g[i].x = yv.x > 0.f ? g[i].x : 0.f; g[i].y = yv.y > 0.f ? g[i].y : 0.f; g[i].z = yv.z > 0.f ? g[i].z : 0.f; g[i].w = yv.w > 0.f ? g[i].w : 0.f;
-    } else if (relu == 2) {
+  }
+  // unconditional loads, all issued before use (see bn_small_fwd_kernel)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = *reinterpret_cast<const float4*>(dy + off[i]);
+    xv[i] = *reinterpret_cast<const float4*>(x + off[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (relu == 1) {                                         // mask from the forward output (a residual was added)
+    float4 yv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) yv[i] = *reinterpret_cast<const float4*>(y + off[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      g[i].x = yv[i].x > 0.f ? g[i].x : 0.f; g[i].y = yv[i].y > 0.f ? g[i].y : 0.f;
+      g[i].z = yv[i].z > 0.f ? g[i].z : 0.f; g[i].w = yv[i].w > 0.f ? g[i].w : 0.f;
+    }
+  } else if (relu == 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
       g[i].x = fmaf(xv[i].x, sc, sh) > 0.f ? g[i].x : 0.f; g[i].y = fmaf(xv[i].y, sc, sh) > 0.f ? g[i].y : 0.f;
       g[i].z = fmaf(xv[i].z, sc, sh) > 0.f ? g[i].z : 0.f; g[i].w = fmaf(xv[i].w, sc, sh) > 0.f ? g[i].w : 0.f;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (threadIdx.x + i * 256 >= n4) { g[i] = make_float4(0.f, 0.f, 0.f, 0.f); xv[i] = g[i]; }
     s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
     s2 += (g[i].x * (xv[i].x - mean) + g[i].y * (xv[i].y - mean)) + (g[i].z * (xv[i].z - mean) + g[i].w * (xv[i].w - mean));
   }
