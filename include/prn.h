@@ -39,7 +39,8 @@ const char* prn_last_error(void);
  *                   w = [4][M][C][2][2], Ho = 2H, Wo = 2W; the four phases run as one launch.  For wgrad, dy is phase-major
  *                   [4][B][M][H][W] (prn_space_to_depth2) and dw is [4][M][C][2][2] (prn_up2_wgrad_combine maps it to 3x3).
  */
-enum { PRN_IN_ZERO = 0, PRN_IN_REFLECT = 1, PRN_IN_UP2_REFLECT = 2, PRN_IN_DILATED = 3, PRN_IN_UP2_PHASE = 4 };
+enum { PRN_IN_ZERO = 0, PRN_IN_REFLECT = 1, PRN_IN_UP2_REFLECT = 2, PRN_IN_DILATED = 3, PRN_IN_UP2_PHASE = 4,
+       PRN_IN_EMBED1 = 5 /* Winograd calls only, see prn_conv3x3_winograd */ };
 enum { PRN_EPI_NONE = 0, PRN_EPI_RELU = 1, PRN_EPI_SIGMOID = 2 };
 
 typedef struct prn_conv_desc {
@@ -106,6 +107,9 @@ int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_item
  *   prn_gemm_batched   : Y_z [M][P] = U_z [M][C] * V_z [C][P] for z < nb, one launch of the MFMA kernel
  *   prn_winograd_output: Y' [36][M][P] -> y [B][M][H][W]  (+ bias[m], + addend, epilogue PRN_EPI_NONE / PRN_EPI_RELU)
  *   prn_conv3x3_winograd: the three in sequence; ws holds 36 * (C + M) * P floats.
+ *   in_mode PRN_IN_EMBED1: H, W describe a VIRTUAL zero tensor of which x [B][C][H-2][W-4] is the block starting at (1, 1);
+ *   with pad 1 the output [B][M][H][W] then holds, in its columns 0 .. W-3, the FULL correlation of x (output (H-2)+2 by
+ *   (W-4)+2) -- the gradient w.r.t. a reflect-padded tensor, folded onto the unpadded one by prn_pad_fold_pitched.
  * U [36][M][C] comes from prn_winograd_weights_batched (u: forward operand, ut [36][C][M]: operand of the input gradient,
  * i.e. the transform of the 180-degree-rotated taps with the channel roles swapped); either pointer may be NULL.
  * `first` / total_blocks count 32 x 32 (M, C) blocks exactly as for prn_flip_item. */
@@ -168,6 +172,8 @@ int prn_up2_wgrad_combine(const float* dwp, float* dw, int M, int C, void* strea
 /* adjoint of the PRN_IN_REFLECT / PRN_IN_UP2_REFLECT gather: folds dP [B,C,Hv+2,Wv+2] (gradient w.r.t. the
  * virtual padded tensor, Hv = H or 2H) back onto dx [B,C,H,W]. */
 int prn_pad_fold(const float* dp, float* dx, int B, int C, int H, int W, int up2, void* stream);
+/* the same (up2 = 0) for a dp whose rows are `pitch` >= W + 2 floats long: dp [B][C][H+2][pitch] */
+int prn_pad_fold_pitched(const float* dp, float* dx, int B, int C, int H, int W, int pitch, void* stream);
 
 /* out[c] = sum_{b,h,w} x[b,c,h,w]    (bias gradients); ws: C*PRN_BN_SPLITS doubles (fixed-order partials) */
 int prn_channel_sum(const float* x, float* out, double* ws, int B, int C, int HW, void* stream);

@@ -23,7 +23,7 @@ class Ragged(ctypes.Structure):
     _fields_ = [("nseg", ctypes.c_int32), ("H", ctypes.c_int32 * 6), ("W", ctypes.c_int32 * 6)]
 
 
-IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE = 0, 1, 2, 3, 4
+IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1 = 0, 1, 2, 3, 4, 5
 EPI_NONE, EPI_RELU, EPI_SIGMOID = 0, 1, 2
 BN_SPLITS = 32
 
@@ -63,6 +63,7 @@ SIGNATURES = {
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),
     "prn_pad_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_pad_fold_pitched": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_up2_phase_weights": (c_int, [P, P, c_int, c_int, P]),
     "prn_up2_dgrad_weights": (c_int, [P, P, c_int, c_int, P]),
     "prn_up2_wgrad_combine": (c_int, [P, P, c_int, c_int, P]),

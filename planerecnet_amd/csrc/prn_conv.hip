@@ -786,13 +786,13 @@ __global__ __launch_bounds__(256) void flip_transpose_batched_kernel(const prn_f
 }
 
 // dx[b,c,h,w] = sum over the virtual padded positions that gather from (h,w)
-__global__ void pad_fold_kernel(const float* __restrict__ dp, float* __restrict__ dx, int BC, int H, int W, int up2) {
+__global__ void pad_fold_kernel(const float* __restrict__ dp, float* __restrict__ dx, int BC, int H, int W, int up2, int pitch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)BC * H * W) return;
   const int w = i % W, h = (i / W) % H;
   const int64_t bc = i / ((int64_t)W * H);
   const int Hv = up2 ? 2 * H : H, Wv = up2 ? 2 * W : W;     // virtual (pre-pad) size
-  const int Wp = Wv + 2;
+  const int Wp = pitch > 0 ? pitch : Wv + 2;
   const float* p = dp + bc * (int64_t)(Hv + 2) * Wp;
   float acc = 0.f;
   const int u0 = up2 ? 2 * h : h, u1 = up2 ? 2 * h + 1 : h, v0 = up2 ? 2 * w : w, v1 = up2 ? 2 * w + 1 : w;
@@ -1382,8 +1382,16 @@ extern "C" int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev,
 extern "C" int prn_pad_fold(const float* dp, float* dx, int B, int C, int H, int W, int up2, void* stream) {
   PRN_REQUIRE(dp && dx && B > 0 && C > 0 && H > 1 && W > 1, "prn_pad_fold: bad arguments");
   const int64_t n = (int64_t)B * C * H * W;
-  hipLaunchKernelGGL(pad_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, B * C, H, W, up2);
+  hipLaunchKernelGGL(pad_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, B * C, H, W, up2, 0);
   PRN_CHECK_LAUNCH("prn_pad_fold");
+  return 0;
+}
+
+extern "C" int prn_pad_fold_pitched(const float* dp, float* dx, int B, int C, int H, int W, int pitch, void* stream) {
+  PRN_REQUIRE(dp && dx && B > 0 && C > 0 && H > 1 && W > 1 && pitch >= W + 2, "prn_pad_fold_pitched: bad arguments");
+  const int64_t n = (int64_t)B * C * H * W;
+  hipLaunchKernelGGL(pad_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, B * C, H, W, 0, pitch);
+  PRN_CHECK_LAUNCH("prn_pad_fold_pitched");
   return 0;
 }
 

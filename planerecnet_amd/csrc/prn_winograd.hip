@@ -79,9 +79,27 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __rest
   const int c = blockIdx.y;
   const TilePos tp = locate(g, p, C);
   const int H = tp.H, W = tp.W, ty = tp.ty;
-  const float* xc = x + tp.base + (size_t)c * H * W;
   const int w0 = 4 * tp.tx;
   float d[6][6];
+  if (MODE == PRN_IN_EMBED1) {
+    // (H, W) is a virtual zero tensor; the real one, [B][C][H-2][W-4], sits at (1, 1) inside it (dense batches only)
+    const int Hr = H - 2, Wr = W - 4;
+    const float* xc = x + ((size_t)tp.b * C + c) * Hr * Wr;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int rr = 4 * ty - 2 + i;
+      const bool okr = (unsigned)rr < (unsigned)Hr;
+      const float* row = xc + (size_t)(okr ? rr : 0) * Wr;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int rc = w0 - 2 + j;
+        const bool ok = okr && (unsigned)rc < (unsigned)Wr;
+        const float v = row[ok ? rc : 0];
+        d[i][j] = ok ? v : 0.f;
+      }
+    }
+  } else {
+  const float* xc = x + tp.base + (size_t)c * H * W;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     int ih = 4 * ty - 1 + i;
@@ -97,6 +115,7 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __rest
     d[i][0] = (ok && okl) ? l : 0.f;
     d[i][1] = ok ? q.x : 0.f; d[i][2] = ok ? q.y : 0.f; d[i][3] = ok ? q.z : 0.f; d[i][4] = ok ? q.w : 0.f;
     d[i][5] = (ok && okr) ? r : 0.f;
+  }
   }
   float t[6][6];
 #pragma unroll
@@ -352,13 +371,15 @@ extern "C" int prn_winograd_weights_batched(const prn_winograd_item* items_dev, 
 namespace {
 int input_impl(const float* x, float* V, const prn_ragged* rg, int B, int C, int H, int W, int in_mode, void* stream) {
   PRN_REQUIRE(x && V && C > 0 && C < 65536, "prn_winograd_input: bad arguments");
-  PRN_REQUIRE(in_mode == PRN_IN_ZERO || in_mode == PRN_IN_REFLECT, "prn_winograd_input: zero or reflect padding only");
+  PRN_REQUIRE(in_mode == PRN_IN_ZERO || in_mode == PRN_IN_REFLECT || (in_mode == PRN_IN_EMBED1 && rg == nullptr && H > 2 && W > 4),
+              "prn_winograd_input: zero / reflect padding, or PRN_IN_EMBED1 on a dense batch");
   PRN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "prn_winograd_input: x must be 16-byte aligned");
   WSeg g;
   const int64_t P = make_seg(g, rg, B, H, W, "prn_winograd_input");
   if (P < 0) return 2;
   const dim3 grid(cdiv(P, 256), C), block(256);
   if (in_mode == PRN_IN_ZERO) hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_ZERO>), grid, block, 0, (hipStream_t)stream, x, V, C, (int)P, (int)pad4(P), g);
+  else if (in_mode == PRN_IN_EMBED1) hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_EMBED1>), grid, block, 0, (hipStream_t)stream, x, V, C, (int)P, (int)pad4(P), g);
   else hipLaunchKernelGGL((winograd_input_kernel<PRN_IN_REFLECT>), grid, block, 0, (hipStream_t)stream, x, V, C, (int)P, (int)pad4(P), g);
   PRN_CHECK_LAUNCH("prn_winograd_input");
   return 0;

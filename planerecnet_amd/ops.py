@@ -15,7 +15,7 @@ import weakref
 import torch
 
 from . import _lib, profiling
-from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
+from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
 _SIDE = {}
@@ -396,8 +396,11 @@ WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    
 
 def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep=None):
     """3x3 / stride 1 / pad 1 convolution of x [B,C,H,W] with transform-domain weights U [36,M,C].
-    keep: a list that receives the workspace (whose head is V = B^T x B) for conv3x3_winograd_wgrad_raw(..., V=...)."""
+    keep: a list that receives the workspace (whose head is V = B^T x B) for conv3x3_winograd_wgrad_raw(..., V=...).
+    mode IN_EMBED1: x is the block at (1, 1) of a virtual zero tensor [B,C,H+2,W+4]; the result has that size (include/prn.h)."""
     B, C, H, W = x.shape
+    if mode == IN_EMBED1:
+        H, W = H + 2, W + 4
     P = lib.prn_winograd_tiles(B, H, W)
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
     ws = torch.empty(36 * (C + M) * P, device=x.device, dtype=torch.float32)
@@ -462,6 +465,13 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
     if mode == IN_ZERO and winograd_ok(B, M, H, W, C, K, stride, pad, IN_ZERO, EPI_NONE) and tuple(dy.shape[2:]) == (H, W):
         return conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, addend, C)
     wt = flip_transpose(w)                                  # [C, M, K, K]
+    if mode == IN_REFLECT and W % 4 == 0 and tuple(dy.shape[2:]) == (H, W) and winograd_ok(B, M, H + 2, W + 4, C, K, 1, 1, IN_ZERO, EPI_NONE):
+        # gradient of the reflect-padded tensor = FULL correlation of dy, on the Winograd path (dy embedded at (1, 1) of a
+        # zero tensor by the input transform's index map), then folded onto the unpadded tensor
+        dp = conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, None, C, IN_EMBED1)          # [B, C, H+2, W+4]
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        check(lib.prn_pad_fold_pitched(_p(dp), _p(dx), B, C, H, W, W + 4, _stream()), "prn_pad_fold_pitched")
+        return dx if addend is None else dx + addend
     if mode in (IN_REFLECT, IN_UP2_REFLECT):
         Hv, Wv = (2 * H, 2 * W) if mode == IN_UP2_REFLECT else (H, W)
         dp = conv_fwd_raw(dy, wt, None, None, C, K, 1, 2, Hv + 2, Wv + 2)       # grad of the virtual padded tensor
