@@ -23,7 +23,9 @@ import sys
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime initialises: see planerecnet_amd/__init__.py
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -123,11 +125,20 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("PRN_BENCH_ONE_DEVICE"):             # validation aid: N ranks time-share GPU 0 (with PRN_DIST_BACKEND=gloo;
+        local = 0                                          # RCCL refuses two ranks on one device) -- exercises the N > 1 code path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("PRN_FORCE_EXCHANGE"):  # (forced: a one-rank group, so that the bucket / RCCL path runs on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        backend = os.environ.get("PRN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from planerecnet_amd import ops, profiling, timer
     from planerecnet_amd.config import cfg, set_cfg
@@ -212,6 +223,10 @@ def main():
         losses = step()
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PRN_EXCHANGE_PROF"):
+        from planerecnet_amd import parallel as _par
+        n_ = max(_par._PROF.get("steps", 1), 1)
+        print({k: (round(v / n_ * 1e3, 2) if isinstance(v, float) else v / n_) for k, v in _par._PROF.items()}, file=sys.stderr)
     if os.environ.get("PRN_BENCH_PHASES"):
         evs = ph.pop("_events")
         ph["gpu_ms_per_step"] = [round(a.elapsed_time(b), 1) for a, b in zip(evs[:-1], evs[1:])]
@@ -271,7 +286,7 @@ def main():
                 "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(line), flush=True)
     prefetch.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

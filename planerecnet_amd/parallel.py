@@ -20,6 +20,10 @@ import torch
 import torch.distributed as dist
 
 
+import os as _os
+_PROF = {} if _os.environ.get("PRN_EXCHANGE_PROF") else None      # host time inside the hooks / launches / finish (debugging aid)
+
+
 class GradAllReduce:
     def __init__(self, params, bucket_bytes=25 << 20, process_group=None, force=False):
         self.group = process_group
@@ -31,8 +35,14 @@ class GradAllReduce:
             return
         dev = self.params[0].device
         self.on_gpu = dev.type == "cuda"
-        self.stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
         self.main = torch.cuda.current_stream(dev) if self.on_gpu else None      # the stream forward / backward are issued on
+        # The exchange shares the weight-gradient side stream (ops.set_wgrad_async): most of a bucket is produced there, the
+        # side stream is never on the critical path, and every extra HIP stream is one more customer for the four hardware
+        # queues (a dedicated exchange stream cost 7 ms/step with ONE rank: 59.7 -> 66.9 ms, see ops.BRANCH_STREAMS).
+        self.stream = None
+        if self.on_gpu:
+            from . import ops
+            self.stream = ops._side_stream(dev, self.main)
         cur, size = [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -43,6 +53,9 @@ class GradAllReduce:
         if cur:
             self.buckets.append(cur)
         self.flat = [torch.empty(sum(p.numel() for p in b), device=dev, dtype=b[0].dtype) for b in self.buckets]
+        # per-parameter windows of the flat buffers, built once: the pack / unpack are then ONE foreach copy each with no
+        # per-step view construction (300 parameters: 3 ms of host time per step on the autograd thread otherwise)
+        self.windows = [[v.view_as(p) for v, p in zip(f.split([p.numel() for p in b]), b)] for f, b in zip(self.flat, self.buckets)]
         self.where = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
@@ -54,6 +67,16 @@ class GradAllReduce:
 
     # called by autograd on the backward thread, once per parameter per backward
     def _on_grad(self, p):
+        if _PROF is not None:
+            import time
+            t0 = time.perf_counter()
+            self._on_grad_impl(p)
+            _PROF["hooks"] = _PROF.get("hooks", 0.0) + time.perf_counter() - t0
+            _PROF["n_hooks"] = _PROF.get("n_hooks", 0) + 1
+            return
+        self._on_grad_impl(p)
+
+    def _on_grad_impl(self, p):
         bi = self.where[p]
         self.arrived[bi] += 1
         if self.arrived[bi] == len(self.buckets[bi]):
@@ -68,28 +91,38 @@ class GradAllReduce:
             self.next += 1
 
     def _launch(self, bi):
+        if _PROF is not None:
+            import time
+            t0 = time.perf_counter()
+            self._launch_impl(bi)
+            _PROF["launch"] = _PROF.get("launch", 0.0) + time.perf_counter() - t0
+            return
+        self._launch_impl(bi)
+
+    def _launch_impl(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
         if self.on_gpu:
             from . import ops
             ops.wgrad_flush()                             # queued deferred weight gradients of this bucket must be in flight
-        for p in bucket:                                  # the pack / unpack below work on flat VIEWS of the gradients
-            if not p.grad.is_contiguous():
-                p.grad = p.grad.contiguous()
         if self.on_gpu:
             # gradients of one bucket come from the backward's own stream AND (deferred weight gradients, ops.WGRAD_ASYNC)
             # from the side streams; the hook that completes a bucket may run under either
-            self.stream.wait_stream(torch.cuda.current_stream())
-            self.stream.wait_stream(self.main)
-            from . import ops
-            for st in ops.wgrad_streams():
-                self.stream.wait_stream(st)
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream != self.stream.cuda_stream:
+                self.stream.wait_stream(cur)
+            if self.main.cuda_stream != cur.cuda_stream:
+                self.stream.wait_stream(self.main)
+            for st in ops.wgrad_streams():                 # (other side streams exist only with stream branches on)
+                if st.cuda_stream != self.stream.cuda_stream:
+                    self.stream.wait_stream(st)
             ctx = torch.cuda.stream(self.stream)
         else:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [p.grad.view(-1) for p in bucket])
-            flat.div_(self.world)
+            torch._foreach_copy_(self.windows[bi], [p.grad for p in bucket])
+            if self.world > 1:
+                flat.div_(self.world)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((bi, work))
 
@@ -97,6 +130,16 @@ class GradAllReduce:
         """Block the compute stream until every bucket has been reduced and written back. Call after backward()."""
         if not self.active:
             return
+        if _PROF is not None:
+            import time
+            t0 = time.perf_counter()
+            self._finish_impl()
+            _PROF["finish"] = _PROF.get("finish", 0.0) + time.perf_counter() - t0
+            _PROF["steps"] = _PROF.get("steps", 0) + 1
+            return
+        self._finish_impl()
+
+    def _finish_impl(self):
         for bi in range(self.next, len(self.buckets)):  # buckets held back by a parameter that received no gradient this step
             if any(p.grad is not None for p in self.buckets[bi]) or self.world > 1:
                 for p in self.buckets[bi]:
@@ -109,10 +152,10 @@ class GradAllReduce:
             if self.on_gpu:
                 with torch.cuda.stream(self.stream):
                     work.wait()                           # orders the SIDE stream (current here) after RCCL's completion
-                    torch._foreach_copy_([p.grad.view(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
+                    torch._foreach_copy_([p.grad for p in bucket], self.windows[bi])
             else:
                 work.wait()
-                torch._foreach_copy_([p.grad.view(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
+                torch._foreach_copy_([p.grad for p in bucket], self.windows[bi])
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending.clear()

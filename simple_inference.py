@@ -12,7 +12,9 @@ import os
 from pathlib import Path
 
 import numpy as np
-import torch
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime initialises: see planerecnet_amd/__init__.py
+import torch  # noqa: E402
 
 from planerecnet_amd.config import COLORS, cfg, set_cfg
 from planerecnet_amd.funcs import FastBaseTransform, calc_size_preserve_ar, pad_even_divided

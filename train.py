@@ -23,7 +23,9 @@ import random
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime initialises: see planerecnet_amd/__init__.py
+import torch  # noqa: E402
 import torch.distributed as dist
 
 from planerecnet_amd.config import cfg, set_cfg, set_dataset
