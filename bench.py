@@ -182,7 +182,7 @@ def main():
     def step():
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        targets = prefetch.get(depths, dev)                 # GT-only targets of THIS step (prepared by the worker processes) + async uploads
+        targets = prefetch.get(depths, dev, overlap=True)                 # GT-only targets of THIS step (prepared by the worker processes) + async uploads
         t1 = time.perf_counter()
         prefetch.submit(inst, hw)                           # targets two steps ahead: recomputed every step, overlapping the GPU work
         t2 = time.perf_counter()

@@ -36,7 +36,8 @@ def _pin(x):
 
 class Targets:
     """Device-resident, GT-only inputs of one loss evaluation (built by PlaneRecNetLoss.prepare)."""
-    __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum")
+    __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum",
+                 "ready")         # ready: event after which the tensors may be read (uploads issued on another stream), or None
 
 
 LOSS_STREAMS = bool(int(os.environ.get("PRN_LOSS_STREAMS", "0")))        # off by default: see ops.BRANCH_STREAMS
@@ -133,6 +134,7 @@ class PlaneRecNetLoss(nn.Module):
     def upload(self, h, gt_depths, device):
         """Asynchronous uploads of prepare_host()'s result + the GT-only device work of the lava term."""
         t = Targets()
+        t.ready = None
         t.B, t.n_pos, t.num_ins = h["B"], h["n_pos"], h["num_ins"]
         up = lambda x: x.to(device, non_blocking=True)
         t.cell_ids = list(up(h["cell_ids"]).split(h["n_pos"]))
@@ -163,6 +165,9 @@ class PlaneRecNetLoss(nn.Module):
         B = mask_preds.shape[0]
         fh, fw = mask_preds.shape[-2:]
         t = targets if targets is not None else self.prepare(gt_instances, gt_depths, dev, (fh, fw))
+        if getattr(t, "ready", None) is not None:            # uploads were issued on the side stream (TargetPrefetcher.get(overlap=True))
+            torch.cuda.current_stream().wait_event(t.ready)
+            t.ready = None
         E = kernel_preds[0].shape[1]
 
         def instance_terms():
@@ -658,13 +663,33 @@ class TargetPrefetcher:
             fv = self.pool_v.submit(_worker_vnl, host, hw) if proc else self.pool_v.submit(self.criterion.vnl.prepare_host, host, hw)
         self.queue.append((ft, fv))
 
-    def get(self, gt_depths, device):
+    def get(self, gt_depths, device, overlap=False):
         """Targets of the OLDEST submitted batch (blocks only if a worker has not finished yet).  Keeping two batches in
         flight hides the workers' latency (~40 ms per batch of 8 next to a ~60 ms step) completely."""
         ft, fv = self.queue.popleft()
         h = ft.result()
         h["vnl"] = fv.result() if fv is not None else None
-        return self.criterion.upload(h, gt_depths, device)
+        if not overlap or not torch.cuda.is_available():
+            return self.criterion.upload(h, gt_depths, device)
+        # The uploads (~20 MB of indices / labels), the device-side sort of the triplet indices and the lava preparation go to
+        # the weight-gradient side stream, which is idle during the forward pass; the loss waits for `ready`.  On the compute
+        # stream they delayed the forward pass by 2.6 ms per step (tools/host_vs_gpu.py, FIXED_TARGETS=1: 58.0 vs 60.6 ms).
+        main = torch.cuda.current_stream()
+        side = ops._side_stream(torch.device(device), main)
+        side.wait_stream(main)                               # gt_depths (and the previous step's readers of recycled memory)
+        with torch.cuda.stream(side):
+            t = self.criterion.upload(h, gt_depths, device)
+            t.ready = torch.cuda.Event()
+            t.ready.record()
+        for obj in (t, t.vnl):
+            if obj is None:
+                continue
+            for name in obj.__slots__:
+                v = getattr(obj, name, None)
+                for x in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if torch.is_tensor(x) and x.is_cuda:
+                        x.record_stream(main)               # allocated under the side stream, read (and released) under main
+        return t
 
     def discard(self):
         """Drop every batch that was submitted but not fetched (end of an epoch, early exit from a loop)."""

@@ -43,7 +43,7 @@ def step():
             FIXED[0] = pf.get(depths, dev)
         t = FIXED[0]
     else:
-        t = pf.get(depths, dev)
+        t = pf.get(depths, dev, overlap=True)
         pf.submit(inst, (480, 640))
     out = net(images)
     losses = crit(net, *out, inst, depths, targets=t)

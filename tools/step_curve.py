@@ -32,7 +32,7 @@ ops.set_wgrad_async(True)
 
 def step():
     opt.zero_grad(set_to_none=True)
-    t = pf.get(depths, dev)
+    t = pf.get(depths, dev, overlap=True)
     pf.submit(inst, (480, 640))
     out = net(images)
     losses = crit(net, *out, inst, depths, targets=t)

@@ -246,7 +246,7 @@ def main():
                 optimizer.zero_grad(set_to_none=True)
                 x = torch.stack(images).to(dev, non_blocking=True)
                 d = torch.stack(gt_depths).to(dev, non_blocking=True)
-                targets = prefetch.get(d, dev)
+                targets = prefetch.get(d, dev, overlap=True)
                 ahead.popleft()
                 b_ = next(it, None)                        # fetch + start preparing a later batch while this one runs
                 if b_ is not None:
