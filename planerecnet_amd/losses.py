@@ -341,11 +341,12 @@ class VNL_Loss(nn.Module):
         t.B, t.n_seg, t.n_tot = h["B"], h["n_seg"], h["n_tot"]
         for k in ("N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal"):
             setattr(t, k, h[k].to(device, non_blocking=True))
+        gid32 = t.gid                                        # int32 as uploaded: the radix sort below has half the key bits to do
         t.gid, t.seg = t.gid.long(), t.seg.long()
         # inverse of the triplet gather, built once per step (GT only): which gathered rows land on which cloud point
         # (sort + per-point counts over ALL B*H*W cloud points: fixed-size outputs, so no device->host sync)
         t.gid_flat = t.gid.reshape(-1)
-        t.gid_order = torch.sort(t.gid_flat).indices
+        t.gid_order = torch.sort(gid32.reshape(-1)).indices if gid32.dtype == torch.int32 else torch.sort(t.gid_flat).indices
         t.gid_counts = None                                  # filled by _triplets_t, which knows the size of the cloud
         return t
 
