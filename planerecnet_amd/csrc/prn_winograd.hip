@@ -450,8 +450,10 @@ int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_r
     if (P4 != P) {                                     // the products reduce over P4 columns: the padding must be zero
       // (at most 3 columns per row: cleared with one strided memset per operand; a kept V has finite padding only
       // if its producer cleared it, so it is cleared here as well)
-      hipMemset2DAsync(V + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)C, (hipStream_t)stream);
-      hipMemset2DAsync(Yt + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)M, (hipStream_t)stream);
+      const hipError_t e1 = hipMemset2DAsync(V + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)C, (hipStream_t)stream);
+      const hipError_t e2 = hipMemset2DAsync(Yt + P, P4 * 4, 0, (P4 - P) * 4, 36 * (size_t)M, (hipStream_t)stream);
+      PRN_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "prn_conv3x3_winograd_wgrad: clearing the tile padding failed: %s",
+                  hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
   }
   if (phase == 0 || phase == 2)
