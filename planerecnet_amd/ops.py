@@ -526,7 +526,7 @@ class _Conv2d(torch.autograd.Function):
         dy = _c(dy)
         dfork = _c(dfork)
         if epi == EPI_RELU:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)      # dy * (y > 0) in one pass
         elif epi == EPI_SIGMOID:
             dy = dy * y * (1 - y)
         M, C, K, _ = w.shape
