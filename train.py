@@ -220,14 +220,31 @@ def main():
             it = iter(loader)
             prefetch.discard()                             # (batches of the previous epoch that were prepared but not used)
             ahead = collections.deque()                    # batches whose GT-only targets are being prepared (two in flight)
-            for _ in range(2):
+
+            def refill():
                 b_ = next(it, None)
                 if b_ is not None:
                     ahead.append(b_)
                     prefetch.submit(b_[1], tuple(b_[0][0].shape[-2:]))
-            nxt = ahead[0] if ahead else None
-            while nxt is not None:
-                images, gt_instances, gt_depths = nxt
+
+            def stage():
+                """Uploads of the next batch (images, depth, targets): issued one step EARLY, right after the current
+                step's backward has been enqueued, so that a step starts with the forward pass even though every
+                step ends in a host synchronisation (the all-reduced loss values)."""
+                if not ahead:
+                    return None
+                images_, inst_, depths_ = ahead.popleft()
+                x_ = torch.stack(images_).to(dev, non_blocking=True)
+                d_ = torch.stack(depths_).to(dev, non_blocking=True)
+                t_ = prefetch.get(d_, dev, overlap=True)
+                refill()
+                return x_, d_, t_, inst_
+
+            refill()
+            refill()
+            cur = stage()
+            while cur is not None:
+                x, d, targets, gt_instances = cur
                 if iteration == (epoch + 1) * epoch_size or iteration == cfg.max_iter:
                     break
                 changed = [c for c in cfg.delayed_settings if iteration >= c[0]]
@@ -236,7 +253,7 @@ def main():
                     for avg in loss_avgs.values():
                         avg.reset()
                 if changed:
-                    cfg.delayed_settings = [x for x in cfg.delayed_settings if x[0] > iteration]
+                    cfg.delayed_settings = [x_ for x_ in cfg.delayed_settings if x_[0] > iteration]
                 if cfg.lr_warmup_until > 0 and iteration <= cfg.lr_warmup_until:
                     set_lr(optimizer, (args.lr - cfg.lr_warmup_init) * (iteration / cfg.lr_warmup_until) + cfg.lr_warmup_init)
                 while step_index < len(cfg.lr_steps) and iteration >= cfg.lr_steps[step_index]:
@@ -244,20 +261,12 @@ def main():
                     set_lr(optimizer, args.lr * (args.gamma ** step_index))
 
                 optimizer.zero_grad(set_to_none=True)
-                x = torch.stack(images).to(dev, non_blocking=True)
-                d = torch.stack(gt_depths).to(dev, non_blocking=True)
-                targets = prefetch.get(d, dev, overlap=True)
-                ahead.popleft()
-                b_ = next(it, None)                        # fetch + start preparing a later batch while this one runs
-                if b_ is not None:
-                    ahead.append(b_)
-                    prefetch.submit(b_[1], tuple(b_[0][0].shape[-2:]))
-                nxt = ahead[0] if ahead else None
                 losses = net(x, gt_instances, d, targets=targets)
                 loss = sum(losses[k].sum() for k in losses)
                 loss.backward()
                 ops.wgrad_join()                               # deferred weight gradients (ops.set_wgrad_async)
                 exchange.finish()
+                cur = stage()                                  # next batch: uploads behind this step's work, before the sync below
                 shown = [k for k in LOSS_TYPES if k in losses]
                 stats = all_reduce_mean_scalars([losses[k].detach().sum() for k in shown] + [loss.detach()], dev).tolist()
                 del loss, losses                           # drop the step's autograd graph now, not when the next step's loss replaces it (+5 ms/step)
