@@ -265,3 +265,33 @@ def test_r101_highres_inference_shapes_match_oracle():
             close(kern[i], o_kern[i], 5e-4, f"kernel{i}")
     finally:
         set_cfg(CN)
+
+
+def test_prefetched_targets_equal_direct_preparation():
+    """TargetPrefetcher (worker processes, packed pinned blob, uploads on the side stream with the `ready` event) hands the
+    loss the same device tensors as PlaneRecNetLoss.prepare() computes in place -- and the loss values agree."""
+    import numpy as np
+    from planerecnet_amd.config import cfg, set_cfg
+    from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
+    from oracle import synth
+    set_cfg("PlaneRecNet_50_config")
+    dev = torch.device("cuda:0")
+    crit = PlaneRecNetLoss().to(dev)
+    _, inst, gtd = synth.make_batch(2, 480, 640, seed=11)
+    gtd = gtd.to(dev)
+    np.random.seed(3)
+    direct = crit.prepare(inst, gtd, dev)
+    np.random.seed(3)
+    pf = TargetPrefetcher(crit)
+    try:
+        pf.submit(inst, (480, 640))
+        t = pf.get(gtd, dev, overlap=True)
+        assert t.ready is not None
+        torch.cuda.current_stream().wait_event(t.ready)
+        for name in ("pos_img", "ins_labels", "cate_labels", "n_pos_dev", "lava_adj", "lava_gsum"):
+            assert torch.equal(getattr(t, name), getattr(direct, name)), name
+        assert all(torch.equal(a, b) for a, b in zip(t.cell_ids, direct.cell_ids))
+        for name in ("gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal", "N", "fx", "fy"):
+            assert torch.equal(getattr(t.vnl, name), getattr(direct.vnl, name)), name
+    finally:
+        pf.close()
