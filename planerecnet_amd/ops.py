@@ -330,17 +330,27 @@ def _winograd_items(entries, dev):
     return torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev), blocks
 
 
+def _wino_store(w, U, Ut):
+    """Cache entry keyed by the weight's address; holds the weight weakly and disappears with it (the operands are 8x the
+    weight's size -- a dead model must not pin them)."""
+    ptr = w.data_ptr()
+    new = ptr not in _WINO or _WINO[ptr][0]() is not w
+    _WINO[ptr] = (weakref.ref(w), w._version, U, Ut)
+    if new:
+        weakref.finalize(w, lambda p=ptr, r=_WINO[ptr][0]: _WINO.pop(p, None) if (_WINO.get(p) or (None,))[0] is r else None)
+
+
 def winograd_weights(w):
     """(U, Ut) of a [M, C, 3, 3] weight: from the per-step batch (WinogradWeights.refresh) when current, else computed here."""
     e = _WINO.get(w.data_ptr())
-    if e is not None and e[0]._version == e[1] and tuple(e[2].shape[1:]) == tuple(w.shape[:2]):
+    if e is not None and e[0]() is w and w._version == e[1]:
         return e[2], e[3]
     M, C = w.shape[:2]
     U = torch.empty(36, M, C, device=w.device, dtype=torch.float32)
     Ut = torch.empty(36, C, M, device=w.device, dtype=torch.float32)
     items, blocks = _winograd_items([(w, M, C, U, Ut)], w.device)
     check(lib.prn_winograd_weights_batched(_p(items), 1, blocks, _stream()), "prn_winograd_weights_batched")
-    _WINO[w.data_ptr()] = (w, w._version, U, Ut)            # valid until the weight is modified in place (inference: for good)
+    _wino_store(w, U, Ut)                                    # valid until the weight is modified in place (inference: for good)
     if isinstance(w, torch.nn.Parameter):
         _WINO_SEEN[w.data_ptr()] = weakref.ref(w)
     return U, Ut
@@ -388,7 +398,7 @@ class WinogradWeights:
             self._build()
         check(lib.prn_winograd_weights_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_winograd_weights_batched")
         for w, (U, Ut) in zip(self.weights, self.views):
-            _WINO[w.data_ptr()] = (w, w._version, U, Ut)
+            _wino_store(w, U, Ut)
 
 
 WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
