@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PRN_LIB", os.path.join(_HERE, "libprn_hip.so"))   # PRN_LIB: A/B builds in tuning runs
+LIB_PATH = os.environ.get("PRN_LIB") or os.path.join(_HERE, "libprn_hip.so")   # PRN_LIB: A/B builds in tuning runs
 
 c_int, c_float, c_void_p, c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 
