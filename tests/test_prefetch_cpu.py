@@ -74,3 +74,30 @@ def test_prefetcher_is_fifo_and_discard_resynchronises():
             fv.result()
         finally:
             pf.close()
+
+
+def test_pack_tree_round_trip_keeps_dtypes_shapes_and_alignment():
+    """Worker results travel as ONE byte tensor + a skeleton (losses._pack_tree / _unpack_tree)."""
+    from planerecnet_amd.losses import _pack_tree, _unpack_tree
+    g = torch.Generator().manual_seed(0)
+    tree = {"a": torch.randint(0, 255, (7, 3, 5), generator=g, dtype=torch.uint8), "n": 3, "s": "deferred",
+            "l": [torch.randn(4, generator=g, dtype=torch.float64), torch.arange(9, dtype=torch.int32).view(3, 3).t()],     # non-contiguous view
+            "e": torch.zeros(0, dtype=torch.int64), "nested": {"b": torch.tensor([True, False, True]), "t": (1, 2.5, None)}}
+    skel, blob = _pack_tree(tree)
+    assert blob.dtype == torch.uint8 and blob.dim() == 1
+    back = _unpack_tree(skel, blob.clone())
+    assert back["n"] == 3 and back["s"] == "deferred" and back["nested"]["t"] == (1, 2.5, None)
+    for got, want in ((back["a"], tree["a"]), (back["l"][0], tree["l"][0]), (back["l"][1], tree["l"][1]), (back["e"], tree["e"]),
+                      (back["nested"]["b"], tree["nested"]["b"])):
+        assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want)
+
+    def offsets(v):
+        if isinstance(v, tuple) and len(v) == 4 and v[0] == "__t__":
+            yield v[1]
+        elif isinstance(v, dict):
+            for x in v.values():
+                yield from offsets(x)
+        elif isinstance(v, (list, tuple)):
+            for x in v:
+                yield from offsets(x)
+    assert all(o % 16 == 0 for o in offsets(skel))
