@@ -623,6 +623,12 @@ class TargetPrefetcher:
         import pickle
         import sys
         import torch.multiprocessing as mp
+        try:                                                   # batches and results travel through /dev/shm (~60 MB in flight at B=8)
+            st = os.statvfs("/dev/shm")
+            if st.f_bavail * st.f_frsize < (1 << 30):
+                raise RuntimeError("/dev/shm has less than 1 GiB free")
+        except FileNotFoundError:
+            raise RuntimeError("no /dev/shm")
         ctx = mp.get_context("spawn")
         # "file_system" sharing: a shared-memory tensor travels as a file name.  (The default strategy passes file
         # descriptors, which the sender serves from a background thread -- one more GIL customer in the trainer.)
