@@ -105,8 +105,8 @@ def cpu_baseline(config_name, H, W, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="PlaneRecNet_101_config")
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--sync-wgrad", action="store_true", help="weight gradients in line with the input-gradient chain (A/B of ops.WGRAD_ASYNC)")
