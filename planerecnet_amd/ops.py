@@ -251,7 +251,11 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     return dw
 
 
+_FLIP_USED = set()   # data_ptr of every weight whose dgrad layout was asked for (a model prunes its per-step batch with it)
+
+
 def flip_transpose(w):
+    _FLIP_USED.add(w.data_ptr())
     e = _FLIPPED.get(w.data_ptr())
     if e is not None and e[0]._version == e[1] and e[2].shape[1] == w.shape[0]:
         return e[2]                                         # flipped by FlippedWeights.refresh() since the last weight update

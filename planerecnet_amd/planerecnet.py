@@ -76,6 +76,17 @@ class PlaneRecNet(nn.Module):
                     M, C, KH, KW = m.weight.shape
                     items.append((m.weight, (M, C * KH * KW, 1, 1) if id(m.weight) in dcn_w else (M, C, KH, KW)))
             fw = self.__dict__["_flipped"] = ops.FlippedWeights(items)
+            self.__dict__["_flip_steps"] = 0
+        # after two full steps: keep only the weights whose flipped layout was actually requested (the 3x3 layers on the
+        # Winograd path use the transform-domain operand instead -- 60 % of the bytes); anything requested later is flipped
+        # on demand by ops.flip_transpose
+        self.__dict__["_flip_steps"] += 1
+        if self.__dict__["_flip_steps"] == 3:
+            used = [(w, shp) for w, shp in fw.weights if w.data_ptr() in ops._FLIP_USED]
+            if used and len(used) < len(fw.weights):
+                for w, _ in fw.weights:
+                    ops._FLIPPED.pop(w.data_ptr(), None)
+                fw = self.__dict__["_flipped"] = ops.FlippedWeights(used)
         fw.refresh()
         # transform-domain operands of the 3x3 weights the Winograd path asked for in earlier steps (ops.WinogradWeights)
         mine = self.__dict__.get("_param_ids")
