@@ -121,11 +121,21 @@ def main():
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher -- one process per GPU under torch.distributed.run
+        # (the reference's single-process nn.DataParallel, train.py:153-213,266, is replaced by N replicas + RCCL)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    if os.environ.get("PRN_BENCH_ONE_DEVICE"):             # validation aid: N ranks time-share GPU 0 (with PRN_DIST_BACKEND=gloo;
+    if os.environ.get("PRN_BENCH_ONE_DEVICE") or os.environ.get("PRN_ONE_DEVICE"):             # validation aid: N ranks time-share GPU 0 (with PRN_DIST_BACKEND=gloo;
         local = 0                                          # RCCL refuses two ranks on one device) -- exercises the N > 1 code path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -193,6 +193,48 @@ int64_t prn_dcn_sample_bwd_ws_bytes(int B, int C, int H, int W, int Ho, int Wo);
 int prn_dcn_sample_bwd(const float* x, const float* om, const float* dcols, float* dx, float* d_om, void* ws,
                        int B, int C, int H, int W, int Ho, int Wo, int stride, float max_offset, void* stream);
 
+/* ---- DCNv2 as ONE operator: sampler fused into the MFMA contraction (csrc/prn_dcnv2.hip) -----------------------------
+ * replaces torchvision.ops.deform_conv2d(input, offset, weight, bias, stride, padding, mask=mask) -- the reference's single
+ * native-operator call site, models/dcn.py:59-66 -- without the [B, 9*Cin, Ho, Wo] column tensor torchvision (and
+ * prn_dcn_sample above) materialise.  3x3 kernel, dilation 1, groups = offset groups = 1 (all the reference uses).
+ *   raw = 0: torchvision semantics.  offset [B,18,Ho,Wo] (channel 2k = dy, 2k+1 = dx of tap k = 3*i + j), mask [B,9,Ho,Wo] or
+ *            NULL (= 1.0), used as given.
+ *   raw = 1: `offset` is the raw [B,27,Ho,Wo] output of the merged offset(18)|modulator(9) conv and `mask` is ignored:
+ *            offsets are clamped to +-max_offset and the modulation is 2*sigmoid(raw[18+k]) (models/dcn.py:53-57 folded
+ *            in); gradients come back for the raw tensor ([B,27,Ho,Wo] in d_offset, d_mask unused).
+ * Call order:  prn_dcnv2_table (offset, mask -> gather table, prn_dcnv2_table_bytes; valid until offset / mask change)
+ *   forward :  prn_dcnv2_fwd(x, table, w [M,C,3,3], bias) -> y [B,M,Ho,Wo]        (ws: prn_dcnv2_fwd_ws_bytes, K-split partials)
+ *   backward:  prn_dcnv2_bwd_weight(x, table, dy) -> dw [M,C,3,3]                 (re-samples in the operand loader)
+ *              prn_dcnv2_bwd_input(dy, wt [9C,M] = w^T, offset, mask) -> dx       (W^T dy into the head of ws, CSR gather;
+ *                                                                                  dx may be NULL: column gradient only)
+ *              prn_dcnv2_bwd_offset_mask(x, offset, mask) -> d_offset, d_mask     (reads W^T dy from the SAME ws: call it
+ *                                                                                  after prn_dcnv2_bwd_input of that layer)
+ *   the bias gradient is prn_channel_sum(dy).  `*_phase`: 0 = everything, 1 = GEMM launch only, 2 = split reduction only
+ *   (profiler brackets).  dx is order-nondeterministic in the last bits (CSR bins filled through an atomic cursor).      */
+typedef struct prn_dcn_desc {
+  int32_t B, C, H, W;      /* input [B,C,H,W]                                   */
+  int32_t M;               /* output channels                                   */
+  int32_t stride, pad;
+  int32_t Ho, Wo;          /* (H + 2*pad - 3) / stride + 1                      */
+  int32_t raw;             /* see above                                         */
+  float max_offset;        /* raw = 1 only                                      */
+  int32_t epilogue;        /* forward: PRN_EPI_NONE / PRN_EPI_RELU              */
+} prn_dcn_desc;
+int64_t prn_dcnv2_table_bytes(const prn_dcn_desc* d);
+int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const float* mask, void* table, void* stream);
+int64_t prn_dcnv2_fwd_ws_bytes(const prn_dcn_desc* d);
+int prn_dcnv2_fwd(const prn_dcn_desc* d, const float* x, const void* table, const float* w, const float* bias, float* y, void* ws, void* stream);
+int prn_dcnv2_fwd_phase(const prn_dcn_desc* d, const float* x, const void* table, const float* w, const float* bias, float* y, void* ws, void* stream,
+                        int phase);
+int64_t prn_dcnv2_bwd_weight_ws_bytes(const prn_dcn_desc* d);
+int prn_dcnv2_bwd_weight(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream);
+int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream, int phase);
+int64_t prn_dcnv2_bwd_ws_bytes(const prn_dcn_desc* d);
+int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
+                        void* stream);
+int prn_dcnv2_bwd_offset_mask(const prn_dcn_desc* d, const float* x, const float* offset, const float* mask, float* d_offset, float* d_mask,
+                              void* ws, void* stream);
+
 /* ---- BatchNorm2d (+ residual add, + ReLU) --------------------------------------------------------------------
  * replaces ATen batch_norm fwd/bwd: models/backbone.py:24,44,48,102,166 ; planerecnet.py:518..582           */
 /* training statistics: stats[0:C]=mean, stats[C:2C]=invstd; updates running_mean/var (momentum, unbiased var).

@@ -23,6 +23,12 @@ class Ragged(ctypes.Structure):
     _fields_ = [("nseg", ctypes.c_int32), ("H", ctypes.c_int32 * 6), ("W", ctypes.c_int32 * 6)]
 
 
+class DcnDesc(ctypes.Structure):
+    """mirror of prn_dcn_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "H", "W", "M", "stride", "pad", "Ho", "Wo", "raw")] + [("max_offset", ctypes.c_float),
+                                                                                                              ("epilogue", ctypes.c_int32)]
+
+
 IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1 = 0, 1, 2, 3, 4, 5
 EPI_NONE, EPI_RELU, EPI_SIGMOID = 0, 1, 2
 BN_SPLITS = 32
@@ -73,6 +79,17 @@ SIGNATURES = {
     "prn_dcn_sample": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
     "prn_dcn_sample_bwd_ws_bytes": (c_i64, [c_int] * 6),
     "prn_dcn_sample_bwd": (c_int, [P, P, P, P, P, P] + [c_int] * 7 + [c_float, P]),
+    "prn_dcnv2_table_bytes": (c_i64, [P]),
+    "prn_dcnv2_table": (c_int, [P, P, P, P, P]),
+    "prn_dcnv2_fwd_ws_bytes": (c_i64, [P]),
+    "prn_dcnv2_fwd": (c_int, [P] * 8),
+    "prn_dcnv2_fwd_phase": (c_int, [P] * 8 + [c_int]),
+    "prn_dcnv2_bwd_weight_ws_bytes": (c_i64, [P]),
+    "prn_dcnv2_bwd_weight": (c_int, [P] * 7),
+    "prn_dcnv2_bwd_weight_phase": (c_int, [P] * 7 + [c_int]),
+    "prn_dcnv2_bwd_ws_bytes": (c_i64, [P]),
+    "prn_dcnv2_bwd_input": (c_int, [P] * 8),
+    "prn_dcnv2_bwd_offset_mask": (c_int, [P] * 8),
     "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "prn_bn_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "prn_bn_train_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, P]),

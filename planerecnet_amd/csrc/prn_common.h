@@ -47,3 +47,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Internal (not part of the C ABI): the fixed-order split reductions of prn_conv.hip, shared with prn_dcnv2.hip.
+//   y = epi(sum_s ws[s] + bias[m] + addend)  over total = B*M*HoWo elements  /  out[i] = sum_s ws[s][i] over n elements
+int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* addend, float* y, int64_t total, int M, int HoWo, int splits,
+                               int epi, hipStream_t st);
+int prn_launch_reduce_splits(const float* ws, float* out, int64_t n, int splits, hipStream_t st);
+int prn_quantise_splits(int64_t tiles, int splits);

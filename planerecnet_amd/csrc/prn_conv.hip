@@ -1068,6 +1068,19 @@ Geo geo_of(const prn_conv_desc* d) {
 
 }  // namespace
 
+int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* addend, float* y, int64_t total, int M, int HoWo, int splits,
+                               int epi, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, ws, bias, addend, y, total, M, HoWo, splits, epi);
+  PRN_CHECK_LAUNCH("reduce_epilogue");
+  return 0;
+}
+int prn_launch_reduce_splits(const float* ws, float* out, int64_t n, int splits, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, splits);
+  PRN_CHECK_LAUNCH("reduce_splits");
+  return 0;
+}
+int prn_quantise_splits(int64_t tiles, int splits) { return quantise_splits(tiles, splits); }
+
 extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
   if (direct_small_m(d) || direct_one_c(d)) return 0;

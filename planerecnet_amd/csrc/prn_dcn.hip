@@ -17,20 +17,39 @@ struct Tap {
   bool pass_y, pass_x;      // clamp passes gradient
 };
 
+// Where the offsets / modulation come from.  raw = 1: `off` is the raw [B,27,Ho,Wo] output of the merged offset|modulator
+// conv (offsets clamped to +-maxoff, modulation 2*sigmoid: models/dcn.py:53-57 folded in).  raw = 0: torchvision semantics,
+// `off` [B,18,Ho,Wo] and `msk` [B,9,Ho,Wo] (or NULL = 1.0) are used as given.
+struct OmView {
+  const float* off; const float* msk;
+  int64_t off_bs, msk_bs;      // elements per image
+  float maxoff;
+  int raw, pad;
+};
+
 // Sampling geometry of torchvision's deform_conv2d (see oracle/dcn_ref.py for the restated rule).
-__device__ __forceinline__ Tap make_tap(const float* __restrict__ om, int b, int k, int ho, int wo, int Ho, int Wo,
-                                        int H, int W, int stride, float maxoff, bool need_grad) {
+__device__ __forceinline__ Tap make_tap(const OmView& v, int b, int k, int ho, int wo, int Ho, int Wo,
+                                        int H, int W, int stride, bool need_grad) {
   Tap t;
   const size_t plane = (size_t)Ho * Wo, pix = (size_t)ho * Wo + wo;
-  const float* ob = om + (size_t)b * 27 * plane;
-  const float ry = ob[(2 * k) * plane + pix], rx = ob[(2 * k + 1) * plane + pix], rm = ob[(18 + k) * plane + pix];
-  const float dy = fminf(fmaxf(ry, -maxoff), maxoff), dx = fminf(fmaxf(rx, -maxoff), maxoff);
-  t.pass_y = (ry >= -maxoff) && (ry <= maxoff);
-  t.pass_x = (rx >= -maxoff) && (rx <= maxoff);
-  t.sig = 1.f / (1.f + expf(-rm));
-  t.mod = 2.f * t.sig;
+  const float* ob = v.off + (size_t)b * v.off_bs;
+  const float ry = ob[(2 * k) * plane + pix], rx = ob[(2 * k + 1) * plane + pix];
+  float dy = ry, dx = rx;
+  t.pass_y = t.pass_x = true;
+  if (v.raw) {
+    const float maxoff = v.maxoff;
+    const float rm = ob[(18 + k) * plane + pix];
+    dy = fminf(fmaxf(ry, -maxoff), maxoff); dx = fminf(fmaxf(rx, -maxoff), maxoff);
+    t.pass_y = (ry >= -maxoff) && (ry <= maxoff);
+    t.pass_x = (rx >= -maxoff) && (rx <= maxoff);
+    t.sig = 1.f / (1.f + expf(-rm));
+    t.mod = 2.f * t.sig;
+  } else {
+    t.sig = 0.f;
+    t.mod = v.msk ? v.msk[(size_t)b * v.msk_bs + (size_t)k * plane + pix] : 1.f;
+  }
   const int ki = k / 3, kj = k - ki * 3;
-  const float y = (float)(ho * stride - 1 + ki) + dy, x = (float)(wo * stride - 1 + kj) + dx;
+  const float y = (float)(ho * stride - v.pad + ki) + dy, x = (float)(wo * stride - v.pad + kj) + dx;
   const bool inside = (y > -1.f) && (y < (float)H) && (x > -1.f) && (x < (float)W);
   const float fy = floorf(y), fx = floorf(x);
   const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
@@ -49,15 +68,15 @@ __device__ __forceinline__ Tap make_tap(const float* __restrict__ om, int b, int
 }
 
 // forward: blockIdx.y splits the channel loop so that the launch has several blocks per CU even on 30x40 maps
-__global__ __launch_bounds__(256) void dcn_sample_kernel(const float* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(256) void dcn_sample_kernel(const float* __restrict__ x, OmView om,
                                                          float* __restrict__ cols, int B, int C, int H, int W, int Ho,
-                                                         int Wo, int stride, float maxoff) {
+                                                         int Wo, int stride) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t plane = (int64_t)Ho * Wo;
   if (gid >= (int64_t)B * 9 * plane) return;
   const int pix = gid % plane, k = (gid / plane) % 9, b = gid / (9 * plane);
   const int ho = pix / Wo, wo = pix - ho * Wo;
-  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, false);
+  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, false);
   const int cper = (C + gridDim.y - 1) / gridDim.y;
   const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
   const size_t HW = (size_t)H * W;
@@ -90,15 +109,15 @@ __global__ __launch_bounds__(256) void dcn_sample_kernel(const float* __restrict
 
 // backward, part 1: gradients of the raw offset / modulator maps. Thread per (b, tap, pixel), channel loop split over
 // blockIdx.y into fixed-order partials (no atomics): part[g][b][27][Ho*Wo].
-__global__ __launch_bounds__(256) void dcn_dom_partial_kernel(const float* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(256) void dcn_dom_partial_kernel(const float* __restrict__ x, OmView om,
                                                               const float* __restrict__ dcols, float* __restrict__ part, int B,
-                                                              int C, int H, int W, int Ho, int Wo, int stride, float maxoff) {
+                                                              int C, int H, int W, int Ho, int Wo, int stride) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t plane = (int64_t)Ho * Wo;
   if (gid >= (int64_t)B * 9 * plane) return;
   const int pix = gid % plane, k = (gid / plane) % 9, b = gid / (9 * plane);
   const int ho = pix / Wo, wo = pix - ho * Wo;
-  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, true);
+  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, true);
   const int cper = (C + gridDim.y - 1) / gridDim.y;
   const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
   const size_t HW = (size_t)H * W;
@@ -137,15 +156,20 @@ __global__ __launch_bounds__(256) void dcn_dom_partial_kernel(const float* __res
   float* ob = part + ((size_t)blockIdx.y * B + b) * 27 * plane + pix;
   ob[(2 * k) * plane] = t.pass_y ? gy * t.mod : 0.f;
   ob[(2 * k + 1) * plane] = t.pass_x ? gx * t.mod : 0.f;
-  ob[(18 + k) * plane] = gm * 2.f * t.sig * (1.f - t.sig);
+  ob[(18 + k) * plane] = om.raw ? gm * 2.f * t.sig * (1.f - t.sig) : gm;      // (raw: through 2*sigmoid; else d-mask itself)
 }
 
-__global__ void dcn_dom_final_kernel(const float* __restrict__ part, float* __restrict__ d_om, int64_t n, int G) {
+// sums the channel-group partials [G][B][27][plane]; d_msk == NULL: one [B,27,plane] tensor, else d_off [B,18,plane] + d_msk [B,9,plane]
+__global__ void dcn_dom_final_kernel(const float* __restrict__ part, float* __restrict__ d_off, float* __restrict__ d_msk, int64_t n, int G,
+                                     int plane) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
   for (int g = 0; g < G; ++g) s += part[(size_t)g * n + i];
-  d_om[i] = s;
+  if (d_msk == nullptr) { d_off[i] = s; return; }
+  const int64_t b = i / (27 * (int64_t)plane), r = i - b * 27 * (int64_t)plane;
+  if (r < 18 * (int64_t)plane) d_off[b * 18 * plane + r] = s;
+  else d_msk[b * 9 * plane + (r - 18 * (int64_t)plane)] = s;
 }
 
 // backward, part 2: d-input as a GATHER.  Every sampling point (b, tap k, output pixel p) spreads its column gradient onto
@@ -161,14 +185,14 @@ __global__ void dcn_dom_final_kernel(const float* __restrict__ part, float* __re
 // torchvision's atomicAdd backward); d_om stays deterministic.
 struct CsrEntry { int src; float w; };
 
-__global__ __launch_bounds__(256) void dcn_csr_count_kernel(const float* __restrict__ om, int* __restrict__ counts, int B, int H, int W,
-                                                            int Ho, int Wo, int stride, float maxoff) {
+__global__ __launch_bounds__(256) void dcn_csr_count_kernel(OmView om, int* __restrict__ counts, int B, int H, int W,
+                                                            int Ho, int Wo, int stride) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int plane = Ho * Wo;
   if (gid >= (int64_t)B * 9 * plane) return;
   const int pix = gid % plane, k = (gid / plane) % 9, b = gid / (9 * plane);
   const int ho = pix / Wo, wo = pix - ho * Wo;
-  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, false);
+  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, false);
   int* cb = counts + (size_t)(b * 9 + k) * H * W;
   if (t.w00 != 0.f) atomicAdd(cb + t.i00, 1);
   if (t.w01 != 0.f) atomicAdd(cb + t.i01, 1);
@@ -223,15 +247,14 @@ __global__ __launch_bounds__(256) void dcn_csr_scan_kernel(int* __restrict__ cou
     if (base + i < n) { starts[base + i] = off; off += c[i]; counts[base + i] = 0; }
 }
 
-__global__ __launch_bounds__(256) void dcn_csr_fill_kernel(const float* __restrict__ om, const int* __restrict__ starts, int* __restrict__ cursor,
-                                                           CsrEntry* __restrict__ entries, int B, int H, int W, int Ho, int Wo, int stride,
-                                                           float maxoff) {
+__global__ __launch_bounds__(256) void dcn_csr_fill_kernel(OmView om, const int* __restrict__ starts, int* __restrict__ cursor,
+                                                           CsrEntry* __restrict__ entries, int B, int H, int W, int Ho, int Wo, int stride) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int plane = Ho * Wo;
   if (gid >= (int64_t)B * 9 * plane) return;
   const int pix = gid % plane, k = (gid / plane) % 9, b = gid / (9 * plane);
   const int ho = pix / Wo, wo = pix - ho * Wo;
-  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, maxoff, false);
+  const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, false);
   const size_t bb = (size_t)(b * 9 + k) * H * W;
   const int src = k * plane + pix;
   auto put = [&](int idx, float w) {
@@ -295,13 +318,27 @@ static int channel_groups(int C, int64_t threads) {
   return g < 1 ? 1 : g;
 }
 
+namespace {
+OmView raw_view(const float* om, int Ho, int Wo, float max_offset) {
+  OmView v;
+  v.off = om; v.msk = nullptr; v.off_bs = v.msk_bs = (int64_t)27 * Ho * Wo; v.maxoff = max_offset; v.raw = 1; v.pad = 1;
+  return v;
+}
+OmView desc_view(const prn_dcn_desc* d, const float* offset, const float* mask) {
+  if (d->raw) { OmView v = raw_view(offset, d->Ho, d->Wo, d->max_offset); v.pad = d->pad; return v; }
+  OmView v;
+  v.off = offset; v.msk = mask; v.off_bs = (int64_t)18 * d->Ho * d->Wo; v.msk_bs = (int64_t)9 * d->Ho * d->Wo; v.maxoff = 0.f; v.raw = 0; v.pad = d->pad;
+  return v;
+}
+}  // namespace
+
 extern "C" int prn_dcn_sample(const float* x, const float* om, float* cols, int B, int C, int H, int W, int Ho, int Wo,
                               int stride, float max_offset, void* stream) {
   PRN_REQUIRE(x && om && cols && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_dcn_sample: bad arguments");
   PRN_REQUIRE(Ho == (H + 2 - 3) / stride + 1 && Wo == (W + 2 - 3) / stride + 1, "prn_dcn_sample: output size mismatch");
   const int64_t n = (int64_t)B * 9 * Ho * Wo;
-  hipLaunchKernelGGL(dcn_sample_kernel, dim3(cdiv(n, 256), channel_groups(C, n)), dim3(256), 0, (hipStream_t)stream, x, om, cols, B, C, H, W, Ho,
-                     Wo, stride, max_offset);
+  hipLaunchKernelGGL(dcn_sample_kernel, dim3(cdiv(n, 256), channel_groups(C, n)), dim3(256), 0, (hipStream_t)stream, x, raw_view(om, Ho, Wo, max_offset),
+                     cols, B, C, H, W, Ho, Wo, stride);
   PRN_CHECK_LAUNCH("prn_dcn_sample");
   return 0;
 }
@@ -321,6 +358,46 @@ BwdWs bwd_ws_layout(int B, int C, int H, int W, int Ho, int Wo) {
   l.total = l.entries + (int64_t)B * 9 * Ho * Wo * 4 * sizeof(CsrEntry);
   return l;
 }
+
+// d_om (or d_offset + d_mask) from the column gradient: fixed-order channel-group partials, then their sum
+int launch_dom(const float* x, const OmView& v, const float* dcols, float* d_off, float* d_msk, char* wsb, const BwdWs& l, int B, int C, int H, int W,
+               int Ho, int Wo, int stride, hipStream_t st) {
+  const int64_t n = (int64_t)B * 9 * Ho * Wo;
+  const int G = channel_groups(C, n);
+  hipLaunchKernelGGL(dcn_dom_partial_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, x, v, dcols, (float*)(wsb + l.part), B, C, H, W, Ho, Wo, stride);
+  PRN_CHECK_LAUNCH("dcn d_om partial");
+  const int64_t nom = (int64_t)B * 27 * Ho * Wo;
+  hipLaunchKernelGGL(dcn_dom_final_kernel, dim3(cdiv(nom, 256)), dim3(256), 0, st, (const float*)(wsb + l.part), d_off, d_msk, nom, G, Ho * Wo);
+  PRN_CHECK_LAUNCH("dcn d_om final");
+  return 0;
+}
+
+// d-input: invert the scatter into CSR bins, then gather
+int launch_dx(const OmView& v, const float* dcols, float* dx, char* wsb, const BwdWs& l, int B, int C, int H, int W, int Ho, int Wo, int stride,
+              hipStream_t st) {
+  const int64_t n = (int64_t)B * 9 * Ho * Wo;
+  int* counts = (int*)(wsb + l.counts);
+  int* starts = (int*)(wsb + l.starts);
+  int* bsum = (int*)(wsb + l.bsum);
+  CsrEntry* entries = (CsrEntry*)(wsb + l.entries);
+  if (hipMemsetAsync(counts, 0, (size_t)l.nbins * 4, st) != hipSuccess) { prn_set_error("dcn d-input: memset failed"); return 1; }
+  hipLaunchKernelGGL(dcn_csr_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, counts, B, H, W, Ho, Wo, stride);
+  hipLaunchKernelGGL(dcn_csr_block_sums_kernel, dim3(l.nblocks), dim3(256), 0, st, (const int*)counts, bsum, l.nbins);
+  hipLaunchKernelGGL(dcn_csr_scan_kernel, dim3(l.nblocks), dim3(256), 0, st, counts, starts, (const int*)bsum, l.nbins);
+  hipLaunchKernelGGL(dcn_csr_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, (const int*)starts, counts, entries, B, H, W, Ho, Wo, stride);
+  PRN_CHECK_LAUNCH("dcn d-input csr");
+  const int HW = H * W;
+  // channels per thread: 8, or 4 when that leaves fewer than ~4 blocks per CU
+  const int64_t blocks8 = (int64_t)cdiv(HW, 256) * cdiv(C, 8) * B;
+  if (blocks8 >= 1024)
+    hipLaunchKernelGGL((dcn_dx_gather_kernel<8>), dim3(cdiv(HW, 256), cdiv(C, 8), B), dim3(256), 0, st, dcols, (const int*)starts, (const int*)counts,
+                       (const CsrEntry*)entries, dx, C, HW, Ho * Wo);
+  else
+    hipLaunchKernelGGL((dcn_dx_gather_kernel<4>), dim3(cdiv(HW, 256), cdiv(C, 4), B), dim3(256), 0, st, dcols, (const int*)starts, (const int*)counts,
+                       (const CsrEntry*)entries, dx, C, HW, Ho * Wo);
+  PRN_CHECK_LAUNCH("dcn d-input gather");
+  return 0;
+}
 }  // namespace
 
 extern "C" int64_t prn_dcn_sample_bwd_ws_bytes(int B, int C, int H, int W, int Ho, int Wo) {
@@ -334,36 +411,67 @@ extern "C" int prn_dcn_sample_bwd(const float* x, const float* om, const float* 
   PRN_REQUIRE((int64_t)B * 9 * H * W < (1LL << 31) && (int64_t)B * 36 * Ho * Wo < (1LL << 31), "prn_dcn_sample_bwd: map too large");
   hipStream_t st = (hipStream_t)stream;
   const BwdWs l = bwd_ws_layout(B, C, H, W, Ho, Wo);
-  char* wsb = (char*)ws;
-  const int64_t n = (int64_t)B * 9 * Ho * Wo;
-  const int G = channel_groups(C, n);
-  hipLaunchKernelGGL(dcn_dom_partial_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, x, om, dcols, (float*)(wsb + l.part), B, C, H, W, Ho, Wo,
-                     stride, max_offset);
-  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/d_om partial");
-  const int64_t nom = (int64_t)B * 27 * Ho * Wo;
-  hipLaunchKernelGGL(dcn_dom_final_kernel, dim3(cdiv(nom, 256)), dim3(256), 0, st, (const float*)(wsb + l.part), d_om, nom, G);
-  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/d_om final");
-  // d-input: invert the scatter into CSR bins, then gather
-  int* counts = (int*)(wsb + l.counts);
-  int* starts = (int*)(wsb + l.starts);
-  int* bsum = (int*)(wsb + l.bsum);
-  CsrEntry* entries = (CsrEntry*)(wsb + l.entries);
-  if (hipMemsetAsync(counts, 0, (size_t)l.nbins * 4, st) != hipSuccess) { prn_set_error("prn_dcn_sample_bwd: memset failed"); return 1; }
-  hipLaunchKernelGGL(dcn_csr_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, om, counts, B, H, W, Ho, Wo, stride, max_offset);
-  hipLaunchKernelGGL(dcn_csr_block_sums_kernel, dim3(l.nblocks), dim3(256), 0, st, (const int*)counts, bsum, l.nbins);
-  hipLaunchKernelGGL(dcn_csr_scan_kernel, dim3(l.nblocks), dim3(256), 0, st, counts, starts, (const int*)bsum, l.nbins);
-  hipLaunchKernelGGL(dcn_csr_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, om, (const int*)starts, counts, entries, B, H, W, Ho, Wo, stride,
-                     max_offset);
-  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/csr");
-  const int HW = H * W;
-  // channels per thread: 8, or 4 when that leaves fewer than ~4 blocks per CU
-  const int64_t blocks8 = (int64_t)cdiv(HW, 256) * cdiv(C, 8) * B;
-  if (blocks8 >= 1024)
-    hipLaunchKernelGGL((dcn_dx_gather_kernel<8>), dim3(cdiv(HW, 256), cdiv(C, 8), B), dim3(256), 0, st, dcols, (const int*)starts, (const int*)counts,
-                       (const CsrEntry*)entries, dx, C, HW, Ho * Wo);
-  else
-    hipLaunchKernelGGL((dcn_dx_gather_kernel<4>), dim3(cdiv(HW, 256), cdiv(C, 4), B), dim3(256), 0, st, dcols, (const int*)starts, (const int*)counts,
-                       (const CsrEntry*)entries, dx, C, HW, Ho * Wo);
-  PRN_CHECK_LAUNCH("prn_dcn_sample_bwd/dx gather");
+  const OmView v = raw_view(om, Ho, Wo, max_offset);
+  if (int e = launch_dom(x, v, dcols, d_om, nullptr, (char*)ws, l, B, C, H, W, Ho, Wo, stride, st)) return e;
+  return launch_dx(v, dcols, dx, (char*)ws, l, B, C, H, W, Ho, Wo, stride, st);
+}
+
+// ---- the data-gradient half of the fused operator (include/prn.h: prn_dcnv2_bwd_input / prn_dcnv2_bwd_offset_mask) ----------
+// Workspace: [ dcols = W^T dy : B * 9C * Ho * Wo floats ][ split-K partials of that GEMM ][ d_om partials + CSR (bwd_ws_layout) ]
+namespace {
+struct DataWs { int64_t dcols, gemm, rest, total; prn_conv_desc g; };
+int data_ws_layout(const prn_dcn_desc* d, DataWs& l) {
+  auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+  prn_conv_desc& g = l.g;                                  // dcols[9C x N] = wt[9C x M] * dy[M x N]: a 1x1 convolution of dy
+  g.B = d->B; g.C = d->M; g.H = d->Ho; g.W = d->Wo; g.M = d->C * 9; g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.Ho = d->Ho; g.Wo = d->Wo;
+  g.in_mode = PRN_IN_ZERO; g.dil = 1; g.epilogue = PRN_EPI_NONE; g.ystride = 0; g.yH = g.yW = 0;
+  const int64_t gb = prn_conv2d_fwd_ws_bytes(&g);
+  if (gb < 0) return 2;
+  if ((int64_t)d->B * 9 * d->H * d->W >= (1LL << 31) || (int64_t)d->B * 36 * d->Ho * d->Wo >= (1LL << 31)) { prn_set_error("prn_dcnv2_bwd: map too large"); return 2; }
+  l.dcols = 0;
+  l.gemm = up((int64_t)d->B * d->C * 9 * d->Ho * d->Wo * 4);
+  l.rest = l.gemm + up(gb);
+  l.total = l.rest + bwd_ws_layout(d->B, d->C, d->H, d->W, d->Ho, d->Wo).total;
   return 0;
+}
+int check_dcn_desc(const prn_dcn_desc* d, const char* who) {
+  PRN_REQUIRE(d != nullptr && d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->M > 0 && d->Ho > 0 && d->Wo > 0 && d->stride > 0 && d->pad >= 0,
+              "%s: bad descriptor", who);
+  PRN_REQUIRE(d->Ho == (d->H + 2 * d->pad - 3) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - 3) / d->stride + 1, "%s: output size mismatch", who);
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t prn_dcnv2_bwd_ws_bytes(const prn_dcn_desc* d) {
+  if (check_dcn_desc(d, "prn_dcnv2_bwd_ws_bytes")) return -1;
+  DataWs l;
+  if (data_ws_layout(d, l)) return -1;
+  return l.total;
+}
+
+extern "C" int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
+                                   void* stream) {
+  if (int e = check_dcn_desc(d, "prn_dcnv2_bwd_input")) return e;
+  PRN_REQUIRE(dy && wt && offset && ws, "prn_dcnv2_bwd_input: null tensor");
+  DataWs l;
+  if (int e = data_ws_layout(d, l)) return e;
+  char* wsb = (char*)ws;
+  if (int e = prn_conv2d_fwd(&l.g, dy, wt, nullptr, nullptr, (float*)(wsb + l.dcols), wsb + l.gemm, stream)) return e;
+  if (dx == nullptr) return 0;                             // (column gradient only: the caller just wants prn_dcnv2_bwd_offset_mask)
+  const BwdWs bl = bwd_ws_layout(d->B, d->C, d->H, d->W, d->Ho, d->Wo);
+  return launch_dx(desc_view(d, offset, mask), (const float*)(wsb + l.dcols), dx, wsb + l.rest, bl, d->B, d->C, d->H, d->W, d->Ho, d->Wo, d->stride,
+                   (hipStream_t)stream);
+}
+
+extern "C" int prn_dcnv2_bwd_offset_mask(const prn_dcn_desc* d, const float* x, const float* offset, const float* mask, float* d_offset, float* d_mask,
+                                         void* ws, void* stream) {
+  if (int e = check_dcn_desc(d, "prn_dcnv2_bwd_offset_mask")) return e;
+  PRN_REQUIRE(x && offset && d_offset && ws, "prn_dcnv2_bwd_offset_mask: null tensor");
+  PRN_REQUIRE(d->raw || d_mask != nullptr, "prn_dcnv2_bwd_offset_mask: d_mask required unless the descriptor is raw (then d_offset is the [B,27,Ho,Wo] gradient)");
+  DataWs l;
+  if (int e = data_ws_layout(d, l)) return e;
+  char* wsb = (char*)ws;
+  const BwdWs bl = bwd_ws_layout(d->B, d->C, d->H, d->W, d->Ho, d->Wo);
+  return launch_dom(x, desc_view(d, offset, mask), (const float*)(wsb + l.dcols), d_offset, d->raw ? nullptr : d_mask, wsb + l.rest, bl, d->B, d->C, d->H,
+                    d->W, d->Ho, d->Wo, d->stride, (hipStream_t)stream);
 }

@@ -1,0 +1,563 @@
+// DCNv2 (modulated deformable 3x3 convolution) as ONE operator on gfx950: the bilinear 4-corner gather of
+// torchvision.ops.deform_conv2d is the operand loader of the MFMA contraction -- no column tensor exists in HBM.
+//
+//   table   : one small launch turns (offset, mask) into a per-(output pixel, tap) gather table: four byte offsets into
+//             the image's channel-0 plane (0x80000000 = corner outside the image -> the buffer range check returns 0.0
+//             without a memory access) and four weights (mask * bilinear weight).  32 B per entry, 9 entries per pixel.
+//   forward : Y[M x N] = W[M x 9C] * cols[9C x N] with cols[(c,t), n] = sum_q wt[t,n,q] * x[c, off[t,n,q]] evaluated while
+//             the K slice is staged into LDS: the workgroup keeps the table rows of its 64 pixels in LDS (18 KB), the channel
+//             offset is a scalar (soffset), so an operand element costs one ds_read_b128 (offsets), four buffer_load_dword,
+//             one ds_read_b128 (weights) and four FMAs -- VALU / TA work that runs beside the fp32 MFMA pipe (64 cycles
+//             per v_mfma_f32_32x32x2_f32, i.e. 32 VALU issue slots).
+//   d-weight: dW[M x 9C] = dY[M x N] * cols^T: the same gather in the weight-gradient GEMM's operand loader; the table
+//             rows of a 16-pixel chunk (4.6 KB) are staged two chunks ahead, the gathers one chunk ahead of the MFMA loop.
+//   d-input / d-offset / d-mask: the column GRADIENT  W^T dY  [9C x N] is still materialised once (transient workspace):
+//             evaluating it twice (once per consumer) would cost a second 2*M*9C*N GEMM on a 157 TFLOP/s fp32 pipe, i.e.
+//             ~110 us for 256 ch @ 30x40, against ~50 us for writing + re-reading the 88 MB tensor.
+#include <stdlib.h>
+#include <type_traits>
+#include "prn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+  return make_float4(q.x, q.y, q.z, q.w);
+}
+
+// ------------------------------------------------------------------------------------------------ gather table
+// Layout (float4 units): tab[((chunk * 9 + t) * 2 + s) * 16 + p], chunk = n / 16, p = n % 16, s = 0: corner byte offsets
+// (as uint bit patterns), s = 1: corner weights.  One 16-pixel chunk is 4608 contiguous bytes (what the weight-gradient
+// kernel stages per step); the forward kernel's 64-pixel tile is four consecutive chunks.  Pixels up to the next multiple
+// of 64 exist in the table and read as "all corners outside".
+constexpr int TAB_CHUNK4 = 9 * 2 * 16;       // float4 per chunk
+
+struct TabArgs {
+  const float* off; const float* msk; float4* tab;
+  int B, C, H, W, Ho, Wo, stride, pad, raw;
+  int64_t off_bs, msk_bs;     // elements per image in offset / mask (raw: both 27 * Ho * Wo)
+  float maxoff;
+  int N, Npad;
+};
+
+__global__ __launch_bounds__(256) void dcnv2_table_kernel(TabArgs a) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= a.Npad * 9) return;
+  const int p = gid & 15, t = (gid >> 4) % 9, chunk = gid / 144;
+  const int n = chunk * 16 + p;
+  uint4 o = make_uint4(OOB, OOB, OOB, OOB);
+  float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < a.N) {
+    const int plane = a.Ho * a.Wo;
+    const int b = n / plane, pix = n - b * plane, ho = pix / a.Wo, wo = pix - ho * a.Wo;
+    const float* ob = a.off + (size_t)b * a.off_bs;
+    float dy = ob[(size_t)(2 * t) * plane + pix], dx = ob[(size_t)(2 * t + 1) * plane + pix];
+    float mod = 1.f;
+    if (a.raw) {                                           // models/dcn.py:53-57: clamp(+-max_offset), 2 * sigmoid
+      dy = fminf(fmaxf(dy, -a.maxoff), a.maxoff);
+      dx = fminf(fmaxf(dx, -a.maxoff), a.maxoff);
+      mod = 2.f / (1.f + expf(-ob[(size_t)(18 + t) * plane + pix]));
+    } else if (a.msk) {
+      mod = a.msk[(size_t)b * a.msk_bs + (size_t)t * plane + pix];
+    }
+    const int ki = t / 3, kj = t - ki * 3;
+    const float y = (float)(ho * a.stride - a.pad + ki) + dy, x = (float)(wo * a.stride - a.pad + kj) + dx;
+    const bool inside = (y > -1.f) && (y < (float)a.H) && (x > -1.f) && (x < (float)a.W);
+    const float fy = floorf(y), fx = floorf(x);
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+    const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const bool vy0 = inside && y0 >= 0, vy1 = inside && y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
+    const unsigned base = (unsigned)b * (unsigned)a.C * (unsigned)(a.H * a.W);
+    if (vy0 && vx0) { o.x = (base + (unsigned)(y0 * a.W + x0)) * 4u; w.x = mod * hy * hx; }
+    if (vy0 && vx1) { o.y = (base + (unsigned)(y0 * a.W + x1)) * 4u; w.y = mod * hy * lx; }
+    if (vy1 && vx0) { o.z = (base + (unsigned)(y1 * a.W + x0)) * 4u; w.z = mod * ly * hx; }
+    if (vy1 && vx1) { o.w = (base + (unsigned)(y1 * a.W + x1)) * 4u; w.w = mod * ly * lx; }
+  }
+  const size_t e = ((size_t)(chunk * 9 + t) * 2) * 16 + p;
+  a.tab[e] = make_float4(__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w));
+  a.tab[e + 16] = w;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct FwdArgs {
+  const float* x; const float* w; const float* bias; const float4* tab; float* y; float* ws;
+  int B, C, HW, M, K, N, HoWo;
+  int tilesM, nblocks, splits, epi;
+  int xbytes, wbytes;
+};
+
+// Tile (64 * TM) x 64 output channels x pixels, 256 threads = 2 x 2 waves, each wave TM/… see below; K slices of 16, LDS
+// double buffered, next slice's loads in flight during the MFMA loop (same schedule as conv_igemm_kernel in prn_conv.hip).
+// WGM = waves along M: 2 (wave tile 32*TM x 32) for TM <= 2; TM = 4 keeps the 2 x 2 grid as well (wave tile 128 x 32).
+template <int TM, bool K4>
+__global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_fwd_kernel(FwdArgs a) {
+  constexpr int BM = 64 * TM, BN = 64, BK = 16, LDA = BK + 1;
+  constexpr int NB = 4;            // gathered operand elements per thread per K slice: K rows krow0 + 4 * i
+  constexpr int NA = TM;           // float4 weight groups per thread per K slice: rows arow + 64 * i
+  __shared__ float As[2][BM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+  __shared__ uint4 toff[9 * BN];
+  __shared__ float4 twt[9 * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
+  const int m0 = (id % a.tilesM) * BM, n0 = (id / a.tilesM) * BN;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), wr = make_rsrc(a.w, a.wbytes);
+
+  {  // table rows of this tile's 64 pixels: four chunks, contiguous in HBM; LDS layout [tap][pixel] (16-byte lanes: the
+     // ds_read_b128 of 16 consecutive lanes covers all 64 banks)
+    const float4* tg = a.tab + (size_t)(n0 >> 4) * TAB_CHUNK4;
+    for (int i = tid; i < 4 * TAB_CHUNK4; i += 256) {
+      const int cl = i / TAB_CHUNK4, r = i - cl * TAB_CHUNK4, t = r >> 5, s = (r >> 4) & 1, p = r & 15;
+      const float4 v = tg[i];
+      if (s) twt[t * BN + cl * 16 + p] = v;
+      else toff[t * BN + cl * 16 + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+    }
+    __syncthreads();
+  }
+
+  const int nl = tid & 63;
+  const int krow0 = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform K row inside a sweep
+  const int arow = tid >> 2, akq = (tid & 3) * 4;
+  unsigned abase[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + arow + 64 * i;
+    abase[i] = (m < a.M) ? (unsigned)(m * a.K + akq) * 4u : OOB;
+  }
+
+  float ra[NA][4];
+  float g[NB][4];
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto load_tile = [&](int k0) {
+    const int k = k0 + akq;
+    if (K4) {
+      const unsigned tail = k < a.K ? 0u : OOB;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const float4 v = bload4(wr, abase[i] | tail, k0 * 4);
+        ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[i][j] = bload(wr, (k + j < a.K) ? abase[i] + 4u * j : OOB, k0 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int kr = k0 + krow0 + 4 * i;                   // wave-uniform: channel and tap are scalars
+      const int c = kr / 9, t = kr - c * 9;
+      const uint4 o = toff[t * BN + nl];
+      const unsigned dead = kr < a.K ? 0u : OOB;
+      const int so = c * a.HW * 4;
+      g[i][0] = bload(xr, o.x | dead, so);
+      g[i][1] = bload(xr, o.y | dead, so);
+      g[i][2] = bload(xr, o.z | dead, so);
+      g[i][3] = bload(xr, o.w | dead, so);
+    }
+  };
+  auto store_tile = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[buf][(arow + 64 * i) * LDA + akq + j] = ra[i][j];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int kr = k0 + krow0 + 4 * i;
+      const int c = kr / 9, t = kr - c * 9;
+      const float4 wq = twt[t * BN + nl];
+      Bs[buf][(krow0 + 4 * i) * BN + nl] = (wq.x * g[i][0] + wq.y * g[i][1]) + (wq.z * g[i][2] + wq.w * g[i][3]);
+    }
+  };
+  auto mma_tile = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float av[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + kk * 2 + (lane >> 5)];
+      const float bv = Bs[buf][(kk * 2 + (lane >> 5)) * BN + wn * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+    }
+  };
+  const int KTall = (a.K + BK - 1) / BK;
+  const int kt0 = (int)((int64_t)blockIdx.y * KTall / a.splits), KT = (int)((int64_t)(blockIdx.y + 1) * KTall / a.splits);
+  load_tile(kt0 * BK);
+  store_tile(kt0 & 1, kt0 * BK);
+  __syncthreads();
+  for (int kt = kt0; kt + 1 < KT; ++kt) {
+    load_tile((kt + 1) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile((kt + 1) & 1, (kt + 1) * BK);
+    __syncthreads();
+  }
+  mma_tile((KT - 1) & 1);
+
+  // epilogue (C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+  const bool partial = a.splits > 1;
+  float* __restrict__ outp = partial ? a.ws + (size_t)blockIdx.y * a.B * a.M * a.HoWo : a.y;
+  const bool has_bias = !partial && a.bias != nullptr;
+  const int epi = partial ? PRN_EPI_NONE : a.epi;
+  const int nn = n0 + wn * 32 + (lane & 31);
+  if (nn < a.N) {
+    const int bb = nn / a.HoWo, p = nn - bb * a.HoWo;
+    const size_t base = (size_t)bb * a.M * a.HoWo + p;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m >= a.M) continue;
+        float v = acc[i][r];
+        if (has_bias) v += a.bias[m];
+        if (epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+        outp[base + (size_t)m * a.HoWo] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgArgs {
+  const float* x; const float* dy; const float4* tab; float* out;
+  int B, C, HW, M, K, N, HoWo;
+  int tilesM, tilesJ, splits, chunks;
+  int xbytes, dybytes, tabbytes;
+};
+
+// dW tile (64 * TM) x 64 (output channels x (c, tap) columns), reduction over 16-pixel chunks; thread (nl = tid & 15,
+// jrow = tid >> 4) samples columns jrow + 16 * i of pixel nl.  Three-stage software pipeline per chunk ch:
+//   table rows of chunk ch + 2: HBM -> registers (start of the step) -> LDS (end of the step)
+//   corner gathers + dY rows of chunk ch + 1: issued at the start of the step from the LDS table written one step earlier,
+//                                             interpolated and stored to LDS after the MFMA loop
+//   MFMA loop on chunk ch.
+template <int TM, bool N4>
+__global__ __launch_bounds__(256, (TM == 1 ? 4 : 3)) void dcnv2_wgrad_kernel(WgArgs a) {
+  constexpr int BM = 64 * TM, BJ = 64, LD = 17, NBJ = 4;
+  __shared__ float As[2][BM * LD];
+  __shared__ float Bs[2][BJ * LD];
+  __shared__ uint4 toff[2][9 * 16];
+  __shared__ float4 twt[2][9 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wj = wave & 1;
+  const int m0 = (blockIdx.x % a.tilesM) * BM, j0 = (blockIdx.x / a.tilesM) * BJ;
+  const int split = blockIdx.y;
+  const int cbeg = (int)((int64_t)split * a.chunks / a.splits), cend = (int)((int64_t)(split + 1) * a.chunks / a.splits);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), dyr = make_rsrc(a.dy, a.dybytes), tr = make_rsrc(a.tab, a.tabbytes);
+  const int arow = tid >> 2, anq = (tid & 3) * 4;
+  const int nl = tid & 15, jrow = tid >> 4;
+  unsigned jcoff[NBJ];              // channel byte offset (or OOB for columns beyond K)
+  int jt[NBJ];                      // tap
+#pragma unroll
+  for (int i = 0; i < NBJ; ++i) {
+    const int j = j0 + jrow + 16 * i;
+    const int c = j / 9;
+    jt[i] = j - c * 9;
+    jcoff[i] = j < a.K ? (unsigned)(c * a.HW) * 4u : OOB;
+  }
+  bool mok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) mok[i] = m0 + arow + 64 * i < a.M;
+
+  float ra[TM][4], rb[NBJ][4];
+  float4 rt0, rt1;
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  int a_b, a_p;                     // dY cursor: image and pixel of this thread's 4-pixel group
+  {
+    const int n = cbeg * 16 + anq;
+    a_b = n / a.HoWo; a_p = n - a_b * a.HoWo;
+  }
+  auto load_table = [&](int ch) {                          // -> registers; chunks past the range read as zeros (never used)
+    const unsigned ok = ch < cend ? 0u : OOB;
+    rt0 = bload4(tr, ((unsigned)tid * 16u) | ok, ch * (TAB_CHUNK4 * 16));
+    rt1 = bload4(tr, (tid < TAB_CHUNK4 - 256 ? (unsigned)(tid + 256) * 16u : OOB) | ok, ch * (TAB_CHUNK4 * 16));
+  };
+  auto write_table = [&](int tb) {
+    auto put = [&](int r, float4 v) {
+      const int t = r >> 5, s = (r >> 4) & 1, p = r & 15;
+      if (s) twt[tb][t * 16 + p] = v;
+      else toff[tb][t * 16 + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+    };
+    put(tid, rt0);
+    if (tid < TAB_CHUNK4 - 256) put(tid + 256, rt1);
+  };
+  auto load_chunk = [&](int ch, int tb) {
+    {  // dY rows: 4 consecutive pixels of one output channel
+      const int n = ch * 16 + anq;
+      if (N4) {
+        const bool ok = n < a.N;
+        const unsigned base = (unsigned)((a_b * a.M + m0 + arow) * a.HoWo + a_p) * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float4 v = bload4(dyr, (ok && mok[i]) ? base : OOB, i * 64 * a.HoWo * 4);
+          ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+        }
+      } else {
+        int qb = a_b, qp = a_p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = n + q < a.N;
+          const unsigned base = (unsigned)((qb * a.M + m0 + arow) * a.HoWo + qp) * 4u;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ra[i][q] = bload(dyr, (ok && mok[i]) ? base : OOB, i * 64 * a.HoWo * 4);
+          if (++qp >= a.HoWo) { qp = 0; ++qb; }
+        }
+      }
+      a_p += 16;
+      while (a_p >= a.HoWo) { a_p -= a.HoWo; ++a_b; }
+    }
+#pragma unroll
+    for (int i = 0; i < NBJ; ++i) {                        // sampled columns: four corners each
+      const uint4 o = toff[tb][jt[i] * 16 + nl];
+      rb[i][0] = bload(xr, o.x + jcoff[i], 0);             // (OOB + channel offset stays >= 2^31: both are < 2^31)
+      rb[i][1] = bload(xr, o.y + jcoff[i], 0);
+      rb[i][2] = bload(xr, o.z + jcoff[i], 0);
+      rb[i][3] = bload(xr, o.w + jcoff[i], 0);
+    }
+  };
+  auto store_chunk = [&](int buf, int tb) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) As[buf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
+#pragma unroll
+    for (int i = 0; i < NBJ; ++i) {
+      const float4 wq = twt[tb][jt[i] * 16 + nl];
+      Bs[buf][(jrow + 16 * i) * LD + nl] = (wq.x * rb[i][0] + wq.y * rb[i][1]) + (wq.z * rb[i][2] + wq.w * rb[i][3]);
+    }
+  };
+  auto mma_chunk = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float av[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + kk * 2 + (lane >> 5)];
+      const float bv = Bs[buf][(wj * 32 + (lane & 31)) * LD + kk * 2 + (lane >> 5)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+    }
+  };
+
+  if (cbeg < cend) {
+    load_table(cbeg);
+    write_table(0);
+    load_table(cbeg + 1);
+    write_table(1);
+    __syncthreads();
+    load_chunk(cbeg, 0);
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int ch = cbeg; ch + 1 < cend; ++ch) {
+      const int q = (ch - cbeg) & 1;                        // LDS buffers of chunk ch: As/Bs[q], table[q]
+      load_chunk(ch + 1, q ^ 1);
+      load_table(ch + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk(q);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(q ^ 1, q ^ 1);
+      write_table(q);                                      // chunk ch's table rows were last read by the previous step's store
+      __syncthreads();
+    }
+    mma_chunk((cend - 1 - cbeg) & 1);
+  }
+
+  float* out = a.out + (size_t)split * a.M * a.K;
+  const int jj = j0 + wj * 32 + (lane & 31);
+  if (jj < a.K) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M) out[(size_t)m * a.K + jj] = acc[i][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int check_dcn(const prn_dcn_desc* d, const char* who) {
+  PRN_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  PRN_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->M > 0 && d->Ho > 0 && d->Wo > 0 && d->stride > 0 && d->pad >= 0, "%s: empty dimension", who);
+  PRN_REQUIRE(d->Ho == (d->H + 2 * d->pad - 3) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - 3) / d->stride + 1,
+              "%s: output size %dx%d does not match a 3x3 kernel with stride %d pad %d on %dx%d", who, d->Ho, d->Wo, d->stride, d->pad, d->H, d->W);
+  PRN_REQUIRE((int64_t)d->B * d->C * d->H * d->W < (1LL << 29) && (int64_t)d->B * d->M * d->Ho * d->Wo < (1LL << 29) &&
+              ((int64_t)d->M + 256) * d->C * 9 < (1LL << 29) && (int64_t)d->B * d->Ho * d->Wo * 9 * 32 < (1LL << 31),
+              "%s: tensor larger than a buffer descriptor", who);
+  return 0;
+}
+inline int npad(const prn_dcn_desc* d) { return cdiv((int64_t)d->B * d->Ho * d->Wo, 64) * 64; }
+
+struct FPlan { int tm, splits; };
+FPlan plan_dcn_fwd(int M, int N, int K) {
+  static int forced[2] = {-1, 0};                        // PRN_DCN_FWD="tm,splits" (tuning sweeps)
+  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_FWD")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  FPlan p;
+  const int kt = cdiv(K, 16);
+  if (forced[0] > 0) { p.tm = forced[0]; p.splits = forced[1] > 0 ? forced[1] : 1; }
+  else {
+    // Every output-channel tile gathers the SAME operand again, so the tallest tile that still fills the GPU wins:
+    // candidates (tile height, K splits) are scored by how evenly tiles * splits spreads over 256 CUs x resident workgroups.
+    double best = -1.0;
+    p.tm = 1; p.splits = 1;
+    const int tms[3] = {4, 2, 1}, res[3] = {2, 3, 4};
+    for (int q = 0; q < 3; ++q) {
+      const int tm = tms[q];
+      if (tm > 1 && M <= 32 * tm) continue;
+      const int64_t tiles = (int64_t)cdiv(M, 64 * tm) * cdiv(N, 64);
+      for (int s = 1; s <= 8; ++s) {
+        if (s > 1 && kt / s < 8) break;
+        const double waves = (double)(tiles * s) / (256.0 * res[q]);
+        double eff = waves / (double)((int64_t)(waves + 0.999999));
+        if (waves < 1.0) eff = waves;
+        const double score = eff * (1.0 - 0.03 * (s - 1)) * (tm == 4 ? 1.04 : (tm == 2 ? 1.02 : 1.0));
+        if (score > best + 1e-9) { best = score; p.tm = tm; p.splits = s; }
+      }
+    }
+  }
+  if (p.splits > kt) p.splits = kt;
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+struct WPlan { int tm, tilesM, tilesJ, splits, chunks; };
+WPlan plan_dcn_wgrad(int M, int K, int N) {
+  static int forced[2] = {-1, 0};                        // PRN_DCN_WGRAD="tm,splits"
+  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_WGRAD")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  WPlan p;
+  p.tm = (forced[0] > 0) ? forced[0] : (M > 64 ? 2 : 1);
+  p.tilesM = cdiv(M, 64 * p.tm);
+  p.tilesJ = cdiv(K, 64);
+  p.chunks = cdiv(N, 16);
+  const int tiles = p.tilesM * p.tilesJ;
+  const int slots = 256 * (p.tm == 1 ? 4 : 3);
+  int s = tiles < slots ? 2 * slots / tiles : 1;
+  int cap = p.chunks / 8 > 0 ? p.chunks / 8 : 1;          // at least 128 pixels per split
+  const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;   // workspace round trip stays small
+  if (sbw < cap) cap = sbw;
+  if (cap > 256) cap = 256;
+  if (s > cap) s = prn_quantise_splits(tiles, cap);
+  if (forced[0] > 0 && forced[1] > 0) s = forced[1] < p.chunks ? forced[1] : p.chunks;
+  p.splits = s < 1 ? 1 : s;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int64_t prn_dcnv2_table_bytes(const prn_dcn_desc* d) {
+  if (check_dcn(d, "prn_dcnv2_table_bytes")) return -1;
+  return (int64_t)npad(d) * 9 * 32;
+}
+
+extern "C" int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const float* mask, void* table, void* stream) {
+  if (int e = check_dcn(d, "prn_dcnv2_table")) return e;
+  PRN_REQUIRE(offset && table, "prn_dcnv2_table: null tensor");
+  TabArgs a;
+  a.off = offset; a.msk = d->raw ? nullptr : mask; a.tab = (float4*)table;
+  a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.stride = d->stride; a.pad = d->pad; a.raw = d->raw;
+  const int64_t plane = (int64_t)d->Ho * d->Wo;
+  a.off_bs = (d->raw ? 27 : 18) * plane; a.msk_bs = 9 * plane;
+  a.maxoff = d->max_offset;
+  a.N = d->B * d->Ho * d->Wo; a.Npad = npad(d);
+  hipLaunchKernelGGL(dcnv2_table_kernel, dim3(cdiv((int64_t)a.Npad * 9, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  PRN_CHECK_LAUNCH("prn_dcnv2_table");
+  return 0;
+}
+
+extern "C" int64_t prn_dcnv2_fwd_ws_bytes(const prn_dcn_desc* d) {
+  if (check_dcn(d, "prn_dcnv2_fwd_ws_bytes")) return -1;
+  const FPlan p = plan_dcn_fwd(d->M, d->B * d->Ho * d->Wo, d->C * 9);
+  return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
+}
+
+extern "C" int prn_dcnv2_fwd_phase(const prn_dcn_desc* d, const float* x, const void* table, const float* w, const float* bias, float* y, void* ws,
+                                   void* stream, int phase) {
+  if (int e = check_dcn(d, "prn_dcnv2_fwd")) return e;
+  PRN_REQUIRE(x && table && w && y, "prn_dcnv2_fwd: null tensor");
+  FwdArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.tab = (const float4*)table; a.y = y; a.ws = (float*)ws;
+  a.B = d->B; a.C = d->C; a.HW = d->H * d->W; a.M = d->M; a.K = d->C * 9; a.HoWo = d->Ho * d->Wo; a.N = d->B * a.HoWo;
+  a.epi = d->epilogue;
+  a.xbytes = d->B * d->C * a.HW * 4; a.wbytes = d->M * a.K * 4;
+  const FPlan p = plan_dcn_fwd(a.M, a.N, a.K);
+  PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_dcnv2_fwd: workspace required (%d K splits, see prn_dcnv2_fwd_ws_bytes)", p.splits);
+  a.tilesM = cdiv(a.M, 64 * p.tm); a.nblocks = a.tilesM * cdiv(a.N, 64); a.splits = p.splits;
+  hipStream_t st = (hipStream_t)stream;
+  if (phase != 2) {
+    const dim3 grid(a.nblocks, p.splits), block(256);
+    const bool k4 = (a.K & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+#define PRN_DCN_FWD(TM_) do { if (k4) hipLaunchKernelGGL((dcnv2_fwd_kernel<TM_, true>), grid, block, 0, st, a); \
+                              else hipLaunchKernelGGL((dcnv2_fwd_kernel<TM_, false>), grid, block, 0, st, a); } while (0)
+    if (p.tm == 4) PRN_DCN_FWD(4); else if (p.tm == 2) PRN_DCN_FWD(2); else PRN_DCN_FWD(1);
+#undef PRN_DCN_FWD
+    PRN_CHECK_LAUNCH("prn_dcnv2_fwd");
+  }
+  if (phase != 1 && p.splits > 1)
+    return prn_launch_reduce_epilogue((const float*)ws, bias, nullptr, y, (int64_t)a.B * a.M * a.HoWo, a.M, a.HoWo, p.splits, a.epi, st);
+  return 0;
+}
+
+extern "C" int prn_dcnv2_fwd(const prn_dcn_desc* d, const float* x, const void* table, const float* w, const float* bias, float* y, void* ws,
+                             void* stream) {
+  return prn_dcnv2_fwd_phase(d, x, table, w, bias, y, ws, stream, 0);
+}
+
+extern "C" int64_t prn_dcnv2_bwd_weight_ws_bytes(const prn_dcn_desc* d) {
+  if (check_dcn(d, "prn_dcnv2_bwd_weight_ws_bytes")) return -1;
+  const WPlan p = plan_dcn_wgrad(d->M, d->C * 9, d->B * d->Ho * d->Wo);
+  return p.splits > 1 ? (int64_t)p.splits * d->M * d->C * 9 * 4 : 0;
+}
+
+extern "C" int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream,
+                                          int phase) {
+  if (int e = check_dcn(d, "prn_dcnv2_bwd_weight")) return e;
+  PRN_REQUIRE(x && table && dy && dw, "prn_dcnv2_bwd_weight: null tensor");
+  WgArgs a;
+  a.x = x; a.dy = dy; a.tab = (const float4*)table;
+  a.B = d->B; a.C = d->C; a.HW = d->H * d->W; a.M = d->M; a.K = d->C * 9; a.HoWo = d->Ho * d->Wo; a.N = d->B * a.HoWo;
+  a.xbytes = d->B * d->C * a.HW * 4; a.dybytes = d->B * d->M * a.HoWo * 4; a.tabbytes = (int)((int64_t)npad(d) * 9 * 32);
+  const WPlan p = plan_dcn_wgrad(a.M, a.K, a.N);
+  a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
+  PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_dcnv2_bwd_weight: workspace required (%d splits)", p.splits);
+  a.out = p.splits > 1 ? (float*)ws : dw;
+  hipStream_t st = (hipStream_t)stream;
+  if (phase != 2) {
+    const dim3 grid(p.tilesM * p.tilesJ, p.splits), block(256);
+    const bool n4 = (a.HoWo & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+#define PRN_DCN_WG(TM_) do { if (n4) hipLaunchKernelGGL((dcnv2_wgrad_kernel<TM_, true>), grid, block, 0, st, a); \
+                             else hipLaunchKernelGGL((dcnv2_wgrad_kernel<TM_, false>), grid, block, 0, st, a); } while (0)
+    if (p.tm == 2) PRN_DCN_WG(2); else PRN_DCN_WG(1);
+#undef PRN_DCN_WG
+    PRN_CHECK_LAUNCH("prn_dcnv2_bwd_weight");
+  }
+  if (phase != 1 && p.splits > 1) return prn_launch_reduce_splits((const float*)ws, dw, (int64_t)a.M * a.K, p.splits, st);
+  return 0;
+}
+
+extern "C" int prn_dcnv2_bwd_weight(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream) {
+  return prn_dcnv2_bwd_weight_phase(d, x, table, dy, dw, ws, stream, 0);
+}

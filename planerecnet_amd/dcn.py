@@ -4,7 +4,9 @@ Same parameters / state-dict keys as the reference module (`offset_conv`, `modul
 zero-initialised offset and modulator convs, dcn.py:32-43).  Forward differs in *how* it is computed, not
 in what: the 18-channel offset conv and the 9-channel modulator conv read the same input with the same
 geometry, so they run as ONE 27-channel implicit-GEMM launch; the clamp(+-max(h,w)/4) and 2*sigmoid are
-folded into the sampling kernel (prn_dcn_sample), whose output feeds the MFMA contraction.
+folded into the gather table of the fused operator (prn_dcnv2_table), and the bilinear sampling is the operand loader of
+the MFMA contraction (prn_dcnv2_fwd) -- no column tensor.  `ops.deform_conv2d` is the drop-in for the reference's
+`torchvision.ops.deform_conv2d` call (same signature); `forward_reference_form` below calls it exactly as dcn.py:52-67 does.
 """
 import torch
 from torch import nn
@@ -34,5 +36,15 @@ class DeformableConv2d(nn.Module):
             from .backbone import folded_bn
             wf, bf = folded_bn(self.regular_conv.weight, self.regular_conv.bias, fold)
             om = ops.conv2d(x, w27, b27, stride=self.stride, pad=1)
-            return ops.deform_conv2d(x, om, wf, bf, self.stride, max(h, w) / 4.0, relu=True)
+            return ops.deform_conv2d_raw_relu(x, om, wf, bf, self.stride, max(h, w) / 4.0)
         return ops.deform_conv_block(x, w27, b27, self.regular_conv.weight, self.regular_conv.bias, self.stride, max(h, w) / 4.0)
+
+    def forward_reference_form(self, x):
+        """The reference's forward, statement by statement (models/dcn.py:52-67), on the drop-in operator: three separate
+        ops with the torchvision call signature.  Same result as forward(); kept as the binding example and parity check."""
+        h, w = x.shape[2:]
+        max_offset = max(h, w) / 4.0
+        offset = ops.conv2d(x, self.offset_conv.weight, self.offset_conv.bias, stride=self.stride, pad=1).clamp(-max_offset, max_offset)
+        modulator = 2.0 * torch.sigmoid(ops.conv2d(x, self.modulator_conv.weight, self.modulator_conv.bias, stride=self.stride, pad=1))
+        return ops.deform_conv2d(input=x, offset=offset, weight=self.regular_conv.weight, bias=self.regular_conv.bias,
+                                 padding=self.padding, mask=modulator, stride=self.stride)

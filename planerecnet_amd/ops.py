@@ -638,61 +638,165 @@ def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
-_DCN_WS = {}
+# One operator (include/prn.h: prn_dcnv2_*): the bilinear sampler is the operand loader of the MFMA contraction in the
+# forward pass and in the weight gradient; no [B, 9*Cin, Ho, Wo] column tensor exists.  The column GRADIENT W^T dy is the
+# one transient intermediate of the backward pass (it feeds both d-input and d-offset / d-mask).
+_DCN = {}          # geometry key -> (DcnDesc, byref, table bytes, fwd ws bytes, wgrad ws bytes, data-gradient ws bytes)
 
 
-def _dcn_ws_bytes(B, C, H, W, Ho, Wo):
-    key = (B, C, H, W, Ho, Wo)
-    n = _DCN_WS.get(key)
-    if n is None:
-        n = lib.prn_dcn_sample_bwd_ws_bytes(B, C, H, W, Ho, Wo)
-        if n < 0:
-            raise RuntimeError("prn_dcn_sample_bwd_ws_bytes: map too large")
-        _DCN_WS[key] = n
-    return n
+def _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset, epi=EPI_NONE):
+    key = (B, C, H, W, M, stride, pad, raw, float(max_offset), epi)
+    e = _DCN.get(key)
+    if e is None:
+        Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+        d = _lib.DcnDesc(B, C, H, W, M, stride, pad, Ho, Wo, int(raw), float(max_offset), epi)
+        ref = ctypes.byref(d)
+        sizes = [lib.prn_dcnv2_table_bytes(ref), lib.prn_dcnv2_fwd_ws_bytes(ref), lib.prn_dcnv2_bwd_weight_ws_bytes(ref), lib.prn_dcnv2_bwd_ws_bytes(ref)]
+        if min(sizes) < 0:
+            raise RuntimeError(lib.prn_last_error().decode())
+        e = _DCN[key] = (d, ref, sizes[0], sizes[1], sizes[2], sizes[3])
+    return e
+
+
+def _f32(nbytes, dev):
+    return torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+
+
+def dcn_table(x_shape, M, offset, mask, stride, pad, raw, max_offset):
+    """(offset, mask) -> gather table of the fused operator (include/prn.h: prn_dcnv2_table)."""
+    B, C, H, W = x_shape
+    _, ref, tb, _, _, _ = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset)
+    table = _f32(tb, offset.device)
+    check(lib.prn_dcnv2_table(ref, _p(offset), _p(mask), _p(table), _stream()), "prn_dcnv2_table")
+    return table
+
+
+def dcn_fwd_raw(x, table, w, bias, stride, pad, raw, max_offset, epi=EPI_NONE):
+    B, C, H, W = x.shape
+    M = w.shape[0]
+    d, ref, _, fb, _, _ = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset, epi)
+    y = torch.empty(B, M, d.Ho, d.Wo, device=x.device, dtype=torch.float32)
+    ws = _f32(fb, x.device) if fb else None
+    if profiling._enabled:
+        with profiling.span("dcnv2_fwd_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo):
+            check(lib.prn_dcnv2_fwd_phase(ref, _p(x), _p(table), _p(w), _p(bias), _p(y), _p(ws), _stream(), 1), "prn_dcnv2_fwd")
+        if fb:
+            with profiling.span("reduce_epilogue_kernel", "hbm", float(fb) + 4.0 * y.numel()):
+                check(lib.prn_dcnv2_fwd_phase(ref, _p(x), _p(table), _p(w), _p(bias), _p(y), _p(ws), _stream(), 2), "prn_dcnv2_fwd")
+    else:
+        check(lib.prn_dcnv2_fwd(ref, _p(x), _p(table), _p(w), _p(bias), _p(y), _p(ws), _stream()), "prn_dcnv2_fwd")
+    return y
+
+
+def dcn_wgrad_raw(x, table, dy, M, stride, pad, raw, max_offset):
+    B, C, H, W = x.shape
+    _, ref, _, _, wb, _ = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset)
+    dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
+    ws = _f32(wb, x.device) if wb else None
+    if profiling._enabled:
+        with profiling.span("dcnv2_wgrad_kernel", "mfma", 2.0 * M * C * 9 * dy.shape[0] * dy.shape[2] * dy.shape[3]):
+            check(lib.prn_dcnv2_bwd_weight_phase(ref, _p(x), _p(table), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_dcnv2_bwd_weight")
+        if wb:
+            with profiling.span("reduce_splits_kernel", "hbm", float(wb) + 4.0 * dw.numel()):
+                check(lib.prn_dcnv2_bwd_weight_phase(ref, _p(x), _p(table), _p(dy), _p(dw), _p(ws), _stream(), 2), "prn_dcnv2_bwd_weight")
+    else:
+        check(lib.prn_dcnv2_bwd_weight(ref, _p(x), _p(table), _p(dy), _p(dw), _p(ws), _stream()), "prn_dcnv2_bwd_weight")
+    return dw
+
+
+def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, need_x=True, need_om=True):
+    """-> (dx, d_offset, d_mask): the column gradient W^T dy goes to the head of one workspace (1x1 MFMA GEMM), d-input is
+    gathered from it through the per-call CSR inversion of the sampling pattern, d-offset / d-mask are reduced from it."""
+    B, C, H, W = x.shape
+    M = w.shape[0]
+    d, ref, _, _, _, db = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset)
+    wt = flip_transpose(w.view(M, C * 9, 1, 1))                   # [9C, M, 1, 1]
+    ws = _f32(db, x.device)
+    dx = torch.empty_like(x) if need_x else None
+    ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
+    if profiling._enabled:
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo):
+            check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), None, _p(ws), _stream()), "prn_dcnv2_bwd_input")
+        if need_x:                                                  # (re-issues the GEMM: profiling runs only)
+            with profiling.span("dcnv2_bwd_input", "hbm", ncols + 8.0 * x.numel()):
+                check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream()), "prn_dcnv2_bwd_input")
+    else:
+        check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream()), "prn_dcnv2_bwd_input")
+    d_off = d_msk = None
+    if need_om:
+        d_off = torch.empty_like(offset)
+        d_msk = torch.empty_like(mask) if (mask is not None and not raw) else None
+        if not raw and mask is None:                                # (no modulation given: its gradient is computed and dropped)
+            d_msk_tmp = torch.empty(B, 9, d.Ho, d.Wo, device=x.device, dtype=torch.float32)
+        else:
+            d_msk_tmp = d_msk
+        with profiling.span("dcnv2_bwd_offset_mask", "hbm", ncols + 4.0 * x.numel() + 8.0 * offset.numel()):
+            check(lib.prn_dcnv2_bwd_offset_mask(ref, _p(x), _p(offset), _p(mask), _p(d_off), _p(d_msk_tmp), _p(ws), _stream()), "prn_dcnv2_bwd_offset_mask")
+    return dx, d_off, d_msk
 
 
 class _DeformConv(torch.autograd.Function):
+    """torchvision.ops.deform_conv2d(input, offset, weight, bias, stride, padding, mask=mask) (models/dcn.py:59-66)."""
+
     @staticmethod
-    def forward(ctx, x, om, w, bias, stride, max_offset):
-        _dev(x, om, w, bias)
-        x, om, w, bias = _c(x), _c(om), _c(w), _c(bias)
-        B, C, H, W = x.shape
-        M = w.shape[0]
-        Ho, Wo = om.shape[2:]
-        assert om.shape[1] == 27 and w.shape[2] == 3
-        cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
-        with profiling.span("dcn_sample_kernel", "hbm", 4.0 * (x.numel() + om.numel() + cols.numel())):
-            check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
-        y = conv_fwd_raw(cols, w, bias, None, M, 1, 1, 0, Ho, Wo)
-        ctx.save_for_backward(x, om, w, cols)
-        ctx.cfg = (stride, float(max_offset), bias is not None)
+    def forward(ctx, x, offset, weight, bias, mask, stride, pad):
+        _dev(x, offset, weight, bias, mask)
+        x, offset, weight, bias, mask = _c(x), _c(offset), _c(weight), _c(bias), _c(mask)
+        M = weight.shape[0]
+        table = dcn_table(x.shape, M, offset, mask, stride, pad, 0, 0.0)
+        y = dcn_fwd_raw(x, table, weight, bias, stride, pad, 0, 0.0)
+        ctx.save_for_backward(x, offset, mask, weight, table)
+        ctx.cfg = (stride, pad, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, om, w, cols = ctx.saved_tensors
-        stride, max_offset, has_bias = ctx.cfg
+        x, offset, mask, w, table = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
         dy = _c(dy)
-        B, C, H, W = x.shape
         M = w.shape[0]
-        Ho, Wo = om.shape[2:]
-        w1 = w.view(M, C * 9, 1, 1)
-        dcols = conv_dgrad_raw(dy, w1, cols.shape, 1, 0, IN_ZERO)
-        dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[2] else None
-        db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[3]) else None
-        dx = torch.empty_like(x)
-        dom = torch.empty_like(om)
-        ws = torch.empty(_dcn_ws_bytes(B, C, H, W, Ho, Wo) // 4, device=x.device, dtype=torch.float32)
-        with profiling.span("dcn_sample_bwd_kernel", "hbm", 4.0 * (2 * x.numel() + 2 * om.numel() + dcols.numel())):
-            check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx), _p(dom), _p(ws), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
-                  "prn_dcn_sample_bwd")
-        return dx, dom, dw, db, None, None
+        ni = ctx.needs_input_grad
+        dx = d_off = d_msk = dw = db = None
+        if ni[0] or ni[1] or ni[4]:
+            dx, d_off, d_msk = dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, 0, 0.0, need_x=ni[0], need_om=ni[1] or ni[4])
+        if _defer(ni[2], w):
+            _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0))
+        elif ni[2]:
+            dw = dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0)
+        if has_bias and ni[3]:
+            db = channel_sum(dy)
+        return dx, d_off, dw, db, d_msk, None, None
+
+
+def _pair(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2 or v[0] != v[1]:
+            raise NotImplementedError("deform_conv2d: symmetric stride / padding / dilation only (got %r)" % (v,))
+        return int(v[0])
+    return int(v)
+
+
+def deform_conv2d(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask=None):
+    """Drop-in for `torchvision.ops.deform_conv2d` -- same signature, argument meaning and return value -- for what the
+    reference uses (models/dcn.py:59-66): 3x3 kernel, groups = offset groups = 1, dilation 1, symmetric stride / padding.
+    offset [B, 18, Ho, Wo] (channel 2k = dy, 2k+1 = dx of tap k), mask [B, 9, Ho, Wo] or None, weight [M, C, 3, 3]."""
+    if _pair(dilation) != 1:
+        raise NotImplementedError("deform_conv2d: dilation 1 only")
+    if tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != input.shape[1]:
+        raise NotImplementedError("deform_conv2d: 3x3 kernels with groups = 1 only (weight %s, input %s)" % (tuple(weight.shape), tuple(input.shape)))
+    s, p = _pair(stride), _pair(padding)
+    B, _, H, W = input.shape
+    Ho, Wo = (H + 2 * p - 3) // s + 1, (W + 2 * p - 3) // s + 1
+    if tuple(offset.shape) != (B, 18, Ho, Wo) or (mask is not None and tuple(mask.shape) != (B, 9, Ho, Wo)):
+        raise RuntimeError("deform_conv2d: offset %s / mask %s do not match [%d, 18|9, %d, %d] (one offset group)"
+                           % (tuple(offset.shape), None if mask is None else tuple(mask.shape), B, Ho, Wo))
+    return _DeformConv.apply(input, offset, weight, bias, mask, s, p)
 
 
 class _DeformConvBlock(torch.autograd.Function):
-    """27-channel offset/modulator conv + DCNv2 as one node: x feeds both, so its two gradients (through the sampler and
-    through the offset conv) are summed in the offset conv's input-gradient epilogue."""
+    """models/dcn.py:52-67 as one node: 27-channel offset|modulator conv + DCNv2 on its RAW output (clamp and 2*sigmoid
+    folded into the gather table).  x feeds both, so its two gradients (through the sampler and through the offset conv) are
+    summed in the offset conv's input-gradient epilogue."""
 
     @staticmethod
     def forward(ctx, x, w27, b27, w, bias, stride, max_offset):
@@ -702,61 +806,46 @@ class _DeformConvBlock(torch.autograd.Function):
         M = w.shape[0]
         Ho, Wo = _out_hw(H, W, 3, stride, 1, IN_ZERO)
         om = conv_fwd_raw(x, w27, b27, None, 27, 3, stride, 1, Ho, Wo)
-        cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
-        with profiling.span("dcn_sample_kernel", "hbm", 4.0 * (x.numel() + om.numel() + cols.numel())):
-            check(lib.prn_dcn_sample(_p(x), _p(om), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
-        y = conv_fwd_raw(cols, w, bias, None, M, 1, 1, 0, Ho, Wo)
-        ctx.save_for_backward(x, om, w27, w, cols)
+        table = dcn_table(x.shape, M, om, None, stride, 1, 1, max_offset)
+        y = dcn_fwd_raw(x, table, w, bias, stride, 1, 1, max_offset)
+        ctx.save_for_backward(x, om, w27, w, table)
         ctx.cfg = (stride, float(max_offset), bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, om, w27, w, cols = ctx.saved_tensors
+        x, om, w27, w, table = ctx.saved_tensors
         stride, max_offset, has_bias = ctx.cfg
         dy = _c(dy)
-        B, C, H, W = x.shape
         M = w.shape[0]
-        Ho, Wo = om.shape[2:]
-        w1 = w.view(M, C * 9, 1, 1)
-        dcols = conv_dgrad_raw(dy, w1, cols.shape, 1, 0, IN_ZERO)
-        if _defer(ctx.needs_input_grad[3], w):
-            _deferred_wgrad(w, (cols, dy), lambda: conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO))
+        ni = ctx.needs_input_grad
+        dx1, dom, _ = dcn_data_grads_raw(x, om, None, w, dy, stride, 1, 1, max_offset)
+        if _defer(ni[3], w):
+            _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset))
             dw = None
         else:
-            dw = conv_wgrad_raw(cols, dy, M, 1, 1, 0, IN_ZERO).view_as(w) if ctx.needs_input_grad[3] else None
-        db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[4]) else None
-        dx1 = torch.empty_like(x)
-        dom = torch.empty_like(om)
-        ws = torch.empty(_dcn_ws_bytes(B, C, H, W, Ho, Wo) // 4, device=x.device, dtype=torch.float32)
-        with profiling.span("dcn_sample_bwd_kernel", "hbm", 4.0 * (2 * x.numel() + 2 * om.numel() + dcols.numel())):
-            check(lib.prn_dcn_sample_bwd(_p(x), _p(om), _p(dcols), _p(dx1), _p(dom), _p(ws), B, C, H, W, Ho, Wo, stride, max_offset, _stream()),
-                  "prn_dcn_sample_bwd")
-        dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if ctx.needs_input_grad[1] else None
-        db27 = channel_sum(dom) if ctx.needs_input_grad[2] else None
-        dx = conv_dgrad_raw(dom, w27, x.shape, stride, 1, IN_ZERO, dx1) if ctx.needs_input_grad[0] else None
+            dw = dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset) if ni[3] else None
+        db = channel_sum(dy) if (has_bias and ni[4]) else None
+        dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if ni[1] else None
+        db27 = channel_sum(dom) if ni[2] else None
+        dx = conv_dgrad_raw(dom, w27, x.shape, stride, 1, IN_ZERO, dx1) if ni[0] else None
         return dx, dw27, db27, dw, db, None, None
 
 
 def deform_conv_block(x, w27, b27, weight, bias, stride, max_offset):
-    """models/dcn.py:52-67 in one node: om = conv3x3(x; [offset | modulator] weights), y = deform_conv2d(x, om, weight)."""
+    """models/dcn.py:52-67 in one node: om = conv3x3(x; [offset | modulator] weights), y = deform_conv2d(x, clamp(om[:18]), weight,
+    mask = 2 * sigmoid(om[18:]))."""
     return _DeformConvBlock.apply(x, w27, b27, weight, bias, stride, max_offset)
 
 
-def deform_conv2d(x, om_raw, weight, bias, stride, max_offset, relu=False):
-    """torchvision.ops.deform_conv2d replacement with the wrapper's clamp / 2*sigmoid folded in
-    (reference models/dcn.py:52-67). om_raw = raw [offset(18) | modulator(9)] conv output.
-    relu=True (inference only, no autograd): ReLU in the contraction's epilogue (BatchNorm folded into weight / bias)."""
-    if relu:
-        assert not torch.is_grad_enabled()
-        x, om_raw, weight, bias = _c(x), _c(om_raw), _c(weight), _c(bias)
-        _dev(x, om_raw, weight, bias)
-        B, C, H, W = x.shape
-        Ho, Wo = om_raw.shape[2:]
-        cols = torch.empty(B, C * 9, Ho, Wo, device=x.device, dtype=torch.float32)
-        check(lib.prn_dcn_sample(_p(x), _p(om_raw), _p(cols), B, C, H, W, Ho, Wo, stride, float(max_offset), _stream()), "prn_dcn_sample")
-        return conv_fwd_raw(cols, weight, bias, None, weight.shape[0], 1, 1, 0, Ho, Wo, epi=EPI_RELU)
-    return _DeformConv.apply(x, om_raw, weight, bias, stride, max_offset)
+def deform_conv2d_raw_relu(x, om_raw, weight, bias, stride, max_offset):
+    """Inference only (no autograd): DCNv2 on the raw offset|modulator map with ReLU in the contraction's epilogue (the
+    caller folded the eval-mode BatchNorm into weight / bias)."""
+    assert not torch.is_grad_enabled()
+    x, om_raw, weight, bias = _c(x), _c(om_raw), _c(weight), _c(bias)
+    _dev(x, om_raw, weight, bias)
+    table = dcn_table(x.shape, weight.shape[0], om_raw, None, stride, 1, 1, max_offset)
+    return dcn_fwd_raw(x, table, weight, bias, stride, 1, 1, max_offset, EPI_RELU)
 
 
 # ------------------------------------------------------------------------------------------ BatchNorm

@@ -1,0 +1,136 @@
+"""Golden-vector generator for BASELINE config 3 (PlaneRecNet_101 train step) -- runs ONLY in the build container
+(needs /root/reference).
+
+    python tests/golden/make_golden_r101.py
+
+PlaneRecNet_101_config (ResNet-101, 23-block stage with DCN at blocks 0,3,...,21: models/backbone.py:170,184,
+data/config.py:232), training-mode BatchNorm, 480x640, B=2, seeded weights (oracle/synth.py, non-zero DCN offsets):
+
+1. the real reference (shim-imported, CPU fp32): forward, five loss terms, backward -> parameter gradients;
+2. the oracle restatement in fp32: asserted equal to the reference (losses 1e-4, outputs 5e-5, gradients 1e-3 rel-L2:
+   same arithmetic in a different op order);
+3. the oracle in fp64: the per-parameter SPREAD |g32 - g64| / |g64| of the oracle itself, which is what the GPU test
+   (tests/test_r101_train_gpu.py) scales its per-parameter gradient bound with.
+
+Writes tests/golden/e2e_r101_480x640.npz: reference losses, output digests, per-parameter gradient digests of the
+reference, fp64-oracle gradient norms and the fp32-vs-fp64 spreads.  Inputs / weights are regenerated from seeds.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import ref_shim, synth, model_ref, loss_ref  # noqa: E402
+
+CN = "PlaneRecNet_101_config"
+B, H, W = 2, 480, 640
+SEED_W, SEED_X, SEED_NP = 3, 12, 13
+
+
+def digest(t, n=64, seed=123):
+    t = t.detach().double().flatten()
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, t.numel(), (n,), generator=g)
+    return np.concatenate([[t.mean().item(), t.std().item() if t.numel() > 1 else 0.0, t.abs().sum().item(), float(t.numel())], t[idx].numpy()])
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def oracle_step(sd, x, inst, gtd, dtype):
+    arch = model_ref.ARCH[CN]
+    sdg = {k: (v.to(dtype).clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
+               (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
+    names = [k for k, v in sdg.items() if v.requires_grad]
+    np.random.seed(SEED_NP)
+    out = model_ref.forward(sdg, x.to(dtype), arch, training=True)
+    ls = loss_ref.joint_loss(*out, inst, gtd)          # GT stays fp32 (GT-only thresholds / target assignment are the reference's)
+    grads = torch.autograd.grad(sum(ls.values()).sum(), [sdg[n] for n in names], allow_unused=True)
+    return out, ls, dict(zip(names, grads))
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = ref_shim.load_reference(CN)
+    cfg = ref["config"].cfg
+    net = ref["planerecnet"].PlaneRecNet(cfg)
+    sd = synth.make_state_dict(CN, seed=SEED_W)
+    net.load_state_dict(sd)
+    net.train()
+    crit = ref["losses"].PlaneRecNetLoss()
+    x, inst, gtd = synth.make_batch(B, H, W, seed=SEED_X)
+
+    t0 = time.time()
+    np.random.seed(SEED_NP)
+    out = net(x)
+    rl = crit(net, *out, inst, gtd)
+    net.zero_grad()
+    sum(rl.values()).sum().backward()
+    rgrads = {n: p.grad for n, p in net.named_parameters()}
+    print("reference step: %.1f s" % (time.time() - t0), {k: float(v) for k, v in rl.items()})
+
+    t0 = time.time()
+    o32, l32, g32 = oracle_step(sd, x, inst, gtd, torch.float32)
+    print("oracle fp32 step: %.1f s" % (time.time() - t0), {k: float(v) for k, v in l32.items()})
+    for k in rl:
+        assert abs(float(rl[k]) - float(l32[k])) <= 1e-4 * max(1.0, abs(float(rl[k]))), k
+    for a, b, w in ((o32[0], out[0], "mask"), (o32[3], out[3], "depth")):
+        e = ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+        print("oracle vs reference", w, "%.1e" % e)
+        assert e < 5e-5, (w, e)
+    # Conv biases that feed a training-mode BatchNorm have a structurally ZERO gradient (the batch mean removes any constant):
+    # DCN regular_conv.bias (backbone.py:32,44) and the depth decoder's conv / latlayer biases under its BN layers.  What
+    # autograd returns for them is rounding noise (|g| ~ 1e-8), so they are listed and compared by magnitude, not by rel-L2.
+    worst, zero = [], []
+    for n, g in rgrads.items():
+        assert (g is None) == (g32[n] is None), n
+        if g is None:
+            continue
+        if g.norm().item() < 1e-5 and n.endswith(".bias"):
+            zero.append(n)
+            assert g32[n].norm().item() < 1e-5, n
+        else:
+            worst.append((rel_l2(g32[n], g), n, g.norm().item()))
+    worst.sort(reverse=True)
+    print("oracle fp32 vs reference gradients over %d parameters (%d structurally zero); largest rel-L2:" % (len(rgrads), len(zero)))
+    for w in worst[:8]:
+        print("   %.2e  %-60s |g| %.3e" % w)
+    assert worst[0][0] < 1e-3, worst[0]
+
+    t0 = time.time()
+    o64, l64, g64 = oracle_step(sd, x, inst, gtd, torch.float64)
+    print("oracle fp64 step: %.1f s" % (time.time() - t0), {k: float(v) for k, v in l64.items()})
+
+    fix = {k: np.asarray(v.detach().double()) for k, v in rl.items()}
+    for k in l64:
+        fix["fp64_" + k] = np.asarray(l64[k].detach().double())
+    fix["mask_digest"] = digest(out[0], 512)
+    fix["depth_digest"] = digest(out[3], 512)
+    for i in range(4):
+        fix[f"cate{i}_digest"] = digest(out[1][i], 256)
+        fix[f"kern{i}_digest"] = digest(out[2][i], 256)
+    names = sorted(n for n, g in rgrads.items() if g is not None)
+    fix["grad_names"] = np.array(names)
+    fix["grad_structurally_zero"] = np.array(sorted(zero))
+    fix["grad_ref_digest"] = np.stack([digest(rgrads[n]) for n in names])
+    fix["grad_fp64_norm"] = np.array([g64[n].norm().item() for n in names])
+    fix["grad_spread_ref_vs_fp64"] = np.array([rel_l2(rgrads[n], g64[n]) for n in names])
+    fix["grad_spread_oracle32_vs_fp64"] = np.array([rel_l2(g32[n], g64[n]) for n in names])
+    sp = np.maximum(fix["grad_spread_ref_vs_fp64"], fix["grad_spread_oracle32_vs_fp64"])
+    order = np.argsort(-sp)
+    print("fp32-vs-fp64 gradient spread: median %.1e, max %.1e" % (np.median(sp), sp.max()))
+    for i in order[:12]:
+        print("   %-60s %.2e" % (names[i], sp[i]))
+    np.savez_compressed(os.path.join(HERE, "e2e_r101_480x640.npz"), **fix)
+    print("written", os.path.join(HERE, "e2e_r101_480x640.npz"))
+
+
+if __name__ == "__main__":
+    main()

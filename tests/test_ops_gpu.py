@@ -176,30 +176,73 @@ def test_conv2d_is_transpose_safe():
     assert torch.equal(y.cpu(), x[:, perm])
 
 
-@pytest.mark.parametrize("B,C,H,W,M,stride", [(2, 16, 12, 15, 24, 1), (2, 32, 13, 16, 32, 2), (1, 128, 30, 40, 128, 1)])
-def test_deform_conv_fwd_bwd(B, C, H, W, M, stride):
+# toy shapes (tails in every GEMM dimension, C % 4 != 0, pad != 1, no mask) + the five call shapes of the network
+# (Cin = Cout, 3x3, pad 1) at B = 2
+DCN_CASES = [(2, 16, 12, 15, 24, 1, 1, True), (2, 32, 13, 16, 32, 2, 1, True), (1, 6, 9, 11, 5, 1, 0, True), (2, 20, 10, 12, 70, 1, 2, False),
+             (2, 128, 120, 160, 128, 2, 1, True), (2, 128, 60, 80, 128, 1, 1, True), (2, 256, 60, 80, 256, 2, 1, True),
+             (2, 256, 30, 40, 256, 1, 1, True), (2, 512, 30, 40, 512, 2, 1, True)]
+
+
+@pytest.mark.parametrize("B,C,H,W,M,stride,pad,with_mask", DCN_CASES)
+def test_deform_conv2d_torchvision_signature_fwd_bwd(B, C, H, W, M, stride, pad, with_mask):
+    """ops.deform_conv2d(input, offset, weight, bias, stride, padding, mask=...) -- the call of models/dcn.py:59-66 -- against
+    the fp64 oracle: output and all five gradients (input, offset, weight, bias, mask)."""
     from planerecnet_amd import ops
     from oracle.dcn_ref import deform_conv2d_ref
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    maxoff = max(H, W) / 4.0
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     x = rnd(B, C, H, W, seed=1).requires_grad_(True)
-    om = rnd(B, 27, Ho, Wo, seed=2, scale=1.7)
-    om[:, :18] += 0.137                      # keep sampling points off the integer kinks
-    om[0, 3, 0, 0] = 50.0                    # force the clamp branch
-    om[0, 4, 1, 1] = -50.0
-    om = om.requires_grad_(True)
+    off = rnd(B, 18, Ho, Wo, seed=2, scale=1.7) + 0.137       # keep sampling points off the integer kinks
+    off[0, 3, 0, 0] = 50.0                                     # far outside the image: contributes zero
+    off[0, 4, 1, 1] = -50.0
+    off = off.requires_grad_(True)
+    msk = (2 * torch.sigmoid(rnd(B, 9, Ho, Wo, seed=6))).requires_grad_(True) if with_mask else None
     w = rnd(M, C, 3, 3, seed=3, scale=(9 * C) ** -0.5).requires_grad_(True)
     b = rnd(M, seed=4).requires_grad_(True)
-    yr = deform_conv2d_ref(x, om[:, :18].clamp(-maxoff, maxoff), 2 * torch.sigmoid(om[:, 18:]), w, b, stride, 1)
+    yr = deform_conv2d_ref(x, off, msk, w, b, stride, pad)
     go = rnd(*yr.shape, seed=5)
-    gr = torch.autograd.grad(yr, [x, om, w, b], go)
+    leaves = [x, off, w, b] + ([msk] if with_mask else [])
+    gr = torch.autograd.grad(yr, leaves, go)
     d = dev()
-    xs = [t.detach().float().to(d).requires_grad_(True) for t in (x, om, w, b)]
-    yd = ops.deform_conv2d(xs[0], xs[1], xs[2], xs[3], stride, maxoff)
-    close(yd, yr, "dcn fwd")
+    xs = [t.detach().float().to(d).requires_grad_(True) for t in leaves]
+    yd = ops.deform_conv2d(xs[0], xs[1], xs[2], xs[3], stride=(stride, stride), padding=(pad, pad), mask=xs[4] if with_mask else None)
+    close(yd, yr, "dcn fwd")                                   # 2e-4 of the tensor max (the tolerance of every conv test)
     gd = torch.autograd.grad(yd, xs, go.float().to(d))
-    for n, g1, g0 in zip(["dx", "d_om", "dw", "db"], gd, gr):
+    for n, g1, g0 in zip(["dx", "d_offset", "dw", "db", "d_mask"], gd, gr):
         close(g1, g0, "dcn " + n, rtol=5e-4)
+
+
+def test_deform_conv2d_rejects_what_the_path_does_not_cover():
+    from planerecnet_amd import ops
+    d = dev()
+    x, w = torch.zeros(1, 4, 8, 8, device=d), torch.zeros(4, 4, 3, 3, device=d)
+    with pytest.raises(NotImplementedError):
+        ops.deform_conv2d(x, torch.zeros(1, 18, 8, 8, device=d), w, padding=1, dilation=2)
+    with pytest.raises(NotImplementedError):
+        ops.deform_conv2d(x, torch.zeros(1, 50, 8, 8, device=d), torch.zeros(4, 4, 5, 5, device=d), padding=2)
+    with pytest.raises(RuntimeError):
+        ops.deform_conv2d(x, torch.zeros(1, 36, 8, 8, device=d), w, padding=1)          # two offset groups
+
+
+def test_dcn_module_reference_form_equals_fused_block():
+    """DeformableConv2d.forward (27-channel conv + raw-map operator) == the reference's statement sequence on the drop-in
+    operator (dcn.py:52-67: clamp, 2*sigmoid, deform_conv2d(input=, offset=, weight=, bias=, padding=, mask=, stride=))."""
+    from planerecnet_amd.dcn import DeformableConv2d
+    d = dev()
+    torch.manual_seed(0)
+    m = DeformableConv2d(32, 48, 3, stride=2, padding=1, bias=True)
+    with torch.no_grad():
+        m.offset_conv.weight.normal_(0, 0.05); m.offset_conv.bias.normal_(0, 0.3)
+        m.modulator_conv.weight.normal_(0, 0.05); m.modulator_conv.bias.normal_(0, 0.3)
+    m = m.to(d)
+    x = rnd(2, 32, 19, 23, seed=1).float().to(d).requires_grad_(True)
+    go = rnd(2, 48, 10, 12, seed=2).float().to(d)
+    ya = m(x)
+    ga = torch.autograd.grad(ya, [x] + list(m.parameters()), go)
+    yb = m.forward_reference_form(x)
+    gb = torch.autograd.grad(yb, [x] + list(m.parameters()), go)
+    close(ya, yb, "module forms fwd", rtol=2e-5)
+    for a, b_ in zip(ga, gb):
+        close(a, b_, "module forms grad", rtol=2e-4)
 
 
 @pytest.mark.parametrize("stride", [1, 2])
@@ -309,8 +352,8 @@ def test_deform_conv_zero_offsets_equals_conv():
     d = dev()
     x = rnd(2, 24, 11, 13, seed=1).float()
     w = rnd(20, 24, 3, 3, seed=2, scale=0.1).float()
-    om = torch.zeros(2, 27, 11, 13)         # offset 0, modulator 2*sigmoid(0) = 1
-    y = ops.deform_conv2d(x.to(d), om.to(d), w.to(d), None, 1, 3.0)
+    off = torch.zeros(2, 18, 11, 13)        # offset 0, no mask
+    y = ops.deform_conv2d(x.to(d), off.to(d), w.to(d), None, stride=1, padding=1)
     close(y, F.conv2d(x.double(), w.double(), padding=1), "dcn(0) == conv")
 
 

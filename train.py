@@ -141,12 +141,18 @@ def main():
     if args.reproductablity:
         for seed_fn in (random.seed, np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all):
             seed_fn(0)
+    if os.environ.get("PRN_ONE_DEVICE"):                   # validation aid: N ranks time-share GPU 0 (with PRN_DIST_BACKEND=gloo; RCCL
+        local = 0                                          # refuses two ranks on one device) -- exercises the N > 1 code path on a 1-GPU box
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg.device = str(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("PRN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     torch.set_num_threads(4)
 
     from planerecnet_amd import ops, timer
@@ -363,6 +369,14 @@ def main():
     if rank == 0:
         prn_net.save_weights(save_path(epoch, iteration))
     if world > 1:
+        # replica consistency: every rank applied the same all-reduced gradients to the same initial weights, so the
+        # parameters must still agree bit for bit (the reference's DataParallel re-broadcasts rank 0's copy every step instead)
+        chk = torch.stack([p.detach().double().sum() for p in prn_net.parameters()]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print("Replica check over %d ranks: parameter checksum spread %.3e (%s)" % (world, float(hi - lo), "identical" if float(hi - lo) == 0.0 else "DIVERGED"))
         dist.destroy_process_group()
 
 
