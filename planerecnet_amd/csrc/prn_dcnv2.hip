@@ -30,14 +30,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int b
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  const f32x2 q = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+  return make_float2(q.x, q.y);
+}
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
   return make_float4(q.x, q.y, q.z, q.w);
 }
 
 // ------------------------------------------------------------------------------------------------ gather table
-// Layout (float4 units): tab[((chunk * 9 + t) * 2 + s) * 16 + p], chunk = n / 16, p = n % 16, s = 0: corner byte offsets
-// (as uint bit patterns), s = 1: corner weights.  One 16-pixel chunk is 4608 contiguous bytes (what the weight-gradient
+// Layout (float4 units): tab[((chunk * 9 + t) * 2 + s) * 16 + p], chunk = n / 16, p = n % 16, s = 0: byte offsets of the two
+// row pairs (as uint bit patterns in .x / .y; .z / .w unused), s = 1: the four slot weights (row 0 left / right, row 1 left / right).  One 16-pixel chunk is 4608 contiguous bytes (what the weight-gradient
 // kernel stages per step); the forward kernel's 64-pixel tile is four consecutive chunks.  Pixels up to the next multiple
 // of 64 exist in the table and read as "all corners outside".
 constexpr int TAB_CHUNK4 = 9 * 2 * 16;       // float4 per chunk
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void dcnv2_table_kernel(TabArgs a) {
   if (gid >= a.Npad * 9) return;
   const int p = gid & 15, t = (gid >> 4) % 9, chunk = gid / 144;
   const int n = chunk * 16 + p;
-  uint4 o = make_uint4(OOB, OOB, OOB, OOB);
+  uint4 o = make_uint4(OOB, OOB, 0u, 0u);
   float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < a.N) {
     const int plane = a.Ho * a.Wo;
@@ -77,11 +82,15 @@ __global__ __launch_bounds__(256) void dcnv2_table_kernel(TabArgs a) {
     const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
     const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
     const bool vy0 = inside && y0 >= 0, vy1 = inside && y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
+    // The two corners of a row are neighbours in memory: ONE 8-byte load per row fetches the pixel pair (xb, xb + 1) with
+    // xb = clamp(x0, 0, W - 2), always inside the row.  The weights are stored per loaded SLOT: at the left / right image
+    // border the valid corner moves to the other slot and the slot that holds a pixel the sample does not use gets 0.
+    const int xb = x0 < 0 ? 0 : (x0 > a.W - 2 ? (a.W - 2 > 0 ? a.W - 2 : 0) : x0);
+    const float wl = (vx0 && x0 == xb) ? hx : ((vx1 && x1 == xb) ? lx : 0.f);            // weight of pixel xb
+    const float wr = (vx1 && x1 == xb + 1) ? lx : ((vx0 && x0 == xb + 1) ? hx : 0.f);    // weight of pixel xb + 1
     const unsigned base = (unsigned)b * (unsigned)a.C * (unsigned)(a.H * a.W);
-    if (vy0 && vx0) { o.x = (base + (unsigned)(y0 * a.W + x0)) * 4u; w.x = mod * hy * hx; }
-    if (vy0 && vx1) { o.y = (base + (unsigned)(y0 * a.W + x1)) * 4u; w.y = mod * hy * lx; }
-    if (vy1 && vx0) { o.z = (base + (unsigned)(y1 * a.W + x0)) * 4u; w.z = mod * ly * hx; }
-    if (vy1 && vx1) { o.w = (base + (unsigned)(y1 * a.W + x1)) * 4u; w.w = mod * ly * lx; }
+    if (vy0) { o.x = (base + (unsigned)(y0 * a.W + xb)) * 4u; w.x = mod * hy * wl; w.y = mod * hy * wr; }
+    if (vy1) { o.y = (base + (unsigned)(y1 * a.W + xb)) * 4u; w.z = mod * ly * wl; w.w = mod * ly * wr; }
   }
   const size_t e = ((size_t)(chunk * 9 + t) * 2) * 16 + p;
   a.tab[e] = make_float4(__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w));
@@ -99,14 +108,16 @@ struct FwdArgs {
 // Tile (64 * TM) x 64 output channels x pixels, 256 threads = 2 x 2 waves, each wave TM/… see below; K slices of 16, LDS
 // double buffered, next slice's loads in flight during the MFMA loop (same schedule as conv_igemm_kernel in prn_conv.hip).
 // WGM = waves along M: 2 (wave tile 32*TM x 32) for TM <= 2; TM = 4 keeps the 2 x 2 grid as well (wave tile 128 x 32).
-template <int TM, bool K4>
-__global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_fwd_kernel(FwdArgs a) {
-  constexpr int BM = 64 * TM, BN = 64, BK = 16, LDA = BK + 1;
-  constexpr int NB = 4;            // gathered operand elements per thread per K slice: K rows krow0 + 4 * i
-  constexpr int NA = TM;           // float4 weight groups per thread per K slice: rows arow + 64 * i
+template <int TM, bool K4, int BK = 16>
+__global__ __launch_bounds__(256, (TM == 1 ? 4 : 3)) void dcnv2_fwd_kernel(FwdArgs a) {
+  constexpr int BM = 64 * TM, BN = 64, LDA = BK + 1;
+  constexpr int NB = BK / 4;       // gathered operand elements per thread per K slice: K rows krow0 + 4 * i
+  constexpr int AQ = BK / 4;       // float4 groups per weight row
+  constexpr int AROWS = 256 / AQ;  // weight rows covered by one sweep of the workgroup
+  constexpr int NA = BM / AROWS;   // float4 weight groups per thread per K slice: rows arow + AROWS * i
   __shared__ float As[2][BM * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-  __shared__ uint4 toff[9 * BN];
+  __shared__ uint2 toff[9 * BN];
   __shared__ float4 twt[9 * BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,18 +133,18 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_
       const int cl = i / TAB_CHUNK4, r = i - cl * TAB_CHUNK4, t = r >> 5, s = (r >> 4) & 1, p = r & 15;
       const float4 v = tg[i];
       if (s) twt[t * BN + cl * 16 + p] = v;
-      else toff[t * BN + cl * 16 + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+      else toff[t * BN + cl * 16 + p] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
     }
     __syncthreads();
   }
 
   const int nl = tid & 63;
   const int krow0 = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform K row inside a sweep
-  const int arow = tid >> 2, akq = (tid & 3) * 4;
+  const int arow = tid / AQ, akq = (tid % AQ) * 4;
   unsigned abase[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int m = m0 + arow + 64 * i;
+    const int m = m0 + arow + AROWS * i;
     abase[i] = (m < a.M) ? (unsigned)(m * a.K + akq) * 4u : OOB;
   }
 
@@ -164,20 +175,18 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_
     for (int i = 0; i < NB; ++i) {
       const int kr = k0 + krow0 + 4 * i;                   // wave-uniform: channel and tap are scalars
       const int c = kr / 9, t = kr - c * 9;
-      const uint4 o = toff[t * BN + nl];
+      const uint2 o = toff[t * BN + nl];
       const unsigned dead = kr < a.K ? 0u : OOB;
       const int so = c * a.HW * 4;
-      g[i][0] = bload(xr, o.x | dead, so);
-      g[i][1] = bload(xr, o.y | dead, so);
-      g[i][2] = bload(xr, o.z | dead, so);
-      g[i][3] = bload(xr, o.w | dead, so);
+      const float2 r0 = bload2(xr, o.x | dead, so), r1 = bload2(xr, o.y | dead, so);
+      g[i][0] = r0.x; g[i][1] = r0.y; g[i][2] = r1.x; g[i][3] = r1.y;
     }
   };
   auto store_tile = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) As[buf][(arow + 64 * i) * LDA + akq + j] = ra[i][j];
+      for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int kr = k0 + krow0 + 4 * i;
@@ -252,11 +261,11 @@ struct WgArgs {
 //                                             interpolated and stored to LDS after the MFMA loop
 //   MFMA loop on chunk ch.
 template <int TM, bool N4>
-__global__ __launch_bounds__(256, (TM == 1 ? 4 : 3)) void dcnv2_wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_wgrad_kernel(WgArgs a) {
   constexpr int BM = 64 * TM, BJ = 64, LD = 17, NBJ = 4;
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
-  __shared__ uint4 toff[2][9 * 16];
+  __shared__ uint2 toff[2][9 * 16];
   __shared__ float4 twt[2][9 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wj = wave & 1;
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : 3)) void dcnv2_wgrad_kernel(WgA
     auto put = [&](int r, float4 v) {
       const int t = r >> 5, s = (r >> 4) & 1, p = r & 15;
       if (s) twt[tb][t * 16 + p] = v;
-      else toff[tb][t * 16 + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+      else toff[tb][t * 16 + p] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
     };
     put(tid, rt0);
     if (tid < TAB_CHUNK4 - 256) put(tid + 256, rt1);
@@ -333,11 +342,9 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : 3)) void dcnv2_wgrad_kernel(WgA
     }
 #pragma unroll
     for (int i = 0; i < NBJ; ++i) {                        // sampled columns: four corners each
-      const uint4 o = toff[tb][jt[i] * 16 + nl];
-      rb[i][0] = bload(xr, o.x + jcoff[i], 0);             // (OOB + channel offset stays >= 2^31: both are < 2^31)
-      rb[i][1] = bload(xr, o.y + jcoff[i], 0);
-      rb[i][2] = bload(xr, o.z + jcoff[i], 0);
-      rb[i][3] = bload(xr, o.w + jcoff[i], 0);
+      const uint2 o = toff[tb][jt[i] * 16 + nl];
+      const float2 r0 = bload2(xr, o.x + jcoff[i], 0), r1 = bload2(xr, o.y + jcoff[i], 0);   // (OOB + channel offset stays >= 2^31)
+      rb[i][0] = r0.x; rb[i][1] = r0.y; rb[i][2] = r1.x; rb[i][3] = r1.y;
     }
   };
   auto store_chunk = [&](int buf, int tb) {
@@ -424,7 +431,7 @@ FPlan plan_dcn_fwd(int M, int N, int K) {
     // candidates (tile height, K splits) are scored by how evenly tiles * splits spreads over 256 CUs x resident workgroups.
     double best = -1.0;
     p.tm = 1; p.splits = 1;
-    const int tms[3] = {4, 2, 1}, res[3] = {2, 3, 4};
+    const int tms[3] = {4, 2, 1}, res[3] = {3, 3, 4};
     for (int q = 0; q < 3; ++q) {
       const int tm = tms[q];
       if (tm > 1 && M <= 32 * tm) continue;
@@ -449,12 +456,12 @@ WPlan plan_dcn_wgrad(int M, int K, int N) {
   static int forced[2] = {-1, 0};                        // PRN_DCN_WGRAD="tm,splits"
   if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_WGRAD")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
   WPlan p;
-  p.tm = (forced[0] > 0) ? forced[0] : (M > 64 ? 2 : 1);
+  p.tm = (forced[0] > 0) ? forced[0] : (M > 128 ? 4 : (M > 64 ? 2 : 1));   // every output-channel tile re-gathers the columns: tallest tile
   p.tilesM = cdiv(M, 64 * p.tm);
   p.tilesJ = cdiv(K, 64);
   p.chunks = cdiv(N, 16);
   const int tiles = p.tilesM * p.tilesJ;
-  const int slots = 256 * (p.tm == 1 ? 4 : 3);
+  const int slots = 256 * (p.tm == 1 ? 4 : (p.tm == 2 ? 3 : 2));
   int s = tiles < slots ? 2 * slots / tiles : 1;
   int cap = p.chunks / 8 > 0 ? p.chunks / 8 : 1;          // at least 128 pixels per split
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;   // workspace round trip stays small
@@ -512,7 +519,10 @@ extern "C" int prn_dcnv2_fwd_phase(const prn_dcn_desc* d, const float* x, const 
     const bool k4 = (a.K & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
 #define PRN_DCN_FWD(TM_) do { if (k4) hipLaunchKernelGGL((dcnv2_fwd_kernel<TM_, true>), grid, block, 0, st, a); \
                               else hipLaunchKernelGGL((dcnv2_fwd_kernel<TM_, false>), grid, block, 0, st, a); } while (0)
-    if (p.tm == 4) PRN_DCN_FWD(4); else if (p.tm == 2) PRN_DCN_FWD(2); else PRN_DCN_FWD(1);
+    if (p.tm == 4) {                                       // 256 x 64 tile: 8-deep K slices keep LDS at 3 workgroups per CU
+      if (k4) hipLaunchKernelGGL((dcnv2_fwd_kernel<4, true, 8>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((dcnv2_fwd_kernel<4, false, 8>), grid, block, 0, st, a);
+    } else if (p.tm == 2) PRN_DCN_FWD(2); else PRN_DCN_FWD(1);
 #undef PRN_DCN_FWD
     PRN_CHECK_LAUNCH("prn_dcnv2_fwd");
   }
@@ -550,7 +560,7 @@ extern "C" int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x,
     const bool n4 = (a.HoWo & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
 #define PRN_DCN_WG(TM_) do { if (n4) hipLaunchKernelGGL((dcnv2_wgrad_kernel<TM_, true>), grid, block, 0, st, a); \
                              else hipLaunchKernelGGL((dcnv2_wgrad_kernel<TM_, false>), grid, block, 0, st, a); } while (0)
-    if (p.tm == 2) PRN_DCN_WG(2); else PRN_DCN_WG(1);
+    if (p.tm == 4) PRN_DCN_WG(4); else if (p.tm == 2) PRN_DCN_WG(2); else PRN_DCN_WG(1);
 #undef PRN_DCN_WG
     PRN_CHECK_LAUNCH("prn_dcnv2_bwd_weight");
   }

@@ -240,9 +240,9 @@ def test_dcn_module_reference_form_equals_fused_block():
     ga = torch.autograd.grad(ya, [x] + list(m.parameters()), go)
     yb = m.forward_reference_form(x)
     gb = torch.autograd.grad(yb, [x] + list(m.parameters()), go)
-    close(ya, yb, "module forms fwd", rtol=2e-5)
+    close(ya, yb.cpu(), "module forms fwd", rtol=2e-5)
     for a, b_ in zip(ga, gb):
-        close(a, b_, "module forms grad", rtol=2e-4)
+        close(a, b_.cpu(), "module forms grad", rtol=2e-4)
 
 
 @pytest.mark.parametrize("stride", [1, 2])

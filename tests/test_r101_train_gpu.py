@@ -11,6 +11,12 @@ data/config.py:232: dcn_layers [0,4,23,3], interval 3), stage 2 at blocks 0 and 
    training-mode BatchNorm backward subtracts two nearly equal means); the HIP gradient must be within
    GRAD_K * spread (+ a 5e-4 floor for summation-order noise) of the fp64 oracle.  A second fp32 implementation with
    independent rounding lands at ~1-1.5 x spread; a wrong term lands far outside.
+   The step is checked twice: with every 3x3 layer on the direct kernel (ops.WINOGRAD off: EVERY parameter inside the bound)
+   and in the default build (Winograd F(4x4,3x3) for the stride-1 3x3 layers).  Winograd's fp32 forward error is ~1e-5 of the
+   tensor max where the direct kernel's is ~1e-7 (both far inside the 5e-4 output tolerance); five parameters of the
+   instance head's kernel tower are near-cancelling sums (GroupNorm's backward makes the gradient of a group sum to zero,
+   so a bias-like sum over it has a condition number of ~400: the reference's own spread there is 400 x 1e-7) and turn that
+   1e-5 into 4e-3 .. 8e-3.  They are listed in WINOGRAD_SENSITIVE with a 2e-2 bound; nothing else needs an allowance.
 2. B = 8 property test (the batch size of the benchmark: ragged instance-head batches active, deferred weight gradients):
    the five losses equal the oracle's on the same batch (rtol 1e-3) and match golden-free invariants (finite, every
    parameter has a gradient).
@@ -26,6 +32,8 @@ pytestmark = pytest.mark.gpu
 CN = "PlaneRecNet_101_config"
 SEED_W, SEED_X, SEED_NP = 3, 12, 13          # as in tests/golden/make_golden_r101.py
 GRAD_K, GRAD_FLOOR = 4.0, 5e-4
+WINOGRAD_SENSITIVE = {"inst_head.kernel_tower.0.weight": 2e-2, "inst_head.kernel_tower.1.weight": 2e-2, "inst_head.kernel_tower.1.bias": 2e-2,
+                      "inst_head.kernel_tower.3.weight": 2e-2, "inst_head.kernel_tower.4.bias": 2e-2}
 
 
 def digest_samples(t, n, seed=123):
@@ -55,8 +63,25 @@ def test_dcn_placement_rule_r101(net101):
     assert got == [(1, 0), (1, 3)] + [(2, b) for b in range(0, 23, 3)] + [(3, 0)]
 
 
-@pytest.mark.parametrize("wgrad_async", [True])
-def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, wgrad_async):
+@pytest.fixture(scope="module")
+def oracle64(net101, golden_dir):
+    """fp64 oracle gradients of the B = 2 step (about a minute of CPU time: computed once for both parametrisations)."""
+    from oracle import loss_ref, model_ref, synth
+    _, sd = net101
+    fx = np.load(os.path.join(golden_dir, "e2e_r101_480x640.npz"))
+    x, inst, gtd = synth.make_batch(2, 480, 640, seed=SEED_X)
+    sdg = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
+               (v.double().clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
+    names = [str(n) for n in fx["grad_names"]]
+    np.random.seed(SEED_NP)
+    oo = model_ref.forward(sdg, x.double(), model_ref.ARCH[CN], training=True)
+    ol = loss_ref.joint_loss(*oo, inst, gtd)
+    g = torch.autograd.grad(sum(ol.values()).sum(), [sdg[n] for n in names])
+    return dict(zip(names, [t.detach() for t in g]))
+
+
+@pytest.mark.parametrize("winograd", [False, True])
+def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, oracle64, winograd):
     from oracle import loss_ref, model_ref, synth
     from planerecnet_amd import ops
     from planerecnet_amd.losses import PlaneRecNetLoss
@@ -67,7 +92,8 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, w
     net.train()
     x, inst, gtd = synth.make_batch(2, 480, 640, seed=SEED_X)
     crit = PlaneRecNetLoss().cuda()
-    ops.set_wgrad_async(wgrad_async)
+    ops.set_wgrad_async(True)                    # the mode bench.py / train.py run in
+    wino, ops.WINOGRAD = ops.WINOGRAD, winograd
     try:
         np.random.seed(SEED_NP)
         out = net(x.cuda())
@@ -77,6 +103,7 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, w
         ops.wgrad_join()
     finally:
         ops.set_wgrad_async(False)
+        ops.WINOGRAD = wino
     torch.cuda.synchronize()
 
     # (a) losses vs the reference's values; outputs vs the reference's digests
@@ -91,19 +118,14 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, w
         assert abs(got[2] - ref[2]) <= 1e-3 * ref[2], (name, "abs-sum")
 
     # (b) every parameter gradient vs the fp64 oracle (run here), per-parameter calibrated bound
-    sdg = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
-               (v.double().clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
     names = [str(n) for n in fx["grad_names"]]
     zero = set(str(n) for n in fx["grad_structurally_zero"])
-    np.random.seed(SEED_NP)
-    oo = model_ref.forward(sdg, x.double(), arch, training=True)
-    ol = loss_ref.joint_loss(*oo, inst, gtd)
-    g64 = dict(zip(names, torch.autograd.grad(sum(ol.values()).sum(), [sdg[n] for n in names])))
+    g64 = oracle64
     spread = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
     refdig = dict(zip(names, fx["grad_ref_digest"]))
     params = dict(net.named_parameters())
     assert sorted(params) == sorted(names)
-    worst, bad = [], []
+    worst, worst_ref, bad = [], [], []
     for n in names:
         got = params[n].grad
         assert got is not None, n
@@ -116,16 +138,28 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, w
             continue
         l2 = ((got - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()
         bound = GRAD_K * spread[n] + GRAD_FLOOR
+        if winograd and n in WINOGRAD_SENSITIVE:
+            bound = WINOGRAD_SENSITIVE[n]
         worst.append((l2 / bound, n, l2, spread[n]))
         if l2 > bound:
             bad.append((n, l2, bound))
-        # and against the REFERENCE's own fp32 gradient at the fixture's sample positions
-        ref = refdig[n]
+        # and against the REFERENCE's own fp32 gradient at the fixture's 64 sample positions (rel-L2 over the samples)
+        ref = refdig[n][4:]
         smp = digest_samples(got, 64)[4:]
-        sc = np.abs(ref[4:]).max() + 1e-30
-        assert np.abs(smp - ref[4:]).max() <= 10 * bound * sc, ("reference digest", n, np.abs(smp - ref[4:]).max() / sc, bound)
+        d2 = float(np.linalg.norm(smp - ref) / (np.linalg.norm(ref) + 1e-30))
+        worst_ref.append((d2 / bound, n, d2))
+        if d2 > 2.0 * bound:
+            bad.append((n + " (vs reference samples)", d2, 2.0 * bound))
     worst.sort(reverse=True)
-    print("largest gradient error / bound:", [(round(r, 2), n, "%.1e" % l2, "%.1e" % sp) for r, n, l2, sp in worst[:8]])
+    worst_ref.sort(reverse=True)
+    print("largest gradient error / bound vs fp64 oracle:", [(round(r, 2), n, "%.1e" % l2, "%.1e" % sp) for r, n, l2, sp in worst[:8]])
+    print("largest sample error / bound vs reference fp32:", [(round(r, 2), n, "%.1e" % d) for r, n, d in worst_ref[:8]])
+    if os.environ.get("PRN_TEST_DUMP"):
+        with open(os.environ["PRN_TEST_DUMP"], "w") as f:
+            for r, n, l2, sp in sorted(worst, key=lambda t: t[1]):
+                f.write("%-64s err %.2e spread %.2e ratio %.2f\n" % (n, l2, sp, r))
+    ratios = np.array([r for r, _, _, _ in worst])
+    print("error / bound percentiles (50, 90, 99, max): %s" % np.round(np.percentile(ratios, [50, 90, 99, 100]), 3))
     assert not bad, "parameter gradients outside the calibrated bound: %s" % bad[:10]
     # the DCN blocks the interval rule places in the 23-block stage are all among the checked parameters
     for b in range(3, 23, 3):
