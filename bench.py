@@ -8,13 +8,26 @@ gradient exchange + Adam) at 480x640, per-GPU batch 8, synthetic data, random-in
 Prints ONE JSON line on rank 0.  `value` = global images / max-over-ranks wall time of exactly K steps bracketed by
 barrier + device synchronize.  Inputs (images, GT) are resident in HBM / host memory before the timed region.
 
+`--workload` selects the BASELINE.json configuration (default c3, the one the metric is quoted on):
+  c3  PlaneRecNet_101 train step, per-GPU batch 8, 480x640                      (configs[2]; N > 1 is configs[3])
+  c1  PlaneRecNet_50  eval forward + post-process, batch 1, 480x640             (configs[0]: the reference's CPU-runnable case;
+                                                                                  the GPU runs it, cpu_baseline is the CPU side)
+  c2  PlaneRecNet_50  eval forward + post-process, batch 8, 480x640             (configs[1])
+  c5  PlaneRecNet_101 eval forward + post-process, batch 4, max_size=960 -> 736x960   (configs[4])
+For the inference workloads a step is one batch through net.eval() (BatchNorm folded into the conv epilogues, on-device
+post-process, list[dict] result) and `value` is images / s.
+
 Extra objects:
   roofline     -- the dominant kernel family (implicit-GEMM conv on fp32 MFMA: forward + dgrad launches).  Every launch of
-                  one extra, untimed step is bracketed by HIP events on the launch stream; achieved = sum of algorithmic
-                  FLOPs (2*M*K*N of the reference convolution) / sum of event durations.  peak = 157.3 TFLOP/s (fp32 MFMA,
-                  MI355X_MICROARCH.md).  `kernels` lists the other families the same way.
+                  one extra, untimed step is bracketed by HIP events on the launch stream; achieved = sum of EXECUTED
+                  FLOPs / sum of event durations.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  `traffic` puts
+                  the PMC bytes per launch (profiles/*pmc_traffic.json) next to the algorithmic bytes per launch logged live
+                  (4 B x operand + result elements of every launch).  `kernels` lists the other families the same way.
   cpu_baseline -- the oracle (CPU restatement proven equal to the reference) timed on the host cores on a bounded sample:
-                  ONE image, same model/loss, forward+backward.  kind = "port".
+                  ONE image of the same workload; 1 warm-up + 3 timed iterations, median.  kind = "port".
+  dcn_offsets_run (c3) -- the same step re-timed after giving the DCN offset / modulator convs non-zero weights (~0.6 px r.m.s.
+                  offsets): the headline runs at the reference's init state (offset convs zero, models/dcn.py:32-43), where
+                  every deformable gather is a regular 3x3 pattern -- the best case for locality.
 """
 import argparse
 import json
@@ -81,25 +94,60 @@ def pmc_traffic(kernel):
     return None if fam is None else {"bytes_per_launch": fam["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
 
 
-def cpu_baseline(config_name, H, W, threads):
-    """Oracle fwd + loss + bwd on ONE image on the host cores."""
+def physical_cores():
+    """Physical core count of the host (unique (package, core) pairs of /proc/cpuinfo; falls back to the logical count)."""
+    try:
+        seen, pkg = set(), "0"
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((pkg, ln.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(config_name, H, W, train):
+    """The oracle on ONE image of the workload on the host cores: fwd + loss + bwd (train) or eval forward + post-process.
+    1 warm-up + 3 timed iterations, median (BASELINE.md 4 / SURVEY.md 8d).  Threads: min(16, physical cores) -- on the
+    256-core boxes a full-width OpenMP team is ~500x SLOWER on this model (fork/join on hundreds of small ops)."""
     from oracle import loss_ref, model_ref, synth
+    phys = physical_cores()
+    threads = max(1, min(16, phys))
     torch.set_num_threads(threads)
     arch = model_ref.ARCH[config_name]
     sd = synth.make_state_dict(config_name, seed=0)
-    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
     x, inst, gtd = synth.make_batch(1, H, W, seed=0)
-    leaves = [v for v in sd.values() if v.requires_grad]
+    if train:
+        sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+        leaves = [v for v in sd.values() if v.requires_grad]
     times = []
-    for it in range(2):                               # 1 warm-up + 1 timed (about 10-30 s of CPU work in total)
+    for it in range(4):
         np.random.seed(0)
         t0 = time.perf_counter()
-        out = model_ref.forward(sd, x, arch, training=True)
-        ls = loss_ref.joint_loss(*out, inst, gtd)
-        torch.autograd.grad(sum(ls.values()).sum(), leaves, allow_unused=True)
+        if train:
+            out = model_ref.forward(sd, x, arch, training=True)
+            ls = loss_ref.joint_loss(*out, inst, gtd)
+            torch.autograd.grad(sum(ls.values()).sum(), leaves, allow_unused=True)
+        else:
+            with torch.no_grad():
+                model_ref.inference(sd, x, arch)
         times.append(time.perf_counter() - t0)
-    return {"value": 1.0 / times[-1], "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": "1 image, %s fwd+loss+bwd at %dx%d, 2nd of 2 iterations, torch CPU fp32 oracle" % (config_name, H, W)}
+    med = float(np.median(times[1:]))
+    return {"value": 1.0 / med, "unit": "img/s", "cores": threads, "physical_cores": phys, "kind": "port",
+            "sample": "1 image, %s %s at %dx%d, torch CPU fp32 oracle, 1 warm-up + 3 timed iterations (median %.2f s; all: %s)"
+                      % (config_name, "fwd+loss+bwd" if train else "eval forward + post-process", H, W, med, ", ".join("%.2f" % t for t in times))}
+
+
+WORKLOADS = {   # name -> (config, per-GPU batch, H, W, train?, description)
+    "c3": ("PlaneRecNet_101_config", 8, 480, 640, True, "train step (fwd + 5-term loss + bwd + grad all-reduce + Adam)"),
+    "c1": ("PlaneRecNet_50_config", 1, 480, 640, False, "eval forward + on-device post-process"),
+    "c2": ("PlaneRecNet_50_config", 8, 480, 640, False, "eval forward + on-device post-process"),
+    "c5": ("PlaneRecNet_101_config", 4, 736, 960, False, "eval forward + on-device post-process, max_size=960"),
+}
 
 
 def main():
@@ -107,16 +155,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="PlaneRecNet_101_config")
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="BASELINE.json configuration (c3 = headline train step)")
+    ap.add_argument("--config", default=None, help="override the workload's config")
+    ap.add_argument("--batch", type=int, default=None, help="override the workload's per-GPU batch")
+    ap.add_argument("--dcn-offsets", type=float, default=0.6, help="r.m.s. offset (pixels) of the extra `dcn_offsets_run` (0: skip it)")
     ap.add_argument("--sync-wgrad", action="store_true", help="weight gradients in line with the input-gradient chain (A/B of ops.WGRAD_ASYNC)")
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
                     "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.config = args.config or wl[0]
+    args.batch = args.batch or wl[1]
+    args.height = args.height or wl[2]
+    args.width = args.width or wl[3]
+    train = wl[4]
 
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -159,73 +215,93 @@ def main():
     torch.set_num_threads(4)                           # host-side tensor ops are small: a wide OpenMP team only adds fork/join latency
     timer.disable_all()                                # like the reference's train.py:233 (enabled timers synchronise per stage)
     set_cfg(args.config)
+    if args.workload == "c5":
+        cfg.replace({"max_size": 960})                 # BASELINE config 5: 4:3 frames -> 736 x 960 after pad_even_divided
     torch.manual_seed(0)                               # identical replicas on every rank
     net = PlaneRecNet(cfg)
     net.init_head_weights()
-    net = net.to(dev).train()
-    crit = PlaneRecNetLoss().to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
-    exchange = GradAllReduce(list(net.parameters()), force=bool(os.environ.get("PRN_FORCE_EXCHANGE")))    # force: run the bucket / RCCL path with one rank too (overhead probe)
     images, inst, depths = synth_batch(args.batch, args.height, args.width, seed=1000 + rank, device=dev)
     np.random.seed(rank)
+    ph, graphed, prefetch, losses = {}, False, None, None
 
-    # --graph: the network's forward and backward are static, so each can be captured as ONE hipGraph
-    # (torch.cuda.make_graphed_callables: stream capture of every HIP launch our C ABI issues on torch's current stream).
-    # The loss (data-dependent shapes) and Adam stay eager.  Off by default: see the flag's help text.
-    graphed, run_net = False, net
-    if args.graph:
-        try:
-            run_net = torch.cuda.make_graphed_callables(net, (images,))
-            graphed = True
-        except Exception as e:                                   # noqa: BLE001
-            print("bench.py: hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
-            run_net = net
+    def set_dcn_offsets(px):
+        """Non-zero offset / modulator conv weights (~px pixels r.m.s. offset; same rule as the parity tests' weights)."""
+        from planerecnet_amd.dcn import DeformableConv2d
+        g = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, DeformableConv2d):
+                    for c in (m.offset_conv, m.modulator_conv):
+                        c.weight.copy_((torch.randn(c.weight.shape, generator=g) * px / (c.weight.shape[1] * 9) ** 0.5).to(c.weight.device))
+                        c.bias.copy_((torch.randn(c.bias.shape, generator=g) * 0.1).to(c.bias.device))
 
-    ops.set_wgrad_async(not args.sync_wgrad)                 # weight gradients on a side stream, joined after backward (ops.py)
-    hw = (args.height, args.width)
-    prefetch = TargetPrefetcher(crit)
-    prefetch.submit(inst, hw)                                # two batches in flight: the workers never wait for the trainer
-    prefetch.submit(inst, hw)
+    if train:
+        net = net.to(dev).train()
+        crit = PlaneRecNetLoss().to(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+        exchange = GradAllReduce(list(net.parameters()), force=bool(os.environ.get("PRN_FORCE_EXCHANGE")))    # force: run the bucket / RCCL path with one rank too (overhead probe)
 
-    ph = {}
+        # --graph: the network's forward and backward are static, so each can be captured as ONE hipGraph
+        # (torch.cuda.make_graphed_callables: stream capture of every HIP launch our C ABI issues on torch's current stream).
+        # The loss (data-dependent shapes) and Adam stay eager.  Off by default: see the flag's help text.
+        run_net = net
+        if args.graph:
+            try:
+                run_net = torch.cuda.make_graphed_callables(net, (images,))
+                graphed = True
+            except Exception as e:                                   # noqa: BLE001
+                print("bench.py: hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+                run_net = net
 
-    # Software-pipelined by one step: the targets of step k+1 are fetched (worker result, pinned staging, uploads on the side
-    # stream) at the END of step k, so a step starts with the forward pass.  Every step still does exactly one get and one
-    # submit; only the bubble after a device synchronisation shrinks (the GPU no longer idles through the 8 ms hand-over).
-    pipe = {"targets": prefetch.get(depths, dev, overlap=True)}
-    prefetch.submit(inst, hw)
+        ops.set_wgrad_async(not args.sync_wgrad)                 # weight gradients on a side stream, joined after backward (ops.py)
+        hw = (args.height, args.width)
+        prefetch = TargetPrefetcher(crit)
+        prefetch.submit(inst, hw)                                # two batches in flight: the workers never wait for the trainer
+        prefetch.submit(inst, hw)
 
-    def step():
-        t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
-        targets = pipe["targets"]
-        out = run_net(images)
-        t3 = time.perf_counter()
-        losses = crit(net, *out, inst, depths, targets=targets)
-        loss = sum(losses.values()).sum()
-        t4 = time.perf_counter()
-        loss.backward()
-        ops.wgrad_join()
-        exchange.finish()
-        t5 = time.perf_counter()
-        opt.step()
-        t6 = time.perf_counter()
-        pipe["targets"] = prefetch.get(depths, dev, overlap=True)      # GT-only targets of the NEXT step (prepared by the worker processes)
-        t1 = time.perf_counter()
-        prefetch.submit(inst, hw)                           # targets two steps further ahead: recomputed every step
-        t2 = time.perf_counter()
-        t1, t2 = t0 + (t1 - t6), t0 + (t2 - t6)             # (phase report: get / submit durations, fwd measured from t0)
-        ph.setdefault("get_ms_per_step", []).append(round((t1 - t0) * 1e3, 1))
-        ph.setdefault("host_ms_per_step", []).append(round((t6 - t0) * 1e3, 1))
-        if os.environ.get("PRN_BENCH_PHASES"):
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            ph.setdefault("_events", []).append(ev)
-        for k, v in (("get", t1 - t0), ("submit", t2 - t1), ("fwd", t3 - t0), ("loss", t4 - t3), ("bwd", t5 - t4), ("adam", t6 - t5)):
-            ph[k] = ph.get(k, 0.0) + v
-        # (values only: a loss tensor returned with its graph would keep the whole step's autograd nodes -- and the buffers
-        # the operators attach to them -- alive until the NEXT step has finished: +5 ms/step, 65.5 vs 60.5 ms)
-        return {k: v.detach() for k, v in losses.items()}
+        # Software-pipelined by one step: the targets of step k+1 are fetched (worker result, pinned staging, uploads on the side
+        # stream) at the END of step k, so a step starts with the forward pass.  Every step still does exactly one get and one
+        # submit; only the bubble after a device synchronisation shrinks (the GPU no longer idles through the 8 ms hand-over).
+        pipe = {"targets": prefetch.get(depths, dev, overlap=True)}
+        prefetch.submit(inst, hw)
+
+        def step():
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            targets = pipe["targets"]
+            out = run_net(images)
+            t3 = time.perf_counter()
+            losses = crit(net, *out, inst, depths, targets=targets)
+            loss = sum(losses.values()).sum()
+            t4 = time.perf_counter()
+            loss.backward()
+            ops.wgrad_join()
+            exchange.finish()
+            t5 = time.perf_counter()
+            opt.step()
+            t6 = time.perf_counter()
+            pipe["targets"] = prefetch.get(depths, dev, overlap=True)      # GT-only targets of the NEXT step (prepared by the worker processes)
+            t1 = time.perf_counter()
+            prefetch.submit(inst, hw)                           # targets two steps further ahead: recomputed every step
+            t2 = time.perf_counter()
+            t1, t2 = t0 + (t1 - t6), t0 + (t2 - t6)             # (phase report: get / submit durations, fwd measured from t0)
+            ph.setdefault("get_ms_per_step", []).append(round((t1 - t0) * 1e3, 1))
+            ph.setdefault("host_ms_per_step", []).append(round((t6 - t0) * 1e3, 1))
+            if os.environ.get("PRN_BENCH_PHASES"):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ph.setdefault("_events", []).append(ev)
+            for k, v in (("get", t1 - t0), ("submit", t2 - t1), ("fwd", t3 - t0), ("loss", t4 - t3), ("bwd", t5 - t4), ("adam", t6 - t5)):
+                ph[k] = ph.get(k, 0.0) + v
+            # (values only: a loss tensor returned with its graph would keep the whole step's autograd nodes -- and the buffers
+            # the operators attach to them -- alive until the NEXT step has finished: +5 ms/step, 65.5 vs 60.5 ms)
+            return {k: v.detach() for k, v in losses.items()}
+    else:
+        net = net.to(dev).eval()
+
+        def step():                                             # one batch: eval forward (BatchNorm folded) + on-device post-process -> list[dict]
+            with torch.no_grad():
+                return net(images)
 
     def fence():
         torch.cuda.synchronize()
@@ -233,28 +309,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(n_warm, n_steps):
+        out = None
+        for _ in range(n_warm):
+            out = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    elapsed, last = timed(args.warmup, args.steps)
     if os.environ.get("PRN_EXCHANGE_PROF"):
         from planerecnet_amd import parallel as _par
         n_ = max(_par._PROF.get("steps", 1), 1)
         print({k: (round(v / n_ * 1e3, 2) if isinstance(v, float) else v / n_) for k, v in _par._PROF.items()}, file=sys.stderr)
-    if os.environ.get("PRN_BENCH_PHASES"):
+    if os.environ.get("PRN_BENCH_PHASES") and train:
         evs = ph.pop("_events")
         ph["gpu_ms_per_step"] = [round(a.elapsed_time(b), 1) for a, b in zip(evs[:-1], evs[1:])]
         print({k: (v if isinstance(v, list) else round(v / (args.steps + args.warmup) * 1e3, 2)) for k, v in ph.items()}, file=sys.stderr)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_means = all_reduce_mean_scalars([losses[k].detach().sum() for k in sorted(losses)], dev).tolist()
-    finite = all(np.isfinite(v) for v in loss_means)
+    if train:
+        losses = last
+        loss_means = all_reduce_mean_scalars([losses[k].detach().sum() for k in sorted(losses)], dev).tolist()
+        finite = all(np.isfinite(v) for v in loss_means)
+        detections = None
+    else:
+        loss_means, finite = None, all(bool(torch.isfinite(r["pred_depth"]).all()) for r in last)
+        detections = sum(0 if r["pred_scores"] is None else len(r["pred_scores"]) for r in last)
 
     roof, kernels = None, None
     if rank == 0 and not args.no_roofline:
@@ -273,37 +360,60 @@ def main():
         ops.BRANCH_STREAMS = branch_streams
         kernels = fams
         dom = max((f for f in fams if f["bound"] == "mfma"), key=lambda f: f["time_ms"])
+        pmc = pmc_traffic(dom["kernel"])
+        traffic = None
+        if pmc is not None or dom.get("bytes"):
+            alg = dom["bytes"] / dom["launches"] if dom.get("bytes") else None
+            traffic = {"hbm_bytes_per_launch": None if pmc is None else pmc["bytes_per_launch"], "source": None if pmc is None else pmc["source"],
+                       "algorithmic_bytes_per_launch": alg,
+                       "ratio": (pmc["bytes_per_launch"] / alg) if (pmc is not None and alg) else None}
         roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["kernel"]), "launches": dom["launches"],
+                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"],
                 "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"]}
-        # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation).  The Winograd launches
-        # execute a quarter of the multiply-adds of the convolution they evaluate, so the same step is also summarised the
-        # other way round: FLOPs of the REFERENCE convolutions (2*M*C*KH*KW per output pixel, forward + input gradient +
-        # weight gradient) over the time of every kernel of the convolution family, transforms and reductions included.
+        # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation) -- that is the headline
+        # figure.  Footnote: the Winograd launches execute a quarter of the multiply-adds of the convolution they evaluate, so the
+        # same step is also summarised as FLOPs of the REFERENCE convolutions over the time of every kernel of the convolution
+        # family, transforms and reductions included.
         conv = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "reduce_epilogue_kernel", "winograd_input_kernel", "winograd_output_kernel",
                                                     "conv3x3_winograd_ragged", "conv_wgrad_kernel", "reduce_splits_kernel", "winograd_wgrad_transforms",
-                                                    "winograd_dw_kernel", "conv3x3_winograd_wgrad_ragged")]
+                                                    "winograd_dw_kernel", "conv3x3_winograd_wgrad_ragged", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel")]
         ref_flops = sum(f["ref_work"] for f in conv if f["bound"] == "mfma")
         conv_ms = sum(f["time_ms"] for f in conv)
-        roof["reference_operator_view"] = {"families": [f["kernel"] for f in conv], "reference_flops_per_step": ref_flops, "time_ms": conv_ms,
-                                           "achieved": ref_flops / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
-                                           "frac": ref_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        roof["footnote_reference_operator_view"] = {"reference_flops_per_step": ref_flops, "time_ms": conv_ms,
+                                                    "achieved": ref_flops / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                                    "frac": ref_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        # the DCNv2 operator on its own (north_star names it): fused forward + weight-gradient GEMMs against the MFMA peak
+        dcn = [f for f in fams if f["kernel"] in ("dcnv2_fwd_kernel", "dcnv2_wgrad_kernel")]
+        if dcn:
+            roof["dcnv2"] = {f["kernel"]: {"achieved": f["achieved"], "unit": f["unit"], "frac": f["achieved"] / PEAK_FP32_MFMA_TFLOPS,
+                                           "launches": f["launches"], "avg_launch_us": 1e3 * f["time_ms"] / f["launches"]} for f in dcn}
+
+    # the same step with non-trivial deformable offsets (after the headline timing; the weights change)
+    dcn_run = None
+    if train and args.dcn_offsets > 0 and not graphed:
+        set_dcn_offsets(args.dcn_offsets)
+        n2 = max(args.steps // 2, 3)
+        el2, l2 = timed(2, n2)
+        dcn_run = {"offset_px_rms": args.dcn_offsets, "steps": n2, "ms_per_step": 1e3 * el2 / n2, "value": args.batch * world * n2 / el2,
+                   "losses_finite": all(bool(torch.isfinite(v).all()) for v in l2.values())}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.config, args.height, args.width, min(16, os.cpu_count() or 1))
+        cpu = cpu_baseline(args.config, args.height, args.width, train)
 
     if rank == 0:
         gb = args.batch * world
         line = {"metric": METRIC, "value": gb * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "%s train step (fwd + 5-term loss + bwd + grad all-reduce + Adam), per-GPU batch %d, %dx%d synthetic RGB+depth+planes, random-init weights"
-                           % (args.config, args.batch, args.height, args.width), "global_batch": gb, "parallelism": "dp%d" % world},
-                "hip_graph": graphed, "losses_finite": finite, "losses": dict(zip(sorted(losses), loss_means)),
-                "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+                "config": {"workload": "%s: %s %s, per-GPU batch %d, %dx%d synthetic %s, random-init weights"
+                           % (args.workload, args.config, wl[5], args.batch, args.height, args.width, "RGB+depth+planes" if train else "RGB"),
+                           "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},
+                "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
+                "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "kernels": kernels}
         print(json.dumps(line), flush=True)
-    prefetch.close()
+    if prefetch is not None:
+        prefetch.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -282,6 +282,15 @@ int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int
  * gathers through it (dx fully written, no atomics). */
 int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 
+/* ---- depth-error metrics of one frame ------------------------------------------------------------------------------
+ * replaces the ~25 elementwise / boolean-index / reduction launches of compute_depth_metrics (eval.py:164-207):
+ * over the pixels with gt > 0.5 and pred > 0.5, pred clamped to [min_depth, max_depth] (cfg.dataset):
+ *   out[0..7] = abs_rel, sq_rel, rmse, log10, a1, a2, a3 (thresholds 1.25, 1.25^2, 1.25^3), number of valid pixels   (doubles)
+ * ws: prn_depth_metrics_ws_doubles() doubles (fixed-order partials -> deterministic).  The median ratio of the reference's
+ * return tuple is a selection, not a sum, and stays with the caller. */
+int prn_depth_metrics_ws_doubles(void);
+int prn_depth_metrics(const float* pred, const float* gt, double* out, double* ws, int64_t n, float min_depth, float max_depth, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ from .dcn import DeformableConv2d
 
 
 def _bn(m, x, residual=None, relu=False):
-    return ops.batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
+    return ops.batch_norm_module(m, x, residual, relu)
 
 
 def folded_bn(conv_w, conv_b, m):

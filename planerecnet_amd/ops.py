@@ -220,7 +220,8 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
         # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)):
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil),
+                            nbytes=4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0))):
             check(lib.prn_conv2d_fwd_phase(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream(), 1), "prn_conv2d_fwd")
         if nbytes:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
@@ -422,7 +423,7 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
             check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W):
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P)):
             check(lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()), "prn_gemm_batched")
         with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1), 0.0):
             check(lib.prn_winograd_output(_p(Yt), _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
@@ -715,7 +716,7 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
     dx = torch.empty_like(x) if need_x else None
     ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
     if profiling._enabled:
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo):
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo, nbytes=4.0 * (dy.numel() + wt.numel()) + ncols):
             check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), None, _p(ws), _stream()), "prn_dcnv2_bwd_input")
         if need_x:                                                  # (re-issues the GEMM: profiling runs only)
             with profiling.span("dcnv2_bwd_input", "hbm", ncols + 8.0 * x.numel()):
@@ -867,6 +868,10 @@ class _BatchNorm(torch.autograd.Function):
             else:
                 check(lib.prn_bn_train_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean), _p(rvar), _p(ws),
                                            B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd")
+            # the kernel updated the running statistics through raw pointers: tell autograd (version counters), so that
+            # everything keyed on them -- backbone.folded_bn's inference cache -- sees the change
+            torch.autograd.graph.increment_version(rmean)
+            torch.autograd.graph.increment_version(rvar)
         else:
             stats = torch.cat([rmean, torch.rsqrt(rvar + eps)])
             with profiling.span("bn_apply", "hbm", 4.0 * x.numel() * (3 if residual is not None else 2)):
@@ -892,6 +897,15 @@ class _BatchNorm(torch.autograd.Function):
             check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
                                  B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
         return dx, dg, db, None, None, dres, None, None, None, None
+
+
+def batch_norm_module(m, x, residual=None, relu=False):
+    """nn.BatchNorm2d.forward (+ residual add + ReLU) on the HIP kernels, including the module's bookkeeping: in training mode
+    `num_batches_tracked` advances like nn.BatchNorm2d's (counted on the host and written to the buffer when the state dict
+    is read -- PlaneRecNet.state_dict -- instead of one tiny increment kernel per layer per step)."""
+    if m.training and m.track_running_stats:
+        m.__dict__["_prn_nbt_pending"] = m.__dict__.get("_prn_nbt_pending", 0) + 1
+    return batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, residual=None, relu=False):
@@ -997,7 +1011,7 @@ def _ragged_winograd_raw(xp, U, bias, addend, rs, C, M, P, epi=EPI_NONE):
 def _ragged_conv_raw(xp, w, bias, addend, rs, C, M, K, epi=EPI_NONE):
     y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
     _, ref, _ = _rdesc(rs, C, M, K, epi)
-    with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * rs.pixels):
+    with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * rs.pixels, nbytes=4.0 * (xp.numel() + w.numel() + rs.pixels * M)):
         check(lib.prn_conv2d_fwd_ragged(ref, rs.ref, _p(xp), _p(w), _p(bias), _p(addend), _p(y), _stream()), "prn_conv2d_fwd_ragged")
     return y
 

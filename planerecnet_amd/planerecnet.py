@@ -129,6 +129,23 @@ class PlaneRecNet(nn.Module):
         return (ops.resize_bilinear(feats[0], (int(h * 0.5), int(w * 0.5))), feats[1], feats[2], feats[3])
 
     # ---- weight I/O (planerecnet.py:121-153)
+    def _flush_bn_counters(self):
+        """Write the host-side `num_batches_tracked` counts (ops.batch_norm_module) into the buffers."""
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                n = m.__dict__.pop("_prn_nbt_pending", 0)
+                if n and m.num_batches_tracked is not None:
+                    m.num_batches_tracked += n
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_bn_counters()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        for m in self.modules():
+            m.__dict__.pop("_prn_nbt_pending", None)
+        return super().load_state_dict(*args, **kwargs)
+
     def save_weights(self, path):
         torch.save(self.state_dict(), path)
 
@@ -398,7 +415,7 @@ class DepthDecoder_FPN(nn.Module):
         if can_fold(bn) and not up:                       # inference: BatchNorm folded into the conv, ReLU in its epilogue
             return conv_bn(x, conv, bn, 1, 1, relu=True, in_mode=ops.IN_REFLECT)
         y = ops.conv2d(x, conv.weight, conv.bias, pad=1, in_mode=ops.IN_UP2_REFLECT if up else ops.IN_REFLECT)
-        return ops.batch_norm(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps, bn.momentum, None, True)
+        return ops.batch_norm_module(bn, y, None, True)
 
     def _centre_index(self, n, device):
         """Indices {4k+1, 4k+2}: the two centre samples of every 4-block (what the x0.25 bilinear resize reads). Cached per

@@ -33,10 +33,11 @@ class span:
     work: what the launch EXECUTES (FLOPs / bytes) -- the basis of the family's `achieved` rate, i.e. a utilisation.
     ref:  FLOPs of the reference operator the launch stands for, when that differs (a Winograd product executes a quarter of
           the direct convolution's multiply-adds; its transform kernels execute none): summed into `ref_work`."""
-    __slots__ = ("family", "bound", "work", "ref", "s", "e")
+    __slots__ = ("family", "bound", "work", "ref", "nbytes", "s", "e")
 
-    def __init__(self, family, bound, work, ref=None):
-        self.family, self.bound, self.work, self.ref = family, bound, work, (work if ref is None else ref)
+    def __init__(self, family, bound, work, ref=None, nbytes=0.0):
+        """nbytes (MFMA families): algorithmic HBM bytes of the launch, 4 B x (operand + result elements)."""
+        self.family, self.bound, self.work, self.ref, self.nbytes = family, bound, work, (work if ref is None else ref), nbytes
 
     def __enter__(self):
         if _enabled:
@@ -47,14 +48,15 @@ class span:
     def __exit__(self, *exc):
         if _enabled:
             self.e.record()
-            _records.append((self.family, self.bound, self.work, self.s, self.e, self.ref))
+            _records.append((self.family, self.bound, self.work, self.s, self.e, self.ref, self.nbytes))
 
 
 def summary():
     """-> list of {kernel, bound, launches, time_ms, work, achieved, unit} sorted by time (call after a device sync)."""
     fams = {}
-    for fam, bound, work, s, e, ref in _records:
-        f = fams.setdefault(fam, {"kernel": fam, "bound": bound, "launches": 0, "time_ms": 0.0, "work": 0.0, "ref_work": 0.0})
+    for fam, bound, work, s, e, ref, nbytes in _records:
+        f = fams.setdefault(fam, {"kernel": fam, "bound": bound, "launches": 0, "time_ms": 0.0, "work": 0.0, "ref_work": 0.0, "bytes": 0.0})
+        f["bytes"] += float(nbytes)
         f["launches"] += 1
         f["time_ms"] += s.elapsed_time(e)
         f["work"] += float(work)

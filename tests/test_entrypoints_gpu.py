@@ -65,6 +65,21 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert line["losses_finite"] and line["value"] > 0 and line["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("workload,batch,hw", [("c1", 1, "480x640"), ("c2", 8, "480x640"), ("c5", 4, "736x960")])
+def test_bench_inference_workloads(tmp_path, workload, batch, hw):
+    """BASELINE.json configs 1 / 2 / 5 as bench lines: eval forward + on-device post-process, same JSON schema as the headline."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["workload"].startswith(workload + ":") and hw in line["config"]["workload"]
+    assert line["config"]["global_batch"] == batch and line["unit"] == "img/s" and line["value"] > 0 and line["losses_finite"]
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["kernel"] == "conv_igemm_kernel"
+    assert roof["traffic"]["algorithmic_bytes_per_launch"] > 0
+
+
 def test_train_two_ranks_stay_identical(tmp_path):
     """train.py under torch.distributed.run with 2 ranks (global batch 12 -> 6 per rank: BatchNorm stays in training mode,
     reference train.py:115-118): three optimizer steps, then the replica check must report identical parameters."""

@@ -65,6 +65,37 @@ def test_forward_matches_oracle(setup, mode):
             close(got[k], sd2[k], 2e-3, k)
 
 
+def test_batchnorm_bookkeeping_and_fold_cache(setup):
+    """Training-mode forwards advance num_batches_tracked like nn.BatchNorm2d and bump the running statistics' version
+    counters, so the inference path's folded conv+BN weights (cached on those versions) are rebuilt after the statistics move."""
+    from oracle import synth
+    net, sd, _ = setup
+    net.load_state_dict(sd)
+    x, _, _ = synth.make_batch(2, 128, 160, seed=2)
+    xd = x.cuda()
+    net.eval()
+    with torch.no_grad():
+        before = [t.clone() for t in net.backbone(xd)]                   # folded path, caches the folded weights
+    net.train()
+    v0 = net.backbone.bn1.running_mean._version
+    with torch.no_grad():
+        net(xd)
+        net(xd)
+    assert net.backbone.bn1.running_mean._version > v0
+    got = net.state_dict()
+    assert int(got["backbone.bn1.num_batches_tracked"]) == 2 and int(got["depth_decoder.deconv4.3.num_batches_tracked"]) == 2
+    assert int(net.state_dict()["backbone.layers.1.0.bn2.num_batches_tracked"]) == 2          # (flushing twice does not double count)
+    net.eval()
+    with torch.no_grad():
+        after = [t.clone() for t in net.backbone(xd)]                    # folded with the NEW statistics
+    with torch.enable_grad():
+        unfolded = net.backbone(xd)                                      # autograd on: separate conv + BatchNorm launches
+    assert float((after[0] - before[0]).abs().max()) > 1e-4               # the statistics did move
+    for a, u in zip(after, unfolded):
+        close(a, u, 2e-4, "folded vs unfolded after a statistics update")
+    net.load_state_dict(sd)
+
+
 def test_backward_with_ragged_heads_and_deferred_wgrads(setup):
     """B=4 at 128x160 (the batch sizes for which the SOLO grid levels pack into whole GEMM tiles): the instance head runs as
     ragged batches, weight gradients are deferred to the side stream, backbone-feature gradients meet in forked epilogues.

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
-"""Training entry point (drop-in for the reference's train.py: same flags, config autoscaling, Adam param groups,
-LR warm-up / steps, `<name>_<epoch>_<iter>.pth` checkpoints, resume / interrupt handling, 100-iteration console line).
+"""Training entry point for the HOT PATH of the reference's train.py: same flags, config autoscaling, Adam param groups,
+LR warm-up / steps, `<name>_<epoch>_<iter>.pth` checkpoints, resume / interrupt handling, 100-iteration console line.
+Scope: the training step (model + loss + optimizer + data-parallel exchange).  The annotated-dataset readers / augmentations
+(cv2 + pycocotools), the validation pass and tensorboard logging are NOT part of this build: real datasets exit with a
+message, `--validation_*` / `--log_folder` / `--batch_alloc` raise when changed from their defaults, `--dataset synthetic`
+feeds seeded batches with the reference's batch contract.
 
 What differs is the machinery underneath:
   * the model and loss run on the HIP kernels (planerecnet_amd), the device comes from `cfg.device`;
@@ -129,6 +133,22 @@ def main():
             setattr(args, name, getattr(cfg, name))
     if args.max_iter is not None:
         cfg.max_iter = args.max_iter
+    # Flags of the reference's CLI whose machinery (validation pass with pycocotools, tensorboardX logging) is outside this
+    # hot-path build: accepted only at their defaults / off-values -- asking for them is an error, not a silent no-op.
+    ignored = []
+    if args.validation_epoch != 1 or args.validation_size != 2000:
+        ignored.append("--validation_epoch / --validation_size (no validation pass: eval.py's dataset / COCO-metric code is out of scope; "
+                       "planerecnet_amd.metrics.compute_depth_metrics is available for custom loops)")
+    if args.log_folder != "./logs/":
+        ignored.append("--log_folder (no tensorboard writer)")
+    if args.batch_alloc is not None:
+        ignored.append("--batch_alloc (ranks always take equal shares of the batch)")
+    if ignored:
+        raise SystemExit("train.py: not supported by this build:\n  " + "\n  ".join(ignored))
+    if rank == 0 and not args.no_tensorboard:
+        print("Note: tensorboard logging is not part of this build (console log only); pass --no_tensorboard to silence this note.")
+    if rank == 0 and (args.decay != cfg.decay or args.momentum != cfg.momentum):
+        print("Note: --decay / --momentum are parsed but never reach Adam -- exactly as in the reference (train.py:251-256, quirk Q7).")
     if not torch.cuda.is_available():
         raise SystemExit("No GPUs detected. The HIP path has no CPU fallback.")
     if args.batch_size % world:
