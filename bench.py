@@ -356,6 +356,12 @@ def main():
         step()
         torch.cuda.synchronize()
         fams = profiling.summary()
+        if os.environ.get("PRN_BENCH_SHAPES"):                  # per-shape table of the MFMA launches of the bracketed step
+            with open(os.environ["PRN_BENCH_SHAPES"], "w") as fh:
+                fh.write("%-22s %-44s %6s %9s %8s %7s\n" % ("family", "(kind, C, H, W, M, K, stride, mode, dil, B)", "calls", "ms/step", "us/call", "TF/s"))
+                for fam, tag, n, ms, work in profiling.by_shape():
+                    if tag is not None:
+                        fh.write("%-22s %-44s %6d %9.3f %8.1f %7.1f\n" % (fam, str(tag), n, ms, ms / n * 1e3, work / (ms * 1e-3) / 1e12))
         profiling.disable()
         ops.BRANCH_STREAMS = branch_streams
         kernels = fams

@@ -55,6 +55,7 @@ struct ConvArgs {
   int xbytes, wbytes;
   int ystride, yW, yHW;     // output map: GEMM pixel (oh, ow) is stored at (oh*ystride + phase_y, ow*ystride + phase_x) of a yHW plane
   int zx, zw, zy;           // VEC instances: element strides of x / w / y per blockIdx.z (prn_gemm_batched; 0 for a plain conv)
+  int wide_store;           // epilogue through the LDS transpose (float4 stores): output / addend / workspace 16-byte aligned
   float* ws;
   Seg seg;
 };
@@ -134,8 +135,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   constexpr int VG = BN / 4;       // VEC: float4 pixel groups per K row
   constexpr int VROWS = NT / VG;   // VEC: K rows per sweep
   constexpr int NBV = BK / VROWS;  // VEC: float4 loads per thread per K slice
-  __shared__ float As[2][BM * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+  // one LDS allocation: the two operand double buffers during the K loop, then (epilogue) one 32 x 36 transpose pad per wave
+  constexpr int AS = 2 * BM * LDA, BS = 2 * BK * BN, CPITCH = 36, CS = (NT / 64) * 32 * CPITCH;
+  static_assert(AS % 4 == 0, "the im2col buffers must stay 16-byte aligned");
+  __shared__ __attribute__((aligned(16))) float smem[(AS + BS) > CS ? (AS + BS) : CS];
+  float (*As)[BM * LDA] = reinterpret_cast<float (*)[BM * LDA]>(smem);
+  float (*Bs)[BK * BN] = reinterpret_cast<float (*)[BK * BN]>(smem + AS);
   __shared__ unsigned taps[KS > 1 ? KK * BN : 1];   // per-pixel tap byte offsets (or OOB), built once per workgroup
                                                     // (V3: per 4-pixel group: offset of the vector | border code in bits 0-1)
 
@@ -364,6 +369,43 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
   const bool has_bias = !partial && a.bias != nullptr, has_add = !partial && add_ != nullptr;
   const int epi = partial ? PRN_EPI_NONE : a.epi;
   const bool interior = (m0 + BM <= a.M) && (n0 + BN <= N_);
+  if (a.wide_store && a.ystride == 1 && (HoWo_ & 3) == 0) {
+    // Wide stores: an accumulator block holds, per lane, 16 channels of ONE pixel -- stored as is, that is 16 dword stores per
+    // block, each wave instruction touching two 128-byte row segments.  Transposed through LDS (the operand buffers are free
+    // now) a lane owns 4 consecutive pixels of one channel: 4 dwordx4 stores per block, 512 contiguous bytes per 8 lanes,
+    // and bias / addend are applied on float4s.  (n0 and HoWo are multiples of 4: a pixel quad never straddles two images.)
+    __syncthreads();                                       // every wave is done reading As / Bs
+    float* cw = smem + wave * (32 * CPITCH);
+    const int crow = lane >> 3, ccol = (lane & 7) * 4;      // this lane's quad: rows crow + 8 * q, pixels ccol .. ccol + 3
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nq = n0 + wn * TN * 32 + j * 32 + ccol;
+      const bool nok = interior || nq < N_;
+      const int bb = nq / HoWo_, p = nq - bb * HoWo_;
+      const size_t base = (size_t)bb * a.M * HoWo_ + p;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CPITCH + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+        const int mb = m0 + wm * TM * 32 + i * 32 + crow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = mb + 8 * q;
+          float4 v = *reinterpret_cast<const float4*>(&cw[(crow + 8 * q) * CPITCH + ccol]);
+          if (!nok || (!interior && m >= a.M)) continue;
+          const size_t idx = base + (size_t)m * HoWo_;
+          if (has_bias) { const float bm = a.bias[m]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+          if (has_add) { const float4 t = *reinterpret_cast<const float4*>(add_ + idx); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+          if (epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y)); v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w)); }
+          *reinterpret_cast<float4*>(outp + idx) = v;
+        }
+        __builtin_amdgcn_wave_barrier();                   // the pad is rewritten by the next block
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nn = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -908,6 +950,13 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
   a.tilesM = cdiv(a.M, 32 * p.wm * p.tm);
   a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
   a.splits = p.splits;
+  {
+    static int wide = -1;                                    // PRN_CONV_WIDE_STORE=0: the per-element epilogue everywhere (A/B)
+    if (wide < 0) { const char* e = getenv("PRN_CONV_WIDE_STORE"); wide = e ? atoi(e) : 1; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    a.wide_store = wide && a.seg.nseg == 0 && p.wm == 2 && al16(a.y) && al16(a.addend) && al16(a.ws) && (a.zy & 3) == 0 &&
+                   (p.splits == 1 || (((int64_t)a.B * a.M * a.HoWo) & 3) == 0);
+  }
   dim3 grid(a.nblocks, p.splits, phases), block(64 * p.wm * p.wn);
   if constexpr (narrow_available(KS, MODE)) {
     if (p.wm == 1) {

@@ -221,7 +221,8 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
         # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
         with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil),
-                            nbytes=4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0))):
+                            nbytes=4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0)),
+                            tag=("conv", C, H, W, M, K, stride, mode, dil, B)):
             check(lib.prn_conv2d_fwd_phase(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream(), 1), "prn_conv2d_fwd")
         if nbytes:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
@@ -242,7 +243,7 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     _, ref, _, nbytes = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     if profiling._enabled:
-        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo):
+        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo, tag=("wgrad", C, H, W, M, K, stride, mode, 1, B)):
             check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_conv2d_wgrad")
         if nbytes:
             with profiling.span("reduce_splits_kernel", "hbm", float(nbytes) + 4.0 * dw.numel()):
@@ -423,7 +424,8 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
             check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P)):
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P),
+                            tag=("wino-products", C, H, W, M, 3, 1, mode, 1, B)):
             check(lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()), "prn_gemm_batched")
         with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1), 0.0):
             check(lib.prn_winograd_output(_p(Yt), _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
@@ -455,7 +457,7 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
         P = lib.prn_winograd_tiles(B, H, W)
         with profiling.span("winograd_wgrad_transforms", "hbm", 4.0 * (x.numel() + dy.numel()) + 4.0 * 36 * (C + M) * P, 0.0):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 1), "prn_conv3x3_winograd_wgrad")
-        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W):
+        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W, tag=("wino-wgrad-products", C, H, W, M, 3, 1, mode, 1, B)):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 2), "prn_conv3x3_winograd_wgrad")
         with profiling.span("winograd_dw_kernel", "hbm", float(nbytes) - 4.0 * 36 * (C + M) * P + 4.0 * dw.numel(), 0.0):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 3), "prn_conv3x3_winograd_wgrad")

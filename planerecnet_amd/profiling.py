@@ -33,11 +33,11 @@ class span:
     work: what the launch EXECUTES (FLOPs / bytes) -- the basis of the family's `achieved` rate, i.e. a utilisation.
     ref:  FLOPs of the reference operator the launch stands for, when that differs (a Winograd product executes a quarter of
           the direct convolution's multiply-adds; its transform kernels execute none): summed into `ref_work`."""
-    __slots__ = ("family", "bound", "work", "ref", "nbytes", "s", "e")
+    __slots__ = ("family", "bound", "work", "ref", "nbytes", "tag", "s", "e")
 
-    def __init__(self, family, bound, work, ref=None, nbytes=0.0):
+    def __init__(self, family, bound, work, ref=None, nbytes=0.0, tag=None):
         """nbytes (MFMA families): algorithmic HBM bytes of the launch, 4 B x (operand + result elements)."""
-        self.family, self.bound, self.work, self.ref, self.nbytes = family, bound, work, (work if ref is None else ref), nbytes
+        self.family, self.bound, self.work, self.ref, self.nbytes, self.tag = family, bound, work, (work if ref is None else ref), nbytes, tag
 
     def __enter__(self):
         if _enabled:
@@ -48,13 +48,13 @@ class span:
     def __exit__(self, *exc):
         if _enabled:
             self.e.record()
-            _records.append((self.family, self.bound, self.work, self.s, self.e, self.ref, self.nbytes))
+            _records.append((self.family, self.bound, self.work, self.s, self.e, self.ref, self.nbytes, self.tag))
 
 
 def summary():
     """-> list of {kernel, bound, launches, time_ms, work, achieved, unit} sorted by time (call after a device sync)."""
     fams = {}
-    for fam, bound, work, s, e, ref, nbytes in _records:
+    for fam, bound, work, s, e, ref, nbytes, _tag in _records:
         f = fams.setdefault(fam, {"kernel": fam, "bound": bound, "launches": 0, "time_ms": 0.0, "work": 0.0, "ref_work": 0.0, "bytes": 0.0})
         f["bytes"] += float(nbytes)
         f["launches"] += 1
@@ -71,3 +71,14 @@ def summary():
             f["unit"] = "GB/s"
         out.append(f)
     return sorted(out, key=lambda f: -f["time_ms"])
+
+
+def by_shape():
+    """-> list of (family, tag, launches, time_ms, work) aggregated over the launches that carry a shape tag (call after a sync)."""
+    agg = {}
+    for fam, bound, work, s, e, ref, nbytes, tag in _records:
+        a = agg.setdefault((fam, tag), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += s.elapsed_time(e)
+        a[2] += float(work)
+    return sorted(((k[0], k[1], v[0], v[1], v[2]) for k, v in agg.items()), key=lambda t: -t[3])
