@@ -282,6 +282,34 @@ int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int
  * gathers through it (dx fully written, no atomics). */
 int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 
+/* ---- joint loss: fused per-term reductions (csrc/prn_loss.hip) -------------------------------------------------------
+ * Instance masks: Dice (models/functions/losses.py:69-118,355-368) + lava (losses.py:169-197,288-329) in one pass.
+ *   logits [P][HW]  raw dynamic-conv outputs of the P positive grid cells (sigmoid applied inside), rows grouped by image
+ *   labels [P][HW]  uint8 0/1 targets;  img [P] int64 image of each row;  adj [B][HW] depth-gradient map pulled back to mask
+ *   resolution, gsum [B] its full-resolution sum, npos [B] rows per image (adj / gsum / npos NULL: no lava term)
+ *   out2 = { ins = w_ins * mean_i (1 - 2 sum(p t) / (sum p^2 + sum t^2 + 0.002)),
+ *            lav = w_lav * mean over images with gsum > 0 and npos > 0 of  sum_i sum(p adj) / (gsum * npos) }
+ *   coef [P][3]: per-row coefficients kept for prn_mask_loss_bwd; ws: prn_mask_loss_ws_floats(P) floats.
+ *   backward: dlogits [P][HW] from the upstream gradients of the two scalars (device scalars; NULL = 0).  HW % 4 == 0, B <= 64. */
+int prn_mask_loss_ws_floats(int P);
+int prn_mask_loss_fwd(const float* logits, const unsigned char* labels, const float* adj, const int64_t* img, const float* gsum, const float* npos,
+                      float* out2, float* coef, float* ws, int P, int HW, int B, float w_ins, float w_lav, void* stream);
+int prn_mask_loss_bwd(const float* logits, const unsigned char* labels, const float* adj, const int64_t* img, const float* coef, const float* g_ins,
+                      const float* g_lav, float* dlogits, int P, int HW, void* stream);
+
+/* Virtual-normal loss, per-triplet part (models/functions/vnl.py:57-165 for all planes of all images at once):
+ *   pred / gt [B*H*W] depths, gid [3][n] int32 cloud-point index of each triplet's points, seg [n] its segment (plane or
+ *   non-planar region of one image), per segment: is_plane (uint8), plane normal (double[3]), image; fx / fy [B] (double).
+ *   -> loss [n] double = 1 - |cos(predicted normal, plane normal | GT normal)|, valid [n] uint8 (the filter of vnl.py:71-104:
+ *   on the predicted cloud for planes, on the GT cloud for the non-planar region), g3 [n][3] = d loss / d pred depth of the
+ *   triplet's three points (forward-mode differentiation in the same pass; 0 where the loss is NaN).
+ *   prn_vnl_scatter: d_depth[r] = sum over (triplet, point) pairs that sampled cloud point r of g_loss[t] * g3[t][p];
+ *   order = argsort of the flattened gid, start [npts + 1] = exclusive prefix sum of the per-point counts (fixed order).  */
+int prn_vnl_triplets(const float* pred, const float* gt, const int* gid, const int64_t* seg, const unsigned char* seg_is_plane, const double* seg_normal,
+                     const int64_t* seg_img, const double* fx, const double* fy, double* loss, unsigned char* valid, float* g3, int n, int H, int W,
+                     float delta_z, void* stream);
+int prn_vnl_scatter(const double* g_loss, const float* g3, const int64_t* order, const int64_t* start, float* d_depth, int npts, int n, void* stream);
+
 /* ---- depth-error metrics of one frame ------------------------------------------------------------------------------
  * replaces the ~25 elementwise / boolean-index / reduction launches of compute_depth_metrics (eval.py:164-207):
  * over the pixels with gt > 0.5 and pred > 0.5, pred clamped to [min_depth, max_depth] (cfg.dataset):

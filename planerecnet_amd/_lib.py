@@ -90,6 +90,11 @@ SIGNATURES = {
     "prn_dcnv2_bwd_ws_bytes": (c_i64, [P]),
     "prn_dcnv2_bwd_input": (c_int, [P] * 8),
     "prn_dcnv2_bwd_offset_mask": (c_int, [P] * 8),
+    "prn_mask_loss_ws_floats": (c_int, [c_int]),
+    "prn_mask_loss_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, P]),
+    "prn_mask_loss_bwd": (c_int, [P] * 8 + [c_int, c_int, P]),
+    "prn_vnl_triplets": (c_int, [P] * 12 + [c_int, c_int, c_int, c_float, P]),
+    "prn_vnl_scatter": (c_int, [P] * 5 + [c_int, c_int, P]),
     "prn_depth_metrics_ws_doubles": (c_int, []),
     "prn_depth_metrics": (c_int, [P, P, P, P, c_i64, c_float, c_float, P]),
     "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),

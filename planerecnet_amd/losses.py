@@ -182,7 +182,17 @@ class PlaneRecNetLoss(nn.Module):
                     continue
                 w = flat_kb[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
                 preds.append(ops.conv2d(per_image[b], w).view(t.n_pos[b], fh, fw))
-            ins_sig = torch.sigmoid(torch.cat(preds, 0))                                                # [sum n_pos, fh, fw]
+            logits = torch.cat(preds, 0)                                                                # [sum n_pos, fh, fw]
+            if FUSED_LOSS and logits.is_cuda and logits.shape[0] > 0 and (fh * fw) % 4 == 0 and B <= 64:
+                # Dice + lava as ONE pass over the logits each way (include/prn.h: prn_mask_loss_fwd / _bwd)
+                lava = cfg.use_lava_loss
+                ins, lav = _MaskLoss.apply(logits, t.ins_labels, t.pos_img, t.lava_adj if lava else None, t.lava_gsum if lava else None,
+                                           t.n_pos_dev if lava else None, float(self.ins_loss_weight), float(self.lava_loss_weight))
+                out["ins"] = ins
+                if lava:
+                    out["lav"] = lav
+                return out
+            ins_sig = torch.sigmoid(logits)
             out["ins"] = dice_loss(ins_sig, t.ins_labels).mean() * self.ins_loss_weight
             # ---- lav -- losses.py:169-197 : sum(up(s) * g) / (sum(g) * n)  ==  sum(s * up^T(g)) / (sum(g) * n)
             if cfg.use_lava_loss:
@@ -218,6 +228,40 @@ class PlaneRecNetLoss(nn.Module):
         if all(k in losses for k in ("ins", "cat", "dpt", "pln", "lav")):
             losses = {k: losses[k] for k in ("ins", "cat", "dpt", "pln", "lav")}      # reference order (logging)
         return losses
+
+
+FUSED_LOSS = bool(int(os.environ.get("PRN_FUSED_LOSS", "1")))       # 0: the operator-by-operator evaluation below (A/B, cross-check in the tests)
+
+
+class _MaskLoss(torch.autograd.Function):
+    """(ins, lav) from the mask logits of all positive cells: sigmoid, Dice sums and the lava numerator in one pass forward,
+    the logit gradient of both terms in one pass backward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, pos_img, adj, gsum, npos, w_ins, w_lav):
+        logits, labels = logits.contiguous(), labels.contiguous()
+        P, HW = logits.shape[0], logits[0].numel()
+        B = adj.shape[0] if adj is not None else 1
+        dev = logits.device
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        coef = torch.empty(P, 3, device=dev, dtype=torch.float32)
+        ws = torch.empty(ops.lib.prn_mask_loss_ws_floats(P), device=dev, dtype=torch.float32)
+        adj_c = adj.contiguous() if adj is not None else None
+        ops.check(ops.lib.prn_mask_loss_fwd(ops._p(logits), ops._p(labels), ops._p(adj_c), ops._p(pos_img), ops._p(gsum), ops._p(npos), ops._p(out),
+                                            ops._p(coef), ops._p(ws), P, HW, B, w_ins, w_lav, ops._stream()), "prn_mask_loss_fwd")
+        ctx.save_for_backward(logits, labels, pos_img, adj_c, coef)
+        ins, lav = out.unbind(0)
+        return ins, lav
+
+    @staticmethod
+    def backward(ctx, g_ins, g_lav):
+        logits, labels, pos_img, adj, coef = ctx.saved_tensors
+        dz = torch.empty_like(logits)
+        g_ins = None if g_ins is None else g_ins.contiguous().float()
+        g_lav = None if g_lav is None else g_lav.contiguous().float()
+        ops.check(ops.lib.prn_mask_loss_bwd(ops._p(logits), ops._p(labels), ops._p(adj), ops._p(pos_img), ops._p(coef), ops._p(g_ins), ops._p(g_lav),
+                                            ops._p(dz), logits.shape[0], logits[0].numel(), ops._stream()), "prn_mask_loss_bwd")
+        return dz, None, None, None, None, None, None, None
 
 
 def dice_loss(p, t):
@@ -269,9 +313,44 @@ class _GatherRows(torch.autograd.Function):
         return torch.segment_reduce(g[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True), None, None, None
 
 
+class _VnlTriplets(torch.autograd.Function):
+    """(loss [n] float64, valid [n] uint8) of all sampled triplets from the predicted / GT depth maps (include/prn.h:
+    prn_vnl_triplets); the kernel also leaves d loss / d depth of each triplet's three points, so the backward pass is one
+    fixed-order scatter (prn_vnl_scatter) through the GT-only inverse of the sampling pattern."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, t, hw, delta_z):
+        n, dev = t.n_tot, pred.device
+        H, W = hw
+        loss = torch.empty(n, device=dev, dtype=torch.float64)
+        valid = torch.empty(n, device=dev, dtype=torch.uint8)
+        g3 = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        ops.check(ops.lib.prn_vnl_triplets(ops._p(pred), ops._p(gt), ops._p(t.gid32), ops._p(t.seg), ops._p(t.seg_is_plane), ops._p(t.seg_normal),
+                                           ops._p(t.seg_img), ops._p(t.fx), ops._p(t.fy), ops._p(loss), ops._p(valid), ops._p(g3), n, H, W, delta_z,
+                                           ops._stream()), "prn_vnl_triplets")
+        ctx.save_for_backward(g3)
+        ctx.t, ctx.shape = t, pred.shape
+        ctx.mark_non_differentiable(valid)
+        return loss, valid
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_valid):
+        (g3,), t = ctx.saved_tensors, ctx.t
+        npts = 1
+        for d in ctx.shape:
+            npts *= d
+        if t.gid_start is None:                              # GT only: per-point counts -> exclusive prefix sum (once per step)
+            counts = torch.zeros(npts, dtype=torch.int64, device=g3.device).scatter_add_(0, t.gid_flat, torch.ones_like(t.gid_flat))
+            t.gid_start = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
+        dd = torch.empty(npts, device=g3.device, dtype=torch.float32)
+        ops.check(ops.lib.prn_vnl_scatter(ops._p(g_loss.contiguous().double()), ops._p(g3), ops._p(t.gid_order), ops._p(t.gid_start), ops._p(dd), npts,
+                                          t.n_tot, ops._stream()), "prn_vnl_scatter")
+        return dd.view(ctx.shape), None, None, None, None
+
+
 class VNLTargets:
     __slots__ = ("B", "N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal", "n_seg", "n_tot",
-                 "gid_flat", "gid_order", "gid_counts")
+                 "gid_flat", "gid_order", "gid_counts", "gid32", "gid_start")
 
 
 class VNL_Loss(nn.Module):
@@ -342,6 +421,8 @@ class VNL_Loss(nn.Module):
         for k in ("N", "fx", "fy", "gid", "seg", "seg_start", "seg_img", "seg_is_plane", "seg_normal"):
             setattr(t, k, h[k].to(device, non_blocking=True))
         gid32 = t.gid                                        # int32 as uploaded: the radix sort below has half the key bits to do
+        t.gid32 = gid32 if gid32.dtype == torch.int32 else gid32.int()
+        t.gid_start = None                                   # filled by the fused path (prefix sum of the per-point counts)
         t.gid, t.seg = t.gid.long(), t.seg.long()
         # inverse of the triplet gather, built once per step (GT only): which gathered rows land on which cloud point
         # (sort + per-point counts over ALL B*H*W cloud points: fixed-size outputs, so no device->host sync)
@@ -396,6 +477,11 @@ class VNL_Loss(nn.Module):
     def batched(self, pred_depth, gt_depth, t):
         """-> per-image loss [B] (float64), equal to vnl.py:119-165 evaluated image by image."""
         dev = pred_depth.device
+        if FUSED_LOSS and pred_depth.is_cuda and t.n_tot > 0:
+            # per-triplet part (cloud points, filter, normals, cosine term AND its three depth derivatives) in ONE kernel
+            loss, valid = _VnlTriplets.apply(pred_depth.contiguous(), gt_depth.contiguous(), t, self.input_size, float(self.delta_z))
+            valid = valid.bool()
+            return self._trimmed_means(loss, valid, t, dev)
         pc_pred, pc_gt = self._cloud(pred_depth, t), self._cloud(gt_depth, t)
         is_plane = t.seg_is_plane[t.seg]                                                          # per triplet
         tri_pred = self._triplets_t(pc_pred, t)
@@ -414,7 +500,12 @@ class VNL_Loss(nn.Module):
         cos_plane = F.cosine_similarity(dn.double(), t.seg_normal[t.seg], dim=1).abs()
         cos_np = F.cosine_similarity(dn, gn_np, dim=1).abs().double()
         loss = 1 - torch.where(is_plane, cos_plane, cos_np)                                       # [n_tot] float64
-        # segmented "sort ascending, drop the first 25 % of the valid ones, nansum / remaining"
+        return self._trimmed_means(loss, valid, t, dev)
+
+    @staticmethod
+    def _trimmed_means(loss, valid, t, dev):
+        """Per-triplet losses -> per-image loss [B] (vnl.py:106-117,133-165).
+        Segmented "sort ascending, drop the first 25 % of the valid ones, nansum / remaining"."""
         # segments are contiguous runs in triplet order: segment sums are differences of one prefix sum (no atomics)
         seg_end = torch.cat([t.seg_start[1:], t.seg_start.new_full((1,), t.n_tot)])
 

@@ -326,3 +326,36 @@ def test_prefetched_targets_equal_direct_preparation():
             assert torch.equal(getattr(t.vnl, name), getattr(direct.vnl, name)), name
     finally:
         pf.close()
+
+
+def test_fused_virtual_normal_kernel_equals_operator_chain():
+    """prn_vnl_triplets (+ forward-mode depth derivatives, prn_vnl_scatter) against the operator-by-operator evaluation of the
+    same batched loss (itself equal to the oracle's per-plane loops: tests/test_host_cpu.py): per-image values and the gradient
+    w.r.t. the predicted depth map, incl. exact zeros in the prediction (the non-planar zero fix of vnl.py:151)."""
+    import numpy as np
+    from oracle import synth
+    from planerecnet_amd import losses
+    from planerecnet_amd.config import set_cfg
+    set_cfg("PlaneRecNet_50_config")
+    dev = torch.device("cuda:0")
+    crit = losses.PlaneRecNetLoss().to(dev)
+    _, inst, gtd = synth.make_batch(3, 480, 640, seed=8)
+    g = torch.Generator().manual_seed(3)
+    pred = (gtd * (1 + 0.05 * torch.randn(gtd.shape, generator=g)) + 0.02).clamp(min=0.05)
+    pred[0, 0, 100:110, 200:230] = 0.0                    # exact zeros: the zero-fix branch and |d| at its kink
+    np.random.seed(21)
+    t = crit.vnl.prepare(inst, (480, 640), dev)
+    outs = {}
+    for fused in (False, True):
+        losses.FUSED_LOSS = fused
+        try:
+            p = pred.to(dev).requires_grad_(True)
+            per_img = crit.vnl.batched(p, gtd.to(dev), t)
+            w = torch.tensor([1.0, 0.7, 1.3], device=dev, dtype=per_img.dtype)
+            gp, = torch.autograd.grad((per_img * w).sum(), p)
+            outs[fused] = (per_img.detach().cpu(), gp.detach().cpu())
+        finally:
+            losses.FUSED_LOSS = True
+    assert torch.allclose(outs[True][0], outs[False][0], rtol=1e-6, atol=1e-9), (outs[True][0], outs[False][0])
+    a, b = outs[True][1].double(), outs[False][1].double()
+    assert ((a - b).norm() / b.norm()).item() < 1e-4 and (a - b).abs().max().item() <= 1e-3 * b.abs().max().item()

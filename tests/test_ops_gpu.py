@@ -552,3 +552,40 @@ def test_ragged_winograd_matches_direct_ragged_kernel(C, M, monkeypatch):
         close(a, F.conv2d(xs[i].double().cpu(), w.double().cpu(), padding=1), "ragged winograd y[%d] vs torch" % i)
     for i, (a, r) in enumerate(zip(ga, gb)):
         close(a, r.double().cpu(), "ragged winograd grad[%d]" % i, rtol=1e-4)
+
+
+def test_fused_mask_loss_matches_operator_chain():
+    """Dice + lava in one pass (prn_mask_loss_fwd / _bwd) against the reference formulas evaluated operator by operator in
+    fp64 (models/functions/losses.py:69-118,169-197): values and logit gradients, incl. an image without positive cells, an
+    image whose depth-gradient map is all zero, and non-unit upstream gradients."""
+    from planerecnet_amd.losses import _MaskLoss
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    B, fh, fw = 4, 12, 20
+    rows = [9, 0, 17, 11]                                     # image 1 has no positive cell
+    P = sum(rows)
+    img = torch.repeat_interleave(torch.arange(B), torch.tensor(rows))
+    z = (torch.randn(P, fh, fw, generator=g, dtype=torch.float64) * 2).requires_grad_(True)
+    t = (torch.rand(P, fh, fw, generator=g) < 0.3).to(torch.uint8)
+    adj = torch.rand(B, 1, fh, fw, generator=g, dtype=torch.float64)
+    gsum = adj.flatten(1).sum(1) * 16.0
+    adj[3] = 0.0
+    gsum[3] = 0.0                                             # image 3 does not qualify
+    npos = torch.tensor(rows, dtype=torch.float64)
+    w_ins, w_lav = 3.0, 1.0
+    p = torch.sigmoid(z)
+    pf, tf = p.flatten(1), t.flatten(1).double()
+    dice = 1 - 2 * (pf * tf).sum(1) / ((pf * pf).sum(1) + 0.001 + (tf * tf).sum(1) + 0.001)
+    ins_ref = dice.mean() * w_ins
+    num = torch.zeros(B, dtype=torch.float64).index_add_(0, img, (p * adj[img, 0]).flatten(1).sum(1))
+    ok = (gsum > 0) & (npos > 0)
+    lav_ref = torch.where(ok, num / (gsum * npos).clamp(min=1e-30), torch.zeros_like(num)).sum() / ok.sum().clamp(min=1) * w_lav
+    gz_ref, = torch.autograd.grad(0.7 * ins_ref + 1.9 * lav_ref, z)
+    zd = z.detach().float().to(d).requires_grad_(True)
+    ins, lav = _MaskLoss.apply(zd, t.to(d), img.to(d), adj.float().to(d), gsum.float().to(d), npos.float().to(d), w_ins, w_lav)
+    assert abs(float(ins) - float(ins_ref)) <= 1e-5 * abs(float(ins_ref)) and abs(float(lav) - float(lav_ref)) <= 1e-5 * abs(float(lav_ref))
+    gz, = torch.autograd.grad(0.7 * ins + 1.9 * lav, zd)
+    close(gz, gz_ref, "mask loss d logits", rtol=1e-5)
+    # Dice only (no lava inputs)
+    ins2, lav2 = _MaskLoss.apply(zd, t.to(d), img.to(d), None, None, None, w_ins, w_lav)
+    assert abs(float(ins2) - float(ins_ref)) <= 1e-5 * abs(float(ins_ref)) and float(lav2) == 0.0

@@ -1,0 +1,37 @@
+#!/bin/bash
+# rocprofv3 --kernel-trace --stats of bench.py: (1) serialised (--sync-wgrad: every kernel alone on the GPU -- the run whose
+# per-kernel averages match the event-bracketed roofline leg) and (2) the default overlapped run.  Summaries -> gpurun_out/prof/.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r02}
+mkdir -p $R/gpurun_out/prof
+for mode in serial default; do
+  rm -rf /tmp/prof_$mode
+  extra=""; [ $mode = serial ] && extra="--sync-wgrad"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -o t -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-roofline --dcn-offsets 0 $extra > /tmp/prof_$mode.log 2>&1
+  f=$(ls /tmp/prof_$mode/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp $f $R/gpurun_out/prof/${TAG}_kernel_stats_$mode.csv
+  tail -2 /tmp/prof_$mode.log | cut -c1-300
+done
+python3 - <<PY
+import csv
+for mode in ("serial", "default"):
+    rows = list(csv.DictReader(open("$R/gpurun_out/prof/${TAG}_kernel_stats_%s.csv" % mode)))
+    steps = 11
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
+    n = sum(int(r["Calls"]) for r in rows) / steps
+    ours = [r for r in rows if "anonymous namespace" in r["Name"] and "at::" not in r["Name"]]
+    print("%s: %.2f ms of kernels / step, %.0f launches / step; libprn_hip: %.2f ms, %.0f launches" % (mode, tot, n, sum(float(r["TotalDurationNs"]) for r in ours) / steps / 1e6, sum(int(r["Calls"]) for r in ours) / steps))
+    fam = {}
+    for r in rows:
+        nm = r["Name"]
+        key = "ATen / rocprim / copies"
+        for k in ("conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel", "dcnv2_table", "dcn_", "winograd_", "bn_", "gn_relu", "reduce_splits", "reduce_epilogue", "resize_", "mask_loss", "maxpool", "channel_sum", "flip_transpose", "pad_fold", "replicate_fold", "space_to_depth", "up2_", "conv3x3_"):
+            if k in nm and "at::" not in nm:
+                key = k
+                break
+        a = fam.setdefault(key, [0, 0.0])
+        a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"])
+    for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print("   %-28s %7.1f launches/step %8.3f ms/step  avg %7.1f us" % (k, c / steps, t / steps / 1e6, t / c / 1e3))
+PY
