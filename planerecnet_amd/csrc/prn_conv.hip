@@ -857,7 +857,9 @@ __global__ void pad_fold_kernel(const float* __restrict__ dp, float* __restrict_
 }
 
 // out[c] = sum_{b,hw} x[b,c,hw]: grid (C, S) fixed-order fp64 partials, then one thread per channel sums them
-__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int B, int C, int HW) {
+// `direct` != NULL (single split): the channel's sum goes straight to the output -- one launch instead of two
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int B, int C, int HW,
+                                                                  float* __restrict__ direct) {
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const int beg = (int)((int64_t)HW * s / S), end = (int)((int64_t)HW * (s + 1) / S);
   float part = 0.f;
@@ -869,7 +871,10 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
   __shared__ double sm[4];
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) ws[(size_t)c * S + s] = sm[0] + sm[1] + sm[2] + sm[3];
+  if (threadIdx.x == 0) {
+    const double t = sm[0] + sm[1] + sm[2] + sm[3];
+    if (direct) direct[c] = (float)t; else ws[(size_t)c * S + s] = t;
+  }
 }
 
 __global__ void channel_sum_final_kernel(const double* __restrict__ ws, float* __restrict__ out, int C, int S) {
@@ -1462,8 +1467,10 @@ extern "C" int prn_channel_sum(const float* x, float* out, double* ws, int B, in
   int S = (int)(((int64_t)B * HW + 8191) / 8192);
   S = S > PRN_BN_SPLITS ? PRN_BN_SPLITS : (S < 1 ? 1 : S);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
+  if (C >= 128 && (int64_t)B * HW <= 65536) S = 1;       // enough channels to fill the GPU on their own: no split, no second launch
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW, S == 1 ? out : nullptr);
   PRN_CHECK_LAUNCH("prn_channel_sum/partial");
+  if (S == 1) return 0;
   hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, out, C, S);
   PRN_CHECK_LAUNCH("prn_channel_sum/final");
   return 0;

@@ -799,12 +799,14 @@ def deform_conv2d(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0
 class _DeformConvBlock(torch.autograd.Function):
     """models/dcn.py:52-67 as one node: 27-channel offset|modulator conv + DCNv2 on its RAW output (clamp and 2*sigmoid
     folded into the gather table).  x feeds both, so its two gradients (through the sampler and through the offset conv) are
-    summed in the offset conv's input-gradient epilogue."""
+    summed in the offset conv's input-gradient epilogue.  The offset / modulator parameters are passed for autograd; the
+    arithmetic reads the merged [27, C, 3, 3] / [27] tensors they are views of (dcn.DeformableConv2d._merged), and their
+    gradients are returned as views of one 27-channel gradient."""
 
     @staticmethod
-    def forward(ctx, x, w27, b27, w, bias, stride, max_offset):
+    def forward(ctx, x, w_off, w_mod, b_off, b_mod, w27, b27, w, bias, stride, max_offset):
         _dev(x, w27, b27, w, bias)
-        x, w27, b27, w, bias = _c(x), _c(w27), _c(b27), _c(w), _c(bias)
+        x, w, bias = _c(x), _c(w), _c(bias)
         B, C, H, W = x.shape
         M = w.shape[0]
         Ho, Wo = _out_hw(H, W, 3, stride, 1, IN_ZERO)
@@ -823,22 +825,23 @@ class _DeformConvBlock(torch.autograd.Function):
         M = w.shape[0]
         ni = ctx.needs_input_grad
         dx1, dom, _ = dcn_data_grads_raw(x, om, None, w, dy, stride, 1, 1, max_offset)
-        if _defer(ni[3], w):
+        if _defer(ni[7], w):
             _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset))
             dw = None
         else:
-            dw = dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset) if ni[3] else None
-        db = channel_sum(dy) if (has_bias and ni[4]) else None
-        dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if ni[1] else None
-        db27 = channel_sum(dom) if ni[2] else None
+            dw = dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset) if ni[7] else None
+        db = channel_sum(dy) if (has_bias and ni[8]) else None
+        dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if (ni[1] or ni[2]) else None
+        db27 = channel_sum(dom) if (ni[3] or ni[4]) else None
         dx = conv_dgrad_raw(dom, w27, x.shape, stride, 1, IN_ZERO, dx1) if ni[0] else None
-        return dx, dw27, db27, dw, db, None, None
+        return (dx, None if dw27 is None else dw27[:18], None if dw27 is None else dw27[18:], None if db27 is None else db27[:18],
+                None if db27 is None else db27[18:], None, None, dw, db, None, None)
 
 
-def deform_conv_block(x, w27, b27, weight, bias, stride, max_offset):
+def deform_conv_block(x, w_off, w_mod, b_off, b_mod, w27, b27, weight, bias, stride, max_offset):
     """models/dcn.py:52-67 in one node: om = conv3x3(x; [offset | modulator] weights), y = deform_conv2d(x, clamp(om[:18]), weight,
-    mask = 2 * sigmoid(om[18:]))."""
-    return _DeformConvBlock.apply(x, w27, b27, weight, bias, stride, max_offset)
+    mask = 2 * sigmoid(om[18:])).  w27 / b27: the merged storage the four offset / modulator parameters are views of."""
+    return _DeformConvBlock.apply(x, w_off, w_mod, b_off, b_mod, w27, b27, weight, bias, stride, max_offset)
 
 
 def deform_conv2d_raw_relu(x, om_raw, weight, bias, stride, max_offset):
@@ -937,12 +940,12 @@ class _GroupNormReLU(torch.autograd.Function):
         dy = _c(dy)
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
-        dgp = torch.empty(B, C, device=x.device, dtype=torch.float32)
-        dbp = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        part = torch.empty(2, B, C, device=x.device, dtype=torch.float32)       # per-image partials of d gamma / d beta: ONE reduction for both
         with profiling.span("gn_relu_bwd", "hbm", 4.0 * x.numel() * 4):
-            check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(beta), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), B, C, H * W, ctx.groups, _stream()),
+            check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(beta), _p(stats), _p(gamma), _p(dx), _p(part[0]), _p(part[1]), B, C, H * W, ctx.groups, _stream()),
                   "prn_gn_relu_bwd")
-        return dx, dgp.sum(0), dbp.sum(0), None, None
+        dgb = part.sum(1)
+        return dx, dgb[0], dgb[1], None, None
 
 
 def group_norm_relu(x, gamma, beta, groups=32, eps=1e-5):
@@ -1096,12 +1099,12 @@ class _RaggedGNReLU(torch.autograd.Function):
         C = gamma.numel()
         n = len(rs.sizes)
         dx = torch.empty_like(xp)
-        dgp = torch.empty(n * rs.B, C, device=xp.device, dtype=torch.float32)
-        dbp = torch.empty(n * rs.B, C, device=xp.device, dtype=torch.float32)
+        part = torch.empty(2, n * rs.B, C, device=xp.device, dtype=torch.float32)
         with profiling.span("gn_relu_bwd", "hbm", 4.0 * xp.numel() * 4):
-            check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(beta), _p(stats), _p(gamma), _p(dx), _p(dgp), _p(dbp), rs.B, C, n, rs.hw, groups,
+            check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(beta), _p(stats), _p(gamma), _p(dx), _p(part[0]), _p(part[1]), rs.B, C, n, rs.hw, groups,
                                              _stream()), "prn_gn_relu_bwd_ragged")
-        return dx, dgp.sum(0), dbp.sum(0), None, None, None
+        dgb = part.sum(1)
+        return dx, dgb[0], dgb[1], None, None, None
 
 
 def ragged_group_norm_relu(xp, gamma, beta, groups, eps, rs):

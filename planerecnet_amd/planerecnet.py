@@ -26,13 +26,21 @@ from .funcs import bias_init_with_prob
 from .nms import mask_nms, matrix_nms, point_nms
 
 
+_COORD = {}
+
+
 def _coord_channels(feat):
-    """(x, y) in [-1,1], channel order x then y (planerecnet.py:370-376,484-490)."""
+    """(x, y) in [-1,1], channel order x then y (planerecnet.py:370-376,484-490).  Constant per (batch, size, device): built
+    once (the reference rebuilds it with linspace / meshgrid / expand / cat in every forward)."""
     B, _, h, w = feat.shape
-    xr = torch.linspace(-1, 1, w, device=feat.device)
-    yr = torch.linspace(-1, 1, h, device=feat.device)
-    y, x = torch.meshgrid(yr, xr, indexing="ij")
-    return torch.cat([x.expand(B, 1, h, w), y.expand(B, 1, h, w)], 1)
+    key = (B, h, w, feat.device)
+    c = _COORD.get(key)
+    if c is None:
+        xr = torch.linspace(-1, 1, w, device=feat.device)
+        yr = torch.linspace(-1, 1, h, device=feat.device)
+        y, x = torch.meshgrid(yr, xr, indexing="ij")
+        c = _COORD[key] = torch.cat([x.expand(B, 1, h, w), y.expand(B, 1, h, w)], 1).contiguous()
+    return c
 
 
 def _conv_gn_relu(x, conv, gn):

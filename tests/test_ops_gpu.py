@@ -264,11 +264,15 @@ def test_deform_conv_block_matches_unfused(stride):
     go = rnd(*yr.shape, seed=6)
     gr = torch.autograd.grad(yr, ts, go)
     d = dev()
-    xs = [t.detach().float().to(d).requires_grad_(True) for t in (x, w27, b27, w, b)]
-    yd = ops.deform_conv_block(*xs, stride, maxoff)
+    xd, w27d, b27d, wd, bd = [t.detach().float().to(d) for t in (x, w27, b27, w, b)]
+    # the four offset / modulator parameters as views of the merged storage (what dcn.DeformableConv2d keeps)
+    leaves = [xd.requires_grad_(True), w27d[:18].requires_grad_(True), w27d[18:].requires_grad_(True), b27d[:18].requires_grad_(True),
+              b27d[18:].requires_grad_(True), wd.requires_grad_(True), bd.requires_grad_(True)]
+    yd = ops.deform_conv_block(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], w27d, b27d, leaves[5], leaves[6], stride, maxoff)
     close(yd, yr, "dcn block fwd")
-    gd = torch.autograd.grad(yd, xs, go.float().to(d))
-    for n, g1, g0 in zip(["dx", "dw27", "db27", "dw", "db"], gd, gr):
+    gd = torch.autograd.grad(yd, leaves, go.float().to(d))
+    got = [gd[0], torch.cat([gd[1], gd[2]]), torch.cat([gd[3], gd[4]]), gd[5], gd[6]]
+    for n, g1, g0 in zip(["dx", "dw27", "db27", "dw", "db"], got, gr):
         close(g1, g0, "dcn block " + n, rtol=5e-4)
 
 
