@@ -56,6 +56,7 @@ struct ConvArgs {
   int ystride, yW, yHW;     // output map: GEMM pixel (oh, ow) is stored at (oh*ystride + phase_y, ow*ystride + phase_x) of a yHW plane
   int zx, zw, zy;           // VEC instances: element strides of x / w / y per blockIdx.z (prn_gemm_batched; 0 for a plain conv)
   int wide_store;           // epilogue through the LDS transpose (float4 stores): output / addend / workspace 16-byte aligned
+  int tail_first, tail_splits;   // tail split (see plan_tail): blocks >= tail_first are K-split pieces of the last tiles; 0 splits = off
   float* ws;
   Seg seg;
 };
@@ -146,7 +147,19 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
+  // block -> (tile, K split).  Tail split: a launch of R full residency rounds plus a fraction leaves the CUs mostly idle
+  // through the last, partly filled round; the tiles of that round are therefore cut along K into `tail_splits` short
+  // workgroups each (blocks >= tail_first), which fill the machine as the full-length workgroups retire.  Their partial
+  // tiles go to the workspace and reduce_tail_kernel sums them in fixed order.
+  int id, ksplit = blockIdx.y, nsplit = a.splits;
+  if (a.tail_splits > 1 && (int)blockIdx.x >= a.tail_first) {
+    const int q = (int)blockIdx.x - a.tail_first;
+    id = a.tail_first + q / a.tail_splits;
+    ksplit = q - (q / a.tail_splits) * a.tail_splits;
+    nsplit = a.tail_splits;
+  } else {
+    id = prn_xcd_remap(blockIdx.x, a.tail_splits > 1 ? a.tail_first : a.nblocks);
+  }
   const int m0 = (id % a.tilesM) * BM;
   int n0 = (id / a.tilesM) * BN;
   // geometry of the tensor this workgroup works on: the descriptor's, or its segment's in a ragged batch
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
       }
     };
     const int KTall = (a.K + BK - 1) / BK;
-    const int kt0 = (int)((int64_t)blockIdx.y * KTall / a.splits), KT = (int)((int64_t)(blockIdx.y + 1) * KTall / a.splits);
+    const int kt0 = (int)((int64_t)ksplit * KTall / nsplit), KT = (int)((int64_t)(ksplit + 1) * KTall / nsplit);
     load_tile(kt0 * BK);
     store_tile(kt0 & 1);
     __syncthreads();
@@ -364,8 +377,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
 
   // epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel).
   // Uniform decisions (split partial / bias / addend / activation / interior tile) are hoisted out of the element loops.
-  const bool partial = a.splits > 1;
-  float* __restrict__ outp = partial ? a.ws + (size_t)blockIdx.y * a.B * a.M * HoWo_ : y_;
+  const bool partial = nsplit > 1;
+  float* __restrict__ outp = partial ? a.ws + (size_t)ksplit * a.B * a.M * HoWo_ : y_;
   const bool has_bias = !partial && a.bias != nullptr, has_add = !partial && add_ != nullptr;
   const int epi = partial ? PRN_EPI_NONE : a.epi;
   const bool interior = (m0 + BM <= a.M) && (n0 + BN <= N_);
@@ -755,6 +768,27 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __res
   }
 }
 
+// The same for the pixel range [n_start, N) only (tail split of conv_igemm_kernel): one thread per (channel m, 4 pixels).
+__global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restrict__ ws, const float* __restrict__ bias, const float* __restrict__ addend,
+                                                          float* __restrict__ y, int64_t total, int M, int HoWo, int n_start, int ntail4, int splits,
+                                                          int epi) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)M * ntail4) return;
+  const int m = (int)(t / ntail4), q = (int)(t - (int64_t)m * ntail4);
+  const int n = n_start + q * 4, b = n / HoWo, p = n - b * HoWo;
+  const int64_t i = ((int64_t)b * M + m) * HoWo + p;
+  float4 v = *reinterpret_cast<const float4*>(ws + i);
+  for (int s = 1; s < splits; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(ws + (size_t)s * total + i);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  if (bias) { const float bm = bias[m]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+  if (addend) { const float4 u = *reinterpret_cast<const float4*>(addend + i); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+  if (epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  else if (epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y)); v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w)); }
+  *reinterpret_cast<float4*>(y + i) = v;
+}
+
 // out[i] = sum_k ws[k][i] in a fixed order: four wave-sized groups each take every 4th split (four loads in flight per
 // thread), then one LDS step adds the four partials.  n/64 workgroups instead of n/256 single-chain threads: the weight
 // matrices are small (3e4 .. 2e6 elements), so the one-thread-per-element version left most CUs idle and latency-bound.
@@ -887,6 +921,29 @@ __global__ void channel_sum_final_kernel(const double* __restrict__ ws, float* _
 
 struct FwdPlan { int tm, tn, bk, splits, wm, wn; };   // block tile = (32*wm*tm) x (32*wn*tn), 64*wm*wn threads
 
+// Tail split (conv_igemm_kernel): for an unsplit launch of `tiles` workgroups, how many of the last tiles to cut along K and
+// into how many pieces.  Residency: 4 workgroups per CU for the 128-row / 128-column tiles, 8 for 64 x 64.  Returns the number
+// of tail tiles (0 = no tail split) and sets *pieces.  PRN_CONV_TAIL=0 switches it off (A/B).
+int plan_tail(const FwdPlan& p, int64_t tiles, int tilesM, int K, int64_t N, int HoWo, int* pieces) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("PRN_CONV_TAIL"); on = e ? atoi(e) : 1; }
+  *pieces = 0;
+  if (!on || p.splits != 1 || p.wm != 2 || (HoWo & 3) != 0) return 0;
+  const int64_t slots = 256 * ((p.tm * p.tn >= 2) ? 4 : 8);
+  const int64_t full = tiles / slots * slots, r = tiles - full;
+  const int kt = cdiv(K, 16);
+  // deep-K launches only: on the short-K 1x1 layers (16 .. 64 slices) the pieces are all prologue and epilogue -- 256->1024 @30x40
+  // went from 50 to 57 us with its 176 tail tiles cut in five, while the 3x3 layers with K >= 1152 gain 5-6 %
+  if (full == 0 || r == 0 || 20 * r < slots || 10 * r > 6 * slots || r % tilesM != 0 || kt < 64) return 0;     // 5 % .. 60 % of a round
+  if ((N - (int64_t)(full / tilesM) * 32 * p.wn * p.tn) % 4 != 0) return 0;
+  int s = (int)(slots / r);
+  if (s > kt / 4) s = kt / 4;
+  if (s > 8) s = 8;
+  if (s < 2) return 0;
+  *pieces = s;
+  return (int)r;
+}
+
 // All workgroups of these launches are resident at once, so the launch lasts as long as its most loaded CU: 528 workgroups
 // (16 CUs with 3, the rest with 2) ran 27 % longer than 512.  Round the split count down so that tiles * splits lands on
 // (just below) a multiple of the 256 CUs when only a few workgroups per CU exist (never below 3/4 of the request).
@@ -950,7 +1007,7 @@ constexpr bool narrow_available(int ks, int mode) {
 }
 
 template <int KS, int MODE>
-int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases = 1) {
+int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases = 1, int tail_tiles = 0, int tail_pieces = 0) {
   ConvArgs a = a0;
   a.tilesM = cdiv(a.M, 32 * p.wm * p.tm);
   a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
@@ -962,7 +1019,13 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
     a.wide_store = wide && a.seg.nseg == 0 && p.wm == 2 && al16(a.y) && al16(a.addend) && al16(a.ws) && (a.zy & 3) == 0 &&
                    (p.splits == 1 || (((int64_t)a.B * a.M * a.HoWo) & 3) == 0);
   }
-  dim3 grid(a.nblocks, p.splits, phases), block(64 * p.wm * p.wn);
+  a.tail_first = a.nblocks; a.tail_splits = 0;
+  int gx = a.nblocks;
+  if (tail_pieces > 1 && phases == 1 && a.seg.nseg == 0 && a.ystride == 1) {
+    a.tail_first = a.nblocks - tail_tiles; a.tail_splits = tail_pieces;
+    gx = a.tail_first + tail_tiles * tail_pieces;
+  }
+  dim3 grid(gx, p.splits, phases), block(64 * p.wm * p.wn);
   if constexpr (narrow_available(KS, MODE)) {
     if (p.wm == 1) {
       hipLaunchKernelGGL((conv_igemm_kernel<KS, MODE, 1, 1, 16, false, 1>), grid, block, 0, st, a);
@@ -1120,6 +1183,15 @@ Geo geo_of(const prn_conv_desc* d) {
   return g;
 }
 
+// tail split of a dense, unsplit forward launch (plan_tail): number of tail tiles, *pieces = K pieces per tail tile
+int tail_of(const prn_conv_desc* d, const Geo& g, const FwdPlan& p, int* pieces) {
+  *pieces = 0;
+  if (g.phases != 1 || g.nosplit || d->ystride > 1) return 0;
+  const int64_t N = (int64_t)d->B * g.gH * g.gW;
+  const int tilesM = cdiv(d->M, 32 * p.wm * p.tm);
+  return plan_tail(p, (int64_t)tilesM * cdiv(N, 32 * p.wn * p.tn), tilesM, d->C * d->KH * d->KW, N, g.gH * g.gW, pieces);
+}
+
 }  // namespace
 
 int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* addend, float* y, int64_t total, int M, int HoWo, int splits,
@@ -1141,7 +1213,10 @@ extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   const Geo g = geo_of(d);
   const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
                              wide_ks(d->KH, d->in_mode));
-  return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
+  if (p.splits > 1) return (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4;
+  int pieces = 0;
+  tail_of(d, g, p, &pieces);
+  return pieces > 1 ? (int64_t)pieces * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
 
 extern "C" int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -1246,15 +1321,17 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_fwd: workspace required (%d K-splits, see prn_conv2d_fwd_ws_bytes)", p.splits);
   hipStream_t st = (hipStream_t)stream;
   const int mode = d->in_mode;
+  int tail_pieces = 0;
+  const int tail_tiles = (rg == nullptr && ws != nullptr) ? tail_of(d, g, p, &tail_pieces) : 0;     // (no workspace handed in: plain launch)
   if (phase == 2) goto reduce_only;
   if (d->KH == 1) {
     PRN_REQUIRE(mode == PRN_IN_ZERO || mode == PRN_IN_DILATED, "prn_conv2d_fwd: 1x1 kernels take zero or dilated input mode");
-    if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st); else launch_fwd<1, PRN_IN_DILATED>(a, p, st);
+    if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st, 1, tail_tiles, tail_pieces); else launch_fwd<1, PRN_IN_DILATED>(a, p, st);
   } else if (d->KH == 2) {
     launch_fwd<2, PRN_IN_UP2_PHASE>(a, p, st, 4);
   } else if (d->KH == 3) {
-    if (mode == PRN_IN_ZERO) launch_fwd<3, PRN_IN_ZERO>(a, p, st);
-    else if (mode == PRN_IN_REFLECT) launch_fwd<3, PRN_IN_REFLECT>(a, p, st);
+    if (mode == PRN_IN_ZERO) launch_fwd<3, PRN_IN_ZERO>(a, p, st, 1, tail_tiles, tail_pieces);
+    else if (mode == PRN_IN_REFLECT) launch_fwd<3, PRN_IN_REFLECT>(a, p, st, 1, tail_tiles, tail_pieces);
     else if (mode == PRN_IN_UP2_REFLECT) launch_fwd<3, PRN_IN_UP2_REFLECT>(a, p, st);
     else launch_fwd<3, PRN_IN_DILATED>(a, p, st);
   } else if (d->KH == 4) {
@@ -1270,6 +1347,14 @@ reduce_only:
     hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, (const float*)ws, bias, addend, y, total, a.M, a.HoWo,
                        p.splits, a.epi);
     PRN_CHECK_LAUNCH("prn_conv2d_fwd/reduce");
+  } else if (tail_pieces > 1 && (mode == PRN_IN_ZERO || mode == PRN_IN_REFLECT) && (d->KH == 1 || d->KH == 3)) {
+    const int64_t total = (int64_t)a.B * a.M * a.HoWo;
+    const int bn = 32 * p.wn * p.tn, tilesM = cdiv(a.M, 32 * p.wm * p.tm);
+    const int n_start = (int)(((int64_t)tilesM * cdiv(a.N, bn) - tail_tiles) / tilesM) * bn;
+    const int ntail4 = (a.N - n_start) / 4;
+    hipLaunchKernelGGL(reduce_tail_kernel, dim3(cdiv((int64_t)a.M * ntail4, 256)), dim3(256), 0, st, (const float*)ws, bias, addend, y, total, a.M, a.HoWo,
+                       n_start, ntail4, tail_pieces, a.epi);
+    PRN_CHECK_LAUNCH("prn_conv2d_fwd/tail reduce");
   }
   return 0;
 }
