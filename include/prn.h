@@ -282,6 +282,29 @@ int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int
  * gathers through it (dx fully written, no atomics). */
 int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 
+/* ---- composite blocks (csrc/prn_blocks.hip): fixed operator sequences of the reference's forward as one call ------------------
+ * Plain compositions of the launches above on the caller's stream (same arithmetic as issuing them one by one).
+ *
+ * prn_plane_prior_fwd -- the plane prior of the depth decoder (planerecnet.py:586-594), in its exact reduced form: the x0.25
+ *   bilinear resize at the end reads only the two centre samples of every 4-block per axis and everything between is linear
+ *   per pixel, so  resize(conv1x1(sigmoid(K . M)))  ==  conv1x1(mean2x2(sigmoid(K . M[centre samples]))).
+ *   seg [B,E,h,w] mask features (h, w multiples of 4); kernels [B,NK,E] the NK = 3728 predicted kernels of each image, one row
+ *   per grid cell; w1 [F,NK], b1 [F] = depth_decoder.conv1x1.  pooled [B,NK,h/4,w/4] is written for the weight gradient;
+ *   out [B,F,h/4,w/4].  All inputs are detached in the reference (planerecnet.py:589,592), so the only gradients are
+ *   prn_plane_prior_wgrad (dw1 = d_out x pooled^T) and prn_channel_sum(d_out) for b1.
+ * prn_fpn_level_fwd -- one pyramid level (models/fpn.py:51-63): lateral = conv1x1(x) + b_lat + resize(prev -> HxW) (prev = the
+ *   FINER level's lateral or NULL: the reference accumulates bottom-up), p_out = [relu](conv3x3(lateral) + b_out).  u_out: the
+ *   3x3 weights in the Winograd domain ([36][F][F], prn_winograd_weights_batched) or NULL -- with them, qualifying shapes take
+ *   the F(4x4,3x3) path.                                                                                                  */
+int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, int F);
+int prn_plane_prior_fwd(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws, int B, int E,
+                        int h, int w, int NK, int F, void* stream);
+int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F);
+int prn_plane_prior_wgrad(const float* pooled, const float* d_out, float* dw1, void* ws, int B, int h, int w, int NK, int F, void* stream);
+int64_t prn_fpn_level_ws_bytes(int B, int C, int H, int W, int F, int relu, int has_prev, int have_u);
+int prn_fpn_level_fwd(const float* x, const float* w_lat, const float* b_lat, const float* prev, int Hp, int Wp, const float* w_out, const float* u_out,
+                      const float* b_out, float* lateral, float* p_out, void* ws, int B, int C, int H, int W, int F, int relu, void* stream);
+
 /* ---- joint loss: fused per-term reductions (csrc/prn_loss.hip) -------------------------------------------------------
  * Instance masks: Dice (models/functions/losses.py:69-118,355-368) + lava (losses.py:169-197,288-329) in one pass.
  *   logits [P][HW]  raw dynamic-conv outputs of the P positive grid cells (sigmoid applied inside), rows grouped by image

@@ -90,6 +90,12 @@ SIGNATURES = {
     "prn_dcnv2_bwd_ws_bytes": (c_i64, [P]),
     "prn_dcnv2_bwd_input": (c_int, [P] * 8),
     "prn_dcnv2_bwd_offset_mask": (c_int, [P] * 8),
+    "prn_plane_prior_ws_bytes": (c_i64, [c_int] * 6),
+    "prn_plane_prior_fwd": (c_int, [P] * 7 + [c_int] * 6 + [P]),
+    "prn_plane_prior_wgrad_ws_bytes": (c_i64, [c_int] * 5),
+    "prn_plane_prior_wgrad": (c_int, [P] * 4 + [c_int] * 5 + [P]),
+    "prn_fpn_level_ws_bytes": (c_i64, [c_int] * 8),
+    "prn_fpn_level_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P] + [c_int] * 6 + [P]),
     "prn_mask_loss_ws_floats": (c_int, [c_int]),
     "prn_mask_loss_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, P]),
     "prn_mask_loss_bwd": (c_int, [P] * 8 + [c_int, c_int, P]),

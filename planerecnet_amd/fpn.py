@@ -3,8 +3,12 @@ resized to the next coarser level and added to that level's 1x1 lateral (fpn.py:
 `addend` of the lateral's implicit-GEMM epilogue and the ReLU of the 3x3 output conv is its epilogue."""
 from torch import nn
 
+import os
+
 from . import ops
 from .config import cfg
+
+FPN_BLOCK = bool(int(os.environ.get("PRN_FPN_BLOCK", "1")))      # 0: the operator-by-operator level also at inference (cross-check)
 
 
 class FPN(nn.Module):
@@ -33,6 +37,14 @@ class FPN(nn.Module):
         """return_inputs: also hand the (forked) input features back, for the next consumer of the backbone features --
         their gradient then joins this module's lateral-conv input gradient in the GEMM epilogue (ops.conv2d_fork)."""
         assert len(inputs) == len(self.in_channels)
+        import torch
+        if not torch.is_grad_enabled() and inputs[0].is_cuda and self.high_level_mode not in ("original", "retina") and FPN_BLOCK:
+            # inference: one C call per level (include/prn.h: prn_fpn_level_fwd)
+            outs, prev = [], None
+            for i, (lat, c) in enumerate(zip(self.lateral_convs, self.fpn_convs)):
+                prev, p = ops.fpn_level(inputs[i + self.start_level], lat.weight, lat.bias, prev, c.weight, c.bias, self.relu_pred_layers)
+                outs.append(p)
+            return (outs, list(inputs)) if return_inputs else outs
         laterals, prev, idents = [], None, list(inputs)
         for i, lat in enumerate(self.lateral_convs):
             f = inputs[i + self.start_level]

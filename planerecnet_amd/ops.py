@@ -854,6 +854,75 @@ def deform_conv2d_raw_relu(x, om_raw, weight, bias, stride, max_offset):
     return dcn_fwd_raw(x, table, weight, bias, stride, 1, 1, max_offset, EPI_RELU)
 
 
+# ------------------------------------------------------------------------------------------ composite blocks
+class _PlanePrior(torch.autograd.Function):
+    """Plane prior of the depth decoder as one C call (include/prn.h: prn_plane_prior_fwd).  seg / kernels are detached in the
+    reference (planerecnet.py:589,592): only conv1x1's weight and bias receive gradients."""
+
+    @staticmethod
+    def forward(ctx, seg, kernels, w1, b1):
+        _dev(seg, kernels, w1, b1)
+        seg, kernels, w1, b1 = _c(seg), _c(kernels), _c(w1), _c(b1)
+        B, E, h, w = seg.shape
+        NK, F = kernels.shape[1], w1.shape[0]
+        nb = lib.prn_plane_prior_ws_bytes(B, E, h, w, NK, F)
+        if nb < 0:
+            raise RuntimeError(lib.prn_last_error().decode())
+        ws = _f32(nb, seg.device)
+        pooled = torch.empty(B, NK, h // 4, w // 4, device=seg.device, dtype=torch.float32)
+        out = torch.empty(B, F, h // 4, w // 4, device=seg.device, dtype=torch.float32)
+        check(lib.prn_plane_prior_fwd(_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream()),
+              "prn_plane_prior_fwd")
+        ctx.save_for_backward(pooled, w1)
+        ctx.dims = (B, h, w, NK, F, b1 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pooled, w1 = ctx.saved_tensors
+        B, h, w, NK, F, has_bias = ctx.dims
+        d_out = _c(d_out)
+
+        def wgrad():
+            dw = torch.empty(F, NK, 1, 1, device=d_out.device, dtype=torch.float32)
+            ws = _f32(lib.prn_plane_prior_wgrad_ws_bytes(B, h, w, NK, F), d_out.device)
+            check(lib.prn_plane_prior_wgrad(_p(pooled), _p(d_out), _p(dw), _p(ws), B, h, w, NK, F, _stream()), "prn_plane_prior_wgrad")
+            return dw
+        dw = None
+        if _defer(ctx.needs_input_grad[2], w1):
+            _deferred_wgrad(w1, (pooled, d_out), wgrad)
+        elif ctx.needs_input_grad[2]:
+            dw = wgrad().view_as(w1)
+        db = channel_sum(d_out) if (has_bias and ctx.needs_input_grad[3]) else None
+        return None, None, dw, db
+
+
+def plane_prior(seg, kernels, w1, b1):
+    """planerecnet.py:586-594 in its exact reduced form (include/prn.h: prn_plane_prior_fwd): seg [B,E,h,w], kernels [B,NK,E]."""
+    return _PlanePrior.apply(seg, kernels, w1, b1)
+
+
+def fpn_level(x, w_lat, b_lat, prev, w_out, b_out, relu):
+    """One FPN level without autograd (inference): lateral 1x1 (+ resized finer lateral) and the 3x3 output conv as one C call
+    (include/prn.h: prn_fpn_level_fwd).  -> (lateral, p_out)."""
+    assert not torch.is_grad_enabled()
+    _dev(x, w_lat, b_lat, prev, w_out, b_out)
+    x, prev = _c(x), _c(prev)
+    B, C, H, W = x.shape
+    F = w_lat.shape[0]
+    U = winograd_weights(w_out)[0] if winograd_ok(B, F, H, W, F, 3, 1, 1, IN_ZERO, EPI_RELU if relu else EPI_NONE) else None
+    nb = lib.prn_fpn_level_ws_bytes(B, C, H, W, F, int(relu), int(prev is not None), int(U is not None))
+    if nb < 0:
+        raise RuntimeError(lib.prn_last_error().decode())
+    ws = _f32(nb, x.device) if nb else None
+    lateral = torch.empty(B, F, H, W, device=x.device, dtype=torch.float32)
+    p_out = torch.empty(B, F, H, W, device=x.device, dtype=torch.float32)
+    Hp, Wp = (prev.shape[2], prev.shape[3]) if prev is not None else (0, 0)
+    check(lib.prn_fpn_level_fwd(_p(x), _p(w_lat), _p(b_lat), _p(prev), Hp, Wp, _p(w_out), _p(U), _p(b_out), _p(lateral), _p(p_out), _p(ws), B, C, H, W, F,
+                                int(relu), _stream()), "prn_fpn_level_fwd")
+    return lateral, p_out
+
+
 # ------------------------------------------------------------------------------------------ BatchNorm
 class _BatchNorm(torch.autograd.Function):
     @staticmethod

@@ -249,6 +249,7 @@ class PlaneRecNet(nn.Module):
 
 
 RAGGED_HEADS = bool(int(os.environ.get("PRN_RAGGED_HEADS", "1")))
+PLANE_PRIOR_BLOCK = bool(int(os.environ.get("PRN_PLANE_PRIOR_BLOCK", "1")))      # 0: the operator-by-operator plane prior (cross-check)
 
 
 class SOLOv2InsHead(nn.Module):
@@ -436,17 +437,21 @@ class DepthDecoder_FPN(nn.Module):
 
     def plane_prior(self, seg_preds, kernel_preds):
         B = seg_preds.shape[0]
+        h, w = seg_preds.shape[2:]
+        if h % 4 or w % 4:
+            raise NotImplementedError("plane prior expects a mask feature size divisible by 4")
         with torch.no_grad():
             flat = torch.cat([k.permute(0, 2, 3, 1).reshape(B, -1, self.num_kernels) for k in kernel_preds], 1)   # [B, 3728, E]
-            h, w = seg_preds.shape[2:]
-            if h % 4 or w % 4:
-                raise NotImplementedError("plane prior expects a mask feature size divisible by 4")
+        c = self.conv1x1[0]
+        if PLANE_PRIOR_BLOCK and seg_preds.is_cuda:
+            # centre samples -> per-image dynamic conv + sigmoid -> 2x2 mean -> conv1x1, one C call (include/prn.h: prn_plane_prior_fwd)
+            return ops.plane_prior(seg_preds.detach(), flat, c.weight, c.bias)
+        with torch.no_grad():
             hi, wi = self._centre_index(h, seg_preds.device), self._centre_index(w, seg_preds.device)
             centre = seg_preds.detach()[:, :, hi][:, :, :, wi].contiguous()                                            # [B,E,h/2,w/2]
             sig = torch.cat([ops.conv2d(centre[b:b + 1], flat[b].reshape(-1, self.num_kernels, 1, 1).contiguous(),
                                         epilogue=ops.EPI_SIGMOID) for b in range(B)], 0)                                # [B,3728,h/2,w/2]
             pooled = ops.resize_bilinear(sig, (h // 4, w // 4))                                                         # exact 2x2 mean
-        c = self.conv1x1[0]
         return ops.conv2d(pooled, c.weight, c.bias)
 
     def branches(self, feature_maps):

@@ -593,3 +593,46 @@ def test_fused_mask_loss_matches_operator_chain():
     # Dice only (no lava inputs)
     ins2, lav2 = _MaskLoss.apply(zd, t.to(d), img.to(d), None, None, None, w_ins, w_lav)
     assert abs(float(ins2) - float(ins_ref)) <= 1e-5 * abs(float(ins_ref)) and float(lav2) == 0.0
+
+
+def test_plane_prior_block_equals_reference_form():
+    """prn_plane_prior_fwd / _wgrad against the reference's statement sequence (planerecnet.py:586-594): sigmoid(K . M) for every
+    kernel at full mask resolution, conv1x1, x0.25 bilinear resize -- in fp64 on the CPU; output and the conv1x1 gradients."""
+    from planerecnet_amd import ops
+    d = dev()
+    B, E, h, w, NK, Fo = 2, 16, 24, 32, 150, 24
+    seg = rnd(B, E, h, w, seed=1)
+    kern = rnd(B, NK, E, seed=2, scale=0.4)
+    w1 = rnd(Fo, NK, 1, 1, seed=3, scale=NK ** -0.5).requires_grad_(True)
+    b1 = rnd(Fo, seed=4).requires_grad_(True)
+    sig = torch.stack([torch.sigmoid(F.conv2d(seg[b:b + 1], kern[b].reshape(NK, E, 1, 1)))[0] for b in range(B)])
+    ref = F.interpolate(F.conv2d(sig, w1, b1), scale_factor=0.25, mode="bilinear", align_corners=False)
+    go = rnd(*ref.shape, seed=5)
+    gr = torch.autograd.grad(ref, [w1, b1], go)
+    xs = [w1.detach().float().to(d).requires_grad_(True), b1.detach().float().to(d).requires_grad_(True)]
+    out = ops.plane_prior(seg.float().to(d), kern.float().to(d), xs[0], xs[1])
+    close(out, ref, "plane prior fwd")
+    gd = torch.autograd.grad(out, xs, go.float().to(d))
+    close(gd[0], gr[0], "plane prior dw1", rtol=5e-4)
+    close(gd[1], gr[1], "plane prior db1", rtol=5e-4)
+
+
+@pytest.mark.parametrize("B,C,H,W,with_prev", [(2, 96, 16, 20, True), (1, 64, 9, 11, False), (2, 128, 32, 40, True)])
+def test_fpn_level_block_equals_operator_sequence(B, C, H, W, with_prev):
+    """prn_fpn_level_fwd (models/fpn.py:51-63) vs torch CPU fp64: lateral 1x1 + bottom-up resized addend, 3x3 + ReLU."""
+    from planerecnet_amd import ops
+    d = dev()
+    Fo = 64
+    x = rnd(B, C, H, W, seed=1)
+    wl, bl = rnd(Fo, C, 1, 1, seed=2, scale=C ** -0.5), rnd(Fo, seed=3)
+    wo, bo = rnd(Fo, Fo, 3, 3, seed=4, scale=(9 * Fo) ** -0.5), rnd(Fo, seed=5)
+    prev = rnd(B, Fo, 2 * H, 2 * W - 1, seed=6) if with_prev else None
+    lat_ref = F.conv2d(x, wl, bl)
+    if prev is not None:
+        lat_ref = lat_ref + F.interpolate(prev, size=(H, W), mode="bilinear", align_corners=False)
+    p_ref = F.relu(F.conv2d(lat_ref, wo, bo, padding=1))
+    with torch.no_grad():
+        lat, p = ops.fpn_level(x.float().to(d), wl.float().to(d), bl.float().to(d), None if prev is None else prev.float().to(d), wo.float().to(d),
+                               bo.float().to(d), True)
+    close(lat, lat_ref, "fpn lateral")
+    close(p, p_ref, "fpn output")
