@@ -96,6 +96,7 @@ SIGNATURES = {
     "prn_plane_prior_wgrad": (c_int, [P] * 4 + [c_int] * 5 + [P]),
     "prn_fpn_level_ws_bytes": (c_i64, [c_int] * 8),
     "prn_fpn_level_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P] + [c_int] * 6 + [P]),
+    "prn_frame_to_input": (c_int, [P] + [c_int] * 6 + [P, P, c_int, P, P, P]),
     "prn_mask_loss_ws_floats": (c_int, [c_int]),
     "prn_mask_loss_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, P]),
     "prn_mask_loss_bwd": (c_int, [P] * 8 + [c_int, c_int, P]),

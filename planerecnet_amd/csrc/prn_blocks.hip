@@ -127,3 +127,72 @@ extern "C" int prn_fpn_level_fwd(const float* x, const float* w_lat, const float
     return prn_conv3x3_winograd(lateral, u_out, b_out, nullptr, p_out, wsb + l.gemm2, B, F, H, W, F, PRN_IN_ZERO, relu ? PRN_EPI_RELU : PRN_EPI_NONE, stream);
   return prn_conv2d_fwd(&l.d2, lateral, w_out, b_out, nullptr, p_out, wsb + l.gemm2, stream);
 }
+
+// ---- input staging (simple_inference.py:143-152, data/augmentations.py:496-530, models/functions/funcs.py:195-210) -------------
+// The reference resizes the BGR frame on the host (cv2.resize, INTER_LINEAR), zero-pads it to a multiple of 32, uploads it as
+// float and normalises / reorders on the device (FastBaseTransform: 3 ATen launches over a 4x larger tensor).  Here the uint8
+// frame is uploaded as it is (a quarter of the bytes over PCIe) and ONE kernel produces the network input: cv2's fixed-point
+// bilinear resize (11-bit coefficients, two passes: OpenCV resize.cpp HResizeLinear / VResizeLinear), the zero padding, the
+// (x - mean) / std normalisation in BGR order and the BGR -> RGB swap.
+namespace {
+struct FrameArgs {
+  const unsigned char* src; float* dst; float* frame;
+  int Hs, Ws, Hr, Wr, Hp, Wp, mode;
+  double sx, sy;
+  float mean[3], stdv[3];
+};
+__device__ __forceinline__ void lin_coef(int d, double scale, int ssize, int* s, int* a0, int* a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int i = (int)floorf(f);
+  f -= (float)i;
+  if (i < 0) { f = 0.f; i = 0; }
+  if (i >= ssize - 1) { f = 0.f; i = ssize - 1; }
+  *s = i;
+  *a0 = (int)rintf((1.f - f) * 2048.f);                     // saturate_cast<short>: round to nearest even
+  *a1 = (int)rintf(f * 2048.f);
+}
+__global__ __launch_bounds__(256) void frame_to_input_kernel(FrameArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.Hp * a.Wp) return;
+  const int y = i / a.Wp, x = i - y * a.Wp;
+  float bgr[3] = {0.f, 0.f, 0.f};
+  if (y < a.Hr && x < a.Wr) {
+    int sx, ax0, ax1, sy, by0, by1;
+    lin_coef(x, a.sx, a.Ws, &sx, &ax0, &ax1);
+    lin_coef(y, a.sy, a.Hs, &sy, &by0, &by1);
+    const int sx1 = sx + 1 < a.Ws ? sx + 1 : sx, sy1 = sy + 1 < a.Hs ? sy + 1 : sy;
+    const unsigned char* r0 = a.src + ((size_t)sy * a.Ws) * 3;
+    const unsigned char* r1 = a.src + ((size_t)sy1 * a.Ws) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int S0 = r0[sx * 3 + c] * ax0 + r0[sx1 * 3 + c] * ax1, S1 = r1[sx * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
+      int v = (((by0 * (S0 >> 4)) >> 16) + ((by1 * (S1 >> 4)) >> 16) + 2) >> 2;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      bgr[c] = (float)v;
+    }
+  }
+  if (a.frame) { float* f = a.frame + (size_t)i * 3; f[0] = bgr[0]; f[1] = bgr[1]; f[2] = bgr[2]; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = bgr[c];
+    if (a.mode == 0) v = (v - a.mean[c]) / a.stdv[c];
+    else if (a.mode == 1) v = v - a.mean[c];
+    else v = v / 255.f;
+    a.dst[(size_t)(2 - c) * a.Hp * a.Wp + i] = v;            // BGR -> RGB planes
+  }
+}
+}  // namespace
+
+extern "C" int prn_frame_to_input(const unsigned char* src, int Hs, int Ws, int Hr, int Wr, int Hp, int Wp, const float* mean_bgr,
+                                  const float* std_bgr, int mode, float* dst, float* frame_bgr, void* stream) {
+  PRN_REQUIRE(src && dst && mean_bgr && std_bgr && Hs > 0 && Ws > 0 && Hr > 0 && Wr > 0 && Hp >= Hr && Wp >= Wr && mode >= 0 && mode <= 2,
+              "prn_frame_to_input: bad arguments");
+  FrameArgs a;
+  a.src = src; a.dst = dst; a.frame = frame_bgr;
+  a.Hs = Hs; a.Ws = Ws; a.Hr = Hr; a.Wr = Wr; a.Hp = Hp; a.Wp = Wp; a.mode = mode;
+  a.sx = (double)Ws / Wr; a.sy = (double)Hs / Hr;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean_bgr[c]; a.stdv[c] = std_bgr[c]; }      // host arrays (three floats each)
+  hipLaunchKernelGGL(frame_to_input_kernel, dim3(cdiv((int64_t)Hp * Wp, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  PRN_CHECK_LAUNCH("prn_frame_to_input");
+  return 0;
+}

@@ -63,3 +63,29 @@ class FastBaseTransform(torch.nn.Module):
         if self.transform.channel_order != "RGB":
             raise NotImplementedError
         return img[:, (2, 1, 0), :, :].contiguous()
+
+
+def frame_to_input(frame_u8, size_wh, divisor=32, want_frame=True):
+    """Input staging of simple_inference.py:143-152 as ONE HIP launch (include/prn.h: prn_frame_to_input): frame_u8 = the decoded
+    uint8 BGR frame [H,W,3] ON THE DEVICE (upload the bytes, not floats); cv2-style INTER_LINEAR resize to size_wh = (w, h),
+    zero padding to a multiple of `divisor`, FastBaseTransform.  -> (batch [1,3,Hp,Wp] float RGB, frame [Hp,Wp,3] float BGR | None)."""
+    import ctypes
+    from . import ops
+    from .config import MEANS, STD, cfg
+    if not frame_u8.is_cuda or frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
+        raise RuntimeError("frame_to_input needs a uint8 [H,W,3] device tensor (got %s %s %s)" % (frame_u8.device, frame_u8.dtype, tuple(frame_u8.shape)))
+    frame_u8 = frame_u8.contiguous()
+    Hs, Ws = frame_u8.shape[:2]
+    Wr, Hr = int(size_wh[0]), int(size_wh[1])
+    Hp, Wp = Hr + (-Hr) % divisor, Wr + (-Wr) % divisor
+    tr = cfg.backbone.transform
+    mode = 0 if tr.normalize else (1 if tr.subtract_means else 2)
+    if tr.channel_order != "RGB":
+        raise NotImplementedError
+    out = torch.empty(1, 3, Hp, Wp, device=frame_u8.device, dtype=torch.float32)
+    frame = torch.empty(Hp, Wp, 3, device=frame_u8.device, dtype=torch.float32) if want_frame else None
+    mean = (ctypes.c_float * 3)(*[float(v) for v in MEANS])
+    std = (ctypes.c_float * 3)(*[float(v) for v in STD])
+    ops.check(ops.lib.prn_frame_to_input(ops._p(frame_u8), Hs, Ws, Hr, Wr, Hp, Wp, mean, std, mode, ops._p(out), ops._p(frame), ops._stream()),
+              "prn_frame_to_input")
+    return out, frame

@@ -2,8 +2,9 @@
 """Inference entry point (drop-in for the reference's simple_inference.py: same flags, `input:output` colon syntax,
 `<name>_seg.<ext>` / `<name>_dep.png` outputs, nms / threshold overrides written into cfg.solov2).
 
-The tensor path is the reference's: read BGR image -> resize to calc_size_preserve_ar(W, H, cfg.max_size) -> zero-pad to a
-multiple of 32 -> FastBaseTransform -> PlaneRecNet (eval) -> list[dict].  The device comes from `cfg.device`.
+The tensor path is the reference's: read BGR image -> resize to calc_size_preserve_ar(W, H, cfg.max_size) (cv2.INTER_LINEAR
+arithmetic, no antialiasing) -> zero-pad to a multiple of 32 -> FastBaseTransform -> PlaneRecNet (eval) -> list[dict]; the
+three staging steps run as one HIP launch on the uploaded uint8 frame.  The device comes from `cfg.device`.
 Image file I/O and the overlay drawing use Pillow + numpy (OpenCV is not a dependency of this build); the iBims-1 `.mat`
 exporters of the reference are visual / evaluation tooling outside the hot path and are not provided.
 """
@@ -17,7 +18,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime i
 import torch  # noqa: E402
 
 from planerecnet_amd.config import COLORS, cfg, set_cfg
-from planerecnet_amd.funcs import FastBaseTransform, calc_size_preserve_ar, pad_even_divided
+from planerecnet_amd.funcs import calc_size_preserve_ar, frame_to_input
 
 
 def parse_args(argv=None):
@@ -57,11 +58,6 @@ def _imwrite_bgr(path, arr):
         Image.fromarray(arr.astype(np.uint8)).save(path)
 
 
-def _resize_bilinear(img, size_wh):
-    from PIL import Image
-    return np.asarray(Image.fromarray(img).resize(size_wh, Image.BILINEAR))
-
-
 def display_on_frame(result, frame, mask_alpha=0.5, no_mask=False, no_box=False, no_text=False):
     """Blend instance masks / boxes / scores over the (padded) BGR frame; returns (uint8 HxWx3 BGR, depth HxW float)."""
     from PIL import Image, ImageDraw
@@ -91,10 +87,12 @@ def display_on_frame(result, frame, mask_alpha=0.5, no_mask=False, no_box=False,
 def inference_image(net, path, save_path=None, depth_mode="colored"):
     frame_np = _imread_bgr(path)
     H, W, _ = frame_np.shape
-    frame_np = _resize_bilinear(frame_np, calc_size_preserve_ar(W, H, cfg.max_size))
-    frame_np = pad_even_divided(frame_np)                                            # zero-pad to a multiple of 32
-    frame = torch.from_numpy(frame_np).to(cfg.device).float()
-    batch = FastBaseTransform().to(cfg.device)(frame.unsqueeze(0))
+    # the decoded frame goes to the device as BYTES (page-locked, asynchronous); resize (cv2.INTER_LINEAR arithmetic), zero
+    # padding to a multiple of 32 and FastBaseTransform are one HIP launch there (planerecnet_amd.funcs.frame_to_input)
+    staged = torch.from_numpy(np.ascontiguousarray(frame_np))
+    if torch.cuda.is_available():
+        staged = staged.pin_memory()
+    batch, frame = frame_to_input(staged.to(cfg.device, non_blocking=True), calc_size_preserve_ar(W, H, cfg.max_size))
     results = net(batch)
     blended, depth = display_on_frame(results[0], frame, no_mask=args.no_mask, no_box=args.no_box, no_text=args.no_text)
     name, ext = os.path.splitext(path if save_path is None else save_path)
