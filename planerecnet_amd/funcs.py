@@ -36,6 +36,11 @@ def center_of_mass(bitmasks):
 def quarter_mask_u8(masks):
     """uint8 [N,H,W] -> uint8 [N,H/4,W/4]: OpenCV INTER_LINEAR at exact 1/4 samples the centre of each 4x4 block,
     i.e. the mean of its 2x2 middle pixels, rounded half up in fixed point."""
+    if masks.shape[-2] % 4 or masks.shape[-1] % 4:
+        # (the reference's imrescale handles any size through cv2's general sampling, output int(h * 0.25 + 0.5); the hot path
+        # only ever sees 480x640 / sizes padded to a multiple of 32)
+        raise ValueError("quarter_mask_u8: mask size %dx%d is not a multiple of 4 (the closed form of the exact-1/4 resize needs it)"
+                         % (masks.shape[-2], masks.shape[-1]))
     a = masks.to(torch.int32)
     s = a[:, 1::4, 1::4] + a[:, 1::4, 2::4] + a[:, 2::4, 1::4] + a[:, 2::4, 2::4]
     return ((s + 2) >> 2).to(torch.uint8)

@@ -140,7 +140,12 @@ class GradAllReduce:
         self._finish_impl()
 
     def _finish_impl(self):
-        for bi in range(self.next, len(self.buckets)):  # buckets held back by a parameter that received no gradient this step
+        # Buckets held back by a parameter that received no gradient on THIS rank: every rank must still post the same sequence
+        # of collectives, so the missing gradient enters as zeros.  Difference to the reference's single-process training: such
+        # a parameter then has a (zero or other ranks') gradient instead of None, i.e. Adam advances its step count and decays its
+        # moments.  Whether all ranks lacked it is not known without a host round trip; in PlaneRecNet every parameter
+        # receives a gradient in every step (all five loss terms are always active), so the case does not arise on the hot path.
+        for bi in range(self.next, len(self.buckets)):
             if any(p.grad is not None for p in self.buckets[bi]) or self.world > 1:
                 for p in self.buckets[bi]:
                     if p.grad is None:

@@ -136,3 +136,26 @@ print("EXCHANGE_OK")
 ''' % ROOT
     out = run(["-c", code], str(tmp_path))
     assert "EXCHANGE_OK" in out
+
+
+def test_frame_stager_rotating_pinned_uploads():
+    """train.py's input staging (planerecnet_amd/staging.py): batches uploaded from rotating page-locked buffers on a side stream
+    arrive intact while the compute stream is busy, buffers are reused only after their previous upload has left them."""
+    import torch
+    from planerecnet_amd.staging import FrameStager
+    dev = torch.device("cuda:0")
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    st = FrameStager(dev, slots=3)
+    g = torch.Generator().manual_seed(0)
+    kept = []
+    for it in range(8):                                       # more batches than slots: every buffer is reused at least twice
+        B = 4 if it != 5 else 2                              # a ragged last batch re-allocates its slot
+        imgs = [torch.randn(3, 96, 128, generator=g) for _ in range(B)]
+        deps = [torch.rand(1, 96, 128, generator=g) for _ in range(B)]
+        torch.cuda._sleep(int(2e7))                          # keep the compute stream busy while the upload is issued
+        x, d, ev = st.upload(imgs, deps, main, side)
+        kept.append((x, d, ev, torch.stack(imgs), torch.stack(deps)))
+    for x, d, ev, ri, rd in kept:
+        main.wait_event(ev)
+        assert torch.equal(x.cpu(), ri) and torch.equal(d.cpu(), rd)
+    assert st.slots[0]["x"].is_pinned() and st.count == 8

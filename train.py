@@ -179,6 +179,7 @@ def main():
     from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
     from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
     from planerecnet_amd.planerecnet import PlaneRecNet
+    from planerecnet_amd.staging import FrameStager
 
     os.makedirs(args.save_folder, exist_ok=True)
     synthetic = args.dataset == "synthetic" or not os.path.exists(cfg.dataset.train_info)
@@ -234,6 +235,7 @@ def main():
     time_avg, loss_avgs = MovingAverage(), {k: MovingAverage(100) for k in LOSS_TYPES}
     save_path = lambda epoch, it: SavePath(cfg.name, epoch, it).get_path(root=args.save_folder)
     prefetch = TargetPrefetcher(criterion)
+    stager = FrameStager(dev)
     # device-side "skip the update on a non-finite loss": needs an optimizer whose step takes `found_inf` (fused Adam does)
     device_skip = bool(getattr(optimizer, "_step_supports_amp_scaling", False)) and dev.type == "cuda" and not os.environ.get("PRN_TRAIN_SYNC_LOSS")
     if device_skip:
@@ -269,8 +271,6 @@ def main():
                     ahead.append(b_)
                     prefetch.submit(b_[1], tuple(b_[0][0].shape[-2:]))
 
-            staging, stage_no = [{}, {}, {}], [0]
-
             def stage():
                 """Uploads of the next batch (images, depth, targets): issued one step EARLY, right after the current
                 step's backward has been enqueued, so that a step starts with the forward pass even though every
@@ -278,33 +278,10 @@ def main():
                 if not ahead:
                     return None
                 images_, inst_, depths_ = ahead.popleft()
-                # Frames go to HBM on the weight-gradient side stream from page-locked memory (a pageable upload blocks the host
-                # until the compute stream has drained, i.e. until this step's backward is done: 78 vs 68 ms/iteration).
+                # Frames go to HBM on the weight-gradient side stream through rotating page-locked buffers (staging.FrameStager);
+                # the loader's batches stay in the workers' shared memory (the GT goes on to the target workers as handles).
                 main = torch.cuda.current_stream()
-                side = ops._side_stream(dev, main)
-                side.wait_stream(main)
-                # The loader's batches stay in the workers' shared memory (the GT goes on to the target workers as handles, not
-                # copies: a pin_memory=True loader re-allocates everything page-locked and its pinning thread shares the GIL with
-                # the trainer); only the frames are copied here into one of three rotating page-locked staging buffers.
-                shape_x, shape_d = (len(images_),) + tuple(images_[0].shape), (len(depths_),) + tuple(depths_[0].shape)
-                slot = staging[stage_no[0] % len(staging)]
-                stage_no[0] += 1
-                if slot.get("x") is None or slot["x"].shape != shape_x or slot["d"].shape != shape_d:
-                    slot["x"] = torch.empty(shape_x, dtype=images_[0].dtype).pin_memory()
-                    slot["d"] = torch.empty(shape_d, dtype=depths_[0].dtype).pin_memory()
-                elif slot.get("ev") is not None:
-                    slot["ev"].synchronize()                   # (its previous upload, three batches ago)
-                for i_, (im_, dp_) in enumerate(zip(images_, depths_)):
-                    slot["x"][i_].copy_(im_)
-                    slot["d"][i_].copy_(dp_)
-                with torch.cuda.stream(side):
-                    x_ = slot["x"].to(dev, non_blocking=True)
-                    d_ = slot["d"].to(dev, non_blocking=True)
-                    ev_ = torch.cuda.Event()
-                    ev_.record()
-                slot["ev"] = ev_
-                x_.record_stream(main)
-                d_.record_stream(main)
+                x_, d_, ev_ = stager.upload(images_, depths_, main, ops._side_stream(dev, main))
                 t_ = prefetch.get(d_, dev, overlap=True)
                 refill()
                 return x_, d_, t_, inst_, ev_
