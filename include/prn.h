@@ -350,6 +350,18 @@ int prn_vnl_scatter(const double* g_loss, const float* g3, const int64_t* order,
 int prn_depth_metrics_ws_doubles(void);
 int prn_depth_metrics(const float* pred, const float* gt, double* out, double* ws, int64_t n, float min_depth, float max_depth, void* stream);
 
+/* ---- pairwise IoU of one frame's detections against its ground truth ----------------------------------------------------
+ * replaces mask_iou / bbox_iou as compute_segmentation_metrics calls them (eval.py:214-215; models/functions/funcs.py:58-71
+ * and :9-55): masks_a [A, HW] and masks_b [B, HW] are byte masks (non-zero = set; the reference multiplies their 0/1 float
+ * copies), boxes [A, 4] / [B, 4] are fp32 (x1, y1, x2, y2).
+ *   mask_iou[a][b] = |a & b| / (|a| + |b| - |a & b|)   (integer counts, fp32 quotient: bit-identical to the reference; 0/0 = NaN)
+ *   box_iou[a][b]  = inter / (area_a + area_b - inter), inter = clamp(min(x2) - max(x1), 0) * clamp(min(y2) - max(y1), 0)
+ * Either pair of inputs may be NULL (then its output is not written).  ws: prn_pairwise_iou_ws_bytes(A, B, HW) bytes
+ * (the bit-packed masks and their areas).  1 <= A, B < 65536, HW < 2^24. */
+int64_t prn_pairwise_iou_ws_bytes(int A, int B, int64_t HW);
+int prn_pairwise_iou(const unsigned char* masks_a, const unsigned char* masks_b, const float* boxes_a, const float* boxes_b, int A, int B, int64_t HW,
+                     float* mask_iou, float* box_iou, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,8 @@ SIGNATURES = {
     "prn_vnl_scatter": (c_int, [P] * 5 + [c_int, c_int, P]),
     "prn_depth_metrics_ws_doubles": (c_int, []),
     "prn_depth_metrics": (c_int, [P, P, P, P, c_i64, c_float, c_float, P]),
+    "prn_pairwise_iou_ws_bytes": (c_i64, [c_int, c_int, c_i64]),
+    "prn_pairwise_iou": (c_int, [P, P, P, P, c_int, c_int, c_i64, P, P, P, P]),
     "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "prn_bn_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "prn_bn_train_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, c_int, P]),

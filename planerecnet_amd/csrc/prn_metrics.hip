@@ -2,9 +2,78 @@
 // the eight sums behind abs_rel / sq_rel / rmse / log10 / a1 / a2 / a3 (the reference runs ~25 elementwise / boolean-index
 // / reduction launches).  Fixed-order fp64 partials -> deterministic.  The median ratio stays with the caller (a selection,
 // not a sum).
+//
+// Pairwise IoU of one frame's detections against its ground truth (reference eval.py:214-215 -> funcs.py:30-71): the
+// reference multiplies the two [n, H*W] float mask matrices; masks are binary, so the intersection of a pair is a population
+// count.  Here every mask is packed to one bit per pixel once (H*W/8 bytes, read back from L2 by every pair) and a pair costs
+// H*W/32 AND+popcount steps -- integer-exact, so the fp32 quotient equals the reference's bit for bit.
 #include "prn_common.h"
 
 namespace {
+// bit i of word w of mask m = (mask[m][32 w + i] != 0); area[m] += popcount (integer atomics: order-independent)
+__global__ __launch_bounds__(256) void mask_pack_kernel(const unsigned char* __restrict__ masks, unsigned* __restrict__ bits, unsigned* __restrict__ area,
+                                                        int64_t HW, int words) {
+  const int m = blockIdx.y;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  unsigned word = 0;
+  if (w < words) {
+    const unsigned char* src = masks + (size_t)m * HW + (size_t)w * 32;
+    const int64_t left = HW - (int64_t)w * 32;
+    if (left >= 32 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const uint4 q0 = reinterpret_cast<const uint4*>(src)[0], q1 = reinterpret_cast<const uint4*>(src)[1];
+      const unsigned v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) word |= ((v[k] >> (8 * b)) & 0xffu) ? (1u << (4 * k + b)) : 0u;
+    } else {
+      for (int i = 0; i < 32 && i < left; ++i) word |= src[i] ? (1u << i) : 0u;
+    }
+    bits[(size_t)m * words + w] = word;
+  }
+  int cnt = __popc(word);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(area + m, (unsigned)cnt);
+}
+
+// one workgroup per (a, b) pair: intersection = sum_w popcount(bits_a[w] & bits_b[w]); IoU in fp32 with the reference's
+// operation order (funcs.py:67-71: intersection / (area_a + area_b - intersection); 0/0 stays NaN).  Thread 0 also writes
+// the pair's box IoU (funcs.py:23-55), every product / sum rounded separately like the tensor ops (fp contract off).
+__global__ __launch_bounds__(256) void pair_iou_kernel(const unsigned* __restrict__ bits_a, const unsigned* __restrict__ bits_b,
+                                                       const unsigned* __restrict__ area_a, const unsigned* __restrict__ area_b,
+                                                       const float* __restrict__ box_a, const float* __restrict__ box_b, float* __restrict__ mask_iou,
+                                                       float* __restrict__ box_iou, int B, int words) {
+  const int a = blockIdx.y, b = blockIdx.x;
+  if (bits_a) {
+    const unsigned* pa = bits_a + (size_t)a * words;
+    const unsigned* pb = bits_b + (size_t)b * words;
+    int cnt = 0;
+    for (int w = threadIdx.x; w < words; w += 256) cnt += __popc(pa[w] & pb[w]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __shared__ int sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float inter = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
+      mask_iou[(size_t)a * B + b] = inter / (((float)area_a[a] + (float)area_b[b]) - inter);      // (integers < 2^24: exact sums)
+    }
+  }
+  if (box_a && threadIdx.x == 0) {
+#pragma clang fp contract(off)      // every product / sum rounded on its own (contracted, area_a + w_b * h_b became one fma: 1 ulp off in 6 % of the pairs)
+    const float* p = box_a + 4 * a;
+    const float* q = box_b + 4 * b;
+    const float w = fmaxf(fminf(p[2], q[2]) - fmaxf(p[0], q[0]), 0.f);
+    const float h = fmaxf(fminf(p[3], q[3]) - fmaxf(p[1], q[1]), 0.f);
+    const float inter = w * h;
+    const float aa = (p[2] - p[0]) * (p[3] - p[1]);
+    const float ab = (q[2] - q[0]) * (q[3] - q[1]);
+    const float uni = aa + ab;
+    box_iou[(size_t)a * B + b] = inter / (uni - inter);
+  }
+}
+
 constexpr int NQ = 8;      // count, abs_rel, sq_rel, sq_err, log10, a1, a2, a3
 
 __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt, double* __restrict__ part,
@@ -67,5 +136,41 @@ extern "C" int prn_depth_metrics(const float* pred, const float* gt, double* out
   PRN_CHECK_LAUNCH("prn_depth_metrics/partial");
   hipLaunchKernelGGL(depth_metrics_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, out, blocks);
   PRN_CHECK_LAUNCH("prn_depth_metrics/final");
+  return 0;
+}
+
+// ---- pairwise IoU -------------------------------------------------------------------------------------------------
+namespace {
+inline size_t iou_words(int64_t HW) { return (size_t)((HW + 31) / 32); }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" int64_t prn_pairwise_iou_ws_bytes(int A, int B, int64_t HW) {
+  if (A <= 0 || B <= 0 || HW <= 0) return 256;
+  return (int64_t)(align256((size_t)(A + B) * 4) + (size_t)(A + B) * iou_words(HW) * 4);
+}
+
+extern "C" int prn_pairwise_iou(const unsigned char* masks_a, const unsigned char* masks_b, const float* boxes_a, const float* boxes_b, int A, int B,
+                                int64_t HW, float* mask_iou, float* box_iou, void* ws, void* stream) {
+  PRN_REQUIRE(A > 0 && B > 0 && A < 65536 && B < 65536, "prn_pairwise_iou: needs 1 <= A, B < 65536 (got %d, %d)", A, B);
+  const bool want_mask = masks_a != nullptr, want_box = boxes_a != nullptr;
+  PRN_REQUIRE(want_mask || want_box, "prn_pairwise_iou: neither masks nor boxes given");
+  PRN_REQUIRE(!want_mask || (masks_b && mask_iou && ws && HW > 0 && HW < (1LL << 24)),
+              "prn_pairwise_iou: masks need masks_b, mask_iou, ws and 0 < H*W < 2^24 (fp32-exact areas)");
+  PRN_REQUIRE(!want_box || (boxes_b && box_iou), "prn_pairwise_iou: boxes need boxes_b and box_iou");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned *area = nullptr, *bits = nullptr;
+  const int words = (int)iou_words(HW > 0 ? HW : 1);
+  if (want_mask) {
+    area = (unsigned*)ws;
+    bits = (unsigned*)((char*)ws + align256((size_t)(A + B) * 4));
+    PRN_REQUIRE(hipMemsetAsync(area, 0, (size_t)(A + B) * 4, st) == hipSuccess, "prn_pairwise_iou: memset failed");
+    hipLaunchKernelGGL(mask_pack_kernel, dim3(cdiv(words, 256), A), dim3(256), 0, st, masks_a, bits, area, HW, words);
+    hipLaunchKernelGGL(mask_pack_kernel, dim3(cdiv(words, 256), B), dim3(256), 0, st, masks_b, bits + (size_t)A * words, area + A, HW, words);
+    PRN_CHECK_LAUNCH("prn_pairwise_iou/pack");
+  }
+  hipLaunchKernelGGL(pair_iou_kernel, dim3(B, A), dim3(256), 0, st, (const unsigned*)bits, (const unsigned*)(bits ? bits + (size_t)A * words : nullptr),
+                     (const unsigned*)area, (const unsigned*)(area ? area + A : nullptr), want_box ? boxes_a : nullptr, boxes_b, mask_iou, box_iou, B, words);
+  PRN_CHECK_LAUNCH("prn_pairwise_iou/pairs");
   return 0;
 }

@@ -1,5 +1,5 @@
-"""GPU: the two kept entry points run end to end (train.py on synthetic batches incl. checkpoint naming / resume;
-simple_inference.py on an image file incl. the input:output syntax)."""
+"""GPU: the entry points run end to end (train.py on synthetic batches incl. checkpoint naming / resume / validation pass;
+eval.py on a checkpoint; simple_inference.py on an image file incl. the input:output syntax)."""
 import os
 import subprocess
 import sys
@@ -23,8 +23,15 @@ def test_train_synthetic_then_resume(tmp_path):
               "--num_workers", "0", "--no_tensorboard", "--synthetic_size", "16", "--save_interval", "2", "--reproductablity"]
     out = run([os.path.join(ROOT, "train.py")] + common + ["--max_iter", "2"], str(tmp_path))
     assert "Begin training!" in out and "total:" in out
+    # the validation pass after the last iteration (reference train.py:401-402): eval.py's loop on the synthetic validation frames
+    assert "Computing validation metrics" in out and "Calculating mAP..." in out and "  mask |" in out and "Depth Metrics:" in out and "abs_rel:" in out
     ck = sorted(p for p in os.listdir(tmp_path) if p.endswith(".pth"))
     assert "PlaneRecNet_50_0_2.pth" in ck, ck
+    # eval.py on that checkpoint: config parsed from the file name, NMS settings from the flags, table + depth errors printed
+    out = run([os.path.join(ROOT, "eval.py"), "--trained_model", os.path.join(str(tmp_path), "PlaneRecNet_50_0_2.pth"), "--dataset", "synthetic",
+               "--max_images", "3", "--synthetic_size", "4", "--score_threshold", "0.05"], str(tmp_path))
+    assert "Config not specified. Parsed PlaneRecNet_50_config from the file name." in out and "Processing Images" in out
+    assert "   box |" in out and "Depth Metrics:" in out and "ratio:" in out
     out = run([os.path.join(ROOT, "train.py")] + common + ["--max_iter", "3", "--resume", "latest"], str(tmp_path))
     assert "Resuming training" in out
     assert any(p.endswith("_3.pth") for p in os.listdir(tmp_path))

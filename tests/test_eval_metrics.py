@@ -1,0 +1,178 @@
+"""Detection metrics (reference eval.py:210-354): the oracle and the host half of the product against the reference's golden
+values (CPU); the device IoU kernel against the oracle, bit for bit, and the whole path against the golden mAP table (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+SEEDS = (0, 1, 2, 3, 4)
+
+
+def make_frame(seed, H=60, W=80):          # the generator of tests/golden/make_golden_eval.py
+    rng = np.random.RandomState(1000 + seed)
+    n_gt = int(rng.randint(3, 7))
+    gt_masks, gt_boxes = np.zeros((n_gt, H, W), np.uint8), np.zeros((n_gt, 4), np.float64)
+    for i in range(n_gt):
+        w, h = int(rng.randint(8, W // 2)), int(rng.randint(8, H // 2))
+        x0, y0 = int(rng.randint(0, W - w)), int(rng.randint(0, H - h))
+        gt_masks[i, y0:y0 + h, x0:x0 + w] = 1
+        gt_boxes[i] = (x0, y0, x0 + w, y0 + h)
+    pm, pb = [], []
+    for i in range(n_gt):
+        for _ in range(int(rng.randint(0, 3))):
+            x0, y0, x1, y1 = gt_boxes[i] + rng.randint(-4, 5, size=4)
+            x0, y0, x1, y1 = int(max(x0, 0)), int(max(y0, 0)), int(min(max(x1, x0 + 2), W)), int(min(max(y1, y0 + 2), H))
+            m = np.zeros((H, W), bool)
+            m[y0:y1, x0:x1] = True
+            m &= rng.rand(H, W) > 0.05
+            pm.append(m)
+            pb.append((x0 + rng.rand(), y0 + rng.rand(), x1 - rng.rand(), y1 - rng.rand()))
+    for _ in range(int(rng.randint(1, 4))):
+        w, h = int(rng.randint(4, 20)), int(rng.randint(4, 20))
+        x0, y0 = int(rng.randint(0, W - w)), int(rng.randint(0, H - h))
+        m = np.zeros((H, W), bool)
+        m[y0:y0 + h, x0:x0 + w] = True
+        pm.append(m)
+        pb.append((x0, y0, x0 + w, y0 + h))
+    if seed == 3:
+        pm[0][:] = False
+    n = len(pm)
+    scores = np.round(0.15 + 0.85 * rng.rand(n), 1).astype(np.float32)
+    return {"gt_masks": torch.from_numpy(gt_masks), "gt_boxes": torch.from_numpy(gt_boxes), "gt_classes": torch.zeros(n_gt, dtype=torch.int64),
+            "pred_masks": torch.from_numpy(np.stack(pm)), "pred_boxes": torch.tensor(pb, dtype=torch.float32),
+            "pred_classes": torch.zeros(n, dtype=torch.int64), "pred_scores": torch.from_numpy(scores)}
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "eval_metrics.npz"))
+
+
+def _table_row(table):
+    return np.array([table[k] for k in ["all"] + [int(t * 100) for t in [x / 100 for x in range(50, 100, 5)]]])
+
+
+def test_oracle_equals_reference_golden(fx):
+    from oracle import eval_ref
+    data = eval_ref.new_ap_data()
+    for seed in SEEDS:
+        f = make_frame(seed)
+        pm, gm = f["pred_masks"].float(), f["gt_masks"].float()
+        assert np.array_equal(eval_ref.mask_iou_ref(pm, gm).numpy(), fx["mask_iou_%d" % seed], equal_nan=True)
+        assert np.array_equal(eval_ref.bbox_iou_ref(f["pred_boxes"].float(), f["gt_boxes"].float()).numpy(), fx["box_iou_%d" % seed], equal_nan=True)
+        eval_ref.segmentation_metrics_ref(data, gm, f["gt_boxes"], f["gt_classes"], pm, f["pred_boxes"], f["pred_classes"], f["pred_scores"])
+    assert (fx["mask_iou_3"][0] == 0).all()                      # the empty detection mask of frame 3
+    table = eval_ref.calc_map_ref(data)
+    for kind in ("box", "mask"):
+        assert [len(o.points) for o in data[kind]] == fx["points_" + kind].tolist()
+        assert np.allclose([o.ap() for o in data[kind]], fx["ap_" + kind], rtol=0, atol=1e-12)
+        assert np.allclose(np.round(_table_row(table[kind]), 2), fx["map_rounded_" + kind], rtol=0, atol=1e-9)
+
+
+def test_host_matching_and_ap_equal_reference_golden(fx, capsys):
+    """The product's host half (matching, AP integral, table) fed with the reference's IoU matrices."""
+    from planerecnet_amd import metrics
+    data = metrics.new_ap_data()
+    for seed in SEEDS:
+        f = make_frame(seed)
+        metrics.match_frame(data, fx["mask_iou_%d" % seed], fx["box_iou_%d" % seed], f["pred_scores"].numpy(), int((f["gt_classes"] == 0).sum()))
+    for kind in ("box", "mask"):
+        assert [len(o.scores) for o in data[kind]] == fx["points_" + kind].tolist()
+        assert data[kind][0].num_gt_positives == int(fx["gt_positives"])
+        assert np.allclose([o.get_ap() for o in data[kind]], fx["ap_" + kind], rtol=0, atol=1e-12)
+    table = metrics.calc_map(data)
+    out = capsys.readouterr().out
+    assert "Calculating mAP..." in out and "  mask |" in out and " .50  |" in out
+    for kind in ("box", "mask"):
+        assert np.allclose(_table_row(table[kind]), fx["map_rounded_" + kind], rtol=0, atol=1e-9)
+
+
+def test_ap_object_edge_cases():
+    from oracle.eval_ref import APDataRef
+    from planerecnet_amd.metrics import APDataObject, calc_map, new_ap_data
+    o = APDataObject()
+    assert o.is_empty() and o.get_ap() == 0
+    o.add_gt_positives(3)
+    assert not o.is_empty() and o.get_ap() == 0.0            # ground truth but no detections
+    r = APDataRef()
+    r.gt_total = 3
+    rng = np.random.RandomState(7)
+    for _ in range(40):                                         # random pushes with tied scores: same AP as the scalar restatement
+        s, h = round(float(rng.rand()), 1), bool(rng.rand() < 0.4)
+        o.push(s, h)
+        r.points.append((s, h))
+    assert abs(o.get_ap() - r.ap()) < 1e-15
+    table = calc_map(new_ap_data(), quiet=True)                 # nothing seen at all: a table of zeros
+    assert all(v == 0 for v in table["box"].values()) and list(table["mask"].keys())[0] == "all"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_device_iou_equals_oracle_and_golden_bitwise(fx, seed):
+    from oracle import eval_ref
+    from planerecnet_amd import metrics
+    f = make_frame(seed)
+    for pm in (f["pred_masks"], f["pred_masks"].float(), f["pred_masks"].to(torch.uint8)):          # bool (model output), float (eval.py:99), bytes
+        miou, biou = metrics.pairwise_iou(pm.cuda(), f["gt_masks"].cuda(), f["pred_boxes"].cuda(), f["gt_boxes"].cuda())
+        assert np.array_equal(miou.cpu().numpy(), fx["mask_iou_%d" % seed], equal_nan=True)
+        assert np.array_equal(biou.cpu().numpy(), fx["box_iou_%d" % seed], equal_nan=True)
+    assert np.array_equal(metrics.mask_iou(f["pred_masks"].cuda(), f["gt_masks"].cuda()).cpu().numpy(),
+                          eval_ref.mask_iou_ref(f["pred_masks"], f["gt_masks"]).numpy(), equal_nan=True)
+    assert np.array_equal(metrics.bbox_iou(f["pred_boxes"].cuda(), f["gt_boxes"].float().cuda()).cpu().numpy(), fx["box_iou_%d" % seed])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,A,B", [((480, 640), 100, 24), ((736, 960), 37, 9), ((17, 23), 5, 3), ((1, 33), 2, 2), ((5, 13), 1, 1)])
+def test_device_iou_full_size_and_ragged_word_tails(shape, A, B):
+    """Full-size frames (the top_k = 100 detections of eval.py), plane sizes that are not multiples of 32 pixels (tail word) or of
+    16 bytes (unaligned rows), against the oracle's float matmul -- integer counts, so equality is exact."""
+    from oracle import eval_ref
+    from planerecnet_amd import metrics
+    g = torch.Generator().manual_seed(A * 1000 + B)
+    pm = torch.rand(A, *shape, generator=g) < 0.3
+    gm = (torch.rand(B, *shape, generator=g) < 0.4).to(torch.uint8)
+    if A > 1:
+        pm[0], gm[0] = False, 0                                    # two empty masks: 0/0 = NaN on both sides
+    pb = torch.rand(A, 4, generator=g) * 100
+    pb[:, 2:] += pb[:, :2]
+    gb = (torch.rand(B, 4, generator=g) * 100).double()
+    gb[:, 2:] += gb[:, :2]
+    miou, biou = metrics.pairwise_iou(pm.cuda(), gm.cuda(), pb.cuda(), gb.cuda())
+    assert np.array_equal(miou.cpu().numpy(), eval_ref.mask_iou_ref(pm, gm).numpy(), equal_nan=True)
+    assert np.array_equal(biou.cpu().numpy(), eval_ref.bbox_iou_ref(pb, gb.float()).numpy(), equal_nan=True)
+    # size-independent properties: IoU of a set with itself is 1, the matrix of (a, b) is the transpose of (b, a)
+    self_iou = metrics.mask_iou(gm.cuda(), gm.cuda()).cpu()
+    assert torch.equal(torch.diagonal(self_iou)[1:], torch.ones(B - 1))
+    assert np.array_equal(metrics.mask_iou(gm.cuda(), pm.cuda()).cpu().numpy(), miou.cpu().t().numpy(), equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_segmentation_metrics_end_to_end_equal_reference_golden(fx):
+    from planerecnet_amd import metrics
+    data = metrics.new_ap_data()
+    for seed in SEEDS:
+        f = make_frame(seed)
+        # the argument types evaluate() hands over: device masks / scores, boxes on the host (planerecnet.py:282), float64 gt boxes
+        metrics.compute_segmentation_metrics(data, f["gt_masks"].cuda().float(), f["gt_boxes"].cuda(), f["gt_classes"].cuda(),
+                                             f["pred_masks"].cuda().float(), f["pred_boxes"], f["pred_classes"].cuda(), f["pred_scores"].cuda())
+    table = metrics.calc_map(data, quiet=True)
+    for kind in ("box", "mask"):
+        assert np.allclose([o.get_ap() for o in data[kind]], fx["ap_" + kind], rtol=0, atol=1e-12)
+        assert np.allclose(_table_row(table[kind]), fx["map_rounded_" + kind], rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_pairwise_iou_rejects_and_empty_sets():
+    from planerecnet_amd import metrics
+    with pytest.raises(RuntimeError):
+        metrics.pairwise_iou(torch.ones(2, 4, 4), torch.ones(2, 4, 4))
+    with pytest.raises(RuntimeError):
+        metrics.pairwise_iou(torch.ones(2, 4, 4).cuda(), torch.ones(2, 4, 5).cuda())
+    with pytest.raises(NotImplementedError):
+        metrics.mask_iou(torch.ones(2, 4, 4).cuda(), torch.ones(2, 4, 4).cuda(), iscrowd=True)
+    m, b = metrics.pairwise_iou(torch.ones(3, 4, 4).cuda(), torch.ones(0, 4, 4).cuda(), torch.ones(3, 4).cuda(), torch.ones(0, 4).cuda())
+    assert m.shape == (3, 0) and b.shape == (3, 0)
+    data = metrics.new_ap_data()                                   # a frame without ground truth: every detection is a miss
+    metrics.match_frame(data, m.cpu().numpy(), b.cpu().numpy(), np.array([0.9, 0.5, 0.7], np.float32), 0)
+    assert data["mask"][0].hits == [False] * 3 and data["mask"][0].scores == pytest.approx([0.9, 0.7, 0.5])

@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """Training entry point for the HOT PATH of the reference's train.py: same flags, config autoscaling, Adam param groups,
 LR warm-up / steps, `<name>_<epoch>_<iter>.pth` checkpoints, resume / interrupt handling, 100-iteration console line.
-Scope: the training step (model + loss + optimizer + data-parallel exchange).  The annotated-dataset readers / augmentations
-(cv2 + pycocotools), the validation pass and tensorboard logging are NOT part of this build: real datasets exit with a
-message, `--validation_*` / `--log_folder` / `--batch_alloc` raise when changed from their defaults, `--dataset synthetic`
-feeds seeded batches with the reference's batch contract.
+Scope: the training step (model + loss + optimizer + data-parallel exchange) and the validation pass (eval.py: depth errors +
+box / mask AP every `--validation_epoch` epochs over `--validation_size` frames and once after the last iteration, reference
+train.py:395-402,440-448).  The annotated-dataset readers / augmentations (cv2 + pycocotools) and tensorboard logging are NOT
+part of this build: real datasets exit with a message, `--log_folder` / `--batch_alloc` raise when changed from their
+defaults, `--dataset synthetic` feeds seeded batches with the reference's batch contract.
 
 What differs is the machinery underneath:
   * the model and loss run on the HIP kernels (planerecnet_amd), the device comes from `cfg.device`;
@@ -32,7 +33,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime i
 import torch  # noqa: E402
 import torch.distributed as dist
 
-from planerecnet_amd.config import cfg, set_cfg, set_dataset
+import eval as eval_script  # noqa: E402
+from planerecnet_amd.config import cfg, set_cfg, set_dataset  # noqa: E402
+from planerecnet_amd.datasets import SyntheticPlaneDataset, detection_collate  # noqa: E402
 from planerecnet_amd.utils import MovingAverage, SavePath
 
 parser = argparse.ArgumentParser(description="PlaneRecNet Training Script (MI355X)")
@@ -61,42 +64,10 @@ parser.add_argument("--no_interrupt", dest="interrupt", action="store_false")
 parser.add_argument("--batch_alloc", default=None, type=str, help="Accepted for CLI compatibility; ranks always take equal shares.")
 parser.add_argument("--max_iter", default=None, type=int, help="(extension) stop after this many iterations.")
 parser.add_argument("--synthetic_size", default=64, type=int, help="(extension) samples per synthetic epoch.")
+parser.add_argument("--synthetic_val_size", default=8, type=int, help="(extension) frames in the synthetic validation set.")
 parser.set_defaults(keep_latest=False, interrupt=True, autoscale=True)
 
 LOSS_TYPES = ["ins", "lav", "cat", "dpt", "pln"]
-
-
-class SyntheticPlaneDataset(torch.utils.data.Dataset):
-    """Seeded samples with the reference's contract: (image [3,H,W] float, instances dict, depth [1,H,W] metres)."""
-
-    def __init__(self, length, hw=(480, 640)):
-        self.length, self.hw = length, hw
-
-    def __len__(self):
-        return self.length
-
-    def __getitem__(self, idx):
-        H, W = self.hw
-        rng = np.random.RandomState(idx)
-        g = torch.Generator().manual_seed(idx)
-        n = int(rng.randint(3, 9))
-        masks, boxes = np.zeros((n, H, W), np.uint8), np.zeros((n, 4), np.float64)
-        for i in range(n):
-            bw, bh = int(rng.randint(max(W // 16, 8), W // 2)), int(rng.randint(max(H // 16, 8), H // 2))
-            x0, y0 = int(rng.randint(0, W - bw)), int(rng.randint(0, H - bh))
-            masks[i, y0:y0 + bh, x0:x0 + bw] = 1
-            boxes[i] = (x0, y0, x0 + bw, y0 + bh)
-        nrm = rng.randn(n, 3)
-        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
-        inst = {"masks": torch.from_numpy(masks), "boxes": torch.from_numpy(boxes), "classes": torch.zeros(n, dtype=torch.int64),
-                "plane_paras": torch.from_numpy(np.concatenate([nrm, rng.rand(n, 1) * 3.0, np.zeros((n, 2))], 1)),
-                "k_matrix": torch.tensor([[577.0, 0, W / 2], [0, 577.0, H / 2], [0, 0, 1]], dtype=torch.float64)}
-        return torch.randn(3, H, W, generator=g), inst, 0.5 + 4.0 * torch.rand(1, H, W, generator=g)
-
-
-def detection_collate(batch):
-    """lists of images / instance dicts / depths (reference data/datasets.py:250-273)"""
-    return [s[0] for s in batch], [s[1] for s in batch], [s[2] for s in batch]
 
 
 class NetLoss(torch.nn.Module):
@@ -108,6 +79,19 @@ class NetLoss(torch.nn.Module):
 
     def forward(self, images, gt_instances, gt_depths, targets=None):
         return self.criterion(self.net, *self.net(images), gt_instances, gt_depths, targets=targets)
+
+
+def compute_validation_metrics(epoch, iteration, prn_net, val_dataset, eval_nums=-1, rank=0, world=1):
+    """Reference train.py:440-448.  Rank 0 evaluates its replica (all replicas are identical), the others wait."""
+    if rank == 0:
+        with torch.no_grad():
+            prn_net.eval()
+            print()
+            print("Computing validation metrics (this may take a while)...", flush=True)
+            eval_script.evaluate(prn_net, val_dataset, during_training=True, eval_nums=eval_nums)
+            prn_net.train()
+    if world > 1:
+        dist.barrier()
 
 
 def set_lr(optimizer, new_lr):
@@ -133,12 +117,9 @@ def main():
             setattr(args, name, getattr(cfg, name))
     if args.max_iter is not None:
         cfg.max_iter = args.max_iter
-    # Flags of the reference's CLI whose machinery (validation pass with pycocotools, tensorboardX logging) is outside this
+    # Flags of the reference's CLI whose machinery (tensorboardX logging, DataParallel batch allocation) is outside this
     # hot-path build: accepted only at their defaults / off-values -- asking for them is an error, not a silent no-op.
     ignored = []
-    if args.validation_epoch != 1 or args.validation_size != 2000:
-        ignored.append("--validation_epoch / --validation_size (no validation pass: eval.py's dataset / COCO-metric code is out of scope; "
-                       "planerecnet_amd.metrics.compute_depth_metrics is available for custom loops)")
     if args.log_folder != "./logs/":
         ignored.append("--log_folder (no tensorboard writer)")
     if args.batch_alloc is not None:
@@ -186,6 +167,8 @@ def main():
     if not synthetic:
         raise SystemExit("The annotated dataset readers (cv2 + pycocotools) are outside this build; use --dataset synthetic.")
     dataset = SyntheticPlaneDataset(args.synthetic_size)
+    val_dataset = SyntheticPlaneDataset(args.synthetic_val_size)
+    eval_script.parse_args(["--no_bar"])                   # (reference train.py:436-437)
 
     torch.manual_seed(0)
     prn_net = PlaneRecNet(cfg).train()
@@ -353,8 +336,13 @@ def main():
                     if latest is not None and (args.keep_latest_interval <= 0 or iteration % args.keep_latest_interval != args.save_interval):
                         print("Deleting old save...")
                         os.remove(latest)
+            if args.validation_epoch > 0 and epoch % args.validation_epoch == 0 and iteration > 0 and epoch < num_epochs - 2:
+                flush_stats()                              # (no validation at iteration 0 or in the last epochs: reference train.py:396-399)
+                compute_validation_metrics(epoch, iteration, prn_net, val_dataset, args.validation_size, rank, world)
             if iteration >= cfg.max_iter:
                 break
+        flush_stats()
+        compute_validation_metrics(epoch, iteration, prn_net, val_dataset, -1, rank, world)       # after training (reference train.py:401-402)
     except KeyboardInterrupt:
         if args.interrupt and rank == 0:
             print("Stopping early. Saving network...")
