@@ -63,6 +63,17 @@ typedef struct prn_conv_desc {
 int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
+/* The same with the K-split sum folded into the GEMM launch (no second kernel, one launch less per split layer): `counters` is
+ * a caller-owned buffer of PRN_TILE_COUNTERS uint32, ALL ZERO on entry and all zero again once the launch has completed --
+ * allocate and clear it once per stream and hand the same buffer to every call on that stream (launches that may run
+ * concurrently must not share one).  Partial tiles are written with agent scope; the workgroup arriving last at a tile's
+ * counter sums them in split order, so the result is bit-identical to prn_conv2d_fwd's.  counters == NULL, or a launch the
+ * fold does not cover (strided / phase outputs, unaligned tensors), behaves exactly like prn_conv2d_fwd_phase.  The fold is
+ * opt-in (environment PRN_CONV_FUSED_REDUCE=1, read per call): measured faster per layer, neutral on the training step.
+ * phase: 0 = whole operator, 1 = GEMM launch only, 2 = the separate sum only (a no-op when the fold was used).  */
+#define PRN_TILE_COUNTERS 4096
+int prn_conv2d_fwd_counted(const prn_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y, void* ws,
+                           unsigned* counters, void* stream, int phase);
 /* Ragged batch: `nseg` dense tensors [B, C, H[s], W[s]] stored back to back, convolved with the SAME weights as one
  * GEMM over all their pixels (SOLOv2 applies its instance-head towers to five grid sizes, planerecnet.py:337-360).  Output
  * and addend are packed the same way with M channels.  Stride-1 "same" 1x1 / 3x3 convolutions with zero padding; desc->H,

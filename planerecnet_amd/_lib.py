@@ -46,6 +46,7 @@ SIGNATURES = {
     "prn_gn_relu_fwd_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, c_int, c_float, P]),
     "prn_gn_relu_bwd_ragged": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P]),
     "prn_conv2d_fwd_phase": (c_int, [_DP, P, P, P, P, P, P, P, c_int]),
+    "prn_conv2d_fwd_counted": (c_int, [_DP, P, P, P, P, P, P, P, P, c_int]),
     "prn_conv2d_wgrad_phase": (c_int, [_DP, P, P, P, P, P, c_int]),
     "prn_weight_flip_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_weight_flip_transpose_batched": (c_int, [P, c_int, c_i64, P]),

@@ -58,6 +58,7 @@ struct ConvArgs {
   int wide_store;           // epilogue through the LDS transpose (float4 stores): output / addend / workspace 16-byte aligned
   int tail_first, tail_splits;   // tail split (see plan_tail): blocks >= tail_first are K-split pieces of the last tiles; 0 splits = off
   float* ws;
+  unsigned* cnt;                 // per-tile arrival counters (zero between launches) when the K-split sum is folded into this kernel, else null
   Seg seg;
 };
 
@@ -76,6 +77,18 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   // (bit_cast the whole vector: __builtin_bit_cast on a single vector element reads element 0 with hipcc 7.2)
   const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+  return make_float4(q.x, q.y, q.z, q.w);
+}
+
+// Agent-scope accesses (sc1): the store is written through to memory, the load is served from memory -- visible across the
+// eight XCDs, whose L2s are not coherent with each other, without a cache-wide write-back / invalidate.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bstore4_agent(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+  const f32x4 q = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), r, (int)voff, 0, 16);
+}
+__device__ __forceinline__ float4 bload4_agent(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 16));
   return make_float4(q.x, q.y, q.z, q.w);
 }
 
@@ -390,6 +403,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
     __syncthreads();                                       // every wave is done reading As / Bs
     float* cw = smem + wave * (32 * CPITCH);
     const int crow = lane >> 3, ccol = (lane & 7) * 4;      // this lane's quad: rows crow + 8 * q, pixels ccol .. ccol + 3
+    // K-split sum folded into this kernel (a.cnt != null): partial tiles are stored with agent scope; the workgroup that
+    // arrives LAST at the tile's counter sums the nsplit partials in split order (the order of reduce_epilogue_kernel, so
+    // the result does not depend on which workgroup that is) and applies bias / addend / activation.
+    const bool fuse = partial && a.cnt != nullptr;
+    const unsigned total4 = (unsigned)(a.B * a.M * HoWo_) * 4u;              // bytes of one partial slice
+    const __amdgpu_buffer_rsrc_t wsr = make_rsrc(a.ws, fuse ? (int)(total4 * (unsigned)nsplit) : 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nq = n0 + wn * TN * 32 + j * 32 + ccol;
@@ -412,9 +431,49 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
           if (has_add) { const float4 t = *reinterpret_cast<const float4*>(add_ + idx); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
           if (epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           else if (epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y)); v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w)); }
-          *reinterpret_cast<float4*>(outp + idx) = v;
+          if (fuse) bstore4_agent(wsr, (unsigned)ksplit * total4 + (unsigned)idx * 4u, v);
+          else *reinterpret_cast<float4*>(outp + idx) = v;
         }
         __builtin_amdgcn_wave_barrier();                   // the pad is rewritten by the next block
+      }
+    }
+    if (!fuse) return;
+    __shared__ int last_arrival;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partial stores have reached memory ...
+    __syncthreads();                                       // ... and so have the other waves'
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(a.cnt + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_arrival = prev == (unsigned)nsplit - 1u;
+      if (last_arrival) __hip_atomic_store(a.cnt + id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+    }
+    __syncthreads();
+    if (!last_arrival) return;
+    const bool f_bias = a.bias != nullptr, f_add = add_ != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nq = n0 + wn * TN * 32 + j * 32 + ccol;
+      const bool nok = interior || nq < N_;
+      const int bb = nq / HoWo_, p = nq - bb * HoWo_;
+      const size_t base = (size_t)bb * a.M * HoWo_ + p;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * TM * 32 + i * 32 + crow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = mb + 8 * q;
+          if (!nok || (!interior && m >= a.M)) continue;
+          const size_t idx = base + (size_t)m * HoWo_;
+          float4 v = bload4_agent(wsr, (unsigned)idx * 4u);
+          for (int sp = 1; sp < nsplit; ++sp) {
+            const float4 t = bload4_agent(wsr, (unsigned)sp * total4 + (unsigned)idx * 4u);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+          }
+          if (f_bias) { const float bm = a.bias[m]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+          if (f_add) { const float4 t = *reinterpret_cast<const float4*>(add_ + idx); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+          if (a.epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (a.epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y)); v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w)); }
+          *reinterpret_cast<float4*>(y_ + idx) = v;
+        }
       }
     }
     return;
@@ -735,9 +794,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_m_wgrad_kernel(const float*
 }
 
 // y = epi( sum_s ws[s] + bias[m] + addend ) for split-K launches (fixed summation order).
-// (Folding this into the GEMM kernel -- last workgroup to arrive at a per-tile counter sums the partials -- was tried and is
-// 4x SLOWER on MI355X: the release/acquire pair it needs is a device-scope __threadfence(), which writes back and
-// invalidates the XCD's whole L2 because the eight L2s are not coherent with each other; 57 -> 257 us on 1x1 1024->256.)
+// (Folding this into the GEMM kernel -- last workgroup to arrive at a per-tile counter sums the partials: with a device-scope
+// __threadfence() as the release / acquire pair it was 4x SLOWER, 57 -> 257 us on 1x1 1024->256, because the fence writes back and
+// invalidates the XCD's whole L2; with agent-scope stores / loads instead of fences it works, see fused_reduce_ok.)
 __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                const float* __restrict__ addend, float* __restrict__ y, int64_t total,
                                                                int M, int HoWo, int splits, int epi) {
@@ -1006,25 +1065,45 @@ constexpr bool narrow_available(int ks, int mode) {
   return (ks == 3 && (mode == PRN_IN_ZERO || mode == PRN_IN_REFLECT)) || (ks == 1 && mode == PRN_IN_ZERO);
 }
 
+// epilogue through the LDS transpose (float4 stores)?
+bool wide_store_ok(const ConvArgs& a, const FwdPlan& p) {
+  static int wide = -1;                                    // PRN_CONV_WIDE_STORE=0: the per-element epilogue everywhere (A/B)
+  if (wide < 0) { const char* e = getenv("PRN_CONV_WIDE_STORE"); wide = e ? atoi(e) : 1; }
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return wide && a.seg.nseg == 0 && p.wm == 2 && al16(a.y) && al16(a.addend) && al16(a.ws) && (a.zy & 3) == 0 && (a.HoWo & 3) == 0 &&
+         (p.splits == 1 || (((int64_t)a.B * a.M * a.HoWo) & 3) == 0);
+}
+
+// K-split (or tail-split) sum inside the GEMM launch?  Needs the caller's zeroed tile counters (prn_conv2d_fwd_counted), the
+// float4 epilogue, a dense output and partial slices addressable through one buffer descriptor.
+// OFF unless PRN_CONV_FUSED_REDUCE=1 (read per call): bit-identical to the two-kernel path and 2-8 % faster per split layer
+// in isolation (62 -> 57 us on 1x1 1024->256 @30x40, 118 -> 108 us on 2304->256), but the training step does not move
+// (54.8-54.9 ms either way, four alternating runs): inside a step the 7 us sum kernels already ran in the shadow of the
+// weight-gradient stream, and the fold lengthens conv_igemm_kernel itself (roofline.frac 0.54 -> 0.53).
+bool fused_reduce_ok(const ConvArgs& a, const FwdPlan& p, int phases, int tail_pieces, const unsigned* counters) {
+  if (counters == nullptr) return false;
+  const char* e = getenv("PRN_CONV_FUSED_REDUCE");
+  const int on = e ? atoi(e) : 0;
+  const int pieces = p.splits > 1 ? p.splits : tail_pieces;
+  const int64_t tiles = (int64_t)cdiv(a.M, 32 * p.wm * p.tm) * cdiv(a.N, 32 * p.wn * p.tn);
+  return on && counters != nullptr && pieces > 1 && phases == 1 && a.ystride == 1 && a.zy == 0 && tiles <= PRN_TILE_COUNTERS && wide_store_ok(a, p) &&
+         (int64_t)pieces * a.B * a.M * a.HoWo * 4 < (1LL << 31);
+}
+
 template <int KS, int MODE>
-int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases = 1, int tail_tiles = 0, int tail_pieces = 0) {
+int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases = 1, int tail_tiles = 0, int tail_pieces = 0, unsigned* counters = nullptr) {
   ConvArgs a = a0;
   a.tilesM = cdiv(a.M, 32 * p.wm * p.tm);
   a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
   a.splits = p.splits;
-  {
-    static int wide = -1;                                    // PRN_CONV_WIDE_STORE=0: the per-element epilogue everywhere (A/B)
-    if (wide < 0) { const char* e = getenv("PRN_CONV_WIDE_STORE"); wide = e ? atoi(e) : 1; }
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    a.wide_store = wide && a.seg.nseg == 0 && p.wm == 2 && al16(a.y) && al16(a.addend) && al16(a.ws) && (a.zy & 3) == 0 &&
-                   (p.splits == 1 || (((int64_t)a.B * a.M * a.HoWo) & 3) == 0);
-  }
+  a.wide_store = wide_store_ok(a, p);
   a.tail_first = a.nblocks; a.tail_splits = 0;
   int gx = a.nblocks;
   if (tail_pieces > 1 && phases == 1 && a.seg.nseg == 0 && a.ystride == 1) {
     a.tail_first = a.nblocks - tail_tiles; a.tail_splits = tail_pieces;
     gx = a.tail_first + tail_tiles * tail_pieces;
   }
+  a.cnt = fused_reduce_ok(a, p, phases, a.tail_splits, counters) ? counters : nullptr;
   dim3 grid(gx, p.splits, phases), block(64 * p.wm * p.wn);
   if constexpr (narrow_available(KS, MODE)) {
     if (p.wm == 1) {
@@ -1253,13 +1332,18 @@ int64_t seg_pixels(const prn_ragged* rg, int B) {
   return n;
 }
 int conv_fwd_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias, const float* addend, float* y,
-                  void* ws, void* stream, int phase);
+                  void* ws, void* stream, int phase, unsigned* counters = nullptr);
 int conv_wgrad_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase);
 }  // namespace
 
 extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                                     const float* addend, float* y, void* ws, void* stream, int phase) {
   return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase);
+}
+
+extern "C" int prn_conv2d_fwd_counted(const prn_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y, void* ws,
+                                      unsigned* counters, void* stream, int phase) {
+  return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase, counters);
 }
 
 extern "C" int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias,
@@ -1270,7 +1354,7 @@ extern "C" int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* r
 
 namespace {
 int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x, const float* w, const float* bias, const float* addend, float* y,
-                  void* ws, void* stream, int phase) {
+                  void* ws, void* stream, int phase, unsigned* counters) {
   prn_conv_desc dd;
   const prn_conv_desc* d = d0;
   if (rg && d0) {                                       // geometry fields of the descriptor are per segment: validate with the first one
@@ -1326,22 +1410,26 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
   if (phase == 2) goto reduce_only;
   if (d->KH == 1) {
     PRN_REQUIRE(mode == PRN_IN_ZERO || mode == PRN_IN_DILATED, "prn_conv2d_fwd: 1x1 kernels take zero or dilated input mode");
-    if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st, 1, tail_tiles, tail_pieces); else launch_fwd<1, PRN_IN_DILATED>(a, p, st);
+    if (mode == PRN_IN_ZERO) launch_fwd<1, PRN_IN_ZERO>(a, p, st, 1, tail_tiles, tail_pieces, counters); else launch_fwd<1, PRN_IN_DILATED>(a, p, st, 1, 0, 0, counters);
   } else if (d->KH == 2) {
     launch_fwd<2, PRN_IN_UP2_PHASE>(a, p, st, 4);
   } else if (d->KH == 3) {
-    if (mode == PRN_IN_ZERO) launch_fwd<3, PRN_IN_ZERO>(a, p, st, 1, tail_tiles, tail_pieces);
-    else if (mode == PRN_IN_REFLECT) launch_fwd<3, PRN_IN_REFLECT>(a, p, st, 1, tail_tiles, tail_pieces);
-    else if (mode == PRN_IN_UP2_REFLECT) launch_fwd<3, PRN_IN_UP2_REFLECT>(a, p, st);
-    else launch_fwd<3, PRN_IN_DILATED>(a, p, st);
+    if (mode == PRN_IN_ZERO) launch_fwd<3, PRN_IN_ZERO>(a, p, st, 1, tail_tiles, tail_pieces, counters);
+    else if (mode == PRN_IN_REFLECT) launch_fwd<3, PRN_IN_REFLECT>(a, p, st, 1, tail_tiles, tail_pieces, counters);
+    else if (mode == PRN_IN_UP2_REFLECT) launch_fwd<3, PRN_IN_UP2_REFLECT>(a, p, st, 1, 0, 0, counters);
+    else launch_fwd<3, PRN_IN_DILATED>(a, p, st, 1, 0, 0, counters);
   } else if (d->KH == 4) {
-    launch_fwd<4, PRN_IN_ZERO>(a, p, st);
+    launch_fwd<4, PRN_IN_ZERO>(a, p, st, 1, 0, 0, counters);
   } else {
-    if (mode == PRN_IN_ZERO) launch_fwd<7, PRN_IN_ZERO>(a, p, st); else launch_fwd<7, PRN_IN_DILATED>(a, p, st);
+    if (mode == PRN_IN_ZERO) launch_fwd<7, PRN_IN_ZERO>(a, p, st, 1, 0, 0, counters); else launch_fwd<7, PRN_IN_DILATED>(a, p, st, 1, 0, 0, counters);
   }
   PRN_CHECK_LAUNCH("prn_conv2d_fwd");
   if (phase == 1) return 0;
 reduce_only:
+  {
+    const bool tail_launch = tail_pieces > 1 && (mode == PRN_IN_ZERO || mode == PRN_IN_REFLECT) && (d->KH == 1 || d->KH == 3);
+    if (fused_reduce_ok(a, p, g.phases, tail_launch ? tail_pieces : 0, counters)) return 0;       // summed inside the GEMM launch
+  }
   if (p.splits > 1) {
     const int64_t total = (int64_t)a.B * a.M * a.HoWo;
     hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, (const float*)ws, bias, addend, y, total, a.M, a.HoWo,

@@ -206,6 +206,20 @@ def _out_hw(H, W, K, stride, pad, mode):
     return (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
 
 
+FUSED_SPLIT_SUM = os.environ.get("PRN_CONV_FUSED_REDUCE", "0") == "1"      # see fused_reduce_ok in csrc/prn_conv.hip: neutral on the step
+_COUNTERS = {}     # (device index, raw stream) -> zeroed uint32[PRN_TILE_COUNTERS]: the tile-arrival counters of prn_conv2d_fwd_counted
+TILE_COUNTERS = 4096
+
+
+def _counters(dev):
+    """One counter buffer per stream: launches on a stream are ordered, and every launch leaves the counters at zero."""
+    key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = _COUNTERS[key] = torch.zeros(TILE_COUNTERS, device=dev, dtype=torch.int32)
+    return c
+
+
 # ------------------------------------------------------------------------------------------ raw launches
 def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None):
     """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor."""
@@ -217,18 +231,19 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
         _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    cnt = _counters(x.device) if (nbytes and FUSED_SPLIT_SUM) else None      # K-split layers: the sum inside the GEMM launch (opt-in)
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
         # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
         with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil),
                             nbytes=4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0)),
                             tag=("conv", C, H, W, M, K, stride, mode, dil, B)):
-            check(lib.prn_conv2d_fwd_phase(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream(), 1), "prn_conv2d_fwd")
+            check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 1), "prn_conv2d_fwd")
         if nbytes:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
-                check(lib.prn_conv2d_fwd_phase(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream(), 2), "prn_conv2d_fwd")
+                check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 2), "prn_conv2d_fwd")
     else:
-        check(lib.prn_conv2d_fwd(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _stream()), "prn_conv2d_fwd")
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 0), "prn_conv2d_fwd")
     return y
 
 

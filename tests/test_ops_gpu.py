@@ -163,6 +163,51 @@ def test_ragged_shape_rejects_unaligned_segments():
     assert ops.RaggedShape(8, [(40, 40), (36, 36), (24, 24), (16, 16), (12, 12)]).supported()
 
 
+@pytest.mark.parametrize("shape", [
+    # C, H, W, M, K, pad, mode (0 zero / 1 reflect), bias, addend, epilogue (0 none / 1 relu / 2 sigmoid)      (B = 8: the K-split layers of the network, and tail-split ones)
+    (1024, 30, 40, 256, 1, 0, 0, False, False, 0),      # stage-3 1x1 (split 2..3)
+    (256, 30, 40, 1024, 1, 0, 0, True, True, 1),
+    (2048, 15, 20, 512, 1, 0, 0, True, False, 2),    # stage 4: 2400 pixels
+    (512, 15, 20, 512, 3, 1, 0, False, True, 0),
+    (256, 16, 16, 256, 3, 1, 1, True, False, 1),
+    (3728, 30, 40, 256, 1, 0, 0, True, False, 0),       # plane prior: K = 3728
+    (64, 120, 160, 64, 3, 1, 0, True, False, 0),        # no K split, tail split only (or none)
+])
+def test_conv_split_sum_inside_the_gemm_is_bit_identical(shape, monkeypatch):
+    """prn_conv2d_fwd_counted (K-split partials summed by the last workgroup to arrive, agent-scope stores / loads across the
+    eight XCDs) against the two-kernel path (counters = NULL): bit-identical output, counters back at zero, 30 launches in
+    a row on the same workspace and counters (a stale or not-yet-visible partial would show up as a mismatch)."""
+    from planerecnet_amd import ops
+    monkeypatch.setenv("PRN_CONV_FUSED_REDUCE", "1")        # (opt-in: neutral on the training step, see fused_reduce_ok in prn_conv.hip)
+    C, H, W, M, K, pad, mode, has_b, has_a, epi = shape
+    B = 8
+    g = torch.Generator().manual_seed(C + M)
+    lib, _p, _stream, check = ops.lib, ops._p, ops._stream, ops.check
+    x0 = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.randn(M, C * K * K, generator=g) * (C * K * K) ** -0.5).cuda()
+    bias = torch.randn(M, generator=g).cuda() if has_b else None
+    add = torch.randn(B, M, H, W, generator=g).cuda() if has_a else None
+    _, ref, nbytes, _ = ops._desc(B, C, H, W, M, K, 1, pad, H, W, mode, 1, epi)
+    ws = torch.empty(max(nbytes, 16) // 4, device="cuda")
+    cnt = torch.zeros(ops.TILE_COUNTERS, device="cuda", dtype=torch.int32)
+    y_two, y_one = torch.empty(B, M, H, W, device="cuda"), torch.empty(B, M, H, W, device="cuda")
+    for rep in range(30):
+        x = x0 * (1.0 + rep)                                # different partials every round
+        ws.fill_(float("nan"))
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w), _p(bias), _p(add), _p(y_two), _p(ws), None, _stream(), 0), "two-kernel")
+        ws.fill_(float("nan"))
+        y_one.fill_(float("nan"))
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w), _p(bias), _p(add), _p(y_one), _p(ws), _p(cnt), _stream(), 0), "folded")
+        assert torch.equal(y_one, y_two), (rep, float((y_one - y_two).abs().max()))
+        assert int(cnt.abs().sum()) == 0
+    ref_y = F.conv2d(F.pad(x.double().cpu(), (pad,) * 4, mode="reflect") if mode == ops.IN_REFLECT else x.double().cpu(),
+                     w.double().cpu().view(M, C, K, K), bias.double().cpu() if has_b else None, padding=0 if mode == ops.IN_REFLECT else pad)
+    if has_a:
+        ref_y = ref_y + add.double().cpu()
+    ref_y = torch.relu(ref_y) if epi == ops.EPI_RELU else (torch.sigmoid(ref_y) if epi == ops.EPI_SIGMOID else ref_y)
+    assert float((y_one.double().cpu() - ref_y).abs().max()) <= 2e-4 * max(float(ref_y.abs().max()), 1.0)
+
+
 def test_conv2d_is_transpose_safe():
     """A = I style check with asymmetric data: 1x1 conv with a permutation weight must permute channels."""
     from planerecnet_amd import ops
