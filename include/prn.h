@@ -287,6 +287,10 @@ int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* beta, c
  * losses.py:143,299.  bwd is the exact adjoint in gather form (overwrites dx, deterministic). */
 int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
 int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
+/* y = resize(x) + addend ([BC, Ho, Wo], may be NULL): the running sum over the pyramid levels of SOLOv2MaskHead
+ * (planerecnet.py:431-441: `feature_add_all_level += self.convs_all_levels[i](...)`, every level but the first ends in an
+ * nn.Upsample) without a separate add pass per level. */
+int prn_resize_bilinear_add_fwd(const float* x, const float* addend, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
 /* MaxPool2d(3, stride 2, pad 1): models/backbone.py:104 */
 int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int H, int W, int Ho, int Wo, void* stream);
 /* arg (may be NULL in the forward): window position r*3+s of every output's maximum, one byte per output; the backward

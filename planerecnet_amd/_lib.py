@@ -115,6 +115,7 @@ SIGNATURES = {
     "prn_gn_relu_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),
     "prn_resize_bilinear_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
     "prn_resize_bilinear_bwd": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "prn_resize_bilinear_add_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_bwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
 }

@@ -19,7 +19,7 @@ __device__ __forceinline__ Lerp lerp_idx(int o, int in, float scale) {
   return l;
 }
 
-__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total,
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, const float* __restrict__ addend, float* __restrict__ y, int64_t total,
                                                          int H, int W, int Ho, int Wo, float sh, float sw) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict
   const int64_t bc = i / ((int64_t)Wo * Ho);
   const Lerp a = lerp_idx(ho, H, sh), b = lerp_idx(wo, W, sw);
   const float* p = x + bc * (int64_t)H * W;
-  y[i] = a.w0 * (b.w0 * p[a.i0 * W + b.i0] + b.w1 * p[a.i0 * W + b.i1]) + a.w1 * (b.w0 * p[a.i1 * W + b.i0] + b.w1 * p[a.i1 * W + b.i1]);
+  const float v = a.w0 * (b.w0 * p[a.i0 * W + b.i0] + b.w1 * p[a.i0 * W + b.i1]) + a.w1 * (b.w0 * p[a.i1 * W + b.i0] + b.w1 * p[a.i1 * W + b.i1]);
+  y[i] = addend ? v + addend[i] : v;
 }
 
 // Adjoint of the bilinear resize in GATHER form (deterministic, no atomics): one thread per INPUT pixel sums the
@@ -173,14 +174,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 }  // namespace
 
 extern "C" int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  return prn_resize_bilinear_add_fwd(x, nullptr, y, BC, H, W, Ho, Wo, stream);
+}
+
+extern "C" int prn_resize_bilinear_add_fwd(const float* x, const float* addend, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(x && y && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_fwd: bad arguments");
   const int64_t n = (int64_t)BC * Ho * Wo;
-  if (H == 2 * Ho && W == 2 * Wo && (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
+  if (addend == nullptr && H == 2 * Ho && W == 2 * Wo && (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
     hipLaunchKernelGGL(resize_down2_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, Ho, Wo);
     PRN_CHECK_LAUNCH("prn_resize_bilinear_fwd/down2");
     return 0;
   }
-  hipLaunchKernelGGL(resize_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, addend, y, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
   PRN_CHECK_LAUNCH("prn_resize_bilinear_fwd");
   return 0;
 }

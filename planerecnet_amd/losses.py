@@ -36,7 +36,7 @@ def _pin(x):
 
 class Targets:
     """Device-resident, GT-only inputs of one loss evaluation (built by PlaneRecNetLoss.prepare)."""
-    __slots__ = ("B", "cell_ids", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum",
+    __slots__ = ("B", "cell_ids", "cell_gidx", "cell_inv", "cells_unique", "n_pos", "n_pos_dev", "pos_img", "ins_labels", "cate_labels", "num_ins", "vnl", "lava_adj", "lava_gsum",
                  "ready")         # ready: event after which the tensors may be read (uploads issued on another stream), or None
 
 
@@ -123,7 +123,16 @@ class PlaneRecNetLoss(nn.Module):
             for lv in range(L):
                 cate_rows[lv].append(cate_l[lv].flatten())
         pin = _pin if (pin and torch.cuda.is_available()) else (lambda x: x)       # page-locked staging: the later H2D copies are truly async
+        n_cells = int(level_start[-1])
+        cell_gidx = np.concatenate([b * n_cells + cell_ids[b] for b in range(B)]) if B else np.zeros(0, np.int64)
+        cell_u, cell_inv, cell_cnt = np.unique(cell_gidx, return_inverse=True, return_counts=True)
+        cell_mult = int(cell_cnt.max()) if cell_cnt.size else 1
         return {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
+                # rows of the positive cells in the [B * n_cells, E] matrix of predicted kernels: the distinct ones, and where each
+                # listed cell is among them (a cell claimed by two instances is listed twice); see instance_terms
+                "cell_gidx": pin(torch.from_numpy(cell_u if cell_mult > 1 else cell_gidx)),          # (np.unique sorts: listed order when nothing repeats)
+                "cell_inv": pin(torch.from_numpy(cell_inv)) if cell_mult > 1 else None,
+                "cells_unique": cell_mult <= 2,
                 "cell_ids": pin(torch.from_numpy(np.concatenate(cell_ids))), "pos_img": pin(torch.from_numpy(np.repeat(np.arange(B), n_pos))),
                 "ins_labels": pin(torch.cat(ins_labels, 0)),
                 # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
@@ -138,6 +147,8 @@ class PlaneRecNetLoss(nn.Module):
         t.B, t.n_pos, t.num_ins = h["B"], h["n_pos"], h["num_ins"]
         up = lambda x: x.to(device, non_blocking=True)
         t.cell_ids = list(up(h["cell_ids"]).split(h["n_pos"]))
+        t.cell_gidx, t.cells_unique = up(h["cell_gidx"]), h["cells_unique"]
+        t.cell_inv = up(h["cell_inv"]) if h["cell_inv"] is not None else None
         t.n_pos_dev = up(torch.as_tensor(h["n_pos"], dtype=torch.float32))
         t.pos_img, t.ins_labels, t.cate_labels = up(h["pos_img"]), up(h["ins_labels"]), up(h["cate_labels"])
         t.vnl = self.vnl.upload(h["vnl"], device) if h["vnl"] is not None else None
@@ -176,12 +187,22 @@ class PlaneRecNetLoss(nn.Module):
             flat_k = torch.cat([k.reshape(B, E, -1) for k in kernel_preds], 2)                          # [B, E, 3728]
             preds = []
             per_image = torch.split(mask_preds, 1)          # one backward node (cat) instead of B zero-filled slice gradients + adds
-            flat_kb = flat_k.unbind(0)
+            if t.cells_unique and sum(t.n_pos) > 0:
+                # all images' positive cells in ONE gather of the distinct rows (index_select: its gradient is one index_add_,
+                # collision-free) plus, when a cell is listed more than once, one expansion whose gradient adds at most two rows
+                # per cell (order-free: a + b == b + a) -- instead of B advanced-indexing ops with B sort-based index_put gradients.
+                # (A cell claimed by three or more instances takes the per-image path below: deterministic there too.)
+                rows = flat_k.transpose(1, 2).reshape(B * flat_k.shape[2], E).index_select(0, t.cell_gidx)
+                if t.cell_inv is not None:
+                    rows = rows.index_select(0, t.cell_inv)
+                w_img = [r.reshape(-1, E, 1, 1) for r in torch.split(rows, t.n_pos)]
+            else:
+                flat_kb = flat_k.unbind(0)
+                w_img = [flat_kb[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous() if t.n_pos[b] else None for b in range(B)]
             for b in range(B):
                 if t.n_pos[b] == 0:
                     continue
-                w = flat_kb[b][:, t.cell_ids[b]].t().reshape(t.n_pos[b], E, 1, 1).contiguous()
-                preds.append(ops.conv2d(per_image[b], w).view(t.n_pos[b], fh, fw))
+                preds.append(ops.conv2d(per_image[b], w_img[b]).view(t.n_pos[b], fh, fw))
             logits = torch.cat(preds, 0)                                                                # [sum n_pos, fh, fw]
             if FUSED_LOSS and logits.is_cuda and logits.shape[0] > 0 and (fh * fw) % 4 == 0 and B <= 64:
                 # Dice + lava as ONE pass over the logits each way (include/prn.h: prn_mask_loss_fwd / _bwd)
@@ -311,6 +332,23 @@ class _GatherRows(torch.autograd.Function):
     def backward(ctx, g):
         order, counts = ctx.saved_tensors
         return torch.segment_reduce(g[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True), None, None, None
+
+
+class _TrimmedMeans(torch.autograd.Function):
+    """VNL_Loss._trimmed_means with its gradient written out (see there)."""
+
+    @staticmethod
+    def forward(ctx, loss, valid, t):
+        out, order, coef, img_s = VNL_Loss._trimmed_means_autograd(loss.detach(), valid, t, loss.device, want_coef=True)
+        ctx.save_for_backward(order, coef, img_s)
+        ctx.n = loss.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        order, coef, img_s = ctx.saved_tensors
+        grad = torch.empty(ctx.n, device=g.device, dtype=coef.dtype).index_copy_(0, order, coef * g.to(coef.dtype)[img_s])   # order is a permutation
+        return grad, None, None
 
 
 class _VnlTriplets(torch.autograd.Function):
@@ -504,8 +542,17 @@ class VNL_Loss(nn.Module):
 
     @staticmethod
     def _trimmed_means(loss, valid, t, dev):
-        """Per-triplet losses -> per-image loss [B] (vnl.py:106-117,133-165).
-        Segmented "sort ascending, drop the first 25 % of the valid ones, nansum / remaining"."""
+        """Per-triplet losses -> per-image loss [B] (vnl.py:106-117,133-165).  The value is computed by
+        `_trimmed_means_autograd`'s operator chain without a graph; the result is linear in the kept losses, so its gradient is
+        one coefficient per triplet (0 for dropped / invalid / NaN ones) scattered back through the sort permutation -- three
+        launches instead of the ~30 (incl. a sort-based index_put and a reversed cumsum) autograd replays for the chain."""
+        if not loss.requires_grad:
+            return VNL_Loss._trimmed_means_autograd(loss, valid, t, dev)
+        return _TrimmedMeans.apply(loss, valid, t)
+
+    @staticmethod
+    def _trimmed_means_autograd(loss, valid, t, dev, want_coef=False):
+        """Segmented "sort ascending, drop the first 25 % of the valid ones, nansum / remaining"."""
         # segments are contiguous runs in triplet order: segment sums are differences of one prefix sum (no atomics)
         seg_end = torch.cat([t.seg_start[1:], t.seg_start.new_full((1,), t.n_tot)])
 
@@ -529,7 +576,13 @@ class VNL_Loss(nn.Module):
         seg_loss = seg_sum / den
         img_sum = torch.zeros(t.B, device=dev, dtype=torch.float64).index_add_(0, t.seg_img, torch.where(use, seg_loss, torch.zeros_like(seg_loss)))
         extra = torch.zeros(t.B, device=dev, dtype=torch.float64).index_add_(0, t.seg_img, np_ok.double())
-        return img_sum / (t.N + extra)
+        out = img_sum / (t.N + extra)
+        if want_coef:
+            # d out[img] / d loss[order[j]]: kept, not NaN, in a segment that counts -> 1 / (segment denominator * image denominator)
+            img_s = t.seg_img[seg_s]
+            coef = torch.where(keep & ~torch.isnan(loss[order]) & use[seg_s], 1.0 / (den[seg_s] * (t.N + extra)[img_s]), torch.zeros_like(contrib))
+            return out, order, coef, img_s
+        return out
 
     def forward(self, pred_depth, gt_masks, gt_planes, gt_depth, k_matrix, select=True):
         """Single-image entry with the reference's signature (vnl.py:119); routes through the batched path."""

@@ -1198,12 +1198,14 @@ def ragged_group_norm_relu(xp, gamma, beta, groups, eps, rs):
 # ------------------------------------------------------------------------------------------ resampling
 class _Resize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, Ho, Wo):
-        _dev(x)
-        x = _c(x)
+    def forward(ctx, x, Ho, Wo, addend=None):
+        _dev(x, addend)
+        x, addend = _c(x), _c(addend)
         B, C, H, W = x.shape
         y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
-        check(lib.prn_resize_bilinear_fwd(_p(x), _p(y), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_fwd")
+        if addend is not None:
+            assert addend.shape == y.shape, (addend.shape, y.shape)
+        check(lib.prn_resize_bilinear_add_fwd(_p(x), _p(addend), _p(y), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_fwd")
         ctx.shape = (B, C, H, W, Ho, Wo)
         return y
 
@@ -1211,14 +1213,17 @@ class _Resize(torch.autograd.Function):
     def backward(ctx, dy):
         B, C, H, W, Ho, Wo = ctx.shape
         dy = _c(dy)
-        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
-        check(lib.prn_resize_bilinear_bwd(_p(dy), _p(dx), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_bwd")
-        return dx, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+            check(lib.prn_resize_bilinear_bwd(_p(dy), _p(dx), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_bwd")
+        return dx, None, None, (dy if ctx.needs_input_grad[3] else None)
 
 
-def resize_bilinear(x, size):
-    """F.interpolate(mode='bilinear', align_corners=False) replacement; size = (Ho, Wo)."""
-    return _Resize.apply(x, int(size[0]), int(size[1]))
+def resize_bilinear(x, size, addend=None):
+    """F.interpolate(mode='bilinear', align_corners=False) replacement; size = (Ho, Wo).  addend ([B, C, Ho, Wo]): returns
+    resize(x) + addend from the same launch (the level sum of SOLOv2MaskHead)."""
+    return _Resize.apply(x, int(size[0]), int(size[1]), addend)
 
 
 class _MaxPool(torch.autograd.Function):

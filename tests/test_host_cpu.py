@@ -141,6 +141,42 @@ def test_batched_virtual_normal_loss_matches_oracle_per_image():
     assert torch.allclose(gg[ok], gr[ok], rtol=1e-4, atol=1e-9)
 
 
+def test_trimmed_means_hand_written_gradient_equals_autograd():
+    """VNL_Loss._trimmed_means: value and gradient of the custom autograd node (one coefficient per triplet, scattered through the
+    sort permutation) against autograd replaying the operator chain -- ties, NaN losses, invalid triplets, an empty-valid plane."""
+    from planerecnet_amd.losses import VNL_Loss, VNLTargets
+    rng = np.random.RandomState(11)
+    seg_len = np.array([40, 7, 120, 3, 64, 16])
+    n = int(seg_len.sum())
+    t = VNLTargets()
+    t.B, t.n_seg, t.n_tot = 2, len(seg_len), n
+    t.seg = torch.from_numpy(np.repeat(np.arange(len(seg_len)), seg_len))
+    t.seg_start = torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]))
+    t.seg_img = torch.tensor([0, 0, 0, 1, 1, 1])
+    t.seg_is_plane = torch.tensor([True, True, False, True, True, False])
+    t.N = torch.tensor([2.0, 2.0], dtype=torch.float64)
+    loss = torch.from_numpy(np.round(rng.rand(n), 2)).double()           # rounded: equal losses inside a segment
+    loss[5] = float("nan")
+    valid = torch.from_numpy(rng.rand(n) < 0.8)
+    la, lb = loss.clone().requires_grad_(True), loss.clone().requires_grad_(True)
+    ya = VNL_Loss._trimmed_means(la, valid, t, torch.device("cpu"))
+    yb = VNL_Loss._trimmed_means_autograd(lb, valid, t, torch.device("cpu"))
+    assert torch.equal(ya, yb) and bool(torch.isfinite(ya).all())
+    w = torch.tensor([1.0, 0.37], dtype=torch.float64)
+    (ga,) = torch.autograd.grad((ya * w).sum(), la)
+    (gb,) = torch.autograd.grad((yb * w).sum(), lb)
+    assert torch.allclose(ga, gb, rtol=1e-12, atol=0) and float(ga.abs().sum()) > 0 and float(ga[5]) == 0.0
+    # a plane without a valid triplet: 0 / 0 = NaN for its image like the reference (the step is then skipped); the other image's
+    # value is unaffected and the hand-written gradient stays finite (autograd's chain leaks the NaN through the prefix sums)
+    valid[t.seg == 3] = False
+    lc = loss.clone().requires_grad_(True)
+    yc = VNL_Loss._trimmed_means(lc, valid, t, torch.device("cpu"))
+    yd = VNL_Loss._trimmed_means_autograd(loss, valid, t, torch.device("cpu"))
+    assert torch.allclose(yc, yd, equal_nan=True) and bool(torch.isnan(yc[1])) and float(yc[0]) == float(ya[0])
+    (gc,) = torch.autograd.grad(yc[0], lc)
+    assert bool(torch.isfinite(gc).all()) and torch.allclose(gc[t.seg < 3], ga[t.seg < 3], rtol=1e-12, atol=0)
+
+
 def test_train_cli_surface_and_synthetic_dataset_contract():
     import train
     a = train.parser.parse_args(["--config", "PlaneRecNet_101_config", "--batch_size", "16", "--resume", "latest", "--keep_latest",

@@ -205,6 +205,31 @@ def test_loss_matches_oracle_and_golden(setup, golden_dir):
             close(a, b, 2e-3, f"loss grad {i}")
 
 
+def test_kernel_gather_branches_agree(setup):
+    """The Dice term gathers the predicted kernels of all positive cells with ONE index_select when no cell is listed twice, and
+    image by image (advanced indexing, sort-based gradient) otherwise: same loss, same gradients."""
+    from planerecnet_amd.losses import PlaneRecNetLoss
+    _, _, arch = setup
+    mask_pred, cate, kern, depth, inst, gtd = _loss_inputs(arch)
+    crit = PlaneRecNetLoss().cuda()
+    inst_d = [{k: v.cuda() for k, v in g.items()} for g in inst]
+    res = []
+    for unique in (True, False):
+        dl = [t.detach().cuda().requires_grad_(True) for t in [mask_pred] + cate + kern + [depth]]
+        np.random.seed(7)
+        t = crit.prepare(inst_d, gtd.cuda(), torch.device("cuda"))
+        assert t.cells_unique                                 # (no cell claimed by three instances; doubly claimed ones are expanded)
+        t.cells_unique = unique
+        out = crit(None, dl[0], dl[1:5], dl[5:9], dl[9], inst_d, gtd.cuda(), targets=t)
+        g = torch.autograd.grad(out["ins"].sum() + out["lav"].sum(), [dl[0]] + dl[5:9], allow_unused=True)
+        res.append((out["ins"].detach(), out["lav"].detach(), g))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-6) and torch.allclose(res[0][1], res[1][1], rtol=1e-6)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            close(a, b, 1e-5, "kernel gather branches")
+
+
 def test_gt_assignment_bit_exact_vs_golden(setup, golden_dir):
     import os
     from oracle import synth

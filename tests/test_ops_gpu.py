@@ -471,6 +471,24 @@ def test_resize_bilinear_fwd_bwd(H, W, Ho, Wo):
     close(gd, gr, "resize bwd", rtol=1e-5)
 
 
+@pytest.mark.parametrize("H,W,Ho,Wo", [(15, 20, 30, 40), (30, 40, 15, 20), (7, 9, 16, 11)])
+def test_resize_bilinear_with_addend_fwd_bwd(H, W, Ho, Wo):
+    """resize(x) + addend from one launch (the level sum of SOLOv2MaskHead): value, and both gradients (d addend = dy as is)."""
+    from planerecnet_amd import ops
+    x = rnd(2, 5, H, W, seed=1).requires_grad_(True)
+    a = rnd(2, 5, Ho, Wo, seed=3).requires_grad_(True)
+    yr = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) + a
+    go = rnd(*yr.shape, seed=2)
+    gr = torch.autograd.grad(yr, [x, a], go)
+    d = dev()
+    xd, ad = x.detach().float().to(d).requires_grad_(True), a.detach().float().to(d).requires_grad_(True)
+    yd = ops.resize_bilinear(xd, (Ho, Wo), ad)
+    close(yd, yr, "resize+addend fwd", rtol=1e-5)
+    gd = torch.autograd.grad(yd, [xd, ad], go.float().to(d))
+    close(gd[0], gr[0], "resize+addend d x", rtol=1e-5)
+    assert torch.equal(gd[1].cpu(), go.float())
+
+
 def test_resize_matches_scale_factor_semantics():
     """x0.5 / x0.25 / x2 with scale_factor (recompute_scale_factor=False) == size-based resize at these exact ratios."""
     from planerecnet_amd import ops
