@@ -238,7 +238,11 @@ def main():
     if train:
         net = net.to(dev).train()
         crit = PlaneRecNetLoss().to(dev)
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+        if os.environ.get("PRN_TORCH_ADAM"):                     # A/B: torch's multi-tensor Adam (14 launches) instead of the one-launch kernel
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+        else:
+            from planerecnet_amd.optim import FusedAdam
+            opt = FusedAdam(net.parameters(), lr=1e-4)
         exchange = GradAllReduce(list(net.parameters()), force=bool(os.environ.get("PRN_FORCE_EXCHANGE")))    # force: run the bucket / RCCL path with one rank too (overhead probe)
 
         # --graph: the network's forward and backward are static, so each can be captured as ONE hipGraph

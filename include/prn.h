@@ -377,6 +377,19 @@ int64_t prn_pairwise_iou_ws_bytes(int A, int B, int64_t HW);
 int prn_pairwise_iou(const unsigned char* masks_a, const unsigned char* masks_b, const float* boxes_a, const float* boxes_b, int A, int B, int64_t HW,
                      float* mask_iou, float* box_iou, void* ws, void* stream);
 
+/* ---- optimizer step ------------------------------------------------------------------------------------------------------
+ * replaces optimizer.step() of the reference's optim.Adam (train.py:251-256,362; no weight decay, no amsgrad): every
+ * parameter tensor of the model in ONE launch.  Tables (device memory, built once by the caller): chunks [nchunks][2] =
+ * (tensor index, first element) covering each tensor in pieces of prn_adam_chunk_elems() elements; p / m / v [ntensors]
+ * device pointers, numel [ntensors], lr [ntensors] (a group's learning rate, per tensor); g [ntensors] is rewritten every
+ * step (gradients are fresh allocations).  step: device scalar, the number of updates applied so far (advanced here).
+ * found_inf (device scalar or NULL): non-zero => nothing is updated and step stays (the collective skip of train.py:353).
+ * grad_scale (device scalar or NULL): gradients are divided by it.
+ *   m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),  t = step + 1 */
+int prn_adam_chunk_elems(void);
+int prn_adam_step(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
+                  const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""Adam as ONE device launch over all parameter tensors (include/prn.h: prn_adam_step) -- the optimizer of the reference's
+train.py:251-256 (optim.Adam with per-group learning rates; no weight decay, no amsgrad) behind torch.optim's interface:
+`param_groups` (so `set_lr` keeps working), `zero_grad`, `state_dict` with the usual exp_avg / exp_avg_sq / step entries, and
+the `found_inf` / `grad_scale` attributes torch's fused optimizers take from a GradScaler (train.py uses `found_inf` to skip
+the update on a non-finite loss without reading the loss on the host)."""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.found_inf = None
+        self.grad_scale = None
+        self._tab = None
+
+    # ---- tables of the launch: rebuilt only when the set of parameters that have a gradient changes
+    def _build(self, plist):
+        dev = plist[0][0].device
+        ce = lib.prn_adam_chunk_elems()
+        chunks, numel = [], []
+        step = None
+        for i, (p, _) in enumerate(plist):
+            if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                raise RuntimeError("FusedAdam: parameters must be contiguous fp32 device tensors")
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+            if step is None:
+                # one counter for all tensors (they are always stepped together); every state entry refers to it
+                step = next((self.state[q]["step"] for q, _ in plist if "step" in self.state[q]), None)
+                if step is None:
+                    step = torch.zeros((), device=dev, dtype=torch.float32)
+            st["step"] = step
+            numel.append(p.numel())
+            chunks += [(i, o) for o in range(0, p.numel(), ce)]
+        ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)      # noqa: E731
+        tab = {"ids": [id(p) for p, _ in plist], "dev": dev, "step": step, "n": len(plist), "nchunks": len(chunks),
+               "chunks": torch.tensor(chunks, dtype=torch.int32, device=dev), "numel": torch.tensor(numel, dtype=torch.int32, device=dev),
+               "p": ptr([p for p, _ in plist]), "m": ptr([self.state[p]["exp_avg"] for p, _ in plist]),
+               "v": ptr([self.state[p]["exp_avg_sq"] for p, _ in plist]),
+               "g": torch.empty(len(plist), dtype=torch.int64, device=dev), "lr": torch.empty(len(plist), dtype=torch.float32, device=dev),
+               "lr_key": None, "slot": 0,
+               # The gradient pointers (and the learning rates, when they change) travel through page-locked staging buffers; the
+               # host runs up to a step ahead of the GPU, so a buffer is only rewritten after the copy that read it has executed.
+               "ring": [{"g": torch.empty(len(plist), dtype=torch.int64).pin_memory(), "lr": torch.empty(len(plist), dtype=torch.float32).pin_memory(),
+                         "done": None} for _ in range(4)]}
+        for r in tab["ring"]:
+            r["g_np"], r["lr_np"] = r["g"].numpy(), r["lr"].numpy()
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        plist = [(p, g) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not plist:
+            return loss
+        betas, eps = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        if any(g["betas"] != betas or g["eps"] != eps for g in self.param_groups):
+            raise RuntimeError("FusedAdam: betas / eps must be the same in every parameter group")
+        tab = self._tab
+        if tab is None or tab["ids"] != [id(p) for p, _ in plist]:
+            tab = self._tab = self._build(plist)
+        r = tab["ring"][tab["slot"]]
+        tab["slot"] = (tab["slot"] + 1) % len(tab["ring"])
+        if r["done"] is not None:
+            r["done"].synchronize()
+        for p, _ in plist:
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise RuntimeError("FusedAdam: gradients must be contiguous fp32 tensors")
+        r["g_np"][:] = [p.grad.data_ptr() for p, _ in plist]
+        tab["g"].copy_(r["g"], non_blocking=True)
+        lr_key = tuple(float(g["lr"]) for g in self.param_groups)
+        if tab["lr_key"] != lr_key:
+            r["lr_np"][:] = [float(g["lr"]) for _, g in plist]
+            tab["lr"].copy_(r["lr"], non_blocking=True)
+            tab["lr_key"] = lr_key
+        r["done"] = torch.cuda.Event()
+        r["done"].record()
+        vp = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)      # noqa: E731
+        fi = self.found_inf.float().reshape(()) if self.found_inf is not None else None
+        gs = self.grad_scale.float().reshape(()) if self.grad_scale is not None else None
+        stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(tab["dev"].index))
+        check(lib.prn_adam_step(vp(tab["chunks"]), tab["nchunks"], vp(tab["p"]), vp(tab["g"]), vp(tab["m"]), vp(tab["v"]), vp(tab["numel"]), vp(tab["lr"]),
+                                vp(tab["step"]), vp(fi), vp(gs), float(betas[0]), float(betas[1]), float(eps), stream), "prn_adam_step")
+        return loss

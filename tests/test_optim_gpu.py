@@ -1,0 +1,72 @@
+"""planerecnet_amd.optim.FusedAdam (one launch over all parameter tensors) against torch.optim.Adam -- the optimizer of the
+reference's train.py:251-256 -- over several steps: per-group learning rates, a learning-rate change (warm-up, train.py:320-323), a
+skipped update (`found_inf`, train.py:353), a parameter without a gradient, odd tensor sizes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 3, 7, 7), (27,), (256, 64, 1, 1), (5,), (1,), (128, 128, 3, 3), (4099,), (2, 3, 5, 7)]
+    return [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+
+
+def test_fused_adam_matches_torch_adam():
+    from planerecnet_amd.optim import FusedAdam
+    pa, pb = _params(0), _params(0)
+    groups = lambda ps: [{"params": ps[:3], "lr": 5e-3}, {"params": ps[3:6], "lr": 1e-3}, {"params": ps[6:], "lr": 2e-3}]      # noqa: E731
+    ref = torch.optim.Adam(groups(pa), lr=1e-3, fused=True)
+    mine = FusedAdam(groups(pb), lr=1e-3)
+    assert getattr(mine, "_step_supports_amp_scaling", False)
+    g = torch.Generator().manual_seed(1)
+    for it in range(7):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (it % 3 - 1))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        pa[4].grad = pb[4].grad = None                              # a parameter that never receives a gradient is left alone
+        if it == 4:                                                 # learning-rate change between steps (warm-up / decay)
+            for o in (ref, mine):
+                for grp in o.param_groups:
+                    grp["lr"] *= 0.5
+        skip = torch.tensor(1.0 if it == 2 else 0.0, device="cuda")
+        ref.found_inf = mine.found_inf = skip                       # the device-side "do not update" flag of a GradScaler
+        ref.grad_scale = mine.grad_scale = None
+        before = [b.detach().clone() for b in pb]
+        ref.step()
+        mine.step()
+        if it == 2:
+            assert all(torch.equal(x, y.detach()) for x, y in zip(before, pb))
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (it, i, float((a - b).abs().max()))
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        if i == 4:
+            assert "exp_avg" not in mine.state.get(b, {})
+            continue
+        sa, sb = ref.state[a], mine.state[b]
+        # (moments of O(1)..O(100) gradients; exp_avg has cancelling terms, hence the absolute part)
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-6, atol=2e-6) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-6, atol=1e-9)
+        assert float(sa["step"]) == float(sb["step"]) == 6.0        # seven calls, one skipped
+    sd = mine.state_dict()
+    assert len(sd["param_groups"]) == 3 and len(sd["state"]) == 7
+
+
+def test_fused_adam_runs_ahead_of_the_device():
+    """Many steps enqueued behind a parked stream: the page-locked staging buffers of the gradient-pointer table must not be
+    rewritten before their copies have executed (each step's gradients live at different addresses)."""
+    from planerecnet_amd.optim import FusedAdam
+    pa, pb = _params(2), _params(2)
+    ref, mine = torch.optim.Adam(pa, lr=1e-2, fused=True), FusedAdam(pb, lr=1e-2)
+    g = torch.Generator().manual_seed(3)
+    grads = [[torch.randn(a.shape, generator=g).cuda() for a in pa] for _ in range(10)]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(0.05 * 2.4e9))                            # ~50 ms: the host enqueues all ten steps meanwhile
+    for it in range(10):
+        for a, b, gr in zip(pa, pb, grads[it]):
+            a.grad, b.grad = gr, gr.clone()                         # fresh allocation per step for the device under test
+        ref.step()
+        mine.step()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=5e-6, atol=1e-7)

@@ -22,7 +22,7 @@ net = PlaneRecNet(cfg)
 net.init_head_weights()
 net = net.to(dev).train()
 crit = PlaneRecNetLoss().to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+opt = __import__("planerecnet_amd.optim", fromlist=["FusedAdam"]).FusedAdam(net.parameters(), lr=1e-4)
 images, inst, depths = bench.synth_batch(8, 480, 640, 1000, dev)
 pf = TargetPrefetcher(crit)
 pf.submit(inst, (480, 640))

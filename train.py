@@ -158,6 +158,7 @@ def main():
 
     from planerecnet_amd import ops, timer
     from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher
+    from planerecnet_amd.optim import FusedAdam
     from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
     from planerecnet_amd.planerecnet import PlaneRecNet
     from planerecnet_amd.staging import FrameStager
@@ -193,10 +194,10 @@ def main():
     prn_net = prn_net.to(dev)
     criterion = PlaneRecNetLoss().to(dev)
     net = NetLoss(prn_net, criterion)
-    optimizer = torch.optim.Adam([
+    optimizer = FusedAdam([
         {"params": prn_net.backbone.parameters(), "lr": 5 * args.lr}, {"params": prn_net.fpn.parameters(), "lr": args.lr},
         {"params": prn_net.inst_head.parameters(), "lr": args.lr}, {"params": prn_net.mask_head.parameters(), "lr": args.lr},
-        {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr, fused=True)
+        {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr)      # optim.Adam of train.py:251-256 as one launch
     exchange = GradAllReduce([p for p in prn_net.parameters()])
     ops.set_wgrad_async(True)          # weight gradients on a side stream; joined by ops.wgrad_join() after every backward()
 
