@@ -166,6 +166,13 @@ int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, cons
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
 int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);
 int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream);
+/* The same for G layers of one shape in ONE launch (blockIdx.z = layer; x[g], dy[g]: HOST arrays of G device pointers;
+ * dw: [G, M, C*KH*KW], caller-owned like the workspace of prn_conv2d_wgrad_grouped_ws_bytes(d, G) bytes).  The 1x1 layers of a
+ * ResNet stage are 23 such layers (models/backbone.py:170-184): one of them alone needs ~30 pixel splits to fill the machine,
+ * a group of 8 needs 4.  Dense 1x1 / 3x3 / 7x7 descriptors (not the 2x2 phases, not the 1- / 2-channel direct path). */
+#define PRN_WGRAD_GROUP_MAX 16
+int64_t prn_conv2d_wgrad_grouped_ws_bytes(const prn_conv_desc* d, int G);
+int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const float* const* x, const float* const* dy, float* dw, void* ws, void* stream);
 int prn_conv2d_wgrad_phase(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase);
 
 /* --- sub-pixel form of Upsample(x2, nearest) -> ReflectionPad2d(1) -> Conv3x3 (planerecnet.py:540-566), see PRN_IN_UP2_PHASE.

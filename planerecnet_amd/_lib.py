@@ -68,6 +68,8 @@ SIGNATURES = {
     "prn_conv3x3_winograd_wgrad_v": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
+    "prn_conv2d_wgrad_grouped_ws_bytes": (c_i64, [_DP, c_int]),
+    "prn_conv2d_wgrad_grouped": (c_int, [_DP, c_int, P, P, P, P, P]),
     "prn_conv2d_wgrad": (c_int, [_DP, P, P, P, P, P]),
     "prn_pad_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "prn_pad_fold_pitched": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -516,8 +516,19 @@ struct WgArgs {
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
   int xbytes, dybytes;       // dybytes: one phase of dy
   int xz;                    // element stride of x per blockIdx.z (prn_gemm_batched_nt; 0 for a convolution)
+  int ngroup;                // > 0: blockIdx.z = layer of a group of same-shape layers (prn_conv2d_wgrad_grouped): x / dy from the tables below
+  const float* gx[PRN_WGRAD_GROUP_MAX];
+  const float* gdy[PRN_WGRAD_GROUP_MAX];
   Seg seg;
 };
+
+// entry `i` of one of the pointer tables of the by-value kernel argument, read with scalar loads (see seg_read)
+template <class Args>
+__device__ __forceinline__ const float* kernarg_ptr(size_t member_offset, int i) {
+  typedef __attribute__((address_space(4))) const uint64_t* kptr;
+  kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  return reinterpret_cast<const float*>(base[member_offset / 8 + i]);
+}
 
 template <int KS, int MODE, int TM, int TJ, int WM = 2, bool RAG = false>      // RAG: ragged-batch instance (keeps the dense ones at 152 VGPRs)
 __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad_kernel(WgArgs a) {
@@ -535,9 +546,10 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   // PRN_IN_UP2_PHASE: blockIdx.z = phase; dy is phase-major [4][B][M][H][W] (prn_space_to_depth2), out is [4][M][4C]
   const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
   const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
-  const float* dyz = a.dy + (size_t)blockIdx.z * (a.dybytes / 4);
+  const float* dyz = a.ngroup > 0 ? kernarg_ptr<WgArgs>(offsetof(WgArgs, gdy), blockIdx.z) : a.dy + (size_t)blockIdx.z * (a.dybytes / 4);
+  const float* xz_ = a.ngroup > 0 ? kernarg_ptr<WgArgs>(offsetof(WgArgs, gx), blockIdx.z) : a.x + (size_t)blockIdx.z * a.xz;
   int H_ = a.H, W_ = a.W, HW_ = a.HW, Ho_ = a.Ho, Wo_ = a.Wo, HoWo_ = a.HoWo, N_ = a.N;     // current segment's geometry (ragged) / the tensor's
-  __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (size_t)blockIdx.z * a.xz, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
+  __amdgpu_buffer_rsrc_t xr = make_rsrc(xz_, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
   const int arow = tid >> 2, anq = (tid & 3) * 4;
   const bool n4 = ((HoWo_ & 3) == 0 || a.seg.nseg > 0) && ((reinterpret_cast<uintptr_t>(dyz) & 15) == 0);   // (ragged: host checked every segment)
   const int nl = tid & 15, jrow = tid >> 4;
@@ -1465,6 +1477,62 @@ extern "C" int prn_conv2d_wgrad_phase(const prn_conv_desc* d, const float* x, co
   return conv_wgrad_impl(d, nullptr, x, dy, dw, ws, stream, phase);
 }
 
+// G layers of one shape in one launch (blockIdx.z = layer): with G x the tiles, the launch fills the CUs with far fewer pixel
+// splits than a single small-map layer needs (1x1 1024->256 @30x40: 33 splits alone, 4 with 8 layers), i.e. far less partial
+// traffic, and one fixed-order reduction instead of G.
+extern "C" int64_t prn_conv2d_wgrad_grouped_ws_bytes(const prn_conv_desc* d, int G) {
+  if (check_desc(d, "prn_conv2d_wgrad_grouped_ws_bytes")) return -1;
+  if (G < 1 || G > PRN_WGRAD_GROUP_MAX || geo_of(d).phases != 1 || direct_small_m(d)) { prn_set_error("prn_conv2d_wgrad_grouped_ws_bytes: unsupported group"); return -1; }
+  const int K = d->C * d->KH * d->KW;
+  const WgPlan p = plan_wgrad(d->M, K, (int64_t)d->B * d->Ho * d->Wo, G);
+  return p.splits > 1 ? (int64_t)p.splits * G * d->M * K * 4 : 0;
+}
+
+extern "C" int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const float* const* x, const float* const* dy, float* dw, void* ws, void* stream) {
+  if (int e = check_desc(d, "prn_conv2d_wgrad_grouped")) return e;
+  PRN_REQUIRE(G >= 1 && G <= PRN_WGRAD_GROUP_MAX, "prn_conv2d_wgrad_grouped: 1 <= G <= %d", PRN_WGRAD_GROUP_MAX);
+  PRN_REQUIRE(x && dy && dw, "prn_conv2d_wgrad_grouped: null argument");
+  const Geo g = geo_of(d);
+  PRN_REQUIRE(g.phases == 1 && !direct_small_m(d) && d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->KH != 2 && d->ystride <= 1,
+              "prn_conv2d_wgrad_grouped: dense 1x1 / 3x3 / 7x7 weight gradients only");
+  WgArgs a;
+  a.x = x[0]; a.dy = dy[0];
+  a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
+  a.Ho = g.gH; a.Wo = g.gW;
+  a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
+  a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * a.HoWo * 4;
+  a.xz = 0;
+  a.seg.nseg = 0;
+  a.ngroup = G;
+  for (int i = 0; i < PRN_WGRAD_GROUP_MAX; ++i) {
+    a.gx[i] = x[i < G ? i : 0]; a.gdy[i] = dy[i < G ? i : 0];
+    PRN_REQUIRE(a.gx[i] && a.gdy[i], "prn_conv2d_wgrad_grouped: null tensor in the group");
+  }
+  const WgPlan p = plan_wgrad(a.M, a.K, a.N, G);
+  a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
+  PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad_grouped: workspace required (%d splits)", p.splits);
+  a.out = p.splits > 1 ? (float*)ws : dw;
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = d->in_mode;
+  if (d->KH == 1) {
+    PRN_REQUIRE(mode == PRN_IN_ZERO, "prn_conv2d_wgrad_grouped: 1x1 kernels take zero input mode");
+    launch_wgrad<1, PRN_IN_ZERO>(a, p, st, G);
+  } else if (d->KH == 3) {
+    if (mode == PRN_IN_ZERO) launch_wgrad<3, PRN_IN_ZERO>(a, p, st, G);
+    else if (mode == PRN_IN_REFLECT) launch_wgrad<3, PRN_IN_REFLECT>(a, p, st, G);
+    else launch_wgrad<3, PRN_IN_UP2_REFLECT>(a, p, st, G);
+  } else {
+    launch_wgrad<7, PRN_IN_ZERO>(a, p, st, G);
+  }
+  PRN_CHECK_LAUNCH("prn_conv2d_wgrad_grouped");
+  if (p.splits > 1) {
+    const int64_t n = (int64_t)G * a.M * a.K;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
+    PRN_CHECK_LAUNCH("prn_conv2d_wgrad_grouped/reduce");
+  }
+  return 0;
+}
+
 extern "C" int64_t prn_conv2d_wgrad_ragged_ws_bytes(const prn_conv_desc* d, const prn_ragged* rg) {
   if (d == nullptr || rg == nullptr || rg->nseg < 1 || rg->nseg > MAX_SEG) return -1;
   const int K = d->C * d->KH * d->KW;
@@ -1511,6 +1579,7 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
   a.K = d->C * d->KH * d->KW; a.N = d->B * g.gH * g.gW; a.HoWo = g.gH * g.gW; a.HW = d->H * d->W;
   a.xbytes = d->B * d->C * d->H * d->W * 4; a.dybytes = d->B * d->M * a.HoWo * 4;
   a.xz = 0;
+  a.ngroup = 0;
   a.seg.nseg = 0;
   if (rg) {
     a.N = (int)seg_pixels(rg, d->B);
@@ -1604,6 +1673,7 @@ extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, 
   a.x = Bm; a.dy = A; a.out = ws;
   a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P;
   a.K = C; a.N = P; a.HoWo = P; a.HW = P; a.xbytes = C * P * 4; a.dybytes = M * P * 4; a.xz = C * P;
+  a.ngroup = 0;
   a.seg.nseg = 0;
   const WgPlan p = plan_batched_nt(M, C, P, nb);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;

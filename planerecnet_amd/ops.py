@@ -64,34 +64,73 @@ WGRAD_BATCH = int(os.environ.get("PRN_WGRAD_BATCH", "6"))
 _PENDING = {}       # raw stream handle -> (stream object, [(weight, inputs, compute)])
 
 
-def _deferred_wgrad(w, inputs, compute):
+# Layers of one shape (the 1x1 convolutions of a ResNet stage: 23 blocks in stage 3) are held back until WGRAD_GROUP of them are
+# queued and then computed by ONE grouped launch (conv_wgrad_grouped_raw): a single small-map layer needs ~30 pixel splits to
+# fill the CUs, a group of 8 needs 4 -- less partial traffic, one reduction instead of 8.  PRN_WGRAD_GROUP=1 switches it off.
+WGRAD_GROUP = min(int(os.environ.get("PRN_WGRAD_GROUP", "8")), 16)
+WGRAD_GROUP_AGE = int(os.environ.get("PRN_WGRAD_GROUP_AGE", "9"))      # a group that saw no new layer for this many deferred ops goes out as it is
+WGRAD_GROUP_PIXELS = 40000       # only maps up to this many pixels per batch (stages 2-4): larger ones need few splits anyway, and the
+                                 # last layers of the backward pass must not wait for a group to fill (they would run after it, alone)
+_GROUPS = {}        # raw stream handle -> {shape key: [[(weight, (x, dy)), ...], sequence number of the last append]}
+_DEFER_SEQ = [0]
+
+
+def _deferred_wgrad(w, inputs, compute, group=None):
     main = torch.cuda.current_stream()
     e = _PENDING.get(main.cuda_stream)
     if e is None:
         e = _PENDING[main.cuda_stream] = (main, [])
-    e[1].append((w, inputs, compute))
+    _DEFER_SEQ[0] += 1
+    groups = _GROUPS.get(main.cuda_stream)
+    if group is not None and WGRAD_GROUP > 1:
+        if groups is None:
+            groups = _GROUPS[main.cuda_stream] = {}
+        pend = groups.setdefault(group, [[], 0])
+        pend[0].append((w, inputs))
+        pend[1] = _DEFER_SEQ[0]
+        if len(pend[0]) >= WGRAD_GROUP:
+            _emit_group(e, main.cuda_stream, group)
+    else:
+        e[1].append((w, inputs, compute))
+    if groups:
+        for key in [k for k, v in groups.items() if _DEFER_SEQ[0] - v[1] >= WGRAD_GROUP_AGE]:       # the backward pass has left that stage
+            _emit_group(e, main.cuda_stream, key)
     if len(e[1]) >= WGRAD_BATCH:
         _flush_one(e)
 
 
-def _flush_one(e):
+def _emit_group(e, handle, key):
+    """Move a shape group to the launch queue as ONE item (its compute returns the [G, ...] gradient stack)."""
+    pend = _GROUPS[handle].pop(key)[0]
+    ws_, ins = [w for w, _ in pend], [i for _, i in pend]
+    M, K, stride, pad, mode = key[-5:]
+    e[1].append((ws_, tuple(t for i in ins for t in i), lambda: conv_wgrad_grouped_raw([i[0] for i in ins], [i[1] for i in ins], M, K, stride, pad, mode)))
+
+
+def _flush_one(e, everything=False):
     main, items = e
+    if everything:
+        for key in list(_GROUPS.get(main.cuda_stream, {})):     # incomplete shape groups go out as they are
+            _emit_group(e, main.cuda_stream, key)
     if not items:
         return
     todo = items[:]
     del items[:]
-    side = _side_stream(todo[0][0].device, main)          # (keyed by the originating stream)
+    first = todo[0][0][0] if isinstance(todo[0][0], list) else todo[0][0]
+    side = _side_stream(first.device, main)                 # (keyed by the originating stream)
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
         for w, _, compute in todo:
             dw = compute()
-            if dw.shape != w.shape:
-                dw = dw.view_as(w)
-            dw.record_stream(main)                          # read by the optimizer on the main stream after wgrad_join()
-            if w.grad is None:
-                w.grad = dw
-            else:
-                w.grad.add_(dw)
+            pairs = zip(w, dw.unbind(0)) if isinstance(w, list) else [(w, dw)]      # a shape group: one weight per slice of the stack
+            for w_, dw_ in pairs:
+                if dw_.shape != w_.shape:
+                    dw_ = dw_.view_as(w_)
+                dw_.record_stream(main)                     # read by the optimizer on the main stream after wgrad_join()
+                if w_.grad is None:
+                    w_.grad = dw_
+                else:
+                    w_.grad.add_(dw_)
             # (post-accumulate-grad hooks still fire: the engine runs the parameter's AccumulateGrad node -- a no-op for the
             # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
     for _, inputs, _ in todo:
@@ -103,7 +142,7 @@ def wgrad_flush():
     """Launch every queued weight gradient (on its side stream).  Called by wgrad_join() and by the gradient exchange
     before it reads a bucket's gradients."""
     for e in list(_PENDING.values()):
-        _flush_one(e)
+        _flush_one(e, everything=True)
 
 
 # Off by default.  With the extra streams on, the SAME binary ran either 60.5 or 65.7 ms/step (bimodal between runs, minutes
@@ -265,6 +304,27 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
                 check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 2), "prn_conv2d_wgrad")
     else:
         check(lib.prn_conv2d_wgrad(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad")
+    return dw
+
+
+WGRAD_GROUP_MAX = 16
+
+
+def conv_wgrad_grouped_raw(xs, dys, M, K, stride, pad, mode):
+    """Weight gradients of len(xs) layers of ONE shape in one launch (include/prn.h: prn_conv2d_wgrad_grouped) -> [G, M, C, K, K]."""
+    G = len(xs)
+    B, C, H, W = xs[0].shape
+    Ho, Wo = dys[0].shape[2:]
+    dev = xs[0].device
+    _, ref, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
+    nbytes = lib.prn_conv2d_wgrad_grouped_ws_bytes(ref, G)
+    if nbytes < 0:
+        raise RuntimeError(lib.prn_last_error().decode())
+    dw = torch.empty(G, M, C, K, K, device=dev, dtype=torch.float32)
+    ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    px = (ctypes.c_void_p * G)(*[t.data_ptr() for t in xs])
+    pdy = (ctypes.c_void_p * G)(*[t.data_ptr() for t in dys])
+    check(lib.prn_conv2d_wgrad_grouped(ref, G, px, pdy, _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad_grouped")
     return dw
 
 
@@ -575,7 +635,10 @@ class _Conv2d(torch.autograd.Function):
         if _defer(ctx.needs_input_grad[1], w):
             # every buffer the deferred launch reads must be listed: it is released here, on the main stream, possibly before
             # the side stream has run (a kept Winograd operand is one of them)
-            _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad)
+            gkey = None
+            if V is None and K in (1, 3, 7) and mode in (IN_ZERO, IN_REFLECT) and M > 2 and dy.shape[0] * dy.shape[2] * dy.shape[3] <= WGRAD_GROUP_PIXELS:
+                gkey = ("conv", tuple(x.shape), tuple(dy.shape[2:]), M, K, stride, pad, mode)
+            _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad, gkey)
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None

@@ -208,6 +208,43 @@ def test_conv_split_sum_inside_the_gemm_is_bit_identical(shape, monkeypatch):
     assert float((y_one.double().cpu() - ref_y).abs().max()) <= 2e-4 * max(float(ref_y.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("G,C,H,W,M,K,stride,pad,mode", [
+    (8, 1024, 30, 40, 256, 1, 1, 0, 0),       # the 1x1 layers of stage 3: a group fills the CUs with 4 pixel splits instead of ~30
+    (5, 256, 30, 40, 1024, 1, 1, 0, 0),
+    (16, 96, 15, 20, 40, 1, 1, 0, 0),         # tile tails in both GEMM dimensions, the largest group
+    (1, 64, 24, 32, 64, 1, 1, 0, 0),
+    (3, 32, 17, 23, 48, 3, 1, 1, 0),          # 3x3 zero padding, odd plane
+    (2, 24, 16, 16, 32, 3, 1, 1, 1),          # reflect
+    (2, 64, 32, 32, 128, 1, 2, 0, 0),         # stride-2 1x1 (downsample)
+])
+def test_conv_wgrad_grouped_equals_layer_by_layer(G, C, H, W, M, K, stride, pad, mode):
+    """prn_conv2d_wgrad_grouped (G same-shape layers, one launch) against G single-layer launches and torch fp64."""
+    from planerecnet_amd import ops
+    B = 8 if C >= 256 else 2
+    g = torch.Generator().manual_seed(G * 100 + C)
+    Ho, Wo = ops._out_hw(H, W, K, stride, pad, mode)
+    xs = [torch.randn(B, C, H, W, generator=g).cuda() for _ in range(G)]
+    dys = [torch.randn(B, M, Ho, Wo, generator=g).cuda() for _ in range(G)]
+    dw = ops.conv_wgrad_grouped_raw(xs, dys, M, K, stride, pad, mode)
+    assert dw.shape == (G, M, C, K, K)
+    for i in range(G):
+        one = ops.conv_wgrad_raw(xs[i], dys[i], M, K, stride, pad, mode)
+        scale = float(one.abs().max())
+        assert float((dw[i] - one).abs().max()) <= 2e-5 * scale, (i, float((dw[i] - one).abs().max()), scale)
+    xr = xs[-1].double().cpu().requires_grad_(False)
+    xp = F.pad(xr, (pad,) * 4, mode="reflect") if mode == 1 else xr
+    wr = torch.zeros(M, C, K, K, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xp, wr, stride=stride, padding=0 if mode == 1 else pad).backward(dys[-1].double().cpu())
+    assert float((dw[-1].double().cpu() - wr.grad).abs().max()) <= 2e-4 * float(wr.grad.abs().max())
+
+
+def test_conv_wgrad_grouped_rejects():
+    from planerecnet_amd import ops
+    x, dy = torch.randn(1, 8, 8, 8).cuda(), torch.randn(1, 8, 8, 8).cuda()
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad_grouped_raw([x] * 17, [dy] * 17, 8, 1, 1, 0, 0)          # more than PRN_WGRAD_GROUP_MAX layers
+
+
 def test_conv2d_is_transpose_safe():
     """A = I style check with asymmetric data: 1x1 conv with a permutation weight must permute channels."""
     from planerecnet_amd import ops
