@@ -57,6 +57,21 @@ def _defer(needs_grad, w):
     return WGRAD_ASYNC and needs_grad and w.is_leaf and w.requires_grad and not profiling.active()
 
 
+# Bias gradients (a per-channel sum of dy: 62 launches, 1 ms per step) have no consumer inside the backward pass either: with the
+# weight gradients deferred they go to the side stream too (PRN_BIAS_ASYNC=0: keep them on the main stream).
+BIAS_ASYNC = bool(int(os.environ.get("PRN_BIAS_ASYNC", "1")))
+
+
+def _bias_grad(needs_grad, bias, dy):
+    """d bias = channel_sum(dy): returned for autograd, or queued for the side stream (then None is returned)."""
+    if not needs_grad or bias is None:
+        return None
+    if BIAS_ASYNC and _defer(True, bias):
+        _deferred_wgrad(bias, (dy,), lambda: channel_sum(dy))
+        return None
+    return channel_sum(dy)
+
+
 # Deferred weight gradients are queued per originating stream and moved to the side stream a few at a time: the stream
 # switch, the event pair of wait_stream and the record_stream calls cost ~25 us of host time per layer when done one by one
 # (128 layers per step on the autograd thread).  Anything that reads `.grad` (wgrad_join, the gradient exchange) flushes first.
@@ -122,7 +137,8 @@ def _flush_one(e, everything=False):
     with torch.cuda.stream(side), torch.no_grad():
         for w, _, compute in todo:
             dw = compute()
-            pairs = zip(w, dw.unbind(0)) if isinstance(w, list) else [(w, dw)]      # a shape group: one weight per slice of the stack
+            # a list of weights: a shape group (one weight per slice of the gradient stack) or a node with several parameters
+            pairs = zip(w, dw if isinstance(dw, (tuple, list)) else dw.unbind(0)) if isinstance(w, list) else [(w, dw)]
             for w_, dw_ in pairs:
                 if dw_.shape != w_.shape:
                     dw_ = dw_.view_as(w_)
@@ -586,7 +602,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, addend, stride, pad, mode, epi, fork=False):
         _dev(x, w, bias, addend)
-        x0 = x
+        x0, bias_param = x, bias
         x, w, bias, addend = _c(x), _c(w), _c(bias), _c(addend)
         M, C, K, _ = w.shape
         assert x.shape[1] == C, (x.shape, w.shape)
@@ -601,6 +617,7 @@ class _Conv2d(torch.autograd.Function):
             y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
         ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
+        ctx.bias = bias_param
         ctx.fork = fork
         if fork:
             # second output = the input itself: whatever else consumes x (the residual add) takes it from here, so both
@@ -648,7 +665,7 @@ class _Conv2d(torch.autograd.Function):
             dw = wgrad() if ctx.needs_input_grad[1] else None
         if dfork is not None and dx is not None:
             dx = dx + dfork
-        db = channel_sum(dy) if (has_bias and ctx.needs_input_grad[2]) else None
+        db = _bias_grad(has_bias and ctx.needs_input_grad[2], ctx.bias, dy)
         da = dy if (has_add and ctx.needs_input_grad[3]) else None
         return dx, dw, db, da, None, None, None, None, None
 
@@ -661,6 +678,7 @@ class _ConvUp2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):
         _dev(x, w, bias)
+        bias_param = bias
         x, w, bias = _c(x), _c(w), _c(bias)
         B, C, H, W = x.shape
         M = w.shape[0]
@@ -670,6 +688,7 @@ class _ConvUp2(torch.autograd.Function):
         y = conv_fwd_raw(x, wp, bias, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bias = bias_param
         return y
 
     @staticmethod
@@ -696,8 +715,7 @@ class _ConvUp2(torch.autograd.Function):
             _deferred_wgrad(w, (x, dy), wgrad)
         elif ctx.needs_input_grad[1]:
             dw = wgrad()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = channel_sum(dy)
+        db = _bias_grad(ctx.has_bias and ctx.needs_input_grad[2], ctx.bias, dy)
         return dx, dw, db
 
 
@@ -822,6 +840,7 @@ class _DeformConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, offset, weight, bias, mask, stride, pad):
         _dev(x, offset, weight, bias, mask)
+        ctx.bias = bias
         x, offset, weight, bias, mask = _c(x), _c(offset), _c(weight), _c(bias), _c(mask)
         M = weight.shape[0]
         table = dcn_table(x.shape, M, offset, mask, stride, pad, 0, 0.0)
@@ -844,8 +863,7 @@ class _DeformConv(torch.autograd.Function):
             _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0))
         elif ni[2]:
             dw = dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0)
-        if has_bias and ni[3]:
-            db = channel_sum(dy)
+        db = _bias_grad(has_bias and ni[3], ctx.bias, dy)
         return dx, d_off, dw, db, d_msk, None, None
 
 
@@ -884,6 +902,7 @@ class _DeformConvBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_off, w_mod, b_off, b_mod, w27, b27, w, bias, stride, max_offset):
         _dev(x, w27, b27, w, bias)
+        ctx.leaves = (w_off, w_mod, b_off, b_mod, bias)
         x, w, bias = _c(x), _c(w), _c(bias)
         B, C, H, W = x.shape
         M = w.shape[0]
@@ -908,9 +927,20 @@ class _DeformConvBlock(torch.autograd.Function):
             dw = None
         else:
             dw = dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset) if ni[7] else None
-        db = channel_sum(dy) if (has_bias and ni[8]) else None
-        dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if (ni[1] or ni[2]) else None
-        db27 = channel_sum(dom) if (ni[3] or ni[4]) else None
+        w_off, w_mod, b_off, b_mod, bias_p = ctx.leaves
+        db = _bias_grad(has_bias and ni[8], bias_p, dy)
+        if BIAS_ASYNC and ni[1] and ni[2] and ni[3] and ni[4] and all(_defer(True, p_) for p_ in (w_off, w_mod, b_off, b_mod)):
+            # the offset / modulator conv's parameter gradients (one 27-channel weight gradient, one channel sum of d om) on the side
+            # stream as well; each lands in two parameters (views of the 27-row results)
+            def om_grads():
+                dw27_ = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO)
+                db27_ = channel_sum(dom)
+                return dw27_[:18], dw27_[18:], db27_[:18], db27_[18:]
+            _deferred_wgrad([w_off, w_mod, b_off, b_mod], (x, dom), om_grads)
+            dw27 = db27 = None
+        else:
+            dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if (ni[1] or ni[2]) else None
+            db27 = channel_sum(dom) if (ni[3] or ni[4]) else None
         dx = conv_dgrad_raw(dom, w27, x.shape, stride, 1, IN_ZERO, dx1) if ni[0] else None
         return (dx, None if dw27 is None else dw27[:18], None if dw27 is None else dw27[18:], None if db27 is None else db27[:18],
                 None if db27 is None else db27[18:], None, None, dw, db, None, None)
@@ -953,6 +983,7 @@ class _PlanePrior(torch.autograd.Function):
               "prn_plane_prior_fwd")
         ctx.save_for_backward(pooled, w1)
         ctx.dims = (B, h, w, NK, F, b1 is not None)
+        ctx.bias = b1
         return out
 
     @staticmethod
@@ -971,7 +1002,7 @@ class _PlanePrior(torch.autograd.Function):
             _deferred_wgrad(w1, (pooled, d_out), wgrad)
         elif ctx.needs_input_grad[2]:
             dw = wgrad().view_as(w1)
-        db = channel_sum(d_out) if (has_bias and ctx.needs_input_grad[3]) else None
+        db = _bias_grad(has_bias and ctx.needs_input_grad[3], ctx.bias, d_out)
         return None, None, dw, db
 
 
