@@ -442,7 +442,7 @@ class VNL_Loss(nn.Module):
         seg_len = np.asarray(seg_len, dtype=np.int64)
         n_seg = len(seg_len)
         pin = _pin if (pin and torch.cuda.is_available()) else (lambda x: x)
-        return {"B": len(host_instances), "n_seg": n_seg, "n_tot": int(seg_len.sum()),
+        return {"B": len(host_instances), "n_seg": n_seg, "n_tot": int(seg_len.sum()), "npts": len(host_instances) * H * W,
                 "N": torch.as_tensor(N_per, dtype=torch.float64), "fx": torch.as_tensor(np.asarray(fx), dtype=torch.float64),
                 "fy": torch.as_tensor(np.asarray(fy), dtype=torch.float64),
                 # the two big index arrays travel as int32 over PCIe (12 B per triplet less) and are widened on the device
@@ -465,7 +465,12 @@ class VNL_Loss(nn.Module):
         # inverse of the triplet gather, built once per step (GT only): which gathered rows land on which cloud point
         # (sort + per-point counts over ALL B*H*W cloud points: fixed-size outputs, so no device->host sync)
         t.gid_flat = t.gid.reshape(-1)
-        t.gid_order = torch.sort(gid32.reshape(-1)).indices if gid32.dtype == torch.int32 else torch.sort(t.gid_flat).indices
+        srt = torch.sort(gid32.reshape(-1)) if gid32.dtype == torch.int32 else torch.sort(t.gid_flat)
+        t.gid_order = srt.indices
+        if h.get("npts"):
+            # first sorted position of every cloud point (= exclusive prefix sum of the per-point counts) by binary search in the
+            # sorted ids: GT only, so it is built here, with the uploads, instead of in the backward pass on the main stream
+            t.gid_start = torch.searchsorted(srt.values, torch.arange(h["npts"] + 1, device=device, dtype=srt.values.dtype))
         t.gid_counts = None                                  # filled by _triplets_t, which knows the size of the cloud
         return t
 
