@@ -1187,8 +1187,16 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false, 
   if (target < 0) { const char* e = getenv("PRN_WGRAD_TARGET"); target = e ? atoi(e) : 2048; }
   static int forced = -1;          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
   if (forced < 0) { const char* e = getenv("PRN_WGRAD_SPLITS"); forced = e ? atoi(e) : 0; }
-  const int R = (p.tm == 2 && p.tj == 2) ? 3 : ((p.tm + p.tj == 3 || p.wm == 1) ? 4 : 6);
-  const int slots = 256 * R;
+  int R = (p.tm == 2 && p.tj == 2) ? 3 : ((p.tm + p.tj == 3 || p.wm == 1) ? 4 : 6);
+  // PRN_WGRAD_WGS (read per call; planerecnet_amd.ops sets it while weight gradients are deferred to the side stream): plan a
+  // launch whose tiles are fewer for THIS many workgroups instead of a full residency round.  A weight gradient that shares the GPU
+  // with the main chain should not fill every CU's registers (3 resident workgroups of 152 VGPRs leave no room for a 128-VGPR wave
+  // of the main stream's GEMMs): 512 workgroups per launch gave the shortest training step (52.6 -> 52.2 ms; 448: 52.3, 640: 52.4,
+  // 768: 52.45, 1024: 52.8), although the launch alone is fastest with the full round.
+  const char* wenv = getenv("PRN_WGRAD_WGS");
+  const int wtot = wenv ? atoi(wenv) : 0;
+  int slots = 256 * R;
+  if (wtot > 0) { slots = wtot; R = 3; }
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;
   const int smax = p.chunks / 8 > 0 ? p.chunks / 8 : 1;   // at least 128 pixels per split
   int cap = sbw < smax ? sbw : smax;

@@ -35,9 +35,23 @@ _SIDE = {}
 WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
 
 
+# Workgroups a deferred weight-gradient launch is planned for (see plan_wgrad in csrc/prn_conv.hip): the side stream shares the CUs
+# with the main chain, and a launch that fills every CU's register file stalls the main chain's small kernels.  0: the library's
+# stand-alone plan.  The library reads PRN_WGRAD_WGS per call; the cached workspace sizes depend on it and are dropped on a change.
+WGRAD_WGS_ASYNC = os.environ.get("PRN_WGRAD_WGS_ASYNC", "512")
+
+
 def set_wgrad_async(on):
     global WGRAD_ASYNC
     WGRAD_ASYNC = bool(on)
+    want = WGRAD_WGS_ASYNC if (WGRAD_ASYNC and WGRAD_WGS_ASYNC not in ("", "0")) else None
+    if os.environ.get("PRN_WGRAD_WGS") != want:
+        if want is None:
+            os.environ.pop("PRN_WGRAD_WGS", None)
+        else:
+            os.environ["PRN_WGRAD_WGS"] = want
+        for cache in ("_DESC", "_RDESC", "_WINO_WG_WS"):
+            globals().get(cache, {}).clear()
 
 
 def wgrad_streams():
@@ -1347,3 +1361,7 @@ class _MaxPool(torch.autograd.Function):
 def max_pool_3x3_s2(x):
     """nn.MaxPool2d(3, 2, 1) replacement (models/backbone.py:104)."""
     return _MaxPool.apply(x)
+
+
+if WGRAD_ASYNC:                      # PRN_WGRAD_ASYNC=1 in the environment: same side effects as calling it
+    set_wgrad_async(True)
