@@ -1183,8 +1183,8 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false, 
   // fill one round; when the bounds below cut that short, land on a whole number of workgroups per CU instead.
   // Bounds: the workspace round trip (2 * splits * M*K*4 bytes) stays a fraction of the MFMA time (splits <= 0.0035 *
   // pixels) and every split keeps at least 128 pixels.  Layers with more tiles than slots only split to ~2048 workgroups.
-  static int target = -1;          // PRN_WGRAD_TARGET overrides (tuning sweeps)
-  if (target < 0) { const char* e = getenv("PRN_WGRAD_TARGET"); target = e ? atoi(e) : 2048; }
+  const char* tenv = getenv("PRN_WGRAD_TARGET");   // (read per call: planerecnet_amd.ops lowers it while weight gradients are deferred, like PRN_WGRAD_WGS)
+  const int target = tenv ? atoi(tenv) : 2048;
   static int forced = -1;          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
   if (forced < 0) { const char* e = getenv("PRN_WGRAD_SPLITS"); forced = e ? atoi(e) : 0; }
   int R = (p.tm == 2 && p.tj == 2) ? 3 : ((p.tm + p.tj == 3 || p.wm == 1) ? 4 : 6);

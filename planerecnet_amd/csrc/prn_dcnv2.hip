@@ -463,6 +463,10 @@ WPlan plan_dcn_wgrad(int M, int K, int N) {
   const int tiles = p.tilesM * p.tilesJ;
   const int slots = 256 * (p.tm == 1 ? 4 : (p.tm == 2 ? 3 : 2));
   int s = tiles < slots ? 2 * slots / tiles : 1;
+  if (const char* wenv = getenv("PRN_WGRAD_WGS")) {         // deferred to the side stream: see plan_wgrad in prn_conv.hip
+    const int wtot = atoi(wenv);
+    if (wtot > 0) s = tiles < wtot ? wtot / tiles : 1;
+  }
   int cap = p.chunks / 8 > 0 ? p.chunks / 8 : 1;          // at least 128 pixels per split
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;   // workspace round trip stays small
   if (sbw < cap) cap = sbw;

@@ -50,7 +50,7 @@ def set_wgrad_async(on):
             os.environ.pop("PRN_WGRAD_WGS", None)
         else:
             os.environ["PRN_WGRAD_WGS"] = want
-        for cache in ("_DESC", "_RDESC", "_WINO_WG_WS"):
+        for cache in ("_DESC", "_RDESC", "_WINO_WG_WS", "_DCN"):
             globals().get(cache, {}).clear()
 
 
