@@ -41,17 +41,22 @@ WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
 WGRAD_WGS_ASYNC = os.environ.get("PRN_WGRAD_WGS_ASYNC", "512")
 
 
-def set_wgrad_async(on):
-    global WGRAD_ASYNC
-    WGRAD_ASYNC = bool(on)
-    want = WGRAD_WGS_ASYNC if (WGRAD_ASYNC and WGRAD_WGS_ASYNC not in ("", "0")) else None
-    if os.environ.get("PRN_WGRAD_WGS") != want:
+_WGS = [os.environ.get("PRN_WGRAD_WGS")]        # the setting the library currently sees; part of every cached workspace-size key
+
+
+def _set_wgs(want):
+    if _WGS[0] != want:
+        _WGS[0] = want
         if want is None:
             os.environ.pop("PRN_WGRAD_WGS", None)
         else:
             os.environ["PRN_WGRAD_WGS"] = want
-        for cache in ("_DESC", "_RDESC", "_WINO_WG_WS", "_DCN"):
-            globals().get(cache, {}).clear()
+
+
+def set_wgrad_async(on):
+    global WGRAD_ASYNC
+    WGRAD_ASYNC = bool(on)
+    _set_wgs(WGRAD_WGS_ASYNC if (WGRAD_ASYNC and WGRAD_WGS_ASYNC not in ("", "0")) else None)
 
 
 def wgrad_streams():
@@ -170,7 +175,8 @@ def _flush_one(e, everything=False):
 
 def wgrad_flush():
     """Launch every queued weight gradient (on its side stream).  Called by wgrad_join() and by the gradient exchange
-    before it reads a bucket's gradients."""
+    before it reads a bucket's gradients.  (Planning the last launches of a step -- which run after the backward pass, alone -- for
+    full residency again changed nothing: 52.1 vs 52.1 ms.)"""
     for e in list(_PENDING.values()):
         _flush_one(e, everything=True)
 
@@ -254,7 +260,7 @@ _DESC = {}        # (shape key) -> (ConvDesc, byref, fwd workspace bytes, wgrad 
 
 
 def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, ystride=0, yH=0, yW=0):
-    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW)
+    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW, _WGS[0])
     e = _DESC.get(key)
     if e is None:
         d = ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW)
@@ -548,7 +554,7 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
     """Weight gradient [M,C,3,3] of a 3x3 / stride 1 / pad 1 convolution on the Winograd path.  V: the forward call's kept
     workspace (see conv3x3_winograd_raw) -- the input transform is then not recomputed."""
     B, C, H, W = x.shape
-    key = (B, C, H, W, M)
+    key = (B, C, H, W, M, _WGS[0])
     nbytes = _WINO_WG_WS.get(key)
     if nbytes is None:
         nbytes = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M)
@@ -758,7 +764,7 @@ _DCN = {}          # geometry key -> (DcnDesc, byref, table bytes, fwd ws bytes,
 
 
 def _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset, epi=EPI_NONE):
-    key = (B, C, H, W, M, stride, pad, raw, float(max_offset), epi)
+    key = (B, C, H, W, M, stride, pad, raw, float(max_offset), epi, _WGS[0])
     e = _DCN.get(key)
     if e is None:
         Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
@@ -1183,7 +1189,7 @@ _RDESC = {}
 
 
 def _rdesc(rs, C, M, K, epi=EPI_NONE):
-    key = (rs.key, C, M, K, epi)
+    key = (rs.key, C, M, K, epi, _WGS[0])
     e = _RDESC.get(key)
     if e is None:
         h, w = rs.sizes[0]
@@ -1238,7 +1244,7 @@ class _RaggedConv(torch.autograd.Function):
             dx = _ragged_winograd_raw(dy, winograd_weights(w)[1], None, None, rs, M, C, P) if P else _ragged_conv_raw(dy, flip_transpose(w), None, None, rs, M, C, K)
         def wgrad():
             if P and WINOGRAD_WGRAD:
-                key = (rs.key, C, M)
+                key = (rs.key, C, M, _WGS[0])
                 nb = _WINO_WG_WS.get(key)
                 if nb is None:
                     nb = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ragged_ws_bytes(rs.ref, rs.B, C, M)
