@@ -363,6 +363,19 @@ int prn_vnl_triplets(const float* pred, const float* gt, const int* gid, const i
                      float delta_z, void* stream);
 int prn_vnl_scatter(const double* g_loss, const float* g3, const int64_t* order, const int64_t* start, float* d_depth, int npts, int n, void* stream);
 
+/* Category and depth terms of the joint loss, one pass each way (fp64 partials in a fixed order; ws: prn_loss_ws_doubles(B) doubles):
+ *   prn_focal_sum: x [rows][C] logits, labels [rows] int64 class of the row's cell (C = background: no positive class);
+ *     out[0] = sum over (row, c) of w * BCEwithLogits(x, t) * (1 - p_t)^gamma, t = (labels[row] == c), p_t = t ? sigmoid(x) : 1 - sigmoid(x),
+ *     w = alpha >= 0 ? (t ? alpha : 1 - alpha) : 1   (models/functions/losses.py:121-138; the caller divides by num_pos + 1);  bwd: dx = g_out[0] * d out / dx
+ *   prn_rmse_log: pred, gt [B][HW]; valid = gt > min_depth; out[0] = mean_b sqrt( sum_valid (log max(pred, clamp) - log max(gt, clamp))^2 / n_valid_b )
+ *     (losses.py:142-147,371-392); coef [B] is kept for the backward pass: dpred = g_out[0] * coef[b] * (log pred - log gt) / pred on valid pixels. */
+int prn_loss_ws_doubles(int B);
+int prn_focal_sum_fwd(const float* x, const int64_t* labels, float* out, double* ws, int64_t rows, int C, float alpha, float gamma, void* stream);
+int prn_focal_sum_bwd(const float* x, const int64_t* labels, const float* g_out, float* dx, int64_t rows, int C, float alpha, float gamma, void* stream);
+int prn_rmse_log_fwd(const float* pred, const float* gt, float* out, float* coef, double* ws, int B, int HW, float min_depth, float clamp, void* stream);
+int prn_rmse_log_bwd(const float* pred, const float* gt, const float* coef, const float* g_out, float* dpred, int B, int HW, float min_depth, float clamp,
+                     void* stream);
+
 /* ---- depth-error metrics of one frame ------------------------------------------------------------------------------
  * replaces the ~25 elementwise / boolean-index / reduction launches of compute_depth_metrics (eval.py:164-207):
  * over the pixels with gt > 0.5 and pred > 0.5, pred clamped to [min_depth, max_depth] (cfg.dataset):

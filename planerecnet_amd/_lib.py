@@ -107,6 +107,11 @@ SIGNATURES = {
     "prn_vnl_scatter": (c_int, [P] * 5 + [c_int, c_int, P]),
     "prn_depth_metrics_ws_doubles": (c_int, []),
     "prn_depth_metrics": (c_int, [P, P, P, P, c_i64, c_float, c_float, P]),
+    "prn_loss_ws_doubles": (c_int, [c_int]),
+    "prn_focal_sum_fwd": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
+    "prn_focal_sum_bwd": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
+    "prn_rmse_log_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),
+    "prn_rmse_log_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),
     "prn_adam_chunk_elems": (c_int, []),
     "prn_adam_step": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P]),
     "prn_pairwise_iou_ws_bytes": (c_i64, [c_int, c_int, c_i64]),

@@ -363,3 +363,151 @@ extern "C" int prn_vnl_scatter(const double* g_loss, const float* g3, const int6
   PRN_CHECK_LAUNCH("prn_vnl_scatter");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- focal and RMSE-log terms
+// Category term (models/functions/losses.py:121-138,331-352): sigmoid focal loss summed over all cells and classes, and the depth
+// term (losses.py:142-147,371-392): per image sqrt(mean over valid pixels of (log pred - log gt)^2), averaged over the images.  Each
+// was ~15 / ~10 elementwise + reduction launches forward and as many backward; here one pass each way, fp64 partials in a fixed order.
+namespace {
+constexpr int RED_BLOCKS = 128;
+
+__device__ __forceinline__ void focal_terms(float x, bool pos, float alpha, float gamma, float& loss, float& dldx) {
+  // ce = -log p_t (binary_cross_entropy_with_logits' stable form), p_t = p if pos else 1 - p
+  const float ax = fabsf(x), l1p = log1pf(expf(-ax));
+  const float ce = fmaxf(x, 0.f) - (pos ? x : 0.f) + l1p;
+  const float p = 1.f / (1.f + expf(-x));
+  const float pt = pos ? p : 1.f - p, q = 1.f - pt;
+  const float w = alpha >= 0.f ? (pos ? alpha : 1.f - alpha) : 1.f;
+  const float qg = gamma == 2.f ? q * q : powf(q, gamma), qg1 = gamma == 2.f ? q : powf(q, gamma - 1.f);
+  loss = w * ce * qg;
+  // d/dp_t [ -log(p_t) q^g ] = -q^g / p_t - g q^(g-1) (-log p_t) ... with -log p_t = ce ; d p_t / dx = +-p(1-p)
+  const float dpt = -qg / fmaxf(pt, 1e-38f) + gamma * qg1 * (-ce);
+  dldx = w * dpt * (pos ? 1.f : -1.f) * p * (1.f - p);
+}
+
+__global__ __launch_bounds__(256) void focal_partial_kernel(const float* __restrict__ x, const int64_t* __restrict__ label, double* __restrict__ part,
+                                                            int64_t n, int C, float alpha, float gamma) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float l, d;
+    focal_terms(x[i], label[i / C] == (int64_t)(i % C), alpha, gamma, l, d);
+    acc += (double)l;
+  }
+  __shared__ double sm[4];
+  const double v = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += part[b];
+    out[0] = (float)t;
+  }
+}
+
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ label, const float* __restrict__ g,
+                                                        float* __restrict__ dx, int64_t n, int C, float alpha, float gamma) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float l, d;
+  focal_terms(x[i], label[i / C] == (int64_t)(i % C), alpha, gamma, l, d);
+  dx[i] = g[0] * d;
+}
+
+// per image b and block: sum over valid pixels of (log max(pred, clamp) - log max(gt, clamp))^2, and the number of valid pixels
+__global__ __launch_bounds__(256) void rmse_log_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt, double* __restrict__ part,
+                                                               int HW, float min_depth, float clamp) {
+  const int b = blockIdx.y;
+  const float* p = pred + (size_t)b * HW;
+  const float* g = gt + (size_t)b * HW;
+  double s = 0.0, c = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float gv = g[i];
+    if (gv > min_depth) {
+      const float d = logf(fmaxf(p[i], clamp)) - logf(fmaxf(gv, clamp));
+      s += (double)(d * d);
+      c += 1.0;
+    }
+  }
+  __shared__ double sm[4][2];
+  const double vs = wave_sum_d(s), vc = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = vs; sm[threadIdx.x >> 6][1] = vc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((size_t)b * gridDim.x + blockIdx.x) * 2] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
+    part[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = (sm[0][1] + sm[1][1]) + (sm[2][1] + sm[3][1]);
+  }
+}
+
+// out[0] = mean_b sqrt(S_b / n_b); coef[b] = 1 / (B * sqrt(S_b / n_b) * n_b): d out / d pred[b][i] = coef[b] * (log p - log g) / p on valid pixels
+__global__ void rmse_log_final_kernel(const double* __restrict__ part, int nb, int B, float* __restrict__ out, float* __restrict__ coef) {
+  if (threadIdx.x != 0) return;
+  double tot = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s = 0.0, c = 0.0;
+    for (int k = 0; k < nb; ++k) { s += part[((size_t)b * nb + k) * 2]; c += part[((size_t)b * nb + k) * 2 + 1]; }
+    const double r = sqrt(s / c);
+    tot += r;
+    coef[b] = (float)(1.0 / ((double)B * r * c));
+  }
+  out[0] = (float)(tot / B);
+}
+
+__global__ __launch_bounds__(256) void rmse_log_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ coef,
+                                                           const float* __restrict__ g, float* __restrict__ dpred, int HW, float min_depth, float clamp) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const size_t k = (size_t)b * HW + i;
+  const float gv = gt[k], pv = pred[k];
+  float d = 0.f;
+  if (gv > min_depth && pv > clamp) d = g[0] * coef[b] * (logf(pv) - logf(fmaxf(gv, clamp))) / pv;     // (pred <= clamp: the clamp's gradient is 0)
+  dpred[k] = d;
+}
+}  // namespace
+
+extern "C" int prn_loss_ws_doubles(int B) { return RED_BLOCKS * 2 * (B > 1 ? B : 1); }
+
+extern "C" int prn_focal_sum_fwd(const float* x, const int64_t* labels, float* out, double* ws, int64_t rows, int C, float alpha, float gamma, void* stream) {
+  PRN_REQUIRE(x && labels && out && ws && rows > 0 && C > 0, "prn_focal_sum_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = rows * C;
+  int nb = cdiv(n, 256 * 4);
+  nb = nb > RED_BLOCKS ? RED_BLOCKS : (nb < 1 ? 1 : nb);
+  hipLaunchKernelGGL(focal_partial_kernel, dim3(nb), dim3(256), 0, st, x, labels, ws, n, C, alpha, gamma);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, out);
+  PRN_CHECK_LAUNCH("prn_focal_sum_fwd");
+  return 0;
+}
+
+extern "C" int prn_focal_sum_bwd(const float* x, const int64_t* labels, const float* g_out, float* dx, int64_t rows, int C, float alpha, float gamma,
+                                 void* stream) {
+  PRN_REQUIRE(x && labels && g_out && dx && rows > 0 && C > 0, "prn_focal_sum_bwd: bad arguments");
+  const int64_t n = rows * C;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, g_out, dx, n, C, alpha, gamma);
+  PRN_CHECK_LAUNCH("prn_focal_sum_bwd");
+  return 0;
+}
+
+extern "C" int prn_rmse_log_fwd(const float* pred, const float* gt, float* out, float* coef, double* ws, int B, int HW, float min_depth, float clamp,
+                                void* stream) {
+  PRN_REQUIRE(pred && gt && out && coef && ws && B > 0 && HW > 0, "prn_rmse_log_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int nb = cdiv(HW, 256 * 8);
+  nb = nb > RED_BLOCKS ? RED_BLOCKS : (nb < 1 ? 1 : nb);
+  hipLaunchKernelGGL(rmse_log_partial_kernel, dim3(nb, B), dim3(256), 0, st, pred, gt, ws, HW, min_depth, clamp);
+  hipLaunchKernelGGL(rmse_log_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, B, out, coef);
+  PRN_CHECK_LAUNCH("prn_rmse_log_fwd");
+  return 0;
+}
+
+extern "C" int prn_rmse_log_bwd(const float* pred, const float* gt, const float* coef, const float* g_out, float* dpred, int B, int HW, float min_depth,
+                                float clamp, void* stream) {
+  PRN_REQUIRE(pred && gt && coef && g_out && dpred && B > 0 && HW > 0, "prn_rmse_log_bwd: bad arguments");
+  hipLaunchKernelGGL(rmse_log_bwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, pred, gt, coef, g_out, dpred, HW, min_depth, clamp);
+  PRN_CHECK_LAUNCH("prn_rmse_log_bwd");
+  return 0;
+}

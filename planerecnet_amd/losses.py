@@ -228,13 +228,18 @@ class PlaneRecNetLoss(nn.Module):
         def category_term():
             # ---- cat (sigmoid focal, sum / (num_pos + 1)) -- losses.py:121-138
             flat_pred = torch.cat([c.permute(0, 2, 3, 1).reshape(-1, self.num_classes) for c in cate_preds])
+            if FUSED_LOSS and FUSED_CAT_DPT and flat_pred.is_cuda:
+                return {"cat": self.conf_loss_weight * _FocalSum.apply(flat_pred, t.cate_labels, self.focal_loss_alpha, self.focal_loss_gamma) / (t.num_ins + 1)}
             onehot = F.one_hot(t.cate_labels, self.num_classes + 1)[:, : self.num_classes].to(flat_pred.dtype)
             return {"cat": self.conf_loss_weight * sigmoid_focal_sum(flat_pred, onehot, self.focal_loss_alpha, self.focal_loss_gamma) / (t.num_ins + 1)}
 
         def depth_terms():
             # ---- dpt (RMSE-log at full resolution) -- losses.py:142-147 (the clamp there is discarded: quirk Q2)
             dp = ops.resize_bilinear(depth_preds, (2 * depth_preds.shape[2], 2 * depth_preds.shape[3]))
-            out = {"dpt": self.depth_loss_weight * rmse_log(dp, gt_depths, gt_depths > cfg.dataset.min_depth)}
+            if FUSED_LOSS and FUSED_CAT_DPT and dp.is_cuda:
+                out = {"dpt": self.depth_loss_weight * _RmseLog.apply(dp, gt_depths, cfg.dataset.min_depth, 1e-9)}
+            else:
+                out = {"dpt": self.depth_loss_weight * rmse_log(dp, gt_depths, gt_depths > cfg.dataset.min_depth)}
             # ---- pln (virtual normals) -- losses.py:151-165
             if cfg.use_plane_loss:
                 out["pln"] = self.vnl.batched(dp, gt_depths, t.vnl).mean() * self.pln_loss_weight
@@ -251,6 +256,7 @@ class PlaneRecNetLoss(nn.Module):
         return losses
 
 
+FUSED_CAT_DPT = bool(int(os.environ.get("PRN_FUSED_CAT_DPT", "1")))  # 0: focal / RMSE-log terms operator by operator (A/B)
 FUSED_LOSS = bool(int(os.environ.get("PRN_FUSED_LOSS", "1")))       # 0: the operator-by-operator evaluation below (A/B, cross-check in the tests)
 
 
@@ -332,6 +338,56 @@ class _GatherRows(torch.autograd.Function):
     def backward(ctx, g):
         order, counts = ctx.saved_tensors
         return torch.segment_reduce(g[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True), None, None, None
+
+
+class _FocalSum(torch.autograd.Function):
+    """sigmoid_focal_sum(x, one_hot(labels)) in one pass each way (include/prn.h: prn_focal_sum_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, labels, alpha, gamma):
+        x = x.contiguous()
+        rows, C = x.shape
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        ws = torch.empty(ops.lib.prn_loss_ws_doubles(1), device=x.device, dtype=torch.float64)
+        ops.check(ops.lib.prn_focal_sum_fwd(ops._p(x), ops._p(labels), ops._p(out), ops._p(ws), rows, C, float(alpha), float(gamma), ops._stream()), "prn_focal_sum_fwd")
+        ctx.save_for_backward(x, labels)
+        ctx.cfg = (float(alpha), float(gamma))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, labels = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        ops.check(ops.lib.prn_focal_sum_bwd(ops._p(x), ops._p(labels), ops._p(g.float().reshape(1).contiguous()), ops._p(dx), x.shape[0], x.shape[1],
+                                            ctx.cfg[0], ctx.cfg[1], ops._stream()), "prn_focal_sum_bwd")
+        return dx, None, None, None
+
+
+class _RmseLog(torch.autograd.Function):
+    """rmse_log(pred, gt, gt > min_depth) in one pass each way (include/prn.h: prn_rmse_log_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, min_depth, clamp):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        B = pred.shape[0]
+        HW = pred.numel() // B
+        out = torch.empty(1, device=pred.device, dtype=torch.float32)
+        coef = torch.empty(B, device=pred.device, dtype=torch.float32)
+        ws = torch.empty(ops.lib.prn_loss_ws_doubles(B), device=pred.device, dtype=torch.float64)
+        ops.check(ops.lib.prn_rmse_log_fwd(ops._p(pred), ops._p(gt), ops._p(out), ops._p(coef), ops._p(ws), B, HW, float(min_depth), float(clamp), ops._stream()),
+                  "prn_rmse_log_fwd")
+        ctx.save_for_backward(pred, gt, coef)
+        ctx.cfg = (float(min_depth), float(clamp))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, coef = ctx.saved_tensors
+        B = pred.shape[0]
+        d = torch.empty_like(pred)
+        ops.check(ops.lib.prn_rmse_log_bwd(ops._p(pred), ops._p(gt), ops._p(coef), ops._p(g.float().reshape(1).contiguous()), ops._p(d), B, pred.numel() // B,
+                                           ctx.cfg[0], ctx.cfg[1], ops._stream()), "prn_rmse_log_bwd")
+        return d, None, None, None
 
 
 class _TrimmedMeans(torch.autograd.Function):
