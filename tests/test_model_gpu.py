@@ -230,6 +230,41 @@ def test_kernel_gather_branches_agree(setup):
             close(a, b, 1e-5, "kernel gather branches")
 
 
+def test_fused_focal_and_rmse_log_equal_operator_chains():
+    """prn_focal_sum / prn_rmse_log (one pass each way) against the operator chains they replace (losses.sigmoid_focal_sum, rmse_log:
+    the reference's formulas, pinned through the whole-loss tests): value and gradient, incl. background rows, pixels without ground
+    truth and a non-positive prediction (below the clamp: zero gradient)."""
+    import torch.nn.functional as F
+    from planerecnet_amd import losses as L
+    g = torch.Generator().manual_seed(0)
+    rows, C = 29824, 2
+    x = (torch.randn(rows, C, generator=g) * 3).cuda()
+    labels = torch.full((rows,), C, dtype=torch.int64)
+    pos = torch.randperm(rows, generator=g)[:600]
+    labels[pos] = torch.randint(0, C, (600,), generator=g)
+    labels = labels.cuda()
+    for alpha, gamma in ((0.25, 2.0), (-1.0, 1.5)):
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        a = L._FocalSum.apply(xa, labels, alpha, gamma)
+        onehot = F.one_hot(labels, C + 1)[:, :C].float()
+        b = L.sigmoid_focal_sum(xb, onehot, alpha, gamma)
+        assert abs(float(a) - float(b)) <= 1e-5 * abs(float(b))
+        (ga,), (gb,) = torch.autograd.grad(a * 0.37, xa), torch.autograd.grad(b * 0.37, xb)
+        close(ga, gb, 1e-5, "focal grad")
+    B, H, W = 3, 96, 128
+    gt = (torch.rand(B, 1, H, W, generator=g) * 5).cuda()
+    gt[:, :, :10] = 0.0                                             # no ground truth there
+    pred = (gt * (1 + 0.3 * torch.randn(B, 1, H, W, generator=g).cuda())).abs() + 0.05
+    pred[0, 0, 50, 50] = 0.0                                        # below the clamp
+    pa, pb = pred.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    a = L._RmseLog.apply(pa, gt, 0.1, 1e-9)
+    b = L.rmse_log(pb, gt, gt > 0.1)
+    assert abs(float(a) - float(b)) <= 1e-5 * abs(float(b))
+    (ga,), (gb,) = torch.autograd.grad(a * 5.0, pa), torch.autograd.grad(b * 5.0, pb)
+    assert float(ga[0, 0, 50, 50]) == 0.0 and float(ga[:, :, :10].abs().max()) == 0.0
+    close(ga, gb, 1e-5, "rmse-log grad")
+
+
 def test_gt_assignment_bit_exact_vs_golden(setup, golden_dir):
     import os
     from oracle import synth
