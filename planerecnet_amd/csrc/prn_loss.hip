@@ -511,3 +511,113 @@ extern "C" int prn_rmse_log_bwd(const float* pred, const float* gt, const float*
   PRN_CHECK_LAUNCH("prn_rmse_log_bwd");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- virtual-normal trimming rule
+// vnl.py:106-117,133-165 after the per-triplet losses: per sampled region sort the valid losses, drop the lowest quarter, average
+// the rest; per image sum the regions' means over (planes + 1 if the non-planar region had a valid triplet).  The operator chain
+// (segment sums as differences of prefix sums, rank arithmetic, masks) was ~65 small launches around one sort; here: the sort key, the
+// sort itself (ATen), one workgroup per region, one thread for the per-image combination.
+namespace {
+__global__ __launch_bounds__(256) void vnl_trim_key_kernel(const double* __restrict__ loss, const unsigned char* __restrict__ valid,
+                                                           const int64_t* __restrict__ seg, double* __restrict__ key, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double l = loss[i];
+  key[i] = (double)seg[i] * 4.0 + (valid[i] ? (isnan(l) ? 1.5 : l) : 2.0);      // valid ascending (losses are in [0, 1]), NaN, invalid
+}
+
+// one workgroup per region s: sorted positions [seg_start[s], seg_start[s+1]) hold its triplets, the m valid ones first
+__global__ __launch_bounds__(256) void vnl_trim_region_kernel(const double* __restrict__ loss, const unsigned char* __restrict__ valid,
+                                                              const int64_t* __restrict__ order, const int64_t* __restrict__ seg_start, int nseg, int n,
+                                                              double* __restrict__ seg_sum, int* __restrict__ seg_m) {
+  const int s = blockIdx.x;
+  const int a = (int)seg_start[s], b = s + 1 < nseg ? (int)seg_start[s + 1] : n;
+  __shared__ int cnt[4];
+  __shared__ double part[4];
+  int m = 0;
+  for (int j = a + threadIdx.x; j < b; j += 256) m += valid[order[j]] ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  const int drop = m / 4;
+  double acc = 0.0;
+  for (int j = a + drop + threadIdx.x; j < a + m; j += 256) {
+    const double l = loss[order[j]];
+    acc += isnan(l) ? 0.0 : l;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { seg_sum[s] = (part[0] + part[1]) + (part[2] + part[3]); seg_m[s] = m; }
+}
+
+// out[b] = sum over the image's counted regions of seg_sum / (m - drop)  /  (planes + [non-planar region counted]);
+// seg_coef[s] = d out[img] / d (a kept loss of region s)
+__global__ void vnl_trim_final_kernel(const double* __restrict__ seg_sum, const int* __restrict__ seg_m, const unsigned char* __restrict__ seg_is_plane,
+                                      const int64_t* __restrict__ seg_img, const double* __restrict__ nplanes, int nseg, int B, double* __restrict__ out,
+                                      double* __restrict__ seg_coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int b = 0; b < B; ++b) {
+    double tot = 0.0, extra = 0.0;
+    for (int s = 0; s < nseg; ++s) {
+      if (seg_img[s] != b) continue;
+      const int m = seg_m[s], drop = m / 4;
+      const bool np_ok = !seg_is_plane[s] && m > 0, use = seg_is_plane[s] || np_ok;
+      if (use) tot += seg_sum[s] / (double)(m - drop);      // (a plane without a valid triplet: 0 / 0 = NaN like the reference)
+      if (np_ok) extra += 1.0;
+    }
+    const double den = nplanes[b] + extra;
+    out[b] = tot / den;
+    for (int s = 0; s < nseg; ++s) {
+      if (seg_img[s] != b) continue;
+      const int m = seg_m[s], drop = m / 4;
+      const bool use = seg_is_plane[s] || m > 0;
+      seg_coef[s] = (use && m - drop > 0) ? 1.0 / ((double)(m - drop) * den) : 0.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vnl_trim_bwd_kernel(const double* __restrict__ loss, const int64_t* __restrict__ order, const int64_t* __restrict__ seg_start,
+                                                           const int* __restrict__ seg_m, const double* __restrict__ seg_coef, const int64_t* __restrict__ seg_img,
+                                                           const double* __restrict__ g, int nseg, int n, double* __restrict__ dloss) {
+  const int s = blockIdx.x;
+  const int a = (int)seg_start[s], b = s + 1 < nseg ? (int)seg_start[s + 1] : n;
+  const int m = seg_m[s], drop = m / 4;
+  const double c = seg_coef[s] * g[seg_img[s]];
+  for (int j = a + threadIdx.x; j < b; j += 256) {
+    const int64_t i = order[j];
+    const bool kept = j - a >= drop && j - a < m && !isnan(loss[i]);
+    dloss[i] = kept ? c : 0.0;
+  }
+}
+}  // namespace
+
+extern "C" int prn_vnl_trim_key(const double* loss, const unsigned char* valid, const int64_t* seg, double* key, int n, void* stream) {
+  PRN_REQUIRE(loss && valid && seg && key && n > 0, "prn_vnl_trim_key: bad arguments");
+  hipLaunchKernelGGL(vnl_trim_key_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, loss, valid, seg, key, n);
+  PRN_CHECK_LAUNCH("prn_vnl_trim_key");
+  return 0;
+}
+
+extern "C" int prn_vnl_trim_fwd(const double* loss, const unsigned char* valid, const int64_t* order, const int64_t* seg_start,
+                                const unsigned char* seg_is_plane, const int64_t* seg_img, const double* nplanes, int nseg, int n, int B, double* out,
+                                double* seg_sum, int* seg_m, double* seg_coef, void* stream) {
+  PRN_REQUIRE(loss && valid && order && seg_start && seg_is_plane && seg_img && nplanes && out && seg_sum && seg_m && seg_coef && nseg > 0 && n > 0 && B > 0,
+              "prn_vnl_trim_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vnl_trim_region_kernel, dim3(nseg), dim3(256), 0, st, loss, valid, order, seg_start, nseg, n, seg_sum, seg_m);
+  hipLaunchKernelGGL(vnl_trim_final_kernel, dim3(1), dim3(64), 0, st, (const double*)seg_sum, (const int*)seg_m, seg_is_plane, seg_img, nplanes, nseg, B, out,
+                     seg_coef);
+  PRN_CHECK_LAUNCH("prn_vnl_trim_fwd");
+  return 0;
+}
+
+extern "C" int prn_vnl_trim_bwd(const double* loss, const int64_t* order, const int64_t* seg_start, const int* seg_m, const double* seg_coef,
+                                const int64_t* seg_img, const double* g_out, int nseg, int n, double* dloss, void* stream) {
+  PRN_REQUIRE(loss && order && seg_start && seg_m && seg_coef && seg_img && g_out && dloss && nseg > 0 && n > 0, "prn_vnl_trim_bwd: bad arguments");
+  hipLaunchKernelGGL(vnl_trim_bwd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, loss, order, seg_start, seg_m, seg_coef, seg_img, g_out, nseg, n, dloss);
+  PRN_CHECK_LAUNCH("prn_vnl_trim_bwd");
+  return 0;
+}

@@ -391,17 +391,43 @@ class _RmseLog(torch.autograd.Function):
 
 
 class _TrimmedMeans(torch.autograd.Function):
-    """VNL_Loss._trimmed_means with its gradient written out (see there)."""
+    """VNL_Loss._trimmed_means with its gradient written out (see there).  On the device: the sort key, ATen's sort, one workgroup per
+    region and one combining thread (include/prn.h: prn_vnl_trim_*) instead of the ~65-launch operator chain around the sort."""
 
     @staticmethod
     def forward(ctx, loss, valid, t):
+        ctx.n = loss.shape[0]
+        if FUSED_LOSS and loss.is_cuda and loss.dtype == torch.float64 and t.n_seg > 0:
+            dev, n, nseg = loss.device, loss.shape[0], int(t.seg_start.shape[0])
+            loss_c = loss.detach().contiguous()
+            v8 = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.contiguous()
+            key = torch.empty(n, device=dev, dtype=torch.float64)
+            ops.check(ops.lib.prn_vnl_trim_key(ops._p(loss_c), ops._p(v8), ops._p(t.seg), ops._p(key), n, ops._stream()), "prn_vnl_trim_key")
+            order = torch.argsort(key)
+            out = torch.empty(t.B, device=dev, dtype=torch.float64)
+            seg_sum, seg_coef = torch.empty(nseg, device=dev, dtype=torch.float64), torch.empty(nseg, device=dev, dtype=torch.float64)
+            seg_m = torch.empty(nseg, device=dev, dtype=torch.int32)
+            plane8 = t.seg_is_plane.view(torch.uint8) if t.seg_is_plane.dtype == torch.bool else t.seg_is_plane
+            ops.check(ops.lib.prn_vnl_trim_fwd(ops._p(loss_c), ops._p(v8), ops._p(order), ops._p(t.seg_start), ops._p(plane8), ops._p(t.seg_img), ops._p(t.N),
+                                               nseg, n, t.B, ops._p(out), ops._p(seg_sum), ops._p(seg_m), ops._p(seg_coef), ops._stream()), "prn_vnl_trim_fwd")
+            ctx.save_for_backward(loss_c, order, seg_m, seg_coef)
+            ctx.t = t
+            ctx.fused = True
+            return out
         out, order, coef, img_s = VNL_Loss._trimmed_means_autograd(loss.detach(), valid, t, loss.device, want_coef=True)
         ctx.save_for_backward(order, coef, img_s)
-        ctx.n = loss.shape[0]
+        ctx.fused = False
         return out
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fused:
+            loss_c, order, seg_m, seg_coef = ctx.saved_tensors
+            t = ctx.t
+            grad = torch.empty(ctx.n, device=g.device, dtype=torch.float64)
+            ops.check(ops.lib.prn_vnl_trim_bwd(ops._p(loss_c), ops._p(order), ops._p(t.seg_start), ops._p(seg_m), ops._p(seg_coef), ops._p(t.seg_img),
+                                               ops._p(g.double().contiguous()), int(t.seg_start.shape[0]), ctx.n, ops._p(grad), ops._stream()), "prn_vnl_trim_bwd")
+            return grad, None, None
         order, coef, img_s = ctx.saved_tensors
         grad = torch.empty(ctx.n, device=g.device, dtype=coef.dtype).index_copy_(0, order, coef * g.to(coef.dtype)[img_s])   # order is a permutation
         return grad, None, None

@@ -265,6 +265,39 @@ def test_fused_focal_and_rmse_log_equal_operator_chains():
     close(ga, gb, 1e-5, "rmse-log grad")
 
 
+def test_trimming_rule_kernels_equal_operator_chain():
+    """prn_vnl_trim_* (sort key, region sums, per-image combination, scattered gradient) against the operator chain
+    (VNL_Loss._trimmed_means_autograd, itself pinned through the oracle's per-plane loops): ties, NaN losses, invalid triplets,
+    a region without any valid triplet (0 / 0 like the reference, with a finite gradient for the other image)."""
+    from planerecnet_amd.losses import VNL_Loss, VNLTargets
+    rng = np.random.RandomState(11)
+    seg_len = np.array([4000, 7, 12000, 3, 640, 1600, 300])
+    n = int(seg_len.sum())
+    t = VNLTargets()
+    t.B, t.n_seg, t.n_tot = 2, len(seg_len), n
+    t.seg = torch.from_numpy(np.repeat(np.arange(len(seg_len)), seg_len)).cuda()
+    t.seg_start = torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]])).cuda()
+    t.seg_img = torch.tensor([0, 0, 0, 1, 1, 1, 1]).cuda()
+    t.seg_is_plane = torch.tensor([True, True, False, True, True, True, False]).cuda()
+    t.N = torch.tensor([2.0, 3.0], dtype=torch.float64).cuda()
+    loss = torch.from_numpy(np.round(rng.rand(n), 3)).double().cuda()
+    loss[5], loss[4100] = float("nan"), float("nan")
+    valid = torch.from_numpy(rng.rand(n) < 0.8).cuda()
+    for degenerate in (False, True):
+        if degenerate:
+            valid[t.seg == 3] = False
+        la, lb = loss.clone().requires_grad_(True), loss.clone().requires_grad_(True)
+        ya = VNL_Loss._trimmed_means(la, valid, t, loss.device)
+        yb = VNL_Loss._trimmed_means_autograd(lb, valid, t, loss.device)
+        assert torch.allclose(ya, yb, rtol=1e-12, atol=0, equal_nan=True) and bool(torch.isnan(ya[1])) == degenerate
+        (ga,) = torch.autograd.grad(ya[0] * 0.7, la, retain_graph=True)
+        assert bool(torch.isfinite(ga).all()) and float(ga[5]) == 0.0
+        if not degenerate:
+            w = torch.tensor([0.7, 1.3], dtype=torch.float64, device=loss.device)
+            (ga,), (gb,) = torch.autograd.grad((ya * w).sum(), la), torch.autograd.grad((yb * w).sum(), lb)
+            assert torch.allclose(ga, gb, rtol=1e-12, atol=0) and float(ga.abs().sum()) > 0
+
+
 def test_gt_assignment_bit_exact_vs_golden(setup, golden_dir):
     import os
     from oracle import synth
