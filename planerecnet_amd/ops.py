@@ -81,6 +81,15 @@ def _defer(needs_grad, w):
 BIAS_ASYNC = bool(int(os.environ.get("PRN_BIAS_ASYNC", "1")))
 
 
+def _small_param_grads(leaves, inputs, compute):
+    """Gradients of a few small parameters (GroupNorm affine pairs, ragged-conv biases) from tensors the backward pass already holds:
+    `compute()` -> tuple matching `leaves`.  Deferred to the side stream with the weight gradients when possible (then None)."""
+    if BIAS_ASYNC and all(p_ is not None and _defer(True, p_) for p_ in leaves):
+        _deferred_wgrad(list(leaves), inputs, compute)
+        return None
+    return compute()
+
+
 def _bias_grad(needs_grad, bias, dy):
     """d bias = channel_sum(dy): returned for autograd, or queued for the side stream (then None is returned)."""
     if not needs_grad or bias is None:
@@ -1122,6 +1131,7 @@ class _GroupNormReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps):
         _dev(x, gamma, beta)
+        gamma_leaf, beta_leaf = gamma, beta
         x = _c(x)
         B, C, H, W = x.shape
         y = torch.empty_like(x)
@@ -1130,6 +1140,7 @@ class _GroupNormReLU(torch.autograd.Function):
             check(lib.prn_gn_relu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, C, H * W, groups, eps, _stream()), "prn_gn_relu_fwd")
         ctx.save_for_backward(x, beta, stats, gamma)       # (the backward re-derives the ReLU mask from x: y is not kept)
         ctx.groups = groups
+        ctx.leaves = (gamma_leaf, beta_leaf)
         return y
 
     @staticmethod
@@ -1142,6 +1153,9 @@ class _GroupNormReLU(torch.autograd.Function):
         with profiling.span("gn_relu_bwd", "hbm", 4.0 * x.numel() * 4):
             check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(beta), _p(stats), _p(gamma), _p(dx), _p(part[0]), _p(part[1]), B, C, H * W, ctx.groups, _stream()),
                   "prn_gn_relu_bwd")
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dgb = _small_param_grads(ctx.leaves, (part,), lambda: part.sum(1).unbind(0))
+            return (dx, None, None, None, None) if dgb is None else (dx, dgb[0], dgb[1], None, None)
         dgb = part.sum(1)
         return dx, dgb[0], dgb[1], None, None
 
@@ -1230,6 +1244,7 @@ class _RaggedConv(torch.autograd.Function):
         y = _ragged_winograd_raw(xp, winograd_weights(w)[0], bias, None, rs, C, M, P) if P else _ragged_conv_raw(xp, w, bias, None, rs, C, M, K)
         ctx.save_for_backward(xp, w)
         ctx.rs, ctx.has_bias = rs, bias is not None
+        ctx.bias = bias
         return y
 
     @staticmethod
@@ -1264,7 +1279,8 @@ class _RaggedConv(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             dw = wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.stack([t.sum((0, 2, 3)) for t in rs.unpack(dy, M)]).sum(0)
+            r = _small_param_grads((ctx.bias,), (dy,), lambda: (torch.stack([t.sum((0, 2, 3)) for t in rs.unpack(dy, M)]).sum(0),))
+            db = None if r is None else r[0]
         return dx, dw, db, None
 
 
@@ -1277,6 +1293,7 @@ class _RaggedGNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, gamma, beta, groups, eps, rs):
         _dev(xp, gamma, beta)
+        ctx.leaves = (gamma, beta)
         xp = _c(xp)
         C = gamma.numel()
         n = len(rs.sizes)
@@ -1301,6 +1318,9 @@ class _RaggedGNReLU(torch.autograd.Function):
         with profiling.span("gn_relu_bwd", "hbm", 4.0 * xp.numel() * 4):
             check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(beta), _p(stats), _p(gamma), _p(dx), _p(part[0]), _p(part[1]), rs.B, C, n, rs.hw, groups,
                                              _stream()), "prn_gn_relu_bwd_ragged")
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dgb = _small_param_grads(ctx.leaves, (part,), lambda: part.sum(1).unbind(0))
+            return (dx, None, None, None, None, None) if dgb is None else (dx, dgb[0], dgb[1], None, None, None)
         dgb = part.sum(1)
         return dx, dgb[0], dgb[1], None, None, None
 
