@@ -88,4 +88,7 @@ class FusedAdam(torch.optim.Optimizer):
         stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(tab["dev"].index))
         check(lib.prn_adam_step(vp(tab["chunks"]), tab["nchunks"], vp(tab["p"]), vp(tab["g"]), vp(tab["m"]), vp(tab["v"]), vp(tab["numel"]), vp(tab["lr"]),
                                 vp(tab["step"]), vp(fi), vp(gs), float(betas[0]), float(betas[1]), float(eps), stream), "prn_adam_step")
+        # the kernel wrote through raw pointers: advance the version counters like an in-place torch op would -- the flipped /
+        # Winograd-domain / BatchNorm-folded weight caches of this package are keyed on them
+        torch.autograd.graph.increment_version([p for p, _ in plist])
         return loss

@@ -96,6 +96,35 @@ def test_batchnorm_bookkeeping_and_fold_cache(setup):
     net.load_state_dict(sd)
 
 
+def test_weight_caches_follow_the_one_launch_adam(setup):
+    """FusedAdam writes the parameters through raw pointers: it must advance their version counters, or the eval path would go on
+    using conv+BN weights folded before the update (validation passes between training epochs).  Eval output after an update ==
+    eval output of the same weights with every cache keyed from scratch (separate conv + BatchNorm launches)."""
+    from oracle import synth
+    from planerecnet_amd.optim import FusedAdam
+    net, sd, _ = setup
+    net.load_state_dict(sd)
+    x, _, _ = synth.make_batch(1, 128, 160, seed=5)
+    xd = x.cuda()
+    net.eval()
+    with torch.no_grad():
+        before = [t.clone() for t in net.backbone(xd)]                   # caches the folded weights
+    opt = FusedAdam(net.backbone.parameters(), lr=1e-2)
+    for p in net.backbone.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    with torch.no_grad():
+        after = [t.clone() for t in net.backbone(xd)]                    # folded again from the updated weights
+    with torch.enable_grad():
+        unfolded = net.backbone(xd)
+    assert float((after[-1] - before[-1]).abs().max()) > 1e-3
+    for a, u in zip(after, unfolded):
+        close(a, u, 5e-4, "folded (cached) vs unfolded after an optimizer step")
+    for p in net.backbone.parameters():
+        p.grad = None
+    net.load_state_dict(sd)
+
+
 def test_backward_with_ragged_heads_and_deferred_wgrads(setup):
     """B=4 at 128x160 (the batch sizes for which the SOLO grid levels pack into whole GEMM tiles): the instance head runs as
     ragged batches, weight gradients are deferred to the side stream, backbone-feature gradients meet in forked epilogues.

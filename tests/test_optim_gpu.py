@@ -34,8 +34,11 @@ def test_fused_adam_matches_torch_adam():
         ref.found_inf = mine.found_inf = skip                       # the device-side "do not update" flag of a GradScaler
         ref.grad_scale = mine.grad_scale = None
         before = [b.detach().clone() for b in pb]
+        versions = [b._version for b in pb]
         ref.step()
         mine.step()
+        # parameters that were stepped look modified to torch (weight caches keyed on _version), the one without a gradient does not
+        assert all((b._version > v) == (i != 4) for i, (b, v) in enumerate(zip(pb, versions)))
         if it == 2:
             assert all(torch.equal(x, y.detach()) for x, y in zip(before, pb))
         for i, (a, b) in enumerate(zip(pa, pb)):
