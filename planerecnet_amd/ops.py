@@ -396,7 +396,10 @@ class FlippedWeights:
     `weights` is a list of (parameter, (M, C, KH, KW)) -- the shape the dgrad sees (a DCN weight is [M, C*9, 1, 1])."""
 
     def __init__(self, weights):
-        self.weights = [(w, tuple(int(v) for v in shp)) for w, shp in weights]
+        # (parameter, shape) or (parameter, shape, data): `data` is the tensor actually read (a DCN block's merged [27, C, 3, 3] offset +
+        # modulator weight, of which the parameter is the leading rows); the parameter supplies the version counter
+        self.weights = [(e[0], tuple(int(v) for v in e[1])) for e in weights]
+        self.data = [e[2] if len(e) > 2 else e[0] for e in weights]
         self.ptrs = None
 
     def _build(self):
@@ -407,7 +410,7 @@ class FlippedWeights:
         items = np.zeros(len(self.weights), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("M", "i4"), ("C", "i4"), ("KH", "i4"), ("KW", "i4"),
                                                              ("first", "i8")]))
         self.views, first, blocks = [], 0, 0
-        for i, (w, (M, C, KH, KW)) in enumerate(self.weights):
+        for i, ((_, (M, C, KH, KW)), w) in enumerate(zip(self.weights, self.data)):
             assert w.is_contiguous() and w.numel() == M * C * KH * KW and w.dtype == torch.float32
             v = self.flat[first:first + w.numel()].view(C, M, KH, KW)
             items[i] = (w.data_ptr(), v.data_ptr(), M, C, KH, KW, blocks)       # `first` counts 32x32 (M, C) blocks
@@ -416,19 +419,19 @@ class FlippedWeights:
             blocks += ((M + 31) // 32) * ((C + 31) // 32)
         self.items = torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev)
         self.total = blocks
-        self.ptrs = [w.data_ptr() for w, _ in self.weights]
+        self.ptrs = [w.data_ptr() for w in self.data]
 
     def refresh(self):
         """Call after the weights changed (once per step, before backward)."""
         if not self.weights:
             return
-        if self.ptrs is None or any(w.data_ptr() != p for (w, _), p in zip(self.weights, self.ptrs)):
+        if self.ptrs is None or any(w.data_ptr() != p for w, p in zip(self.data, self.ptrs)):
             for p in (self.ptrs or []):
                 _FLIPPED.pop(p, None)
             self._build()
         check(lib.prn_weight_flip_transpose_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_weight_flip_transpose_batched")
-        for (w, _), v in zip(self.weights, self.views):
-            _FLIPPED[w.data_ptr()] = (w, w._version, v)
+        for (w, _), d, v in zip(self.weights, self.data, self.views):
+            _FLIPPED[d.data_ptr()] = (w, w._version, v)
 
 
 # ------------------------------------------------------------------------------------------ Winograd F(4x4, 3x3)

@@ -75,14 +75,28 @@ class PlaneRecNet(nn.Module):
     def _refresh_dgrad_weights(self):
         """One launch that lays every conv weight out for its input-gradient GEMM (ops.FlippedWeights)."""
         fw = self.__dict__.get("_flipped")
+        if fw is not None and any(m._merged()[0] is not d for m, d in self.__dict__.get("_flip_dcn", ())):
+            for d in fw.data:                                  # a DCN block re-linked its merged storage (module.to(), .data assignment)
+                ops._FLIPPED.pop(d.data_ptr(), None)
+            fw = None
         if fw is None:
             from .dcn import DeformableConv2d
-            dcn_w = {id(m.regular_conv.weight) for m in self.modules() if isinstance(m, DeformableConv2d)}
+            dcns = [m for m in self.modules() if isinstance(m, DeformableConv2d)]
+            dcn_w = {id(m.regular_conv.weight) for m in dcns}
+            dcn_om = {id(c.weight) for m in dcns for c in (m.offset_conv, m.modulator_conv)}
             items = []
             for m in self.modules():
-                if isinstance(m, nn.Conv2d) and m.weight.requires_grad and m.weight.is_cuda:
+                if isinstance(m, nn.Conv2d) and m.weight.requires_grad and m.weight.is_cuda and id(m.weight) not in dcn_om:
                     M, C, KH, KW = m.weight.shape
                     items.append((m.weight, (M, C * KH * KW, 1, 1) if id(m.weight) in dcn_w else (M, C, KH, KW)))
+            for m in dcns:
+                # the offset + modulator conv is ONE 27-channel conv over the merged weight (dcn.DeformableConv2d._merged): its
+                # input gradient reads the merged tensor's flipped layout; the offset parameter (its leading rows) carries the version
+                if m.offset_conv.weight.requires_grad and m.offset_conv.weight.is_cuda:
+                    w27 = m._merged()[0]
+                    items.append((m.offset_conv.weight, tuple(w27.shape), w27))
+            self.__dict__["_flip_dcn"] = [(m, e[2]) for m, e in zip([m for m in dcns if m.offset_conv.weight.requires_grad and m.offset_conv.weight.is_cuda],
+                                                                     [e for e in items if len(e) > 2])]
             fw = self.__dict__["_flipped"] = ops.FlippedWeights(items)
             self.__dict__["_flip_steps"] = 0
         # after two full steps: keep only the weights whose flipped layout was actually requested (the 3x3 layers on the
@@ -90,10 +104,10 @@ class PlaneRecNet(nn.Module):
         # on demand by ops.flip_transpose
         self.__dict__["_flip_steps"] += 1
         if self.__dict__["_flip_steps"] == 3:
-            used = [(w, shp) for w, shp in fw.weights if w.data_ptr() in ops._FLIP_USED]
+            used = [(w, shp, d) for (w, shp), d in zip(fw.weights, fw.data) if d.data_ptr() in ops._FLIP_USED]
             if used and len(used) < len(fw.weights):
-                for w, _ in fw.weights:
-                    ops._FLIPPED.pop(w.data_ptr(), None)
+                for d in fw.data:
+                    ops._FLIPPED.pop(d.data_ptr(), None)
                 fw = self.__dict__["_flipped"] = ops.FlippedWeights(used)
         fw.refresh()
         # transform-domain operands of the 3x3 weights the Winograd path asked for in earlier steps (ops.WinogradWeights)
