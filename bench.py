@@ -352,6 +352,9 @@ def main():
         if graphed:
             raise SystemExit("bench.py: the roofline leg needs eagerly issued launches; combine --graph with --no-roofline")
         branch_streams, ops.BRANCH_STREAMS = ops.BRANCH_STREAMS, False      # one stream: an event pair then times one launch, not its neighbours
+        was_async = ops.WGRAD_ASYNC
+        if train:
+            ops.set_wgrad_async(False)                               # every kernel alone and planned as a stand-alone launch (ops.WGRAD_WGS_ASYNC)
         profiling.enable()
         # Park the stream behind a ~150 ms spin kernel while the host enqueues the bracketed step: with two event records per
         # launch the host is slower than the GPU, and every event pair would otherwise also time the idle wait for the
@@ -367,6 +370,8 @@ def main():
                     if tag is not None:
                         fh.write("%-22s %-44s %6d %9.3f %8.1f %7.1f\n" % (fam, str(tag), n, ms, ms / n * 1e3, work / (ms * 1e-3) / 1e12))
         profiling.disable()
+        if train:
+            ops.set_wgrad_async(was_async)
         ops.BRANCH_STREAMS = branch_streams
         kernels = fams
         dom = max((f for f in fams if f["bound"] == "mfma"), key=lambda f: f["time_ms"])
