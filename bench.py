@@ -416,6 +416,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.config, args.height, args.width, train)
 
+    # The JSON line must be the LAST thing on the job's stdout: RCCL writes its version banner through C stdio, which sits in the
+    # process's buffer until exit when stdout is a pipe -- i.e. it would follow the line.  Every rank flushes C stdio now, rank 0
+    # prints after a barrier, and then every rank points fd 1 at /dev/null for the teardown.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         gb = args.batch * world
         line = {"metric": METRIC, "value": gb * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
@@ -427,6 +435,8 @@ def main():
                 "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
                 "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "kernels": kernels}
         print(json.dumps(line), flush=True)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
     if prefetch is not None:
         prefetch.close()
     if dist.is_initialized():
