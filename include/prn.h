@@ -61,6 +61,9 @@ typedef struct prn_conv_desc {
  * along K: `ws` is a caller-owned workspace of prn_conv2d_fwd_ws_bytes(d) bytes (0 => may be NULL); the split partials
  * are summed in a fixed order, so results are deterministic. */
 int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
+/* 0: the descriptor's forward runs on the MFMA implicit-GEMM kernel; 1: on the direct HBM-bound kernels (3x3 layers with one or two
+ * output channels, or one input channel, over large maps: the depth head) -- for profilers that attribute launches to a roofline. */
+int prn_conv2d_kernel_kind(const prn_conv_desc* d);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
 /* The same with the K-split sum folded into the GEMM launch (no second kernel, one launch less per split layer): `counters` is

@@ -1356,6 +1356,13 @@ int conv_fwd_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, 
 int conv_wgrad_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase);
 }  // namespace
 
+// which kernel family a descriptor's forward / weight gradient runs on: 0 = the MFMA implicit GEMM, 1 = the direct (one thread per
+// pixel, HBM-bound) kernels for one- or two-channel 3x3 layers -- so that a profiler can attribute a launch to the right roofline
+extern "C" int prn_conv2d_kernel_kind(const prn_conv_desc* d) {
+  if (check_desc(d, "prn_conv2d_kernel_kind")) return -1;
+  return (direct_small_m(d) || direct_one_c(d)) ? 1 : 0;
+}
+
 extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                                     const float* addend, float* y, void* ws, void* stream, int phase) {
   return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase);

@@ -319,9 +319,11 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
         # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil),
-                            nbytes=4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0)),
-                            tag=("conv", C, H, W, M, K, stride, mode, dil, B)):
+        direct = lib.prn_conv2d_kernel_kind(ref) == 1       # the one- / two-channel 3x3 layers run on HBM-bound direct kernels, not on the GEMM
+        nb_ = 4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0))
+        with profiling.span("conv3x3_direct" if direct else "conv_igemm_kernel", "hbm" if direct else "mfma",
+                            nb_ if direct else 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil), nbytes=nb_,
+                            tag=None if direct else ("conv", C, H, W, M, K, stride, mode, dil, B)):
             check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 1), "prn_conv2d_fwd")
         if nbytes:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
@@ -342,7 +344,10 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     _, ref, _, nbytes = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     if profiling._enabled:
-        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * M * C * K * K * B * Ho * Wo, tag=("wgrad", C, H, W, M, K, stride, mode, 1, B)):
+        direct = M <= 2 and lib.prn_conv2d_kernel_kind(ref) == 1       # (the one- / two-channel 3x3 layers: direct HBM-bound kernel)
+        with profiling.span("conv3x3_direct" if direct else "conv_wgrad_kernel", "hbm" if direct else "mfma",
+                            4.0 * (x.numel() + dy.numel()) if direct else 2.0 * M * C * K * K * B * Ho * Wo,
+                            tag=None if direct else ("wgrad", C, H, W, M, K, stride, mode, 1, B)):
             check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_conv2d_wgrad")
         if nbytes:
             with profiling.span("reduce_splits_kernel", "hbm", float(nbytes) + 4.0 * dw.numel()):
