@@ -273,6 +273,10 @@ def main():
             t0 = time.perf_counter()
             opt.zero_grad(set_to_none=True)
             targets = pipe["targets"]
+            if os.environ.get("PRN_BENCH_GAP"):                  # GPU time between the end of a step's Adam and the first launch of the next forward
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ph.setdefault("_gap_b", []).append(ev)
             out = run_net(images)
             t3 = time.perf_counter()
             losses = crit(net, *out, inst, depths, targets=targets)
@@ -283,11 +287,27 @@ def main():
             exchange.finish()
             t5 = time.perf_counter()
             opt.step()
+            if os.environ.get("PRN_BENCH_GAP"):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ph.setdefault("_gap_a", []).append(ev)
+                ev = torch.cuda.Event(enable_timing=True)           # (back to back with the previous one: what two adjacent records measure)
+                ev.record()
+                ph.setdefault("_gap_a2", []).append(ev)
             t6 = time.perf_counter()
-            pipe["targets"] = prefetch.get(depths, dev, overlap=True)      # GT-only targets of the NEXT step (prepared by the worker processes)
-            t1 = time.perf_counter()
-            prefetch.submit(inst, hw)                           # targets two steps further ahead: recomputed every step
-            t2 = time.perf_counter()
+            if os.environ.get("PRN_BENCH_PHASES"):                              # how long does `get` wait for the workers' results?
+                tw = time.perf_counter()
+                prefetch.queue[0][0].result()
+                if prefetch.queue[0][1] is not None:
+                    prefetch.queue[0][1].result()
+                ph["get_wait"] = ph.get("get_wait", 0.0) + time.perf_counter() - tw
+            if os.environ.get("PRN_BENCH_FIXED_TARGETS"):                       # (diagnostic only: the same targets every step, nothing fetched)
+                t1 = t2 = time.perf_counter()
+            else:
+                pipe["targets"] = prefetch.get(depths, dev, overlap=True)      # GT-only targets of the NEXT step (prepared by the worker processes)
+                t1 = time.perf_counter()
+                prefetch.submit(inst, hw)                           # targets two steps further ahead: recomputed every step
+                t2 = time.perf_counter()
             t1, t2 = t0 + (t1 - t6), t0 + (t2 - t6)             # (phase report: get / submit durations, fwd measured from t0)
             ph.setdefault("get_ms_per_step", []).append(round((t1 - t0) * 1e3, 1))
             ph.setdefault("host_ms_per_step", []).append(round((t6 - t0) * 1e3, 1))
@@ -334,6 +354,13 @@ def main():
         from planerecnet_amd import parallel as _par
         n_ = max(_par._PROF.get("steps", 1), 1)
         print({k: (round(v / n_ * 1e3, 2) if isinstance(v, float) else v / n_) for k, v in _par._PROF.items()}, file=sys.stderr)
+    if os.environ.get("PRN_BENCH_GAP") and train:
+        ga, gb = ph.pop("_gap_a"), ph.pop("_gap_b")
+        gaps = [a.elapsed_time(b) for a, b in zip(ga[:-1], gb[1:])]
+        ga2 = ph.pop("_gap_a2")
+        print("  of which between two adjacent event records: last ten %s" % [round(a.elapsed_time(b), 2) for a, b in zip(ga[-10:], ga2[-10:])], file=sys.stderr)
+        print("GPU time from the end of Adam to the start of the next forward: mean %.2f ms, last ten %s" % (sum(gaps) / len(gaps), [round(g, 2) for g in gaps[-10:]]),
+              file=sys.stderr)
     if os.environ.get("PRN_BENCH_PHASES") and train:
         evs = ph.pop("_events")
         ph["gpu_ms_per_step"] = [round(a.elapsed_time(b), 1) for a, b in zip(evs[:-1], evs[1:])]

@@ -19,6 +19,7 @@ structure is different:
 """
 import collections
 import os
+import threading
 
 import numpy as np
 import torch
@@ -128,6 +129,9 @@ class PlaneRecNetLoss(nn.Module):
         cell_u, cell_inv, cell_cnt = np.unique(cell_gidx, return_inverse=True, return_counts=True)
         cell_mult = int(cell_cnt.max()) if cell_cnt.size else 1
         return {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
+                # (as a tensor too: built in upload() it would be pageable memory, and a copy from pageable memory blocks the trainer
+                # until the stream it is issued on has caught up -- the GPU then idles ~1 ms per step behind the blocked trainer)
+                "n_pos_f": pin(torch.as_tensor(n_pos, dtype=torch.float32)),
                 # rows of the positive cells in the [B * n_cells, E] matrix of predicted kernels: the distinct ones, and where each
                 # listed cell is among them (a cell claimed by two instances is listed twice); see instance_terms
                 "cell_gidx": pin(torch.from_numpy(cell_u if cell_mult > 1 else cell_gidx)),          # (np.unique sorts: listed order when nothing repeats)
@@ -149,7 +153,7 @@ class PlaneRecNetLoss(nn.Module):
         t.cell_ids = list(up(h["cell_ids"]).split(h["n_pos"]))
         t.cell_gidx, t.cells_unique = up(h["cell_gidx"]), h["cells_unique"]
         t.cell_inv = up(h["cell_inv"]) if h["cell_inv"] is not None else None
-        t.n_pos_dev = up(torch.as_tensor(h["n_pos"], dtype=torch.float32))
+        t.n_pos_dev = up(h["n_pos_f"])
         t.pos_img, t.ins_labels, t.cate_labels = up(h["pos_img"]), up(h["ins_labels"]), up(h["cate_labels"])
         t.vnl = self.vnl.upload(h["vnl"], device) if h["vnl"] is not None else None
         t.lava_gsum = t.lava_adj = None
@@ -525,14 +529,14 @@ class VNL_Loss(nn.Module):
         n_seg = len(seg_len)
         pin = _pin if (pin and torch.cuda.is_available()) else (lambda x: x)
         return {"B": len(host_instances), "n_seg": n_seg, "n_tot": int(seg_len.sum()), "npts": len(host_instances) * H * W,
-                "N": torch.as_tensor(N_per, dtype=torch.float64), "fx": torch.as_tensor(np.asarray(fx), dtype=torch.float64),
-                "fy": torch.as_tensor(np.asarray(fy), dtype=torch.float64),
+                "N": pin(torch.as_tensor(N_per, dtype=torch.float64)), "fx": pin(torch.as_tensor(np.asarray(fx), dtype=torch.float64)),
+                "fy": pin(torch.as_tensor(np.asarray(fy), dtype=torch.float64)),
                 # the two big index arrays travel as int32 over PCIe (12 B per triplet less) and are widened on the device
                 "gid": pin(torch.from_numpy((np.concatenate(gids, 1) if gids else np.zeros((3, 0), np.int64)).astype(np.int32))),
                 "seg": pin(torch.from_numpy(np.repeat(np.arange(n_seg, dtype=np.int32), seg_len))),
-                "seg_start": torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64)),
-                "seg_img": torch.as_tensor(seg_img, dtype=torch.int64), "seg_is_plane": torch.as_tensor(seg_plane, dtype=torch.bool),
-                "seg_normal": torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3))}
+                "seg_start": pin(torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64))),
+                "seg_img": pin(torch.as_tensor(seg_img, dtype=torch.int64)), "seg_is_plane": pin(torch.as_tensor(seg_plane, dtype=torch.bool)),
+                "seg_normal": pin(torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3)))}
 
     @staticmethod
     def upload(h, device):
@@ -778,6 +782,7 @@ class _PipeWorker:
         child.close()
         self.sent = self.received = 0
         self.results = {}
+        self.lock = threading.Lock()                          # results are taken off the pipe by one thread at a time (trainer or receiver thread)
         self._check(self.conn.recv())
 
     @staticmethod
@@ -792,14 +797,15 @@ class _PipeWorker:
         return _PipeFuture(self, self.sent - 1)
 
     def result(self, index):
-        while index not in self.results:
-            r = self._check(self.conn.recv())
-            skel, blob = r[1]
-            if torch.cuda.is_available():
-                blob = _pin(blob)                             # page-locked staging (cannot cross the process boundary): one copy
-            self.results[self.received] = _unpack_tree(skel, blob)
-            self.received += 1
-        return self.results.pop(index)
+        with self.lock:
+            while index not in self.results:
+                r = self._check(self.conn.recv())
+                skel, blob = r[1]
+                if torch.cuda.is_available():
+                    blob = _pin(blob)                         # page-locked staging (cannot cross the process boundary): one copy
+                self.results[self.received] = _unpack_tree(skel, blob)
+                self.received += 1
+            return self.results.pop(index)
 
     def shutdown(self, wait=True, cancel_futures=True):
         try:
@@ -815,10 +821,12 @@ class _PipeWorker:
 class _PipeFuture:
     def __init__(self, worker, index):
         self.worker, self.index, self.value = worker, index, None
+        self.lock = threading.Lock()
 
     def result(self):
-        if self.worker is not None:
-            self.value, self.worker = self.worker.result(self.index), None
+        with self.lock:                                       # fetched once, whoever asks first
+            if self.worker is not None:
+                self.value, self.worker = self.worker.result(self.index), None
         return self.value
 
 
@@ -849,6 +857,19 @@ class TargetPrefetcher:
             self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
             self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
         self.queue = collections.deque()                      # FIFO: submit() batches ahead of time, get() returns the oldest
+        # Results are taken off the pipes (and copied to page-locked staging, ~30 MB per batch of 8) by a receiver thread as soon
+        # as the workers deliver them -- both steps release the GIL -- instead of by the trainer inside get(): 6.8 of the 8.9 ms
+        # that get() cost the trainer per step, at the point where the GPU waits for the next forward pass (bench.py
+        # PRN_BENCH_PHASES=1: get_wait).  PRN_PREFETCH_EARLY=0 restores the in-line receive.
+        self._early = None
+        if self.workers == "process" and os.environ.get("PRN_PREFETCH_EARLY", "1") != "0":
+            self._early = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-recv")
+
+    @staticmethod
+    def _receive(ft, fv):
+        ft.result()
+        if fv is not None:
+            fv.result()
 
     def _start_processes(self):
         import pickle
@@ -899,12 +920,14 @@ class TargetPrefetcher:
         if cfg.use_plane_loss:
             host = [{k: g[k].cpu() for k in ("masks", "plane_paras", "k_matrix")} for g in gt_instances]
             fv = self.pool_v.submit(_worker_vnl, host, hw) if proc else self.pool_v.submit(self.criterion.vnl.prepare_host, host, hw)
-        self.queue.append((ft, fv))
+        self.queue.append((ft, fv, self._early.submit(self._receive, ft, fv) if self._early is not None else None))
 
     def get(self, gt_depths, device, overlap=False):
         """Targets of the OLDEST submitted batch (blocks only if a worker has not finished yet).  Keeping two batches in
         flight hides the workers' latency (~40 ms per batch of 8 next to a ~60 ms step) completely."""
-        ft, fv = self.queue.popleft()
+        ft, fv, early = self.queue.popleft()
+        if early is not None:
+            early.result()                                    # (re-raises a worker failure)
         h = ft.result()
         h["vnl"] = fv.result() if fv is not None else None
         if not overlap or not torch.cuda.is_available():
@@ -919,8 +942,8 @@ class TargetPrefetcher:
             t = self.criterion.upload(h, gt_depths, device)
             t.ready = torch.cuda.Event()
             t.ready.record()
-        for obj in (t, t.vnl):
-            if obj is None:
+        for obj in (t, t.vnl) if ops.GRAD_RECORD_STREAM else ():    # (not needed, and one marker packet on the main stream per tensor
+            if obj is None:                                          # when the targets are released: see ops.GRAD_RECORD_STREAM)
                 continue
             for name in obj.__slots__:
                 v = getattr(obj, name, None)
@@ -932,12 +955,16 @@ class TargetPrefetcher:
     def discard(self):
         """Drop every batch that was submitted but not fetched (end of an epoch, early exit from a loop)."""
         while self.queue:
-            ft, fv = self.queue.popleft()
+            ft, fv, early = self.queue.popleft()
+            if early is not None:
+                early.result()
             ft.result()
             if fv is not None:
                 fv.result()
 
     def close(self):
         wait = self.workers == "process"                     # (worker processes are joined: nothing left behind at exit)
+        if self._early is not None:
+            self._early.shutdown(wait=True, cancel_futures=True)
         self.pool_t.shutdown(wait=wait, cancel_futures=True)
         self.pool_v.shutdown(wait=wait, cancel_futures=True)

@@ -104,6 +104,13 @@ def _bias_grad(needs_grad, bias, dy):
 # switch, the event pair of wait_stream and the record_stream calls cost ~25 us of host time per layer when done one by one
 # (128 layers per step on the autograd thread).  Anything that reads `.grad` (wgrad_join, the gradient exchange) flushes first.
 WGRAD_BATCH = int(os.environ.get("PRN_WGRAD_BATCH", "6"))
+# The gradients are allocated under the side stream and read under the main stream (gradient exchange, optimizer).  Telling the
+# allocator so (record_stream) makes it record one event on the MAIN stream per gradient when zero_grad() releases them: ~330
+# marker packets in a row, 0.9-1.1 ms in which the GPU does nothing between the optimizer and the next forward pass (bench.py
+# PRN_BENCH_GAP=1).  It is not needed: a released block goes back to the side stream's pool, and everything this module (and
+# TargetPrefetcher.get) puts on the side stream is preceded by side.wait_stream(main) -- issued after the release, since the
+# release happens between steps -- so the next writer of the block is ordered after its last reader.  1 restores the records.
+GRAD_RECORD_STREAM = bool(int(os.environ.get("PRN_GRAD_RECORD_STREAM", "0")))
 _PENDING = {}       # raw stream handle -> (stream object, [(weight, inputs, compute)])
 
 
@@ -170,7 +177,8 @@ def _flush_one(e, everything=False):
             for w_, dw_ in pairs:
                 if dw_.shape != w_.shape:
                     dw_ = dw_.view_as(w_)
-                dw_.record_stream(main)                     # read by the optimizer on the main stream after wgrad_join()
+                if GRAD_RECORD_STREAM:
+                    dw_.record_stream(main)                 # read by the optimizer on the main stream after wgrad_join()
                 if w_.grad is None:
                     w_.grad = dw_
                 else:

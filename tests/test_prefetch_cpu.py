@@ -17,7 +17,9 @@ def _host_results(workers, inst, n):
     try:
         for _ in range(n):
             pf.submit(inst, (480, 640))
-            ft, fv = pf.queue.popleft()
+            ft, fv, early = pf.queue.popleft()
+            if early is not None:                                # the receiver thread owns the pipes until it is done
+                early.result()
             out.append((ft.result(), fv.result() if fv is not None else None))
     finally:
         pf.close()
@@ -60,7 +62,7 @@ def test_prefetcher_is_fifo_and_discard_resynchronises():
                 pf.submit(b, (480, 640))
             got = []
             while pf.queue:
-                ft, fv = pf.queue.popleft()
+                ft, fv = pf.queue.popleft()[:2]
                 got.append(ft.result()["ins_labels"])
                 fv.result()
             assert all(torch.equal(a, b) for a, b in zip(got, want)), workers
@@ -69,7 +71,9 @@ def test_prefetcher_is_fifo_and_discard_resynchronises():
             pf.discard()
             assert not pf.queue
             pf.submit(batches[2], (480, 640))
-            ft, fv = pf.queue.popleft()
+            ft, fv, early = pf.queue.popleft()
+            if early is not None:                                # the receiver thread owns the pipes until it is done
+                early.result()
             assert torch.equal(ft.result()["ins_labels"], want[2]), workers
             fv.result()
         finally:

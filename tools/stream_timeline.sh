@@ -13,8 +13,8 @@ rd = csv.DictReader(open(f))
 print("columns:", rd.fieldnames)
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?'), r.get('Stream_Id', '?')) for r in rd]
 rows.sort()
-adam = [s for s, e, n, q, st in rows if 'fused_adam' in n.lower() or 'FusedAdam' in n]
-marks = adam[::14]
+adam = [s for s, e, n, q, st in rows if 'adam_kernel' in n]          # one launch per step (prn_adam_step)
+marks = adam
 for a, b in list(zip(marks[5:-1], marks[6:]))[:4]:
     iv = [r for r in rows if a <= r[0] < b]
     perq = collections.OrderedDict()
