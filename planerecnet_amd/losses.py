@@ -857,12 +857,13 @@ class TargetPrefetcher:
             self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
             self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
         self.queue = collections.deque()                      # FIFO: submit() batches ahead of time, get() returns the oldest
-        # Results are taken off the pipes (and copied to page-locked staging, ~30 MB per batch of 8) by a receiver thread as soon
-        # as the workers deliver them -- both steps release the GIL -- instead of by the trainer inside get(): 6.8 of the 8.9 ms
-        # that get() cost the trainer per step, at the point where the GPU waits for the next forward pass (bench.py
-        # PRN_BENCH_PHASES=1: get_wait).  PRN_PREFETCH_EARLY=0 restores the in-line receive.
+        # PRN_PREFETCH_EARLY=1: results are taken off the pipes (and copied to page-locked staging, ~30 MB per batch of 8) by a
+        # receiver thread as soon as the workers deliver them, instead of by the trainer inside get() (6.8 of the 8.9 ms get() costs
+        # the trainer per step).  Off by default: the trainer's other phases slow down by the same amount (30 -> 38 ms of enqueue
+        # work per step next to the thread), and the step is GPU-bound either way (bench.py 51.66 vs 51.68 ms, train.py 53.6-55.5 vs
+        # 53.2-55.0 ms per iteration).
         self._early = None
-        if self.workers == "process" and os.environ.get("PRN_PREFETCH_EARLY", "1") != "0":
+        if self.workers == "process" and os.environ.get("PRN_PREFETCH_EARLY", "0") == "1":
             self._early = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-recv")
 
     @staticmethod

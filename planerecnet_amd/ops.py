@@ -187,7 +187,8 @@ def _flush_one(e, everything=False):
             # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
     for _, inputs, _ in todo:
         for t in inputs:
-            t.record_stream(side)
+            t.record_stream(side)                          # (their release puts marker packets on the SIDE stream; holding them back
+                                                            # until wgrad_join() instead changed nothing: 51.49 vs 51.55 ms)
 
 
 def wgrad_flush():

@@ -2,6 +2,7 @@
 one does -- SOLOv2 targets and the virtual-normal triplet draws (numpy global RNG stream continued in the worker) -- over
 consecutive batches, and a worker start does not re-run the caller's script."""
 import numpy as np
+import pytest
 import torch
 
 import bench
@@ -49,8 +50,11 @@ def test_process_prefetcher_matches_thread_prefetcher():
     assert not _same(pr[0][1]["gid"], pr[1][1]["gid"])       # consecutive batches draw different triplets
 
 
-def test_prefetcher_is_fifo_and_discard_resynchronises():
-    """get() order == submit() order with several batches in flight; discard() leaves no stale batch behind."""
+@pytest.mark.parametrize("early", ["0", "1"])
+def test_prefetcher_is_fifo_and_discard_resynchronises(early, monkeypatch):
+    """get() order == submit() order with several batches in flight; discard() leaves no stale batch behind.  early=1: worker
+    results are received by the helper thread (PRN_PREFETCH_EARLY) while the caller asks for the same futures."""
+    monkeypatch.setenv("PRN_PREFETCH_EARLY", early)
     set_cfg("PlaneRecNet_50_config")
     crit = PlaneRecNetLoss()
     batches = [bench.synth_batch(1, 480, 640, 1000 + i, torch.device("cpu"))[1] for i in range(3)]
