@@ -283,7 +283,15 @@ def main():
             loss = sum(losses.values()).sum()
             t4 = time.perf_counter()
             loss.backward()
+            if os.environ.get("PRN_BENCH_GAP"):                  # how long does the compute stream wait for the weight-gradient stream?
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ph.setdefault("_join_b", []).append(ev)
             ops.wgrad_join()
+            if os.environ.get("PRN_BENCH_GAP"):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ph.setdefault("_join_a", []).append(ev)
             exchange.finish()
             t5 = time.perf_counter()
             opt.step()
@@ -357,6 +365,9 @@ def main():
     if os.environ.get("PRN_BENCH_GAP") and train:
         ga, gb = ph.pop("_gap_a"), ph.pop("_gap_b")
         gaps = [a.elapsed_time(b) for a, b in zip(ga[:-1], gb[1:])]
+        jb, ja = ph.pop("_join_b"), ph.pop("_join_a")
+        print("GPU time the compute stream waits at wgrad_join (weight-gradient stream still busy): last ten %s" % [round(b.elapsed_time(a), 2) for b, a in zip(jb[-10:], ja[-10:])],
+              file=sys.stderr)
         ga2 = ph.pop("_gap_a2")
         print("  of which between two adjacent event records: last ten %s" % [round(a.elapsed_time(b), 2) for a, b in zip(ga[-10:], ga2[-10:])], file=sys.stderr)
         print("GPU time from the end of Adam to the start of the next forward: mean %.2f ms, last ten %s" % (sum(gaps) / len(gaps), [round(g, 2) for g in gaps[-10:]]),

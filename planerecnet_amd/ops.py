@@ -103,7 +103,7 @@ def _bias_grad(needs_grad, bias, dy):
 # Deferred weight gradients are queued per originating stream and moved to the side stream a few at a time: the stream
 # switch, the event pair of wait_stream and the record_stream calls cost ~25 us of host time per layer when done one by one
 # (128 layers per step on the autograd thread).  Anything that reads `.grad` (wgrad_join, the gradient exchange) flushes first.
-WGRAD_BATCH = int(os.environ.get("PRN_WGRAD_BATCH", "6"))
+WGRAD_BATCH = int(os.environ.get("PRN_WGRAD_BATCH", "4"))       # (3-4: 50.5-50.7 ms/step, 6: 50.7-51.2, 12: 51.3-51.4)
 # The gradients are allocated under the side stream and read under the main stream (gradient exchange, optimizer).  Telling the
 # allocator so (record_stream) makes it record one event on the MAIN stream per gradient when zero_grad() releases them: ~330
 # marker packets in a row, 0.9-1.1 ms in which the GPU does nothing between the optimizer and the next forward pass (bench.py

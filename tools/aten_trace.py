@@ -65,6 +65,9 @@ class Trace(TorchDispatchMode):
         n = t.numel() if isinstance(t, torch.Tensor) and t.is_cuda else -1
         if n < 0:
             return out                                          # host-side op
+        if os.environ.get("ATEN_SHAPES") and n >= 1000000:     # large ops one by one: shape and strides of the first tensor argument
+            a0 = next((a for a in args if isinstance(a, torch.Tensor)), t)
+            where = "%s %s in%s%s" % (where or "(other)", tuple(t.shape), tuple(a0.shape), "" if a0.is_contiguous() else " strided%s" % (tuple(a0.stride()),))
         e = LOG[(PHASE[0], name, where or "(other)")]
         e[0] += 1
         e[1] += n
