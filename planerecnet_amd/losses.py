@@ -857,13 +857,13 @@ class TargetPrefetcher:
             self.pool_t = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-targets")
             self.pool_v = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-vnl")
         self.queue = collections.deque()                      # FIFO: submit() batches ahead of time, get() returns the oldest
-        # PRN_PREFETCH_EARLY=1: results are taken off the pipes (and copied to page-locked staging, ~30 MB per batch of 8) by a
-        # receiver thread as soon as the workers deliver them, instead of by the trainer inside get() (6.8 of the 8.9 ms get() costs
-        # the trainer per step).  Off by default: the trainer's other phases slow down by the same amount (30 -> 38 ms of enqueue
-        # work per step next to the thread), and the step is GPU-bound either way (bench.py 51.66 vs 51.68 ms, train.py 53.6-55.5 vs
-        # 53.2-55.0 ms per iteration).
+        # Results are taken off the pipes (and copied to page-locked staging, ~30 MB per batch of 8) by a receiver thread as soon
+        # as the workers deliver them -- both steps release the GIL -- instead of by the trainer inside get(): the trainer's enqueue
+        # work per step drops from 42-43 to 35-37 ms against a 51-52 ms GPU step (tools/host_vs_gpu.py, H).  The step itself is
+        # GPU-bound either way on a quiet host (bench.py 51.66 vs 51.68 ms); the margin is what a busy host eats into.
+        # PRN_PREFETCH_EARLY=0: receive in line.
         self._early = None
-        if self.workers == "process" and os.environ.get("PRN_PREFETCH_EARLY", "0") == "1":
+        if self.workers == "process" and os.environ.get("PRN_PREFETCH_EARLY", "1") != "0":
             self._early = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-recv")
 
     @staticmethod
