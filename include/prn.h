@@ -276,6 +276,16 @@ int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const flo
 int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma, const float* beta,
                float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
                int B, int C, int HW, int relu, int frozen, void* stream);
+/* The same two with the layer's OUTPUT (forward) / output GRADIENT (backward) being a channel slice of a wider tensor: element
+ * (b, c, p) at y[b * y_batch_stride + c * HW + p] (stride >= C*HW; a multiple of 4 and a 16-byte aligned slice when HW % 4 == 0).  Two layers whose outputs the
+ * reference concatenates along the channels (planerecnet.py:DepthDecoder_FPN: torch.cat([lateral, x], 1)) write into /
+ * read from the two halves of one buffer: no concatenation kernel, no slice copies of the gradient. */
+int prn_bn_train_fwd_into(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
+                          int64_t y_batch_stride, float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps,
+                          float momentum, int relu, void* stream);
+int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const float* x, const float* y, const float* stats, const float* gamma,
+                    const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
+                    int B, int C, int HW, int relu, int frozen, void* stream);
 
 /* ---- GroupNorm(32) + ReLU ---------------------------------------------------------------------------------------
  * replaces ATen group_norm fwd/bwd + ReLU: planerecnet.py:340-342,419-421,436-437,450-451,463-464           */

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ res, float* __restrict__ y, int C, int HW, int relu,
                                                        const double* __restrict__ ws, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                       int S, double count, float eps, float momentum) {
+                                                       int S, double count, float eps, float momentum, int64_t ybs) {
   const int bc = blockIdx.y, c = bc % C;
   float mean_f, istd_f;
   if (FIN) {
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
   const float sc = istd_f * gamma[c], sh = beta[c] - mean_f * sc;
   const size_t base = (size_t)bc * HW;
+  y += (size_t)(bc / C) * ybs + (size_t)c * HW - base;      // y may be a channel slice of a wider tensor (batch stride ybs)
   if ((HW & 3) == 0) {
     const int n4 = HW >> 2;
     const float4* xp = reinterpret_cast<const float4*>(x + base);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ y, const float* __restrict__ stats,
                                                              double* __restrict__ ws, int B, int C, int HW, int relu, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta) {
+                                                             const float* __restrict__ beta, int64_t dbs) {
   // relu: 0 none | 1 mask = (y > 0) read from the forward output | 2 mask recomputed as fmaf(x, sc, sh) > 0 (the forward's
   // own expression; BN + ReLU without a residual), which saves the y read in both backward passes
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
@@ -151,9 +152,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   float s1 = 0.f, s2 = 0.f;
   for (int b = 0; b < B; ++b) {
     const size_t base = ((size_t)b * C + c) * HW;
+    const float* dyb = dy + (size_t)b * dbs + (size_t)c * HW;      // dy may be a channel slice of a wider tensor
     if (vec) {
       for (int p = beg + threadIdx.x * 4; p < end; p += 1024) {
-        float4 g = *reinterpret_cast<const float4*>(dy + base + p);
+        float4 g = *reinterpret_cast<const float4*>(dyb + p);
         const float4 xv = *reinterpret_cast<const float4*>(x + base + p);
         if (relu == 1) {
           const float4 yv = *reinterpret_cast<const float4*>(y + base + p);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       }
     } else {
       for (int p = beg + threadIdx.x; p < end; p += 256) {
-        float g = dy[base + p];
+        float g = dyb[p];
         if (relu == 1 && !(y[base + p] > 0.f)) g = 0.f;
         if (relu == 2 && !(fmaf(x[base + p], sc, sh) > 0.f)) g = 0.f;
         s1 += g; s2 += g * (x[base + p] - mean);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, float* __restrict__ dres, int C, int HW,
                                                            int S, float inv_count, int relu, int frozen, int have_partials,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           const float* __restrict__ beta) {
+                                                           const float* __restrict__ beta, int64_t dbs) {
   const int bc = blockIdx.y, c = bc % C;
   const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
   const float sc = relu == 2 ? gi : 0.f, sh = relu == 2 ? beta[c] - mean * sc : 0.f;     // (see bn_bwd_partial_kernel)
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float m1 = frozen ? 0.f : (float)t1 * inv_count;
   const float m2 = frozen ? 0.f : (float)t2 * inv_count;
   const size_t base = (size_t)bc * HW;
+  dy += (size_t)(bc / C) * dbs + (size_t)c * HW - base;
   if ((HW & 3) == 0) {
     const int n4 = HW >> 2;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
@@ -243,8 +246,9 @@ template <int NV>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
                                                            float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, int HW, float eps,
-                                                           float momentum, int relu) {
+                                                           float momentum, int relu, int64_t ybs) {
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
+  const int64_t ydelta = ybs - (int64_t)C * HW;             // y as a channel slice of a wider tensor: extra elements per image
   // All NV loads are issued before anything is consumed: they are UNCONDITIONAL (a lane past the end re-reads element 0 and
   // zeroes it afterwards).  With "ok ? load : 0" hipcc wrapped every load in an exec-masked branch and waited for it
   // (s_waitcnt vmcnt(0)) before the next one: NV dependent memory round trips per thread (bn_small_bwd: 19.7 us per launch).
@@ -298,7 +302,9 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     float4 o = v[i];
     o.x = fmaf(o.x, sc, sh) + r[i].x; o.y = fmaf(o.y, sc, sh) + r[i].y; o.z = fmaf(o.z, sc, sh) + r[i].z; o.w = fmaf(o.w, sc, sh) + r[i].w;
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    *reinterpret_cast<float4*>(y + off[i]) = o;
+    size_t oy = off[i];
+    if (ydelta) oy += (size_t)(((threadIdx.x + i * 256) * 4) / HW) * ydelta;
+    *reinterpret_cast<float4*>(y + oy) = o;
   }
 }
 
@@ -308,8 +314,9 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int HW, int relu,
-                                                           int frozen) {
+                                                           int frozen, int64_t dbs) {
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
+  const int64_t ddelta = dbs - (int64_t)C * HW;
   const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
   const float sc = relu == 2 ? gi : 0.f, sh = relu == 2 ? beta[c] - mean * sc : 0.f;
   float4 g[NV], xv[NV];
@@ -324,7 +331,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
   // unconditional loads, all issued before use (see bn_small_fwd_kernel)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    g[i] = *reinterpret_cast<const float4*>(dy + off[i]);
+    const int q = threadIdx.x + i * 256;
+    g[i] = *reinterpret_cast<const float4*>(dy + off[i] + (ddelta ? (size_t)((q < n4 ? q * 4 : 0) / HW) * ddelta : 0));
     xv[i] = *reinterpret_cast<const float4*>(x + off[i]);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -560,7 +568,7 @@ extern "C" int prn_bn_apply(const float* x, const float* stats, const float* gam
   if (gx < 1) gx = 1;
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_apply: B*C too large for grid.y");
   hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, const_cast<float*>(stats), gamma, beta,
-                     residual, y, C, HW, relu, (const double*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0.0, 0.f, 0.f);
+                     residual, y, C, HW, relu, (const double*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0.0, 0.f, 0.f, (int64_t)C * HW);
   PRN_CHECK_LAUNCH("prn_bn_apply");
   return 0;
 }
@@ -568,13 +576,22 @@ extern "C" int prn_bn_apply(const float* x, const float* stats, const float* gam
 extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
                                 float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps, float momentum,
                                 int relu, void* stream) {
+  return prn_bn_train_fwd_into(x, stats, gamma, beta, residual, y, (int64_t)C * HW, running_mean, running_var, ws, B, C, HW, eps, momentum, relu, stream);
+}
+
+extern "C" int prn_bn_train_fwd_into(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
+                                     int64_t y_batch_stride, float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps,
+                                     float momentum, int relu, void* stream) {
   PRN_REQUIRE(x && stats && gamma && beta && y && ws && B > 0 && C > 0 && HW > 0, "prn_bn_train_fwd: bad arguments");
+  PRN_REQUIRE(y_batch_stride >= (int64_t)C * HW && ((HW & 3) || ((y_batch_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)),
+              "prn_bn_train_fwd_into: bad output batch stride / alignment");
+  const int64_t ybs = y_batch_stride;
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_train_fwd: B*C too large for grid.y");
   hipStream_t st = (hipStream_t)stream;
   if (bn_small_ok(B, HW)) {                                // whole channel in one workgroup's registers: one launch, one read
     const int nv = cdiv(B * HW / 4, 256);
 #define PRN_BN_SMALL_FWD(NV_) hipLaunchKernelGGL((bn_small_fwd_kernel<NV_>), dim3(C), dim3(256), 0, st, x, stats, gamma, beta, residual, y, \
-                                                 running_mean, running_var, B, C, HW, eps, momentum, relu)
+                                                 running_mean, running_var, B, C, HW, eps, momentum, relu, ybs)
     if (nv <= 3) PRN_BN_SMALL_FWD(3); else if (nv <= 6) PRN_BN_SMALL_FWD(6); else if (nv <= 10) PRN_BN_SMALL_FWD(10); else PRN_BN_SMALL_FWD(12);
 #undef PRN_BN_SMALL_FWD
     PRN_CHECK_LAUNCH("prn_bn_train_fwd/small");
@@ -586,7 +603,7 @@ extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(gx, B * C), dim3(256), 0, st, x, stats, gamma, beta, residual, y, C, HW, relu,
-                     (const double*)ws, running_mean, running_var, S, (double)B * HW, eps, momentum);
+                     (const double*)ws, running_mean, running_var, S, (double)B * HW, eps, momentum, ybs);
   PRN_CHECK_LAUNCH("prn_bn_train_fwd/apply");
   return 0;
 }
@@ -594,7 +611,16 @@ extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma
 extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const float* stats, const float* gamma, const float* beta,
                           float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
                           int B, int C, int HW, int relu, int frozen, void* stream) {
+  return prn_bn_bwd_from(dy, (int64_t)C * HW, x, y, stats, gamma, beta, dx, dres, dgamma, dbeta, ws, B, C, HW, relu, frozen, stream);
+}
+
+extern "C" int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const float* x, const float* y, const float* stats, const float* gamma,
+                               const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
+                               int B, int C, int HW, int relu, int frozen, void* stream) {
   PRN_REQUIRE(dy && x && stats && gamma && dx && ws && B > 0 && C > 0 && HW > 0, "prn_bn_bwd: bad arguments");
+  PRN_REQUIRE(dy_batch_stride >= (int64_t)C * HW && ((HW & 3) || ((dy_batch_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)),
+              "prn_bn_bwd_from: bad gradient batch stride / alignment");
+  const int64_t dbs = dy_batch_stride;
   PRN_REQUIRE(!relu || y || (beta && !dres), "prn_bn_bwd: relu needs the forward output, or beta (and no residual) to recompute its sign");
   if (relu) relu = y ? 1 : 2;
   PRN_REQUIRE((int64_t)B * C <= 65535, "prn_bn_bwd: B*C too large for grid.y");
@@ -602,7 +628,7 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
   if (bn_small_ok(B, HW)) {
     const int nv = cdiv(B * HW / 4, 256);
 #define PRN_BN_SMALL_BWD(NV_) hipLaunchKernelGGL((bn_small_bwd_kernel<NV_>), dim3(C), dim3(256), 0, st, dy, x, y, stats, gamma, beta, dx, dres, dgamma, \
-                                                 dbeta, B, C, HW, relu, frozen)
+                                                 dbeta, B, C, HW, relu, frozen, dbs)
     if (nv <= 3) PRN_BN_SMALL_BWD(3); else if (nv <= 6) PRN_BN_SMALL_BWD(6); else if (nv <= 10) PRN_BN_SMALL_BWD(10); else PRN_BN_SMALL_BWD(12);
 #undef PRN_BN_SMALL_BWD
     PRN_CHECK_LAUNCH("prn_bn_bwd/small");
@@ -611,13 +637,13 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
   const int S = bn_splits(B, HW);
   const int have = (!frozen || dgamma || dbeta) ? 1 : 0;
   if (have) {
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu, gamma, beta);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu, gamma, beta, dbs);
     PRN_CHECK_LAUNCH("prn_bn_bwd/partial");
   }
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, st, dy, x, y, stats, gamma, (const double*)ws, dx, dres, C, HW,
-                     S, 1.f / ((float)B * HW), relu, frozen, have, dgamma, dbeta, beta);
+                     S, 1.f / ((float)B * HW), relu, frozen, have, dgamma, dbeta, beta, dbs);
   PRN_CHECK_LAUNCH("prn_bn_bwd/apply");
   return 0;
 }

@@ -263,6 +263,7 @@ class PlaneRecNet(nn.Module):
 
 
 RAGGED_HEADS = bool(int(os.environ.get("PRN_RAGGED_HEADS", "1")))
+BN_CAT = bool(int(os.environ.get("PRN_BN_CAT", "1")))      # 0: BatchNorm outputs concatenated by torch.cat (cross-check)
 PLANE_PRIOR_BLOCK = bool(int(os.environ.get("PRN_PLANE_PRIOR_BLOCK", "1")))      # 0: the operator-by-operator plane prior (cross-check)
 
 
@@ -437,15 +438,26 @@ class DepthDecoder_FPN(nn.Module):
         self.refine_conv = block(512, 128, False)
 
     @staticmethod
-    def _cbr(seq, x):
-        """[Upsample] -> ReflectionPad -> Conv -> BN -> ReLU as one gathered conv + one BN launch."""
+    def _cbr(seq, x, defer_bn=False):
+        """[Upsample] -> ReflectionPad -> Conv -> BN -> ReLU as one gathered conv + one BN launch.
+        defer_bn: return (conv output, BatchNorm module) -- the caller normalises two such outputs into one buffer (_bn_cat)."""
         mods = list(seq)
         up = isinstance(mods[0], nn.Upsample)
         conv, bn = mods[2 if up else 1], mods[3 if up else 2]
         if can_fold(bn) and not up:                       # inference: BatchNorm folded into the conv, ReLU in its epilogue
             return conv_bn(x, conv, bn, 1, 1, relu=True, in_mode=ops.IN_REFLECT)
         y = ops.conv2d(x, conv.weight, conv.bias, pad=1, in_mode=ops.IN_UP2_REFLECT if up else ops.IN_REFLECT)
+        if defer_bn:
+            return y, bn
         return ops.batch_norm_module(bn, y, None, True)
+
+    def _defer_bn(self, x):
+        """Training-mode BatchNorm layers whose outputs are concatenated write straight into the concatenated buffer (ops.batch_norm_relu_cat)."""
+        return BN_CAT and x.is_cuda and all(seq[-2].training for seq in (self.conv2, self.conv3, self.conv4, self.refine_conv, self.deconv2, self.deconv3))
+
+    @staticmethod
+    def _bn_cat(a, b):
+        return ops.batch_norm_relu_cat(a[1], a[0], b[1], b[0]) if isinstance(a, tuple) else torch.cat([a, b], 1)
 
     def _centre_index(self, n, device):
         """Indices {4k+1, 4k+2}: the two centre samples of every 4-block (what the x0.25 bilinear resize reads). Cached per
@@ -480,17 +492,19 @@ class DepthDecoder_FPN(nn.Module):
         lateral -> conv branches."""
         c2, c3, c4, c5 = feature_maps
         lat = lambda m, f: ops.conv2d(f, m.weight, m.bias)
+        d = self._defer_bn(c2)
         return [lambda: self._cbr(self.deconv1, self._cbr(self.conv1, lat(self.latlayer1, c5))),
-                lambda: self._cbr(self.conv2, lat(self.latlayer2, c4)),
-                lambda: self._cbr(self.conv3, lat(self.latlayer3, c3)),
-                lambda: self._cbr(self.conv4, lat(self.latlayer4, c2))]
+                lambda: self._cbr(self.conv2, lat(self.latlayer2, c4), d),
+                lambda: self._cbr(self.conv3, lat(self.latlayer3, c3), d),
+                lambda: self._cbr(self.conv4, lat(self.latlayer4, c2), d)]
 
     def forward(self, feature_maps, seg_preds, kernel_preds):
         prior = self.plane_prior(seg_preds, kernel_preds)
         x, l2, l3, l4 = [b() for b in self.branches(feature_maps)]
-        x = self._cbr(self.refine_conv, torch.cat([x, x * prior], 1))
-        x = self._cbr(self.deconv2, torch.cat([l2, x], 1))
-        x = self._cbr(self.deconv3, torch.cat([l3, x], 1))
-        x = self._cbr(self.deconv4, torch.cat([l4, x], 1))
+        d = isinstance(l2, tuple)                            # training: (conv output, BatchNorm) pairs, normalised into the concatenated buffer
+        x = self._cbr(self.refine_conv, torch.cat([x, x * prior], 1), d)
+        x = self._cbr(self.deconv2, self._bn_cat(l2, x), d)
+        x = self._cbr(self.deconv3, self._bn_cat(l3, x), d)
+        x = self._cbr(self.deconv4, self._bn_cat(l4, x))
         c = self.depth_pred[1]
         return F.softplus(ops.conv2d(x, c.weight, c.bias, pad=1, in_mode=ops.IN_REFLECT))

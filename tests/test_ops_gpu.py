@@ -474,6 +474,45 @@ def test_batch_norm_fwd_bwd(B, C, H, W, res, relu, training):
         close(g1, g0, "bn " + n, rtol=5e-4)
 
 
+@pytest.mark.parametrize("B,Ca,Cb,H,W", [(4, 64, 32, 15, 20), (2, 128, 128, 60, 80), (3, 5, 9, 7, 9), (8, 16, 24, 30, 40)])
+def test_batch_norm_relu_cat_equals_two_layers_and_cat(B, Ca, Cb, H, W):
+    """cat([relu(bn_a(xa)), relu(bn_b(xb))], 1) with both layers writing into / reading from channel slices of one buffer
+    (prn_bn_train_fwd_into / prn_bn_bwd_from): one-pass kernels (<= 12288 values per channel) and the two-launch path, HW % 4 != 0."""
+    from planerecnet_amd import ops
+    d = dev()
+    mods, xs, ref_in = [], [], []
+    for k, C in enumerate((Ca, Cb)):
+        m = torch.nn.BatchNorm2d(C, eps=0.001, momentum=0.01)
+        with torch.no_grad():
+            m.weight.copy_(rnd(C, seed=10 + k) * 0.2 + 1)
+            m.bias.copy_(rnd(C, seed=20 + k, scale=0.2))
+            m.running_mean.copy_(rnd(C, seed=30 + k, scale=0.1))
+            m.running_var.copy_(rnd(C, seed=40 + k).abs() + 0.5)
+        mods.append(m)
+        xs.append(rnd(B, C, H, W, seed=50 + k) * 1.5 + 0.3)
+    import copy
+    ref = [copy.deepcopy(m).double().train() for m in mods]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    yr = torch.cat([F.relu(ref[0](xr[0])), F.relu(ref[1](xr[1]))], 1)
+    go = rnd(*yr.shape, seed=7)
+    gr = torch.autograd.grad(yr, xr + [ref[0].weight, ref[0].bias, ref[1].weight, ref[1].bias], go)
+    dm = [m.float().to(d).train() for m in mods]
+    xd = [x.float().to(d).requires_grad_(True) for x in xs]
+    yd = ops.batch_norm_relu_cat(dm[0], xd[0], dm[1], xd[1])
+    assert yd.shape == yr.shape and yd.is_contiguous()
+    close(yd, yr, "bn-cat fwd")
+    for k in range(2):
+        close(dm[k].running_mean, ref[k].running_mean, "running_mean %d" % k)
+        close(dm[k].running_var, ref[k].running_var, "running_var %d" % k)
+    gd = torch.autograd.grad(yd, xd + [dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias], go.float().to(d))
+    for n, g1, g0 in zip(["dxa", "dxb", "dgamma_a", "dbeta_a", "dgamma_b", "dbeta_b"], gd, gr):
+        close(g1, g0, "bn-cat " + n, rtol=5e-4)
+    # bit-identical to the two separate layers followed by torch.cat (same kernels, other addresses)
+    dm2 = [copy.deepcopy(m).float().to(d).train() for m in mods]
+    y2 = torch.cat([ops.batch_norm_module(dm2[0], xd[0].detach(), None, True), ops.batch_norm_module(dm2[1], xd[1].detach(), None, True)], 1)
+    assert torch.equal(yd.detach(), y2)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 256, 16, 16), (2, 128, 30, 40), (1, 128, 9, 7), (1, 128, 96, 88)])   # last: 1024-thread blocks
 def test_group_norm_relu_fwd_bwd(B, C, H, W):
     from planerecnet_amd import ops
