@@ -43,6 +43,18 @@ def _coord_channels(feat):
     return c
 
 
+def _coord_channels_resized(feat, size):
+    """resize_bilinear(_coord_channels(feat), size), cached: the resize works channel by channel, so
+    resize(cat([feat, coords])) == cat([resize(feat), resize(coords)]) bit for bit -- and the second part is a constant."""
+    B, _, h, w = feat.shape
+    key = (B, h, w, feat.device, int(size[0]), int(size[1]))
+    c = _COORD.get(key)
+    if c is None:
+        with torch.no_grad():
+            c = _COORD[key] = ops.resize_bilinear(_coord_channels(feat), size).contiguous()
+    return c
+
+
 def _conv_gn_relu(x, conv, gn):
     return ops.group_norm_relu(ops.conv2d(x, conv.weight, conv.bias, pad=conv.padding[0]), gn.weight, gn.bias, gn.num_groups, gn.eps)
 
@@ -299,10 +311,9 @@ class SOLOv2InsHead(nn.Module):
         return x
 
     def _level(self, idx, feat):
-        kf = torch.cat([feat, _coord_channels(feat)], 1)
         g = self.num_grids[idx]
-        kf = ops.resize_bilinear(kf, (g, g))
-        cf = kf[:, :-2]
+        cf = ops.resize_bilinear(feat, (g, g))               # (the coordinate channels are resized once: _coord_channels_resized)
+        kf = torch.cat([cf, _coord_channels_resized(feat, (g, g))], 1)
         kf = self._tower(self.kernel_tower, kf)
         kp = ops.conv2d(kf, self.kernel_pred.weight, self.kernel_pred.bias, pad=1)
         cf = self._tower(self.cate_tower, cf)
@@ -321,16 +332,20 @@ class SOLOv2InsHead(nn.Module):
         (40^2 .. 12^2 cells) give one GEMM over 3872 cells per image instead of five small ones, and the weight gradients
         come out of one launch instead of five launches plus four accumulation kernels per parameter."""
         B = features[0].shape[0]
-        kfs = []
+        kfs, cfs = [], []
         for idx, feat in enumerate(features):
             g = self.num_grids[idx]
-            kfs.append(ops.resize_bilinear(torch.cat([feat, _coord_channels(feat)], 1), (g, g)))
+            # resize(cat([feat, coords])) == cat([resize(feat), resize(coords)]): the 256 feature channels are not copied at the
+            # level's own resolution just to append two constant channels (23 M elements per step), and the gradient of the
+            # resize arrives as a whole tensor instead of a channel slice that needs a copy
+            cfs.append(ops.resize_bilinear(feat, (g, g)))
+            kfs.append(torch.cat([cfs[-1], _coord_channels_resized(feat, (g, g))], 1))
         rs = self.__dict__.setdefault("_rs", {}).get(B)
         if rs is None:
             rs = self._rs[B] = ops.RaggedShape(B, [(g, g) for g in self.num_grids])
         if not rs.supported():
             return None
-        kp, cp = rs.pack(kfs), rs.pack([k[:, :-2] for k in kfs])
+        kp, cp = rs.pack(kfs), rs.pack(cfs)
 
         def tower(t, x):
             mods = list(t)
