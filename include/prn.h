@@ -311,6 +311,10 @@ int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, in
  * (planerecnet.py:431-441: `feature_add_all_level += self.convs_all_levels[i](...)`, every level but the first ends in an
  * nn.Upsample) without a separate add pass per level. */
 int prn_resize_bilinear_add_fwd(const float* x, const float* addend, float* y, int BC, int H, int W, int Ho, int Wo, void* stream);
+/* dx = resize^T(dy) + addend: `addend` ([BC, H, W], optional) is another gradient of the resized tensor (the FPN lateral that also
+ * feeds its level's 3x3 conv, fpn.py:51-56; the finest FPN map that feeds the mask head AND split_feats, planerecnet.py:98-100):
+ * summed here instead of by autograd's separate accumulation pass over the full-size map. */
+int prn_resize_bilinear_bwd_add(const float* dy, const float* addend, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream);
 /* MaxPool2d(3, stride 2, pad 1): models/backbone.py:104 */
 int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int BC, int H, int W, int Ho, int Wo, void* stream);
 /* arg (may be NULL in the forward): window position r*3+s of every output's maximum, one byte per output; the backward

@@ -131,6 +131,7 @@ SIGNATURES = {
     "prn_resize_bilinear_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
     "prn_resize_bilinear_bwd": (c_int, [P, P] + [c_int] * 5 + [P]),
     "prn_resize_bilinear_add_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+    "prn_resize_bilinear_bwd_add": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_bwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
 }

@@ -44,7 +44,7 @@ __device__ __forceinline__ void cand_range(int i, int out, float scale, int& lo,
   if (i == 0) lo = 0;
 }
 
-__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total,
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ addend, float* __restrict__ dx, int64_t total,
                                                          int H, int W, int Ho, int Wo, float sh, float sw) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
     }
     acc += wh * row;
   }
-  dx[i] = acc;
+  dx[i] = addend ? acc + addend[i] : acc;
 }
 
 // ---- exact factor-2 cases (FPN bottom-up path and split_feats: x0.5; mask-head levels and the depth loss: x2).  Same
@@ -85,13 +85,16 @@ __global__ __launch_bounds__(256) void resize_down2_fwd_kernel(const float* __re
   y[i] = 0.5f * (0.5f * r0.x + 0.5f * r0.y) + 0.5f * (0.5f * r1.x + 0.5f * r1.y);
 }
 
-__global__ __launch_bounds__(256) void resize_down2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void resize_down2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ addend, float* __restrict__ dx, int64_t total, int Ho, int Wo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per PAIR of input pixels (2h', 2wo), (2h', 2wo+1)
   if (i >= total) return;
   const int wo = i % Wo, h = (i / Wo) % (2 * Ho);
   const int64_t bc = i / ((int64_t)Wo * 2 * Ho);
   const float g = 0.5f * (0.5f * dy[(bc * Ho + (h >> 1)) * (int64_t)Wo + wo]);
-  *reinterpret_cast<float2*>(dx + (bc * 2 * Ho + h) * (int64_t)(2 * Wo) + 2 * wo) = make_float2(g, g);
+  const int64_t o = (bc * 2 * Ho + h) * (int64_t)(2 * Wo) + 2 * wo;
+  float2 r = make_float2(g, g);
+  if (addend) { const float2 a = *reinterpret_cast<const float2*>(addend + o); r.x += a.x; r.y += a.y; }      // another gradient of the same tensor
+  *reinterpret_cast<float2*>(dx + o) = r;
 }
 
 // adjoint of the x2 upsample: input (i, j) is touched by output rows 2i-1 .. 2i+2 with weights .25 .75 .75 .25 (1.0 where the
@@ -103,7 +106,7 @@ __device__ __forceinline__ float up2_weight(int o, int i, int in) {         // w
   return (base - 1 == i ? 0.25f : 0.f) + (base == i ? 0.75f : 0.f);
 }
 
-__global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int H, int W) {
+__global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ addend, float* __restrict__ dx, int64_t total, int H, int W) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int w = i % W, h = (i / W) % H;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __rest
     for (int ow = wlo; ow <= whi; ++ow) row += up2_weight(ow, w, W) * p[(int64_t)oh * Wo + ow];
     acc += wh * row;
   }
-  dx[i] = acc;
+  dx[i] = addend ? acc + addend[i] : acc;
 }
 
 // arg (optional): position r*3+s of the maximum inside the window (first maximum in scan order, ATen's
@@ -191,19 +194,23 @@ extern "C" int prn_resize_bilinear_add_fwd(const float* x, const float* addend, 
 }
 
 extern "C" int prn_resize_bilinear_bwd(const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
+  return prn_resize_bilinear_bwd_add(dy, nullptr, dx, BC, H, W, Ho, Wo, stream);
+}
+
+extern "C" int prn_resize_bilinear_bwd_add(const float* dy, const float* addend, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_bwd: bad arguments");
   const int64_t n = (int64_t)BC * H * W;
-  if (H == 2 * Ho && W == 2 * Wo && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {
-    hipLaunchKernelGGL(resize_down2_bwd_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n / 2, Ho, Wo);
+  if (H == 2 * Ho && W == 2 * Wo && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(addend)) & 7) == 0) {
+    hipLaunchKernelGGL(resize_down2_bwd_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n / 2, Ho, Wo);
     PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd/down2");
     return 0;
   }
   if (Ho == 2 * H && Wo == 2 * W) {
-    hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W);
+    hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n, H, W);
     PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd/up2");
     return 0;
   }
-  hipLaunchKernelGGL(resize_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n, H, W, Ho, Wo, (float)H / Ho, (float)W / Wo);
   PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd");
   return 0;
 }

@@ -48,7 +48,10 @@ class FPN(nn.Module):
         laterals, prev, idents = [], None, list(inputs)
         for i, lat in enumerate(self.lateral_convs):
             f = inputs[i + self.start_level]
-            add = None if prev is None else ops.resize_bilinear(prev, f.shape[2:])
+            add = None
+            if prev is not None:
+                # the lateral also feeds its level's 3x3 conv: that gradient joins the resize's backward kernel (resize_bilinear_fork)
+                add, laterals[-1] = ops.resize_bilinear_fork(prev, f.shape[2:])
             if return_inputs:
                 prev, idents[i + self.start_level] = ops.conv2d_fork(f, lat.weight, lat.bias, addend=add)
             else:

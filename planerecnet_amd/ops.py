@@ -1407,8 +1407,9 @@ def ragged_group_norm_relu(xp, gamma, beta, groups, eps, rs):
 # ------------------------------------------------------------------------------------------ resampling
 class _Resize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, Ho, Wo, addend=None):
+    def forward(ctx, x, Ho, Wo, addend=None, fork=False):
         _dev(x, addend)
+        x0 = x
         x, addend = _c(x), _c(addend)
         B, C, H, W = x.shape
         y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
@@ -1416,23 +1417,39 @@ class _Resize(torch.autograd.Function):
             assert addend.shape == y.shape, (addend.shape, y.shape)
         check(lib.prn_resize_bilinear_add_fwd(_p(x), _p(addend), _p(y), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_fwd")
         ctx.shape = (B, C, H, W, Ho, Wo)
+        if fork:                                             # second output = the input itself (see _Conv2d.forward)
+            ctx.set_materialize_grads(False)
+            return y, x0
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dfork=None):
         B, C, H, W, Ho, Wo = ctx.shape
+        if dy is None:                                      # only the forked identity was used
+            return dfork, None, None, None, None
         dy = _c(dy)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
-            check(lib.prn_resize_bilinear_bwd(_p(dy), _p(dx), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_bwd")
-        return dx, None, None, (dy if ctx.needs_input_grad[3] else None)
+            check(lib.prn_resize_bilinear_bwd_add(_p(dy), _p(_c(dfork)), _p(dx), B * C, H, W, Ho, Wo, _stream()), "prn_resize_bilinear_bwd")
+        return dx, None, None, (dy if ctx.needs_input_grad[3] else None), None
 
 
 def resize_bilinear(x, size, addend=None):
     """F.interpolate(mode='bilinear', align_corners=False) replacement; size = (Ho, Wo).  addend ([B, C, Ho, Wo]): returns
     resize(x) + addend from the same launch (the level sum of SOLOv2MaskHead)."""
     return _Resize.apply(x, int(size[0]), int(size[1]), addend)
+
+
+RESIZE_FORK = bool(int(os.environ.get("PRN_RESIZE_FORK", "1")))      # 0: autograd sums the two gradients (cross-check)
+
+
+def resize_bilinear_fork(x, size):
+    """`y, x_id = resize_bilinear_fork(x, size)`: use x_id wherever else x is consumed; the gradient arriving there is then summed
+    inside the resize's backward kernel instead of by autograd's accumulation pass (conv2d_fork's counterpart for the FPN maps)."""
+    if not (RESIZE_FORK and x.requires_grad and torch.is_grad_enabled()):
+        return _Resize.apply(x, int(size[0]), int(size[1]), None), x
+    return _Resize.apply(x, int(size[0]), int(size[1]), None, True)
 
 
 class _MaxPool(torch.autograd.Function):

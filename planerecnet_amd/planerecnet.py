@@ -145,7 +145,8 @@ class PlaneRecNet(nn.Module):
             for i, f in zip(self.fpn_indices, fenc):
                 enc[i] = f
         with timer.env("instance head"):
-            ins_feats = self.split_feats([feats[f] for f in range(len(self.instance_in_features))])
+            # (the finest map also feeds the mask head: it gets it back from the forked resize, whose backward kernel sums the two gradients)
+            ins_feats, feats[0] = self.split_feats([feats[f] for f in range(len(self.instance_in_features))], fork=True)
             cate_pred, kernel_pred = self.inst_head(ins_feats)            # five levels on five streams (ops.run_branches)
         with timer.env("mask head"):
             mask_pred = self.mask_head([feats[f] for f in range(len(self.mask_in_features))])
@@ -158,8 +159,11 @@ class PlaneRecNet(nn.Module):
             return self.inference(mask_pred, cate_pred, kernel_pred, depth_pred, x)
 
     @staticmethod
-    def split_feats(feats):
+    def split_feats(feats, fork=False):
         h, w = feats[0].shape[2:]
+        if fork:                                            # -> (features, the first input handed back: ops.resize_bilinear_fork)
+            r, f0 = ops.resize_bilinear_fork(feats[0], (int(h * 0.5), int(w * 0.5)))
+            return (r, feats[1], feats[2], feats[3]), f0
         return (ops.resize_bilinear(feats[0], (int(h * 0.5), int(w * 0.5))), feats[1], feats[2], feats[3])
 
     # ---- weight I/O (planerecnet.py:121-153)

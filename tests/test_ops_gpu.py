@@ -531,6 +531,34 @@ def test_group_norm_relu_fwd_bwd(B, C, H, W):
         close(g1, g0, "gn " + n, rtol=5e-4)
 
 
+@pytest.mark.parametrize("H,W,Ho,Wo", [(12, 16, 6, 8), (6, 8, 12, 16), (15, 20, 24, 24), (5, 7, 3, 4)])
+def test_resize_bilinear_fork_sums_the_second_gradient_in_the_kernel(H, W, Ho, Wo):
+    """y, x_id = resize_bilinear_fork(x): the gradient arriving at x_id is added inside the resize's backward launch
+    (prn_resize_bilinear_bwd_add: x0.5, x2 and generic kernels); also with only one of the two outputs used."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, 5, H, W, seed=1)
+    go, g2 = rnd(2, 5, Ho, Wo, seed=2), rnd(2, 5, H, W, seed=3)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    (gr,) = torch.autograd.grad((yr * go).sum() + (xr * xr * g2).sum(), xr)
+    xd = x.float().to(d).requires_grad_(True)
+    yd, xid = ops.resize_bilinear_fork(xd, (Ho, Wo))
+    close(yd, yr, "resize fork fwd")
+    assert xid.data_ptr() == xd.data_ptr()
+    (gd,) = torch.autograd.grad((yd * go.float().to(d)).sum() + (xid * xid * g2.float().to(d)).sum(), xd)
+    close(gd, gr, "resize fork: both gradients")
+    xd2 = x.float().to(d).requires_grad_(True)
+    yd2, xid2 = ops.resize_bilinear_fork(xd2, (Ho, Wo))
+    (g_only_id,) = torch.autograd.grad((xid2 * g2.float().to(d)).sum(), xd2)
+    close(g_only_id, g2, "resize fork: identity only")
+    xd3 = x.float().to(d).requires_grad_(True)
+    yd3, _ = ops.resize_bilinear_fork(xd3, (Ho, Wo))
+    (g_only_y,) = torch.autograd.grad((yd3 * go.float().to(d)).sum(), xd3)
+    (gr_y,) = torch.autograd.grad((F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=False) * go).sum(), xr)
+    close(g_only_y, gr_y, "resize fork: resized output only")
+
+
 @pytest.mark.parametrize("H,W,Ho,Wo", [(12, 16, 6, 8), (6, 8, 12, 16), (15, 20, 40, 40), (30, 40, 36, 36), (16, 24, 4, 6), (15, 20, 24, 24),
                                         (2, 2, 4, 4), (4, 6, 2, 3), (3, 5, 6, 10), (1, 1, 2, 2)])
 def test_resize_bilinear_fwd_bwd(H, W, Ho, Wo):
