@@ -194,7 +194,8 @@ def _flush_one(e, everything=False):
 def wgrad_flush():
     """Launch every queued weight gradient (on its side stream).  Called by wgrad_join() and by the gradient exchange
     before it reads a bucket's gradients.  (Planning the last launches of a step -- which run after the backward pass, alone -- for
-    full residency again changed nothing: 52.1 vs 52.1 ms.)"""
+    full residency again changed nothing: 52.1 vs 52.1 ms; neither did running every other one of them on the compute stream itself,
+    which idles ~0.5 ms at the join: 50.9-51.4 vs 51.05-51.1 ms.)"""
     for e in list(_PENDING.values()):
         _flush_one(e, everything=True)
 
