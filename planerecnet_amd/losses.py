@@ -864,7 +864,11 @@ class TargetPrefetcher:
         # PRN_PREFETCH_EARLY=0: receive in line.
         self._early = None
         if self.workers == "process" and os.environ.get("PRN_PREFETCH_EARLY", "1") != "0":
-            self._early = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-recv")
+            # (the current device is per-thread state: without the initializer the thread's page-locked allocations would go through
+            # device 0 on every rank of a multi-GPU job)
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+            self._early = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prn-recv",
+                                             initializer=(lambda: torch.cuda.set_device(dev)) if dev is not None else None)
 
     @staticmethod
     def _receive(ft, fv):
