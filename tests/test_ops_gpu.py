@@ -433,6 +433,47 @@ def test_flipped_weights_batched_matches_single():
     assert torch.equal(ops.flip_transpose(ws[0]), ws[0].flip(2, 3).transpose(0, 1).contiguous())
 
 
+def test_side_stream_gradients_survive_block_reuse_without_allocator_registration():
+    """ops.GRAD_RECORD_STREAM = 0 (the default): gradients are allocated under the weight-gradient stream and read under the compute
+    stream WITHOUT Tensor.record_stream.  Stress the case that registration would protect: the compute stream is kept busy so that its
+    reads of the gradients execute late, the gradients are released on the host at once, and the next iteration's side-stream
+    launches ask the allocator for blocks of the same sizes.  Every side-stream batch starts with side.wait_stream(main), so the
+    results must equal, bit for bit, those of the run with the registrations on."""
+    from planerecnet_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    ws = [(torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(d).requires_grad_(True) for _ in range(6)]
+    xs = [torch.randn(4, 64, 40, 40, generator=g).to(d) for _ in range(8)]
+    big = torch.ones(64, 1024, 1024, device=d)                  # 256 MB: each pass over it keeps the compute stream busy
+
+    def run(registered):
+        saved = ops.GRAD_RECORD_STREAM
+        ops.GRAD_RECORD_STREAM = registered
+        ops.set_wgrad_async(True)
+        sums = []
+        try:
+            for it in range(8):
+                h = xs[it]
+                for w in ws:
+                    h = ops.conv2d(h, w, pad=1)
+                h.square().mean().backward()
+                ops.wgrad_join()
+                for _ in range(3):
+                    big.mul_(1.0)
+                sums.append(torch.stack([w.grad.double().sum() for w in ws] + [w.grad.double().abs().max() for w in ws]))
+                for w in ws:
+                    w.grad = None
+        finally:
+            ops.set_wgrad_async(False)
+            ops.GRAD_RECORD_STREAM = saved
+        torch.cuda.synchronize()
+        return torch.stack(sums).cpu()
+
+    a, b = run(False), run(True)
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    assert torch.equal(a, b)
+
+
 def test_deform_conv_zero_offsets_equals_conv():
     from planerecnet_amd import ops
     d = dev()
