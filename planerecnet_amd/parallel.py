@@ -24,6 +24,9 @@ import os as _os
 _PROF = {} if _os.environ.get("PRN_EXCHANGE_PROF") else None      # host time inside the hooks / launches / finish (debugging aid)
 
 
+ALIAS_GRADS = bool(int(_os.environ.get("PRN_EXCHANGE_ALIAS_GRADS", "1")))      # 0: copy the reduced buckets back into the gradient tensors
+
+
 class GradAllReduce:
     def __init__(self, params, bucket_bytes=25 << 20, process_group=None, force=False):
         self.group = process_group
@@ -157,10 +160,18 @@ class GradAllReduce:
             if self.on_gpu:
                 with torch.cuda.stream(self.stream):
                     work.wait()                           # orders the SIDE stream (current here) after RCCL's completion
-                    torch._foreach_copy_([p.grad for p in bucket], self.windows[bi])
+                    if not ALIAS_GRADS:
+                        torch._foreach_copy_([p.grad for p in bucket], self.windows[bi])
             else:
                 work.wait()
-                torch._foreach_copy_([p.grad for p in bucket], self.windows[bi])
+                if not ALIAS_GRADS:
+                    torch._foreach_copy_([p.grad for p in bucket], self.windows[bi])
+            if ALIAS_GRADS:
+                # no copy back: the reduced values stay where RCCL left them and `.grad` becomes the parameter's window of the bucket
+                # buffer (a second pass over all gradients saved; the windows are rewritten by the next step's pack, which the
+                # exchange stream issues after waiting for the compute stream, i.e. after the optimizer has read them)
+                for p, v in zip(bucket, self.windows[bi]):
+                    p.grad = v
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending.clear()
