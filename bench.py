@@ -28,6 +28,12 @@ Extra objects:
   dcn_offsets_run (c3) -- the same step re-timed after giving the DCN offset / modulator convs non-zero weights (~0.6 px r.m.s.
                   offsets): the headline runs at the reference's init state (offset convs zero, models/dcn.py:32-43), where
                   every deformable gather is a regular 3x3 pattern -- the best case for locality.
+
+Diagnostics (environment, stderr only; none of them changes the timed work except FIXED_TARGETS):
+  PRN_BENCH_PHASES=1        host time per phase of a step (get / submit / fwd / loss / bwd / adam) and GPU time per step
+  PRN_BENCH_GAP=1           GPU time between the end of Adam and the next forward's first kernel, and the compute stream's wait at wgrad_join
+  PRN_BENCH_FIXED_TARGETS=1 the same loss targets every step (nothing fetched from the prefetch workers): isolates the boundary work
+  PRN_FORCE_EXCHANGE=1      the gradient exchange (hooks, bucket pack, RCCL all-reduce) with one rank: its overhead before any wire time
 """
 import argparse
 import json
