@@ -15,10 +15,17 @@ def matrix_nms(cate_labels, seg_masks, sum_masks, cate_scores, sigma=2.0, kernel
     n = len(cate_labels)
     if n == 0:
         return []
-    flat = seg_masks.reshape(n, -1).float()
-    inter = flat @ flat.t()
-    area = sum_masks.expand(n, n)
-    iou = (inter / (area + area.t() - inter)).triu(diagonal=1)
+    if seg_masks.is_cuda:
+        # pairwise IoU of the bit-packed masks by AND + popcount (include/prn.h: prn_pairwise_iou) instead of an [n, h*w] x [h*w, n]
+        # float GEMM: the intersections are the same integers and the quotient inter / ((area_i + area_j) - inter) is formed in the same
+        # order, so the matrix is bit-identical (tests/test_eval_metrics.py pins the kernel on the reference's float matmul)
+        from .metrics import mask_iou
+        iou = mask_iou(seg_masks, seg_masks).triu(diagonal=1)
+    else:
+        flat = seg_masks.reshape(n, -1).float()
+        inter = flat @ flat.t()
+        area = sum_masks.expand(n, n)
+        iou = (inter / (area + area.t() - inter)).triu(diagonal=1)
     lab = cate_labels.expand(n, n)
     decay = iou * (lab == lab.t()).float().triu(diagonal=1)
     comp = decay.max(0)[0].expand(n, n).t()

@@ -223,28 +223,37 @@ class PlaneRecNet(nn.Module):
             results.append(self.inference_single_image(pred_masks[b:b + 1].detach(), cate, kern, pred_depths[b:b + 1].detach(), ori_size))
         return results
 
+    def _cell_strides(self, like):
+        """Instance stride of every grid cell (levels concatenated), built once per device."""
+        key = str(like.device)
+        cache = self.__dict__.setdefault("_cell_stride_cache", {})
+        if key not in cache:
+            cache[key] = torch.cat([torch.full((g * g,), float(s), dtype=like.dtype, device=like.device) for g, s in zip(self.num_grids, self.instance_strides)])
+        return cache[key]
+
     def inference_single_image(self, seg_preds, cate_preds, kernel_preds, depth_pred, ori_size):
         result = {"pred_masks": None, "pred_boxes": None, "pred_classes": None, "pred_scores": None, "pred_depth": None}
         result["pred_depth"] = ops.resize_bilinear(depth_pred, ori_size).detach()
-        inds = cate_preds > self.score_threshold
-        cate_scores = cate_preds[inds]
-        if len(cate_scores) == 0:
+        # Every data-dependent selection below is ONE nonzero (one device->host synchronisation) followed by plain gathers: the
+        # reference's boolean-mask indexing (planerecnet.py:213-262) runs a nonzero -- and waits for its size -- per indexed tensor,
+        # ~12 times per image; the selected values are the same.
+        nz = (cate_preds > self.score_threshold).nonzero(as_tuple=False)
+        if nz.shape[0] == 0:
             return result
-        inds = inds.nonzero(as_tuple=False)
-        cate_labels = inds[:, 1]
-        kernel_preds = kernel_preds[inds[:, 0]]
-        strides = torch.cat([kernel_preds.new_full((g * g,), float(s)) for g, s in zip(self.num_grids, self.instance_strides)])
-        strides = strides[inds[:, 0]]
+        cell, cate_labels = nz[:, 0], nz[:, 1]
+        cate_scores = cate_preds[cell, cate_labels]
+        kernel_preds = kernel_preds.index_select(0, cell)
+        strides = self._cell_strides(kernel_preds).index_select(0, cell)
         # dynamic conv: one 1x1 implicit GEMM over the mask features
         seg_preds = ops.conv2d(seg_preds, kernel_preds.reshape(kernel_preds.shape[0], -1, 1, 1).contiguous(),
                                epilogue=ops.EPI_SIGMOID).squeeze(0)
         seg_masks = seg_preds > self.mask_threshold
         sum_masks = seg_masks.sum((1, 2)).float()
-        keep = sum_masks > strides
-        if keep.sum() == 0:
+        kept = (sum_masks > strides).nonzero(as_tuple=False).flatten()
+        if kept.shape[0] == 0:
             return result
-        seg_masks, seg_preds, sum_masks = seg_masks[keep], seg_preds[keep], sum_masks[keep]
-        cate_scores, cate_labels = cate_scores[keep], cate_labels[keep]
+        seg_masks, seg_preds, sum_masks = seg_masks.index_select(0, kept), seg_preds.index_select(0, kept), sum_masks.index_select(0, kept)
+        cate_scores, cate_labels = cate_scores.index_select(0, kept), cate_labels.index_select(0, kept)
         cate_scores = cate_scores * ((seg_preds * seg_masks.float()).sum((1, 2)) / sum_masks)
         order = torch.argsort(cate_scores, descending=True)[: self.max_before_nms]
         seg_masks, seg_preds, sum_masks = seg_masks[order], seg_preds[order], sum_masks[order]
@@ -256,11 +265,12 @@ class PlaneRecNet(nn.Module):
             keep = mask_nms(cate_labels, seg_masks, sum_masks, cate_scores, nms_thr=self.mask_threshold)
         else:
             raise NotImplementedError
-        if keep.sum() == 0:
+        kept = keep.nonzero(as_tuple=False).flatten()
+        if kept.shape[0] == 0:
             return result
-        seg_preds, cate_scores, cate_labels = seg_preds[keep], cate_scores[keep], cate_labels[keep]
-        order = torch.argsort(cate_scores, descending=True)[: self.max_per_img]
-        seg_preds, cate_scores, cate_labels = seg_preds[order], cate_scores[order], cate_labels[order]
+        # (selection and the final ordering in one gather: positions of the kept detections, by descending score)
+        order = kept.index_select(0, torch.argsort(cate_scores.index_select(0, kept), descending=True)[: self.max_per_img])
+        seg_preds, cate_scores, cate_labels = seg_preds.index_select(0, order), cate_scores.index_select(0, order), cate_labels.index_select(0, order)
         seg_masks = ops.resize_bilinear(seg_preds.unsqueeze(0), ori_size).squeeze(0) > self.mask_threshold
         result["pred_scores"], result["pred_classes"], result["pred_masks"] = cate_scores, cate_labels, seg_masks
         # boxes from masks, vectorised (the reference loops over instances with torch.where, planerecnet.py:282-287);
