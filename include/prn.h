@@ -426,6 +426,9 @@ int prn_depth_metrics(const float* pred, const float* gt, double* out, double* w
 int64_t prn_pairwise_iou_ws_bytes(int A, int B, int64_t HW);
 int prn_pairwise_iou(const unsigned char* masks_a, const unsigned char* masks_b, const float* boxes_a, const float* boxes_b, int A, int B, int64_t HW,
                      float* mask_iou, float* box_iou, void* ws, void* stream);
+/* boxes[n,4] = (x0, y0, x1, y1) of the set pixels of n byte masks [n,H,W] (non-zero = set), as floats: the tight boxes the
+ * reference derives per instance with torch.where (planerecnet.py:282-287); (H+W, H+W, -1, -1) for an empty mask. */
+int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, float* boxes, void* stream);
 
 /* ---- optimizer step ------------------------------------------------------------------------------------------------------
  * replaces optimizer.step() of the reference's optim.Adam (train.py:251-256,362; no weight decay, no amsgrad): every

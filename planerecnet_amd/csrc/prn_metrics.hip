@@ -143,6 +143,26 @@ extern "C" int prn_depth_metrics(const float* pred, const float* gt, double* out
 namespace {
 inline size_t iou_words(int64_t HW) { return (size_t)((HW + 31) / 32); }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// Tight boxes of n binary masks (planerecnet.py:282-287: per instance torch.where -> min / max of the set rows and columns).  One
+// workgroup per mask; a mask without a set pixel gets (H + W, H + W, -1, -1), which is what the vectorised torch form yields.
+__global__ __launch_bounds__(256) void mask_boxes_kernel(const unsigned char* __restrict__ masks, float* __restrict__ boxes, int H, int W) {
+  const unsigned char* m = masks + (size_t)blockIdx.x * H * W;
+  int x0 = H + W, y0 = H + W, x1 = -1, y1 = -1;
+  for (int y = threadIdx.x >> 6; y < H; y += 4) {             // a wave per row: coalesced byte reads
+    const unsigned char* row = m + (size_t)y * W;
+    bool any = false;
+    for (int x = threadIdx.x & 63; x < W; x += 64)
+      if (row[x]) { any = true; x0 = min(x0, x); x1 = max(x1, x); }
+    if (any) { y0 = min(y0, y); y1 = max(y1, y); }
+  }
+  __shared__ int sm[4];
+  if (threadIdx.x == 0) { sm[0] = H + W; sm[1] = H + W; sm[2] = -1; sm[3] = -1; }
+  __syncthreads();
+  atomicMin(&sm[0], x0); atomicMin(&sm[1], y0); atomicMax(&sm[2], x1); atomicMax(&sm[3], y1);      // (integers: order-free)
+  __syncthreads();
+  if (threadIdx.x < 4) boxes[(size_t)blockIdx.x * 4 + threadIdx.x] = (float)sm[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" int64_t prn_pairwise_iou_ws_bytes(int A, int B, int64_t HW) {
@@ -172,5 +192,12 @@ extern "C" int prn_pairwise_iou(const unsigned char* masks_a, const unsigned cha
   hipLaunchKernelGGL(pair_iou_kernel, dim3(B, A), dim3(256), 0, st, (const unsigned*)bits, (const unsigned*)(bits ? bits + (size_t)A * words : nullptr),
                      (const unsigned*)area, (const unsigned*)(area ? area + A : nullptr), want_box ? boxes_a : nullptr, boxes_b, mask_iou, box_iou, B, words);
   PRN_CHECK_LAUNCH("prn_pairwise_iou/pairs");
+  return 0;
+}
+
+extern "C" int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, float* boxes, void* stream) {
+  PRN_REQUIRE(masks && boxes && n > 0 && H > 0 && W > 0, "prn_mask_boxes: bad arguments");
+  hipLaunchKernelGGL(mask_boxes_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, masks, boxes, H, W);
+  PRN_CHECK_LAUNCH("prn_mask_boxes");
   return 0;
 }

@@ -83,6 +83,20 @@ def pairwise_iou(masks_a=None, masks_b=None, boxes_a=None, boxes_b=None):
     return miou, biou
 
 
+def mask_boxes(masks):
+    """[n,H,W] binary masks (bool / uint8, on the device) -> [n,4] float (x0, y0, x1, y1) of their set pixels, one launch
+    (reference planerecnet.py:282-287; an empty mask gives (H+W, H+W, -1, -1) like the vectorised torch form)."""
+    if not masks.is_cuda or masks.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError("mask_boxes needs bool / uint8 device masks")
+    n, H, W = masks.shape
+    out = torch.empty(n, 4, device=masks.device, dtype=torch.float32)
+    if n:
+        m = masks.contiguous().view(torch.uint8)
+        stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(masks.device.index))
+        check(lib.prn_mask_boxes(ctypes.c_void_p(m.data_ptr()), n, H, W, ctypes.c_void_p(out.data_ptr()), stream), "prn_mask_boxes")
+    return out
+
+
 def mask_iou(masks_a, masks_b, iscrowd=False):
     """[a,h,w] x [b,h,w] -> [a,b]  (reference models/functions/funcs.py:58-71)."""
     if iscrowd:

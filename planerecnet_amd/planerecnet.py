@@ -216,11 +216,14 @@ class PlaneRecNet(nn.Module):
     def inference(self, pred_masks, pred_cates, pred_kernels, pred_depths, batched_images):
         assert len(pred_cates) == len(pred_kernels)
         results = []
-        for b in range(len(batched_images)):
-            ori_size = tuple(batched_images[b].shape[1:])
-            cate = torch.cat([c[b].reshape(-1, self.num_classes).detach() for c in pred_cates], 0)
-            kern = torch.cat([k[b].permute(1, 2, 0).reshape(-1, self.num_kernels).detach() for k in pred_kernels], 0)
-            results.append(self.inference_single_image(pred_masks[b:b + 1].detach(), cate, kern, pred_depths[b:b + 1].detach(), ori_size))
+        B = len(batched_images)
+        # level concatenation and the depth up-sampling once for the batch (per-image values unchanged: both work image by image)
+        cate = torch.cat([c.detach().reshape(B, -1, self.num_classes) for c in pred_cates], 1)
+        kern = torch.cat([k.detach().permute(0, 2, 3, 1).reshape(B, -1, self.num_kernels) for k in pred_kernels], 1)
+        ori_size = tuple(batched_images[0].shape[1:])
+        depth = ops.resize_bilinear(pred_depths.detach(), ori_size).detach()
+        for b in range(B):
+            results.append(self.inference_single_image(pred_masks[b:b + 1].detach(), cate[b], kern[b], depth[b:b + 1], ori_size, depth_resized=True))
         return results
 
     def _cell_strides(self, like):
@@ -231,9 +234,9 @@ class PlaneRecNet(nn.Module):
             cache[key] = torch.cat([torch.full((g * g,), float(s), dtype=like.dtype, device=like.device) for g, s in zip(self.num_grids, self.instance_strides)])
         return cache[key]
 
-    def inference_single_image(self, seg_preds, cate_preds, kernel_preds, depth_pred, ori_size):
+    def inference_single_image(self, seg_preds, cate_preds, kernel_preds, depth_pred, ori_size, depth_resized=False):
         result = {"pred_masks": None, "pred_boxes": None, "pred_classes": None, "pred_scores": None, "pred_depth": None}
-        result["pred_depth"] = ops.resize_bilinear(depth_pred, ori_size).detach()
+        result["pred_depth"] = depth_pred if depth_resized else ops.resize_bilinear(depth_pred, ori_size).detach()
         # Every data-dependent selection below is ONE nonzero (one device->host synchronisation) followed by plain gathers: the
         # reference's boolean-mask indexing (planerecnet.py:213-262) runs a nonzero -- and waits for its size -- per indexed tensor,
         # ~12 times per image; the selected values are the same.
@@ -256,8 +259,8 @@ class PlaneRecNet(nn.Module):
         cate_scores, cate_labels = cate_scores.index_select(0, kept), cate_labels.index_select(0, kept)
         cate_scores = cate_scores * ((seg_preds * seg_masks.float()).sum((1, 2)) / sum_masks)
         order = torch.argsort(cate_scores, descending=True)[: self.max_before_nms]
-        seg_masks, seg_preds, sum_masks = seg_masks[order], seg_preds[order], sum_masks[order]
-        cate_scores, cate_labels = cate_scores[order], cate_labels[order]
+        seg_masks, seg_preds, sum_masks = seg_masks.index_select(0, order), seg_preds.index_select(0, order), sum_masks.index_select(0, order)
+        cate_scores, cate_labels = cate_scores.index_select(0, order), cate_labels.index_select(0, order)
         if self.nms_type == "matrix":
             cate_scores = matrix_nms(cate_labels, seg_masks, sum_masks, cate_scores, sigma=self.nms_sigma, kernel=self.nms_kernel)
             keep = cate_scores >= self.update_threshold
@@ -273,18 +276,10 @@ class PlaneRecNet(nn.Module):
         seg_preds, cate_scores, cate_labels = seg_preds.index_select(0, order), cate_scores.index_select(0, order), cate_labels.index_select(0, order)
         seg_masks = ops.resize_bilinear(seg_preds.unsqueeze(0), ori_size).squeeze(0) > self.mask_threshold
         result["pred_scores"], result["pred_classes"], result["pred_masks"] = cate_scores, cate_labels, seg_masks
-        # boxes from masks, vectorised (the reference loops over instances with torch.where, planerecnet.py:282-287);
+        # boxes from the masks in one launch (the reference loops over instances with torch.where, planerecnet.py:282-287);
         # returned on the CPU like the reference's default-device torch.zeros (quirk Q11)
-        rows, cols = seg_masks.any(2), seg_masks.any(1)
-        H, W = seg_masks.shape[1:]
-        ar_h = torch.arange(H, device=seg_masks.device)
-        ar_w = torch.arange(W, device=seg_masks.device)
-        big = H + W
-        y0 = torch.where(rows, ar_h, big).min(1)[0]
-        y1 = torch.where(rows, ar_h, -1).max(1)[0]
-        x0 = torch.where(cols, ar_w, big).min(1)[0]
-        x1 = torch.where(cols, ar_w, -1).max(1)[0]
-        result["pred_boxes"] = torch.stack([x0, y0, x1, y1], 1).float().cpu()
+        from .metrics import mask_boxes
+        result["pred_boxes"] = mask_boxes(seg_masks).cpu()
         return result
 
 

@@ -176,3 +176,30 @@ def test_pairwise_iou_rejects_and_empty_sets():
     data = metrics.new_ap_data()                                   # a frame without ground truth: every detection is a miss
     metrics.match_frame(data, m.cpu().numpy(), b.cpu().numpy(), np.array([0.9, 0.5, 0.7], np.float32), 0)
     assert data["mask"][0].hits == [False] * 3 and data["mask"][0].scores == pytest.approx([0.9, 0.7, 0.5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,H,W", [(7, 480, 640), (3, 37, 129), (1, 1, 1), (5, 736, 960)])
+def test_mask_boxes_equal_the_vectorised_torch_form(n, H, W):
+    """prn_mask_boxes against the where / min / max form of the tight boxes (reference planerecnet.py:282-287), incl. an empty mask,
+    single pixels in the corners and sizes that are not multiples of the wave width."""
+    from planerecnet_amd import metrics
+    g = torch.Generator().manual_seed(n * 1000 + W)
+    m = torch.zeros(n, H, W, dtype=torch.bool)
+    for i in range(n):
+        if i == 1:
+            continue                                                # stays empty
+        if i == 2:
+            m[i, H - 1, W - 1] = True                               # one pixel, last row / column
+            continue
+        y0, x0 = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+        y1, x1 = int(torch.randint(y0, H, (1,), generator=g)), int(torch.randint(x0, W, (1,), generator=g))
+        m[i, y0:y1 + 1, x0:x1 + 1] = torch.rand(y1 - y0 + 1, x1 - x0 + 1, generator=g) < 0.3
+        m[i, y0, x0] = True
+    rows, cols = m.any(2), m.any(1)
+    ar_h, ar_w, big = torch.arange(H), torch.arange(W), H + W
+    want = torch.stack([torch.where(cols, ar_w, big).min(1)[0], torch.where(rows, ar_h, big).min(1)[0],
+                        torch.where(cols, ar_w, -1).max(1)[0], torch.where(rows, ar_h, -1).max(1)[0]], 1).float()
+    assert torch.equal(metrics.mask_boxes(m.cuda()).cpu(), want)
+    assert torch.equal(metrics.mask_boxes(m.to(torch.uint8).cuda()).cpu(), want)
+    assert metrics.mask_boxes(m[:0].cuda()).shape == (0, 4)
