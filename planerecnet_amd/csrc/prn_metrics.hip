@@ -163,6 +163,38 @@ __global__ __launch_bounds__(256) void mask_boxes_kernel(const unsigned char* __
   if (threadIdx.x < 4) boxes[(size_t)blockIdx.x * 4 + threadIdx.x] = (float)sm[threadIdx.x];
 }
 
+// Matrix NMS (models/functions/nms.py:15-50) on the [n, n] mask-IoU matrix of detections sorted by score: for detection j,
+//   decay[i][j] = iou[i][j] if i < j and label_i == label_j else 0;  comp_i = max_k decay[k][i];
+//   coef_j = min_i  exp(-sigma decay[i][j]^2) / exp(-sigma comp_i^2)        (gaussian)   |   (1 - decay[i][j]) / (1 - comp_i)   (linear)
+// over ALL i (rows at or below the diagonal contribute 1 / exp(-sigma comp_i^2), as in the dense torch form).  One workgroup, n <= 2048.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void matrix_nms_kernel(const float* __restrict__ iou, const int64_t* __restrict__ labels, const float* __restrict__ scores,
+                                                         float* __restrict__ out, int n, float sigma, int gaussian) {
+  __shared__ float den[2048];
+  __shared__ int64_t lab[2048];
+  for (int j = threadIdx.x; j < n; j += 256) lab[j] = labels[j];
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float comp = 0.f;                                             // (column maximum of a matrix whose diagonal and lower part are 0)
+    for (int i = 0; i < j; ++i) {
+      const float d = lab[i] == lab[j] ? iou[(size_t)i * n + j] : 0.f;
+      comp = fmaxf(comp, d);
+    }
+    den[j] = gaussian ? expf(-sigma * (comp * comp)) : 1.f - comp;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float coef = INFINITY;
+    for (int i = 0; i < n; ++i) {
+      const float d = (i < j && lab[i] == lab[j]) ? iou[(size_t)i * n + j] : 0.f;
+      const float num = gaussian ? expf(-sigma * (d * d)) : 1.f - d;
+      coef = fminf(coef, num / den[i]);
+    }
+    out[j] = scores[j] * coef;
+  }
+}
+#pragma clang fp contract(on)
+
 }  // namespace
 
 extern "C" int64_t prn_pairwise_iou_ws_bytes(int A, int B, int64_t HW) {
@@ -199,5 +231,12 @@ extern "C" int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, f
   PRN_REQUIRE(masks && boxes && n > 0 && H > 0 && W > 0, "prn_mask_boxes: bad arguments");
   hipLaunchKernelGGL(mask_boxes_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, masks, boxes, H, W);
   PRN_CHECK_LAUNCH("prn_mask_boxes");
+  return 0;
+}
+
+extern "C" int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores, int n, float sigma, int gaussian, float* out, void* stream) {
+  PRN_REQUIRE(iou && labels && scores && out && n > 0 && n <= 2048, "prn_matrix_nms: needs 1 <= n <= 2048 (got %d)", n);
+  hipLaunchKernelGGL(matrix_nms_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, iou, labels, scores, out, n, sigma, gaussian);
+  PRN_CHECK_LAUNCH("prn_matrix_nms");
   return 0;
 }

@@ -203,3 +203,28 @@ def test_mask_boxes_equal_the_vectorised_torch_form(n, H, W):
     assert torch.equal(metrics.mask_boxes(m.cuda()).cpu(), want)
     assert torch.equal(metrics.mask_boxes(m.to(torch.uint8).cuda()).cpu(), want)
     assert metrics.mask_boxes(m[:0].cuda()).shape == (0, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,kernel", [(1, "gaussian"), (2, "gaussian"), (37, "gaussian"), (300, "gaussian"), (500, "linear"), (64, "linear")])
+def test_matrix_nms_kernel_equals_the_dense_torch_form_bitwise(n, kernel):
+    """prn_matrix_nms against the dense [n, n] form of models/functions/nms.py:15-50 evaluated with torch on the device (same IoU matrix)."""
+    from planerecnet_amd import metrics
+    g = torch.Generator().manual_seed(n)
+    H, W = 60, 80
+    masks = torch.zeros(n, H, W, dtype=torch.bool)
+    for i in range(n):
+        y0, x0 = int(torch.randint(0, H - 8, (1,), generator=g)), int(torch.randint(0, W - 8, (1,), generator=g))
+        masks[i, y0:y0 + int(torch.randint(4, 30, (1,), generator=g)), x0:x0 + int(torch.randint(4, 40, (1,), generator=g))] = True
+    labels = torch.randint(0, 3, (n,), generator=g)
+    scores = torch.sort(torch.rand(n, generator=g), descending=True)[0]
+    md, ld, sd = masks.cuda(), labels.cuda(), scores.cuda()
+    iou = metrics.mask_iou(md, md)
+    got = metrics.matrix_nms_scores(iou, ld, sd, 2.0, kernel == "gaussian")
+    it = iou.triu(diagonal=1)
+    lab = ld.expand(n, n)
+    decay = it * (lab == lab.t()).float().triu(diagonal=1)
+    comp = decay.max(0)[0].expand(n, n).t()
+    coef = ((1 - decay) / (1 - comp)).min(0)[0] if kernel == "linear" else (torch.exp(-2 * decay ** 2) / torch.exp(-2 * comp ** 2)).min(0)[0]
+    want = sd * coef
+    assert torch.equal(got, want), float((got - want).abs().max())
