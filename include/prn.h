@@ -431,8 +431,9 @@ int prn_pairwise_iou(const unsigned char* masks_a, const unsigned char* masks_b,
 int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, float* boxes, void* stream);
 /* Matrix NMS score decay (models/functions/nms.py:15-50) from the [n, n] mask-IoU matrix of the detections in descending score order
  * (prn_pairwise_iou of the masks with themselves), their labels and scores: out[j] = scores[j] * min_i kernel(decay[i][j]) / kernel(comp_i),
- * gaussian (exp(-sigma x^2)) or linear (1 - x) -- the dense torch form's ~15 [n, n] passes in one launch, same operations per element. */
-int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores, int n, float sigma, int gaussian, float* out, void* stream);
+ * gaussian (exp(-sigma x^2)) or linear (1 - x) -- the dense torch form's ~15 [n, n] passes in two launches, same operations per element.
+ * ws: n floats. */
+int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores, int n, float sigma, int gaussian, float* out, float* ws, void* stream);
 
 /* ---- optimizer step ------------------------------------------------------------------------------------------------------
  * replaces optimizer.step() of the reference's optim.Adam (train.py:251-256,362; no weight decay, no amsgrad): every

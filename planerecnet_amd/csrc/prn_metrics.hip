@@ -144,21 +144,41 @@ namespace {
 inline size_t iou_words(int64_t HW) { return (size_t)((HW + 31) / 32); }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // Tight boxes of n binary masks (planerecnet.py:282-287: per instance torch.where -> min / max of the set rows and columns).  One
-// workgroup per mask; a mask without a set pixel gets (H + W, H + W, -1, -1), which is what the vectorised torch form yields.
-__global__ __launch_bounds__(256) void mask_boxes_kernel(const unsigned char* __restrict__ masks, float* __restrict__ boxes, int H, int W) {
+// workgroup per mask (a frame has a handful of detections: 1024 threads reading 16-byte words, so that one workgroup streams its
+// 300 KB mask in ~20 loads per thread); a mask without a set pixel gets (H + W, H + W, -1, -1) like the vectorised torch form.
+__global__ __launch_bounds__(1024) void mask_boxes_kernel(const unsigned char* __restrict__ masks, float* __restrict__ boxes, int H, int W) {
   const unsigned char* m = masks + (size_t)blockIdx.x * H * W;
   int x0 = H + W, y0 = H + W, x1 = -1, y1 = -1;
-  for (int y = threadIdx.x >> 6; y < H; y += 4) {             // a wave per row: coalesced byte reads
-    const unsigned char* row = m + (size_t)y * W;
-    bool any = false;
-    for (int x = threadIdx.x & 63; x < W; x += 64)
-      if (row[x]) { any = true; x0 = min(x0, x); x1 = max(x1, x); }
-    if (any) { y0 = min(y0, y); y1 = max(y1, y); }
+  if ((W & 15) == 0 && (reinterpret_cast<uintptr_t>(m) & 15) == 0) {          // a 16-byte word never straddles two rows
+    const int words = (H * W) >> 4, wpr = W >> 4;
+    const uint4* q = reinterpret_cast<const uint4*>(m);
+    for (int i = threadIdx.x; i < words; i += 1024) {
+      const uint4 v = q[i];
+      if ((v.x | v.y | v.z | v.w) == 0u) continue;
+      const int y = i / wpr, xb = (i - y * wpr) << 4;
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+      int lo = 16, hi = -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if ((w4[k] >> (8 * t)) & 0xffu) { lo = min(lo, 4 * k + t); hi = max(hi, 4 * k + t); }
+      x0 = min(x0, xb + lo); x1 = max(x1, xb + hi);
+      y0 = min(y0, y); y1 = max(y1, y);
+    }
+  } else {
+    for (int y = threadIdx.x >> 6; y < H; y += 16) {          // a wave per row: coalesced byte reads
+      const unsigned char* row = m + (size_t)y * W;
+      bool any = false;
+      for (int x = threadIdx.x & 63; x < W; x += 64)
+        if (row[x]) { any = true; x0 = min(x0, x); x1 = max(x1, x); }
+      if (any) { y0 = min(y0, y); y1 = max(y1, y); }
+    }
   }
   __shared__ int sm[4];
   if (threadIdx.x == 0) { sm[0] = H + W; sm[1] = H + W; sm[2] = -1; sm[3] = -1; }
   __syncthreads();
-  atomicMin(&sm[0], x0); atomicMin(&sm[1], y0); atomicMax(&sm[2], x1); atomicMax(&sm[3], y1);      // (integers: order-free)
+  if (x1 >= 0) { atomicMin(&sm[0], x0); atomicMin(&sm[1], y0); atomicMax(&sm[2], x1); atomicMax(&sm[3], y1); }      // (integers: order-free)
   __syncthreads();
   if (threadIdx.x < 4) boxes[(size_t)blockIdx.x * 4 + threadIdx.x] = (float)sm[threadIdx.x];
 }
@@ -166,32 +186,45 @@ __global__ __launch_bounds__(256) void mask_boxes_kernel(const unsigned char* __
 // Matrix NMS (models/functions/nms.py:15-50) on the [n, n] mask-IoU matrix of detections sorted by score: for detection j,
 //   decay[i][j] = iou[i][j] if i < j and label_i == label_j else 0;  comp_i = max_k decay[k][i];
 //   coef_j = min_i  exp(-sigma decay[i][j]^2) / exp(-sigma comp_i^2)        (gaussian)   |   (1 - decay[i][j]) / (1 - comp_i)   (linear)
-// over ALL i (rows at or below the diagonal contribute 1 / exp(-sigma comp_i^2), as in the dense torch form).  One workgroup, n <= 2048.
+// over ALL i (rows at or below the diagonal contribute 1 / exp(-sigma comp_i^2), as in the dense torch form).  Two launches (the
+// second needs every comp_i): one WAVE per column j, its lanes stride over the rows, max / min across the wave -- order-free, so the
+// result equals the dense form bit for bit.
 #pragma clang fp contract(off)
-__global__ __launch_bounds__(256) void matrix_nms_kernel(const float* __restrict__ iou, const int64_t* __restrict__ labels, const float* __restrict__ scores,
-                                                         float* __restrict__ out, int n, float sigma, int gaussian) {
-  __shared__ float den[2048];
-  __shared__ int64_t lab[2048];
-  for (int j = threadIdx.x; j < n; j += 256) lab[j] = labels[j];
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += 256) {
-    float comp = 0.f;                                             // (column maximum of a matrix whose diagonal and lower part are 0)
-    for (int i = 0; i < j; ++i) {
-      const float d = lab[i] == lab[j] ? iou[(size_t)i * n + j] : 0.f;
-      comp = fmaxf(comp, d);
-    }
-    den[j] = gaussian ? expf(-sigma * (comp * comp)) : 1.f - comp;
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void matrix_nms_den_kernel(const float* __restrict__ iou, const int64_t* __restrict__ labels, float* __restrict__ den,
+                                                             int n, float sigma, int gaussian) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n) return;
+  const int64_t lj = labels[j];
+  float comp = 0.f;                                               // (column maximum of a matrix whose diagonal and lower part are 0)
+  for (int i = lane; i < j; i += 64) comp = fmaxf(comp, labels[i] == lj ? iou[(size_t)i * n + j] : 0.f);
+  comp = wave_max(comp);
+  if (lane == 0) den[j] = gaussian ? expf(-sigma * (comp * comp)) : 1.f - comp;
+}
+
+__global__ __launch_bounds__(256) void matrix_nms_coef_kernel(const float* __restrict__ iou, const int64_t* __restrict__ labels, const float* __restrict__ scores,
+                                                              const float* __restrict__ den, float* __restrict__ out, int n, float sigma, int gaussian) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n) return;
+  const int64_t lj = labels[j];
+  float coef = INFINITY;
+  for (int i = lane; i < n; i += 64) {
+    const float d = (i < j && labels[i] == lj) ? iou[(size_t)i * n + j] : 0.f;
+    const float num = gaussian ? expf(-sigma * (d * d)) : 1.f - d;
+    coef = fminf(coef, num / den[i]);
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += 256) {
-    float coef = INFINITY;
-    for (int i = 0; i < n; ++i) {
-      const float d = (i < j && lab[i] == lab[j]) ? iou[(size_t)i * n + j] : 0.f;
-      const float num = gaussian ? expf(-sigma * (d * d)) : 1.f - d;
-      coef = fminf(coef, num / den[i]);
-    }
-    out[j] = scores[j] * coef;
-  }
+  coef = wave_min(coef);
+  if (lane == 0) out[j] = scores[j] * coef;
 }
 #pragma clang fp contract(on)
 
@@ -229,14 +262,18 @@ extern "C" int prn_pairwise_iou(const unsigned char* masks_a, const unsigned cha
 
 extern "C" int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, float* boxes, void* stream) {
   PRN_REQUIRE(masks && boxes && n > 0 && H > 0 && W > 0, "prn_mask_boxes: bad arguments");
-  hipLaunchKernelGGL(mask_boxes_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, masks, boxes, H, W);
+  hipLaunchKernelGGL(mask_boxes_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, masks, boxes, H, W);
   PRN_CHECK_LAUNCH("prn_mask_boxes");
   return 0;
 }
 
-extern "C" int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores, int n, float sigma, int gaussian, float* out, void* stream) {
-  PRN_REQUIRE(iou && labels && scores && out && n > 0 && n <= 2048, "prn_matrix_nms: needs 1 <= n <= 2048 (got %d)", n);
-  hipLaunchKernelGGL(matrix_nms_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, iou, labels, scores, out, n, sigma, gaussian);
-  PRN_CHECK_LAUNCH("prn_matrix_nms");
+extern "C" int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores, int n, float sigma, int gaussian, float* out, float* ws,
+                              void* stream) {
+  PRN_REQUIRE(iou && labels && scores && out && ws && n > 0, "prn_matrix_nms: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(matrix_nms_den_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, iou, labels, ws, n, sigma, gaussian);
+  PRN_CHECK_LAUNCH("prn_matrix_nms/den");
+  hipLaunchKernelGGL(matrix_nms_coef_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, iou, labels, scores, (const float*)ws, out, n, sigma, gaussian);
+  PRN_CHECK_LAUNCH("prn_matrix_nms/coef");
   return 0;
 }

@@ -101,11 +101,11 @@ def matrix_nms_scores(iou, labels, scores, sigma, gaussian):
     """Matrix-NMS decayed scores from the [n, n] mask-IoU matrix of detections in descending score order (include/prn.h: prn_matrix_nms)."""
     n = scores.shape[0]
     iou, labels, scores = iou.contiguous(), labels.contiguous().long(), scores.contiguous().float()
-    out = torch.empty_like(scores)
+    out = torch.empty(2, n, device=scores.device, dtype=torch.float32)          # decayed scores | workspace (per-column denominators)
     stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(scores.device.index))
     check(lib.prn_matrix_nms(ctypes.c_void_p(iou.data_ptr()), ctypes.c_void_p(labels.data_ptr()), ctypes.c_void_p(scores.data_ptr()), n, float(sigma),
-                             int(bool(gaussian)), ctypes.c_void_p(out.data_ptr()), stream), "prn_matrix_nms")
-    return out
+                             int(bool(gaussian)), ctypes.c_void_p(out[0].data_ptr()), ctypes.c_void_p(out[1].data_ptr()), stream), "prn_matrix_nms")
+    return out[0]
 
 
 def mask_iou(masks_a, masks_b, iscrowd=False):

@@ -21,8 +21,8 @@ def matrix_nms(cate_labels, seg_masks, sum_masks, cate_scores, sigma=2.0, kernel
         # order, so the matrix is bit-identical (tests/test_eval_metrics.py pins the kernel on the reference's float matmul)
         from .metrics import mask_iou, matrix_nms_scores
         iou = mask_iou(seg_masks, seg_masks)
-        if n <= 2048 and kernel in ("gaussian", "linear"):
-            # the decay of the scores from the IoU matrix in one launch (prn_matrix_nms): the same operations per element as the dense form below
+        if kernel in ("gaussian", "linear"):
+            # the decay of the scores from the IoU matrix in two launches (prn_matrix_nms): the same operations per element as the dense form below
             return matrix_nms_scores(iou, cate_labels, cate_scores, float(sigma), kernel == "gaussian")
         iou = iou.triu(diagonal=1)
     else:

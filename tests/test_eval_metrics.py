@@ -179,7 +179,7 @@ def test_pairwise_iou_rejects_and_empty_sets():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,H,W", [(7, 480, 640), (3, 37, 129), (1, 1, 1), (5, 736, 960)])
+@pytest.mark.parametrize("n,H,W", [(7, 480, 640), (3, 37, 129), (1, 1, 1), (5, 736, 960), (4, 30, 48)])
 def test_mask_boxes_equal_the_vectorised_torch_form(n, H, W):
     """prn_mask_boxes against the where / min / max form of the tight boxes (reference planerecnet.py:282-287), incl. an empty mask,
     single pixels in the corners and sizes that are not multiples of the wave width."""
@@ -206,7 +206,7 @@ def test_mask_boxes_equal_the_vectorised_torch_form(n, H, W):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,kernel", [(1, "gaussian"), (2, "gaussian"), (37, "gaussian"), (300, "gaussian"), (500, "linear"), (64, "linear")])
+@pytest.mark.parametrize("n,kernel", [(1, "gaussian"), (2, "gaussian"), (37, "gaussian"), (300, "gaussian"), (500, "linear"), (64, "linear"), (2500, "gaussian")])
 def test_matrix_nms_kernel_equals_the_dense_torch_form_bitwise(n, kernel):
     """prn_matrix_nms against the dense [n, n] form of models/functions/nms.py:15-50 evaluated with torch on the device (same IoU matrix)."""
     from planerecnet_amd import metrics
