@@ -429,6 +429,10 @@ int prn_pairwise_iou(const unsigned char* masks_a, const unsigned char* masks_b,
 /* boxes[n,4] = (x0, y0, x1, y1) of the set pixels of n byte masks [n,H,W] (non-zero = set), as floats: the tight boxes the
  * reference derives per instance with torch.where (planerecnet.py:282-287); (H+W, H+W, -1, -1) for an empty mask. */
 int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, float* boxes, void* stream);
+/* count[r] = #{seg[r][p] > thr}, msum[r] = sum of those values, for n rows of HW floats: seg_masks.sum((1,2)) and
+ * (seg_preds * seg_masks.float()).sum((1,2)) of the post-process (planerecnet.py:227-240) in one pass; fixed summation order per row,
+ * independent of n. */
+int prn_mask_stats(const float* seg, int n, int64_t HW, float thr, float* count, float* msum, void* stream);
 /* Matrix NMS score decay (models/functions/nms.py:15-50) from the [n, n] mask-IoU matrix of the detections in descending score order
  * (prn_pairwise_iou of the masks with themselves), their labels and scores: out[j] = scores[j] * min_i kernel(decay[i][j]) / kernel(comp_i),
  * gaussian (exp(-sigma x^2)) or linear (1 - x) -- the dense torch form's ~15 [n, n] passes in two launches, same operations per element.

@@ -143,6 +143,27 @@ extern "C" int prn_depth_metrics(const float* pred, const float* gt, double* out
 namespace {
 inline size_t iou_words(int64_t HW) { return (size_t)((HW + 31) / 32); }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// Per soft mask (row of n x HW sigmoid values): number of values above the threshold and their sum -- the reference's
+// seg_masks.sum((1, 2)) and (seg_preds * seg_masks.float()).sum((1, 2)) (planerecnet.py:227-240) in one pass.  One workgroup per
+// row, fixed summation order (strided per-thread partials, then a tree over the 256 partials): the result of a row does not depend
+// on how many rows the launch has, i.e. on which other images share the batch.
+__global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict__ seg, float* __restrict__ count, float* __restrict__ msum, int64_t HW, float thr) {
+  const float* row = seg + (size_t)blockIdx.x * HW;
+  float c = 0.f, s = 0.f;
+  for (int64_t i = threadIdx.x; i < HW; i += 256) {
+    const float v = row[i];
+    if (v > thr) { c += 1.f; s += v; }
+  }
+  __shared__ float sc[256], ss[256];
+  sc[threadIdx.x] = c; ss[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sc[threadIdx.x] += sc[threadIdx.x + o]; ss[threadIdx.x] += ss[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { count[blockIdx.x] = sc[0]; msum[blockIdx.x] = ss[0]; }
+}
+
 // Tight boxes of n binary masks (planerecnet.py:282-287: per instance torch.where -> min / max of the set rows and columns).  One
 // workgroup per mask (a frame has a handful of detections: 1024 threads reading 16-byte words, so that one workgroup streams its
 // 300 KB mask in ~20 loads per thread); a mask without a set pixel gets (H + W, H + W, -1, -1) like the vectorised torch form.
@@ -275,5 +296,12 @@ extern "C" int prn_matrix_nms(const float* iou, const int64_t* labels, const flo
   PRN_CHECK_LAUNCH("prn_matrix_nms/den");
   hipLaunchKernelGGL(matrix_nms_coef_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, iou, labels, scores, (const float*)ws, out, n, sigma, gaussian);
   PRN_CHECK_LAUNCH("prn_matrix_nms/coef");
+  return 0;
+}
+
+extern "C" int prn_mask_stats(const float* seg, int n, int64_t HW, float thr, float* count, float* msum, void* stream) {
+  PRN_REQUIRE(seg && count && msum && n > 0 && HW > 0 && HW < (1LL << 24), "prn_mask_stats: bad arguments (0 < H*W < 2^24: counts are exact floats)");
+  hipLaunchKernelGGL(mask_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, seg, count, msum, HW, thr);
+  PRN_CHECK_LAUNCH("prn_mask_stats");
   return 0;
 }

@@ -83,6 +83,20 @@ def pairwise_iou(masks_a=None, masks_b=None, boxes_a=None, boxes_b=None):
     return miou, biou
 
 
+def mask_stats(seg, thr):
+    """[n,h,w] soft masks -> (count [n], msum [n]) of the values above thr, fp32 (include/prn.h: prn_mask_stats)."""
+    if not seg.is_cuda or seg.dtype != torch.float32:
+        raise RuntimeError("mask_stats needs fp32 device tensors")
+    n = seg.shape[0]
+    out = torch.empty(2, n, device=seg.device, dtype=torch.float32)
+    if n:
+        seg = seg.contiguous()
+        stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(seg.device.index))
+        check(lib.prn_mask_stats(ctypes.c_void_p(seg.data_ptr()), n, int(seg[0].numel()), float(thr), ctypes.c_void_p(out[0].data_ptr()),
+                                 ctypes.c_void_p(out[1].data_ptr()), stream), "prn_mask_stats")
+    return out[0], out[1]
+
+
 def mask_boxes(masks):
     """[n,H,W] binary masks (bool / uint8, on the device) -> [n,4] float (x0, y0, x1, y1) of their set pixels, one launch
     (reference planerecnet.py:282-287; an empty mask gives (H+W, H+W, -1, -1) like the vectorised torch form)."""

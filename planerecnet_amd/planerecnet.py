@@ -214,50 +214,64 @@ class PlaneRecNet(nn.Module):
 
     # ---- post-process (planerecnet.py:155-289)
     def inference(self, pred_masks, pred_cates, pred_kernels, pred_depths, batched_images):
+        """Reference planerecnet.py:155-289 (`inference` + `inference_single_image`) for the whole batch.  The steps that do not mix
+        images -- candidate selection, dynamic mask convolution, mask statistics, the small-mask filter -- run once over the candidates of
+        ALL images (two device->host synchronisations per step for the batch instead of one or more per image); sorting, matrix NMS and
+        the final selection run per image on slices.  Every per-candidate value is computed by an operation that works row by row with a
+        fixed summation order, so an image's result does not depend on what else is in the batch."""
+        from .metrics import mask_boxes, mask_stats
         assert len(pred_cates) == len(pred_kernels)
-        results = []
         B = len(batched_images)
-        # level concatenation and the depth up-sampling once for the batch (per-image values unchanged: both work image by image)
-        cate = torch.cat([c.detach().reshape(B, -1, self.num_classes) for c in pred_cates], 1)
-        kern = torch.cat([k.detach().permute(0, 2, 3, 1).reshape(B, -1, self.num_kernels) for k in pred_kernels], 1)
         ori_size = tuple(batched_images[0].shape[1:])
         depth = ops.resize_bilinear(pred_depths.detach(), ori_size).detach()
-        for b in range(B):
-            results.append(self.inference_single_image(pred_masks[b:b + 1].detach(), cate[b], kern[b], depth[b:b + 1], ori_size, depth_resized=True))
-        return results
-
-    def _cell_strides(self, like):
-        """Instance stride of every grid cell (levels concatenated), built once per device."""
-        key = str(like.device)
-        cache = self.__dict__.setdefault("_cell_stride_cache", {})
-        if key not in cache:
-            cache[key] = torch.cat([torch.full((g * g,), float(s), dtype=like.dtype, device=like.device) for g, s in zip(self.num_grids, self.instance_strides)])
-        return cache[key]
-
-    def inference_single_image(self, seg_preds, cate_preds, kernel_preds, depth_pred, ori_size, depth_resized=False):
-        result = {"pred_masks": None, "pred_boxes": None, "pred_classes": None, "pred_scores": None, "pred_depth": None}
-        result["pred_depth"] = depth_pred if depth_resized else ops.resize_bilinear(depth_pred, ori_size).detach()
-        # Every data-dependent selection below is ONE nonzero (one device->host synchronisation) followed by plain gathers: the
-        # reference's boolean-mask indexing (planerecnet.py:213-262) runs a nonzero -- and waits for its size -- per indexed tensor,
-        # ~12 times per image; the selected values are the same.
-        nz = (cate_preds > self.score_threshold).nonzero(as_tuple=False)
+        results = [{"pred_masks": None, "pred_boxes": None, "pred_classes": None, "pred_scores": None, "pred_depth": depth[b:b + 1]} for b in range(B)]
+        cate = torch.cat([c.detach().reshape(B, -1, self.num_classes) for c in pred_cates], 1)                         # [B, cells, classes]
+        kern = torch.cat([k.detach().permute(0, 2, 3, 1).reshape(B, -1, self.num_kernels) for k in pred_kernels], 1)   # [B, cells, E]
+        pred_masks = pred_masks.detach()
+        # candidates: (image, cell, class) with a category score above the threshold, image-major like the per-image nonzero
+        nz = (cate > self.score_threshold).nonzero(as_tuple=False)
         if nz.shape[0] == 0:
-            return result
-        cell, cate_labels = nz[:, 0], nz[:, 1]
-        cate_scores = cate_preds[cell, cate_labels]
-        kernel_preds = kernel_preds.index_select(0, cell)
-        strides = self._cell_strides(kernel_preds).index_select(0, cell)
-        # dynamic conv: one 1x1 implicit GEMM over the mask features
-        seg_preds = ops.conv2d(seg_preds, kernel_preds.reshape(kernel_preds.shape[0], -1, 1, 1).contiguous(),
-                               epilogue=ops.EPI_SIGMOID).squeeze(0)
-        seg_masks = seg_preds > self.mask_threshold
-        sum_masks = seg_masks.sum((1, 2)).float()
+            return results
+        img, cell, labels = nz[:, 0], nz[:, 1], nz[:, 2]
+        n_img = torch.bincount(img, minlength=B).tolist()
+        scores = cate[img, cell, labels]
+        kernels = kern[img, cell]
+        strides = self._cell_strides(kernels).index_select(0, cell)
+        # dynamic conv: per image one 1x1 implicit GEMM over its mask features (candidates of an image are contiguous)
+        segs, o = [], 0
+        for b in range(B):
+            if n_img[b]:
+                k = kernels[o:o + n_img[b]]
+                segs.append(ops.conv2d(pred_masks[b:b + 1], k.reshape(n_img[b], -1, 1, 1), epilogue=ops.EPI_SIGMOID).squeeze(0))
+                o += n_img[b]
+        seg = segs[0] if len(segs) == 1 else torch.cat(segs, 0)                                                         # [N, h, w]
+        sum_masks, msum = mask_stats(seg, self.mask_threshold)          # pixels above the mask threshold and the sum of their values
         kept = (sum_masks > strides).nonzero(as_tuple=False).flatten()
         if kept.shape[0] == 0:
-            return result
-        seg_masks, seg_preds, sum_masks = seg_masks.index_select(0, kept), seg_preds.index_select(0, kept), sum_masks.index_select(0, kept)
-        cate_scores, cate_labels = cate_scores.index_select(0, kept), cate_labels.index_select(0, kept)
-        cate_scores = cate_scores * ((seg_preds * seg_masks.float()).sum((1, 2)) / sum_masks)
+            return results
+        img = img.index_select(0, kept)
+        n_img = torch.bincount(img, minlength=B).tolist()
+        seg, sum_masks = seg.index_select(0, kept), sum_masks.index_select(0, kept)
+        labels = labels.index_select(0, kept)
+        scores = scores.index_select(0, kept) * (msum.index_select(0, kept) / sum_masks)       # mask-quality ("maskness") weighting
+        seg_masks = seg > self.mask_threshold
+        boxes, o = [], 0
+        for b in range(B):
+            if n_img[b]:
+                sl = slice(o, o + n_img[b])
+                o += n_img[b]
+                boxes.append(self._finish_image(results[b], seg[sl], seg_masks[sl], sum_masks[sl], scores[sl], labels[sl], ori_size))
+        # boxes of all images in one transfer; returned on the CPU like the reference's default-device torch.zeros (quirk Q11)
+        boxes = [(r, bx) for r, bx in boxes if bx is not None]
+        if boxes:
+            host = torch.cat([bx for _, bx in boxes], 0).cpu().split([bx.shape[0] for _, bx in boxes])
+            for (r, _), h in zip(boxes, host):
+                r["pred_boxes"] = h
+        return results
+
+    def _finish_image(self, result, seg_preds, seg_masks, sum_masks, cate_scores, cate_labels, ori_size):
+        """Sort, NMS, final selection, full-size masks and (device) boxes of one image's candidates.  -> (result, boxes | None)"""
+        from .metrics import mask_boxes
         order = torch.argsort(cate_scores, descending=True)[: self.max_before_nms]
         seg_masks, seg_preds, sum_masks = seg_masks.index_select(0, order), seg_preds.index_select(0, order), sum_masks.index_select(0, order)
         cate_scores, cate_labels = cate_scores.index_select(0, order), cate_labels.index_select(0, order)
@@ -270,17 +284,30 @@ class PlaneRecNet(nn.Module):
             raise NotImplementedError
         kept = keep.nonzero(as_tuple=False).flatten()
         if kept.shape[0] == 0:
-            return result
+            return result, None
         # (selection and the final ordering in one gather: positions of the kept detections, by descending score)
         order = kept.index_select(0, torch.argsort(cate_scores.index_select(0, kept), descending=True)[: self.max_per_img])
         seg_preds, cate_scores, cate_labels = seg_preds.index_select(0, order), cate_scores.index_select(0, order), cate_labels.index_select(0, order)
         seg_masks = ops.resize_bilinear(seg_preds.unsqueeze(0), ori_size).squeeze(0) > self.mask_threshold
         result["pred_scores"], result["pred_classes"], result["pred_masks"] = cate_scores, cate_labels, seg_masks
-        # boxes from the masks in one launch (the reference loops over instances with torch.where, planerecnet.py:282-287);
-        # returned on the CPU like the reference's default-device torch.zeros (quirk Q11)
-        from .metrics import mask_boxes
-        result["pred_boxes"] = mask_boxes(seg_masks).cpu()
-        return result
+        # tight boxes of the masks in one launch (the reference loops over instances with torch.where, planerecnet.py:282-287)
+        return result, mask_boxes(seg_masks)
+
+    def _cell_strides(self, like):
+        """Instance stride of every grid cell (levels concatenated), built once per device."""
+        key = str(like.device)
+        cache = self.__dict__.setdefault("_cell_stride_cache", {})
+        if key not in cache:
+            cache[key] = torch.cat([torch.full((g * g,), float(s), dtype=like.dtype, device=like.device) for g, s in zip(self.num_grids, self.instance_strides)])
+        return cache[key]
+
+    def inference_single_image(self, seg_preds, cate_preds, kernel_preds, depth_pred, ori_size):
+        """One image through the post-process (the reference's entry point of the same name, planerecnet.py:199-289):
+        seg_preds [1,E,h,w], cate_preds [cells, classes], kernel_preds [cells, E], depth_pred [1,1,H',W']."""
+        levels = [g * g for g in self.num_grids]
+        cates = [c.reshape(1, g, g, self.num_classes) for c, g in zip(cate_preds.split(levels, 0), self.num_grids)]
+        kerns = [k.reshape(1, g, g, self.num_kernels).permute(0, 3, 1, 2) for k, g in zip(kernel_preds.split(levels, 0), self.num_grids)]
+        return self.inference(seg_preds, cates, kerns, depth_pred, [torch.empty(0, *ori_size, device="meta")])[0]
 
 
 RAGGED_HEADS = bool(int(os.environ.get("PRN_RAGGED_HEADS", "1")))

@@ -228,3 +228,19 @@ def test_matrix_nms_kernel_equals_the_dense_torch_form_bitwise(n, kernel):
     coef = ((1 - decay) / (1 - comp)).min(0)[0] if kernel == "linear" else (torch.exp(-2 * decay ** 2) / torch.exp(-2 * comp ** 2)).min(0)[0]
     want = sd * coef
     assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w", [(1, 60, 80), (9, 120, 160), (40, 17, 23)])
+def test_mask_stats_counts_exact_and_rows_independent_of_the_batch(n, h, w):
+    from planerecnet_amd import metrics
+    g = torch.Generator().manual_seed(n)
+    seg = torch.sigmoid(torch.randn(n, h, w, generator=g) * 2)
+    seg[0, :2] = 0.05                                               # values below the threshold
+    cnt, msum = metrics.mask_stats(seg.cuda(), 0.1)
+    m = seg > 0.1
+    assert torch.equal(cnt.cpu(), m.sum((1, 2)).float())
+    want = (seg.double() * m).sum((1, 2))
+    assert torch.allclose(msum.cpu().double(), want, rtol=2e-6, atol=0)
+    c1, s1 = metrics.mask_stats(seg[n // 2:n // 2 + 1].cuda(), 0.1)   # the same row alone: bit-identical
+    assert torch.equal(c1, cnt[n // 2:n // 2 + 1]) and torch.equal(s1, msum[n // 2:n // 2 + 1])

@@ -190,6 +190,45 @@ def test_inference_matches_oracle(setup):
     net.load_state_dict(sd)
 
 
+def test_batched_post_process_equals_image_by_image(setup):
+    """PlaneRecNet.inference over a batch (candidate selection, mask statistics and the small-mask filter run once over all images)
+    against the same images post-processed one at a time through inference_single_image: every output bit-identical, including an
+    image without candidates and one whose candidates are all filtered out."""
+    net, _, arch = setup
+    g = torch.Generator().manual_seed(21)
+    B, E, h, w = 4, net.inst_head.num_kernels, 60, 80
+    C = net.inst_head.num_classes
+    masks = (torch.randn(B, E, h, w, generator=g) * 0.5).cuda()
+    masks[2] = 1.0                                                  # (with its kernels at -3: every soft mask of image 2 is empty)
+    depth = (torch.rand(B, 1, 2 * h, 2 * w, generator=g) * 4 + 0.3).cuda()
+    cates, kerns = [], []
+    for S in arch.num_grids:
+        c = torch.where(torch.rand(B, S, S, C, generator=g) < 0.02, 0.3 + 0.6 * torch.rand(B, S, S, C, generator=g), torch.zeros(B, S, S, C))
+        c[1] = 0.0                                                  # image 1: no candidate at all
+        cates.append(c.cuda())
+        k = torch.randn(B, E, S, S, generator=g) * 0.3
+        k[2] = -3.0                                                 # image 2: masks of sigmoid(very negative) -> empty -> all filtered out
+        kerns.append(k.cuda())
+    imgs = [torch.empty(3, 4 * h, 4 * w) for _ in range(B)]
+    with torch.no_grad():
+        batch = net.inference(masks, cates, kerns, depth, imgs)
+        single = []
+        for b in range(B):
+            cate_b = torch.cat([c[b].reshape(-1, C) for c in cates], 0)
+            kern_b = torch.cat([k[b].permute(1, 2, 0).reshape(-1, E) for k in kerns], 0)
+            single.append(net.inference_single_image(masks[b:b + 1], cate_b, kern_b, depth[b:b + 1], (4 * h, 4 * w)))
+    assert batch[1]["pred_scores"] is None and batch[2]["pred_scores"] is None
+    assert batch[0]["pred_scores"] is not None and batch[3]["pred_scores"] is not None and len(batch[0]["pred_scores"]) > 1
+    for rb, rs in zip(batch, single):
+        for key in ("pred_masks", "pred_boxes", "pred_classes", "pred_scores", "pred_depth"):
+            assert (rb[key] is None) == (rs[key] is None), key
+            if rb[key] is not None:
+                assert torch.equal(rb[key], rs[key]), key
+        if rb["pred_boxes"] is not None:
+            assert not rb["pred_boxes"].is_cuda and rb["pred_masks"].shape[1:] == (4 * h, 4 * w)
+            assert (rb["pred_scores"][:-1] >= rb["pred_scores"][1:]).all()
+
+
 def _loss_inputs(arch):
     from oracle import synth
     g = torch.Generator().manual_seed(5)
