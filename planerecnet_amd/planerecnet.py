@@ -213,7 +213,7 @@ class PlaneRecNet(nn.Module):
                 module.bias.requires_grad = enable
 
     # ---- post-process (planerecnet.py:155-289)
-    def inference(self, pred_masks, pred_cates, pred_kernels, pred_depths, batched_images):
+    def inference(self, pred_masks, pred_cates, pred_kernels, pred_depths, batched_images, ori_size=None):
         """Reference planerecnet.py:155-289 (`inference` + `inference_single_image`) for the whole batch.  The steps that do not mix
         images -- candidate selection, dynamic mask convolution, mask statistics, the small-mask filter -- run once over the candidates of
         ALL images (two device->host synchronisations per step for the batch instead of one or more per image); sorting, matrix NMS and
@@ -221,8 +221,8 @@ class PlaneRecNet(nn.Module):
         fixed summation order, so an image's result does not depend on what else is in the batch."""
         from .metrics import mask_boxes, mask_stats
         assert len(pred_cates) == len(pred_kernels)
-        B = len(batched_images)
-        ori_size = tuple(batched_images[0].shape[1:])
+        B = pred_masks.shape[0]
+        ori_size = tuple(batched_images[0].shape[1:]) if ori_size is None else tuple(ori_size)
         depth = ops.resize_bilinear(pred_depths.detach(), ori_size).detach()
         results = [{"pred_masks": None, "pred_boxes": None, "pred_classes": None, "pred_scores": None, "pred_depth": depth[b:b + 1]} for b in range(B)]
         cate = torch.cat([c.detach().reshape(B, -1, self.num_classes) for c in pred_cates], 1)                         # [B, cells, classes]
@@ -307,7 +307,7 @@ class PlaneRecNet(nn.Module):
         levels = [g * g for g in self.num_grids]
         cates = [c.reshape(1, g, g, self.num_classes) for c, g in zip(cate_preds.split(levels, 0), self.num_grids)]
         kerns = [k.reshape(1, g, g, self.num_kernels).permute(0, 3, 1, 2) for k, g in zip(kernel_preds.split(levels, 0), self.num_grids)]
-        return self.inference(seg_preds, cates, kerns, depth_pred, [torch.empty(0, *ori_size, device="meta")])[0]
+        return self.inference(seg_preds, cates, kerns, depth_pred, None, ori_size)[0]
 
 
 RAGGED_HEADS = bool(int(os.environ.get("PRN_RAGGED_HEADS", "1")))
