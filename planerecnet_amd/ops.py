@@ -776,6 +776,30 @@ def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE,
     return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue)
 
 
+_UP2_PHASE = {}     # weight data_ptr -> (weakref(weight), version, phase weights): inference only
+
+
+def conv_up2_inference(x, w, bias=None, relu=False):
+    """Upsample(x2, nearest) -> ReflectionPad2d(1) -> Conv3x3 (+ bias, + ReLU) in its sub-pixel form WITHOUT autograd: the
+    eval-mode decoder blocks with BatchNorm folded into (w, bias) -- one launch per block instead of conv + rsqrt / cat / BatchNorm
+    kernels; the four 2x2 phase kernels are rebuilt only when the weight changes."""
+    _dev(x, w, bias)
+    x, w, bias = _c(x), _c(w), _c(bias)
+    B, C, H, W = x.shape
+    M = w.shape[0]
+    assert w.shape[1:] == (C, 3, 3), (x.shape, w.shape)
+    if not (UP2_SUBPIXEL and H > 1 and W > 1):
+        return conv2d(x, w, bias, 1, 1, IN_UP2_REFLECT, EPI_RELU if relu else EPI_NONE)
+    e = _UP2_PHASE.get(w.data_ptr())
+    if e is None or e[0]() is not w or e[1] != w._version:
+        wp = torch.empty(4, M, C, 2, 2, device=x.device, dtype=torch.float32)
+        check(lib.prn_up2_phase_weights(_p(w), _p(wp), M, C, _stream()), "prn_up2_phase_weights")
+        ptr = w.data_ptr()
+        e = _UP2_PHASE[ptr] = (weakref.ref(w), w._version, wp)
+        weakref.finalize(w, lambda p=ptr, r=e[0]: _UP2_PHASE.pop(p, None) if (_UP2_PHASE.get(p) or (None,))[0] is r else None)
+    return conv_fwd_raw(x, e[2], bias, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE, 1, EPI_RELU if relu else EPI_NONE)
+
+
 def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
     """conv2d that also hands its input back: `y, x_id = conv2d_fork(x, w)`.  Use x_id wherever else x is consumed
     (the identity branch of a residual block): the two gradients of x are then summed inside the input-gradient GEMM's

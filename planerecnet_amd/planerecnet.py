@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, timer
-from .backbone import can_fold, construct_backbone, conv_bn
+from .backbone import can_fold, construct_backbone, conv_bn, folded_bn
 from .config import cfg
 from .fpn import FPN
 from .funcs import bias_init_with_prob
@@ -495,8 +495,11 @@ class DepthDecoder_FPN(nn.Module):
         mods = list(seq)
         up = isinstance(mods[0], nn.Upsample)
         conv, bn = mods[2 if up else 1], mods[3 if up else 2]
-        if can_fold(bn) and not up:                       # inference: BatchNorm folded into the conv, ReLU in its epilogue
-            return conv_bn(x, conv, bn, 1, 1, relu=True, in_mode=ops.IN_REFLECT)
+        if can_fold(bn):                                  # inference: BatchNorm folded into the conv, ReLU in its epilogue
+            if not up:
+                return conv_bn(x, conv, bn, 1, 1, relu=True, in_mode=ops.IN_REFLECT)
+            w, b = folded_bn(conv.weight, conv.bias, bn)
+            return ops.conv_up2_inference(x, w, b, relu=True)
         y = ops.conv2d(x, conv.weight, conv.bias, pad=1, in_mode=ops.IN_UP2_REFLECT if up else ops.IN_REFLECT)
         if defer_bn:
             return y, bn
