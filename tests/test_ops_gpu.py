@@ -115,6 +115,26 @@ def test_up2_subpixel_form_matches_gather_form():
         close(a, r.double().cpu(), "up2 subpixel vs gather " + name, rtol=2e-5)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_up2_inference_equals_upsample_pad_conv(relu):
+    """The no-autograd sub-pixel form with bias + ReLU epilogue (eval-mode decoder blocks with folded BatchNorm) against
+    Upsample(2, nearest) -> ReflectionPad2d(1) -> Conv2d(3) (-> ReLU); the phase kernels follow an in-place weight update."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, 48, 11, 14, seed=1)
+    w = rnd(36, 48, 3, 3, seed=2, scale=(48 * 9) ** -0.5)
+    b = rnd(36, seed=3)
+
+    def ref(wt):
+        y = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), wt, b)
+        return F.relu(y) if relu else y
+    wd = w.float().to(d)
+    with torch.no_grad():
+        close(ops.conv_up2_inference(x.float().to(d), wd, b.float().to(d), relu), ref(w), "up2 inference")
+        wd.mul_(0.5)                                               # version bump: cached phase kernels must be rebuilt
+        close(ops.conv_up2_inference(x.float().to(d), wd, b.float().to(d), relu), ref(w * 0.5), "up2 inference after weight update")
+
+
 @pytest.mark.parametrize("K,C,M,bias", [(3, 40, 72, False), (3, 258, 256, False), (3, 64, 2, True), (1, 48, 40, True)])
 def test_ragged_conv_and_group_norm_match_per_segment_ops(K, C, M, bias):
     """One GEMM over the pixels of five differently sized maps (shared weights) == the five dense convolutions; same for the
