@@ -233,7 +233,7 @@ class PlaneRecNet(nn.Module):
         if nz.shape[0] == 0:
             return results
         img, cell, labels = nz[:, 0], nz[:, 1], nz[:, 2]
-        n_img = torch.bincount(img, minlength=B).tolist()
+        n_img = self._per_image_counts(img, B)
         scores = cate[img, cell, labels]
         kernels = kern[img, cell]
         strides = self._cell_strides(kernels).index_select(0, cell)
@@ -250,7 +250,7 @@ class PlaneRecNet(nn.Module):
         if kept.shape[0] == 0:
             return results
         img = img.index_select(0, kept)
-        n_img = torch.bincount(img, minlength=B).tolist()
+        n_img = self._per_image_counts(img, B)
         seg, sum_masks = seg.index_select(0, kept), sum_masks.index_select(0, kept)
         labels = labels.index_select(0, kept)
         scores = scores.index_select(0, kept) * (msum.index_select(0, kept) / sum_masks)       # mask-quality ("maskness") weighting
@@ -292,6 +292,15 @@ class PlaneRecNet(nn.Module):
         result["pred_scores"], result["pred_classes"], result["pred_masks"] = cate_scores, cate_labels, seg_masks
         # tight boxes of the masks in one launch (the reference loops over instances with torch.where, planerecnet.py:282-287)
         return result, mask_boxes(seg_masks)
+
+    def _per_image_counts(self, img, B):
+        """How many entries of the sorted image-index vector belong to each image (one synchronisation; torch.bincount adds one of its own
+        to find the largest index)."""
+        key = (B, str(img.device))
+        cache = self.__dict__.setdefault("_image_ids", {})
+        if key not in cache:
+            cache[key] = torch.arange(B, device=img.device).unsqueeze(1)
+        return (img.unsqueeze(0) == cache[key]).sum(1).tolist()
 
     def _cell_strides(self, like):
         """Instance stride of every grid cell (levels concatenated), built once per device."""
