@@ -433,6 +433,10 @@ int prn_mask_boxes(const unsigned char* masks, int n, int H, int W, float* boxes
  * (seg_preds * seg_masks.float()).sum((1,2)) of the post-process (planerecnet.py:227-240) in one pass; fixed summation order per row,
  * independent of n. */
 int prn_mask_stats(const float* seg, int n, int64_t HW, float thr, float* count, float* msum, void* stream);
+/* out[b][(y * S + x)][c] = s if s == max(s over the window {y-1, y} x {x-1, x}) else 0, s = sigmoid(x[b][c][y][x]): the category scores of one
+ * S x S grid level after the reference's sigmoid + point_nms (planerecnet.py:113, models/functions/nms.py:8-12), channels-last; `out` points at
+ * the level's first row of the [B, cells, C] matrix over all levels (out_batch_stride = cells * C). */
+int prn_sigmoid_point_nms(const float* x, float* out, int B, int C, int S, int64_t out_batch_stride, void* stream);
 /* Matrix NMS score decay (models/functions/nms.py:15-50) from the [n, n] mask-IoU matrix of the detections in descending score order
  * (prn_pairwise_iou of the masks with themselves), their labels and scores: out[j] = scores[j] * min_i kernel(decay[i][j]) / kernel(comp_i),
  * gaussian (exp(-sigma x^2)) or linear (1 - x) -- the dense torch form's ~15 [n, n] passes in two launches, same operations per element.

@@ -122,6 +122,7 @@ SIGNATURES = {
     "prn_pairwise_iou": (c_int, [P, P, P, P, c_int, c_int, c_i64, P, P, P, P]),
     "prn_mask_boxes": (c_int, [P, c_int, c_int, c_int, P, P]),
     "prn_mask_stats": (c_int, [P, c_int, c_i64, c_float, P, P, P]),
+    "prn_sigmoid_point_nms": (c_int, [P, P, c_int, c_int, c_int, c_i64, P]),
     "prn_matrix_nms": (c_int, [P, P, P, c_int, c_float, c_int, P, P, P]),
     "prn_bn_stats": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "prn_bn_apply": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

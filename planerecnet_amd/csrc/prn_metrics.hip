@@ -143,6 +143,26 @@ extern "C" int prn_depth_metrics(const float* pred, const float* gt, double* out
 namespace {
 inline size_t iou_words(int64_t HW) { return (size_t)((HW + 31) / 32); }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// Category scores of one grid level for the post-process: sigmoid, then the 2x2 "point NMS" of models/functions/nms.py:8-12 (a cell
+// keeps its score iff it is the maximum of the window {i-1, i} x {j-1, j}), written channels-last into the level's rows of the
+// [B, cells, C] score matrix the candidate selection reads -- sigmoid + max_pool2d + eq + float + mul + permute + cat in one launch.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void sigmoid_point_nms_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int S, int64_t out_bs, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over (b, c, y, x) of the input
+  if (i >= total) return;
+  const int xx = i % S, yy = (i / S) % S, c = (i / ((int64_t)S * S)) % C;
+  const int64_t b = i / ((int64_t)S * S * C);
+  const float* plane = x + (b * C + c) * (int64_t)S * S;
+  auto sig = [](float v) { return 1.f / (1.f + expf(-v)); };
+  const float h = sig(plane[yy * S + xx]);
+  float m = h;
+  if (xx > 0) m = fmaxf(m, sig(plane[yy * S + xx - 1]));
+  if (yy > 0) m = fmaxf(m, sig(plane[(yy - 1) * S + xx]));
+  if (xx > 0 && yy > 0) m = fmaxf(m, sig(plane[(yy - 1) * S + xx - 1]));
+  out[b * out_bs + ((int64_t)yy * S + xx) * C + c] = (m == h) ? h : 0.f;
+}
+#pragma clang fp contract(on)
+
 // Per soft mask (row of n x HW sigmoid values): number of values above the threshold and their sum -- the reference's
 // seg_masks.sum((1, 2)) and (seg_preds * seg_masks.float()).sum((1, 2)) (planerecnet.py:227-240) in one pass.  One workgroup per
 // row, fixed summation order (strided per-thread partials, then a tree over the 256 partials): the result of a row does not depend
@@ -303,5 +323,13 @@ extern "C" int prn_mask_stats(const float* seg, int n, int64_t HW, float thr, fl
   PRN_REQUIRE(seg && count && msum && n > 0 && HW > 0 && HW < (1LL << 24), "prn_mask_stats: bad arguments (0 < H*W < 2^24: counts are exact floats)");
   hipLaunchKernelGGL(mask_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, seg, count, msum, HW, thr);
   PRN_CHECK_LAUNCH("prn_mask_stats");
+  return 0;
+}
+
+extern "C" int prn_sigmoid_point_nms(const float* x, float* out, int B, int C, int S, int64_t out_batch_stride, void* stream) {
+  PRN_REQUIRE(x && out && B > 0 && C > 0 && S > 0 && out_batch_stride >= (int64_t)S * S * C, "prn_sigmoid_point_nms: bad arguments");
+  const int64_t total = (int64_t)B * C * S * S;
+  hipLaunchKernelGGL(sigmoid_point_nms_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, C, S, out_batch_stride, total);
+  PRN_CHECK_LAUNCH("prn_sigmoid_point_nms");
   return 0;
 }

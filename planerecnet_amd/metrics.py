@@ -83,6 +83,24 @@ def pairwise_iou(masks_a=None, masks_b=None, boxes_a=None, boxes_b=None):
     return miou, biou
 
 
+def category_scores(cate_logits):
+    """list of [B, C, S, S] category logits (one per grid level) -> [B, cells, C] scores after sigmoid + 2x2 point NMS, levels concatenated
+    (reference planerecnet.py:113 + models/functions/nms.py:8-12 + the level concatenation of `inference`), one launch per level."""
+    B, C = cate_logits[0].shape[:2]
+    cells = sum(int(c.shape[2]) * int(c.shape[3]) for c in cate_logits)
+    out = torch.empty(B, cells, C, device=cate_logits[0].device, dtype=torch.float32)
+    stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(out.device.index))
+    off = 0
+    for c in cate_logits:
+        S = int(c.shape[2])
+        if not c.is_cuda or c.dtype != torch.float32 or c.shape[3] != S or c.shape[:2] != (B, C):
+            raise RuntimeError("category_scores needs square fp32 device maps of one batch / class count")
+        c = c.detach().contiguous()
+        check(lib.prn_sigmoid_point_nms(ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(out.data_ptr() + 4 * off * C), B, C, S, cells * C, stream), "prn_sigmoid_point_nms")
+        off += S * S
+    return out
+
+
 def mask_stats(seg, thr):
     """[n,h,w] soft masks -> (count [n], msum [n]) of the values above thr, fp32 (include/prn.h: prn_mask_stats)."""
     if not seg.is_cuda or seg.dtype != torch.float32:

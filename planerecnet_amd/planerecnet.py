@@ -155,8 +155,9 @@ class PlaneRecNet(nn.Module):
         with timer.env("Inferencing"):
             if self.training:
                 return mask_pred, cate_pred, kernel_pred, depth_pred
-            cate_pred = [point_nms(c.sigmoid(), kernel=2).permute(0, 2, 3, 1) for c in cate_pred]
-            return self.inference(mask_pred, cate_pred, kernel_pred, depth_pred, x)
+            from .metrics import category_scores
+            # sigmoid + point NMS (planerecnet.py:113) + level concatenation, one launch per level (include/prn.h: prn_sigmoid_point_nms)
+            return self.inference(mask_pred, category_scores(cate_pred), kernel_pred, depth_pred, x)
 
     @staticmethod
     def split_feats(feats, fork=False):
@@ -220,12 +221,12 @@ class PlaneRecNet(nn.Module):
         the final selection run per image on slices.  Every per-candidate value is computed by an operation that works row by row with a
         fixed summation order, so an image's result does not depend on what else is in the batch."""
         from .metrics import mask_boxes, mask_stats
-        assert len(pred_cates) == len(pred_kernels)
+        assert torch.is_tensor(pred_cates) or len(pred_cates) == len(pred_kernels)
         B = pred_masks.shape[0]
         ori_size = tuple(batched_images[0].shape[1:]) if ori_size is None else tuple(ori_size)
         depth = ops.resize_bilinear(pred_depths.detach(), ori_size).detach()
         results = [{"pred_masks": None, "pred_boxes": None, "pred_classes": None, "pred_scores": None, "pred_depth": depth[b:b + 1]} for b in range(B)]
-        cate = torch.cat([c.detach().reshape(B, -1, self.num_classes) for c in pred_cates], 1)                         # [B, cells, classes]
+        cate = pred_cates if torch.is_tensor(pred_cates) else torch.cat([c.detach().reshape(B, -1, self.num_classes) for c in pred_cates], 1)   # [B, cells, classes]
         kern = torch.cat([k.detach().permute(0, 2, 3, 1).reshape(B, -1, self.num_kernels) for k in pred_kernels], 1)   # [B, cells, E]
         pred_masks = pred_masks.detach()
         # candidates: (image, cell, class) with a category score above the threshold, image-major like the per-image nonzero

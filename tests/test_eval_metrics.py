@@ -244,3 +244,22 @@ def test_mask_stats_counts_exact_and_rows_independent_of_the_batch(n, h, w):
     assert torch.allclose(msum.cpu().double(), want, rtol=2e-6, atol=0)
     c1, s1 = metrics.mask_stats(seg[n // 2:n // 2 + 1].cuda(), 0.1)   # the same row alone: bit-identical
     assert torch.equal(c1, cnt[n // 2:n // 2 + 1]) and torch.equal(s1, msum[n // 2:n // 2 + 1])
+
+
+@pytest.mark.gpu
+def test_category_scores_equal_sigmoid_point_nms_and_concatenation_bitwise():
+    """prn_sigmoid_point_nms against sigmoid -> max_pool2d(2, stride 1, pad 1)[:-1, :-1] -> eq -> mul -> permute -> cat evaluated with
+    torch on the device (reference planerecnet.py:113, models/functions/nms.py:8-12), incl. ties between neighbouring cells."""
+    from planerecnet_amd import metrics
+    from planerecnet_amd.nms import point_nms
+    g = torch.Generator().manual_seed(3)
+    B, C = 3, 2
+    levels = []
+    for S in (40, 36, 24, 16, 12):
+        x = torch.randn(B, C, S, S, generator=g) * 3
+        x[:, :, 2:4, 5:7] = 1.25                                    # a plateau: equal scores in one window
+        levels.append(x.cuda())
+    got = metrics.category_scores(levels)
+    want = torch.cat([point_nms(c.sigmoid(), kernel=2).permute(0, 2, 3, 1).reshape(B, -1, C) for c in levels], 1)
+    assert got.shape == want.shape
+    assert torch.equal(got, want), float((got - want).abs().max())
