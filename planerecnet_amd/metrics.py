@@ -14,7 +14,6 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import _lib
 from ._lib import check, lib
 from .config import cfg
 

@@ -23,7 +23,7 @@ from .backbone import can_fold, construct_backbone, conv_bn, folded_bn
 from .config import cfg
 from .fpn import FPN
 from .funcs import bias_init_with_prob
-from .nms import mask_nms, matrix_nms, point_nms
+from .nms import mask_nms, matrix_nms
 
 
 _COORD = {}
