@@ -347,7 +347,7 @@ int prn_fpn_level_fwd(const float* x, const float* w_lat, const float* b_lat, co
 /* prn_frame_to_input -- input staging of the inference entry point in ONE launch (simple_inference.py:143-152): src = the decoded
  *   uint8 BGR frame [Hs][Ws][3] on the device (uploaded as bytes); cv2.resize(INTER_LINEAR) to Hr x Wr in OpenCV's fixed-point
  *   arithmetic, zero padding to Hp x Wp (funcs.py:204-210), FastBaseTransform (augmentations.py:496-530): mode 0 (x - mean) / std,
- *   1 x - mean, 2 x / 255, BGR -> RGB.  mean_bgr / std_bgr: HOST arrays of three floats.  dst [3][Hp][Wp] float; frame_bgr
+ *   1 x - mean, 2 x / 255 (transform.to_float), 3 unchanged, BGR -> RGB.  mean_bgr / std_bgr: HOST arrays of three floats.  dst [3][Hp][Wp] float; frame_bgr
  *   (may be NULL) [Hp][Wp][3] float: the resized, padded frame itself (what the caller draws on).                            */
 int prn_frame_to_input(const unsigned char* src, int Hs, int Ws, int Hr, int Wr, int Hp, int Wp, const float* mean_bgr, const float* std_bgr, int mode,
                        float* dst, float* frame_bgr, void* stream);

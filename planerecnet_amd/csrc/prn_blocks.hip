@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void frame_to_input_kernel(FrameArgs a) {
     float v = bgr[c];
     if (a.mode == 0) v = (v - a.mean[c]) / a.stdv[c];
     else if (a.mode == 1) v = v - a.mean[c];
-    else v = v / 255.f;
+    else if (a.mode == 2) v = v / 255.f;                     // (mode 3: values pass through, 0..255)
     a.dst[(size_t)(2 - c) * a.Hp * a.Wp + i] = v;            // BGR -> RGB planes
   }
 }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void frame_to_input_kernel(FrameArgs a) {
 
 extern "C" int prn_frame_to_input(const unsigned char* src, int Hs, int Ws, int Hr, int Wr, int Hp, int Wp, const float* mean_bgr,
                                   const float* std_bgr, int mode, float* dst, float* frame_bgr, void* stream) {
-  PRN_REQUIRE(src && dst && mean_bgr && std_bgr && Hs > 0 && Ws > 0 && Hr > 0 && Wr > 0 && Hp >= Hr && Wp >= Wr && mode >= 0 && mode <= 2,
+  PRN_REQUIRE(src && dst && mean_bgr && std_bgr && Hs > 0 && Ws > 0 && Hr > 0 && Wr > 0 && Hp >= Hr && Wp >= Wr && mode >= 0 && mode <= 3,
               "prn_frame_to_input: bad arguments");
   FrameArgs a;
   a.src = src; a.dst = dst; a.frame = frame_bgr;

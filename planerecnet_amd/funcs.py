@@ -84,7 +84,8 @@ def frame_to_input(frame_u8, size_wh, divisor=32, want_frame=True):
     Wr, Hr = int(size_wh[0]), int(size_wh[1])
     Hp, Wp = Hr + (-Hr) % divisor, Wr + (-Wr) % divisor
     tr = cfg.backbone.transform
-    mode = 0 if tr.normalize else (1 if tr.subtract_means else 2)
+    # FastBaseTransform (augmentations.py:518-530): normalize, else subtract_means, else to_float (x / 255), else the values as they are
+    mode = 0 if tr.normalize else (1 if tr.subtract_means else (2 if tr.to_float else 3))
     if tr.channel_order != "RGB":
         raise NotImplementedError
     out = torch.empty(1, 3, Hp, Wp, device=frame_u8.device, dtype=torch.float32)

@@ -394,7 +394,7 @@ _FLIP_USED = set()   # data_ptr of every weight whose dgrad layout was asked for
 def flip_transpose(w):
     _FLIP_USED.add(w.data_ptr())
     e = _FLIPPED.get(w.data_ptr())
-    if e is not None and e[0]._version == e[1] and e[2].shape[1] == w.shape[0]:
+    if e is not None and tuple(t._version for t in e[0]) == e[1] and e[2].shape[1] == w.shape[0]:
         return e[2]                                         # flipped by FlippedWeights.refresh() since the last weight update
     M, C, KH, KW = w.shape
     wt = torch.empty(C, M, KH, KW, device=w.device, dtype=torch.float32)
@@ -402,7 +402,7 @@ def flip_transpose(w):
     return wt
 
 
-_FLIPPED = {}       # weight data_ptr -> (weight, version at flip time, flipped tensor)
+_FLIPPED = {}       # weight data_ptr -> (tensors whose version counters guard the entry, their versions at flip time, flipped tensor)
 
 
 class FlippedWeights:
@@ -411,10 +411,12 @@ class FlippedWeights:
     `weights` is a list of (parameter, (M, C, KH, KW)) -- the shape the dgrad sees (a DCN weight is [M, C*9, 1, 1])."""
 
     def __init__(self, weights):
-        # (parameter, shape) or (parameter, shape, data): `data` is the tensor actually read (a DCN block's merged [27, C, 3, 3] offset +
-        # modulator weight, of which the parameter is the leading rows); the parameter supplies the version counter
+        # (parameter, shape) or (parameter, shape, data[, more parameters]): `data` is the tensor actually read (a DCN block's merged
+        # [27, C, 3, 3] offset + modulator weight, of which the two parameters are views); the version counters of the parameter AND of
+        # the extra ones guard the cached layout (an in-place update of the modulator weight alone must invalidate it too)
         self.weights = [(e[0], tuple(int(v) for v in e[1])) for e in weights]
         self.data = [e[2] if len(e) > 2 else e[0] for e in weights]
+        self.guards = [(e[0],) + tuple(e[3] if len(e) > 3 else ()) for e in weights]
         self.ptrs = None
 
     def _build(self):
@@ -445,8 +447,8 @@ class FlippedWeights:
                 _FLIPPED.pop(p, None)
             self._build()
         check(lib.prn_weight_flip_transpose_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_weight_flip_transpose_batched")
-        for (w, _), d, v in zip(self.weights, self.data, self.views):
-            _FLIPPED[d.data_ptr()] = (w, w._version, v)
+        for gd, d, v in zip(self.guards, self.data, self.views):
+            _FLIPPED[d.data_ptr()] = (gd, tuple(t._version for t in gd), v)
 
 
 # ------------------------------------------------------------------------------------------ Winograd F(4x4, 3x3)
@@ -1202,21 +1204,38 @@ class _BatchNormCat(torch.autograd.Function):
         return tuple(grads) + (None, None, None, None)
 
 
+def flush_batch_count(m):
+    """Write a BatchNorm module's host-side batch count into its `num_batches_tracked` buffer."""
+    n = m.__dict__.pop("_prn_nbt_pending", 0)
+    if n and m.num_batches_tracked is not None:
+        m.num_batches_tracked += n
+
+
+def _count_batch(m):
+    """One more training batch through BatchNorm module `m`: counted on the host (one tiny increment kernel per layer per step
+    otherwise) and written to `num_batches_tracked` whenever ANY state dict containing the module is taken -- a state-dict pre-hook on
+    the module itself, so net.backbone.state_dict() or a sub-module's are as current as the root's."""
+    d = m.__dict__
+    d["_prn_nbt_pending"] = d.get("_prn_nbt_pending", 0) + 1
+    if "_prn_nbt_hook" not in d:
+        d["_prn_nbt_hook"] = m.register_state_dict_pre_hook(lambda mod, prefix, keep_vars: flush_batch_count(mod))
+
+
 def batch_norm_relu_cat(ma, xa, mb, xb):
     """torch.cat([relu(ma(xa)), relu(mb(xb))], 1) for two nn.BatchNorm2d modules in training mode (see _BatchNormCat)."""
     for m in (ma, mb):
         if m.track_running_stats:
-            m.__dict__["_prn_nbt_pending"] = m.__dict__.get("_prn_nbt_pending", 0) + 1
+            _count_batch(m)
     return _BatchNormCat.apply(xa, ma.weight, ma.bias, ma.running_mean, ma.running_var, xb, mb.weight, mb.bias, mb.running_mean, mb.running_var,
                                float(ma.eps), float(ma.momentum), float(mb.eps), float(mb.momentum))
 
 
 def batch_norm_module(m, x, residual=None, relu=False):
     """nn.BatchNorm2d.forward (+ residual add + ReLU) on the HIP kernels, including the module's bookkeeping: in training mode
-    `num_batches_tracked` advances like nn.BatchNorm2d's (counted on the host and written to the buffer when the state dict
-    is read -- PlaneRecNet.state_dict -- instead of one tiny increment kernel per layer per step)."""
+    `num_batches_tracked` advances like nn.BatchNorm2d's (counted on the host and written to the buffer when a state dict
+    is read, see _count_batch)."""
     if m.training and m.track_running_stats:
-        m.__dict__["_prn_nbt_pending"] = m.__dict__.get("_prn_nbt_pending", 0) + 1
+        _count_batch(m)
     return batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
 
 

@@ -19,7 +19,14 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = None
         self._tab = None
 
-    # ---- tables of the launch: rebuilt only when the set of parameters that have a gradient changes
+    def load_state_dict(self, state_dict):
+        """torch re-creates the state tensors (new exp_avg / exp_avg_sq storage, `step` possibly left on the host): the launch
+        tables hold raw pointers, so they are rebuilt at the next step."""
+        super().load_state_dict(state_dict)
+        self._tab = None
+
+    # ---- tables of the launch: rebuilt when the set of parameters that have a gradient changes, when a parameter's storage moved
+    # (module.to() / .float(), a re-linked .data) or after load_state_dict -- the kernel works through raw pointers
     def _build(self, plist):
         dev = plist[0][0].device
         ce = lib.prn_adam_chunk_elems()
@@ -31,16 +38,22 @@ class FusedAdam(torch.optim.Optimizer):
             st = self.state[p]
             if "exp_avg" not in st:
                 st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+            for k in ("exp_avg", "exp_avg_sq"):
+                if st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous():
+                    st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
             if step is None:
                 # one counter for all tensors (they are always stepped together); every state entry refers to it
                 step = next((self.state[q]["step"] for q, _ in plist if "step" in self.state[q]), None)
                 if step is None:
                     step = torch.zeros((), device=dev, dtype=torch.float32)
+                elif not (torch.is_tensor(step) and step.device == dev and step.dtype == torch.float32 and step.dim() == 0):
+                    # (a loaded state keeps `step` wherever the checkpoint had it, e.g. on the host: the kernel needs a device scalar)
+                    step = torch.as_tensor(float(step), dtype=torch.float32).to(dev).reshape(())
             st["step"] = step
             numel.append(p.numel())
             chunks += [(i, o) for o in range(0, p.numel(), ce)]
         ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)      # noqa: E731
-        tab = {"ids": [id(p) for p, _ in plist], "dev": dev, "step": step, "n": len(plist), "nchunks": len(chunks),
+        tab = {"ids": [id(p) for p, _ in plist], "pptr": [p.data_ptr() for p, _ in plist], "dev": dev, "step": step, "n": len(plist), "nchunks": len(chunks),
                "chunks": torch.tensor(chunks, dtype=torch.int32, device=dev), "numel": torch.tensor(numel, dtype=torch.int32, device=dev),
                "p": ptr([p for p, _ in plist]), "m": ptr([self.state[p]["exp_avg"] for p, _ in plist]),
                "v": ptr([self.state[p]["exp_avg_sq"] for p, _ in plist]),
@@ -64,7 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
         if any(g["betas"] != betas or g["eps"] != eps for g in self.param_groups):
             raise RuntimeError("FusedAdam: betas / eps must be the same in every parameter group")
         tab = self._tab
-        if tab is None or tab["ids"] != [id(p) for p, _ in plist]:
+        if tab is None or tab["ids"] != [id(p) for p, _ in plist] or tab["pptr"] != [p.data_ptr() for p, _ in plist]:
             tab = self._tab = self._build(plist)
         r = tab["ring"][tab["slot"]]
         tab["slot"] = (tab["slot"] + 1) % len(tab["ring"])

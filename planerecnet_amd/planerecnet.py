@@ -106,7 +106,7 @@ class PlaneRecNet(nn.Module):
                 # input gradient reads the merged tensor's flipped layout; the offset parameter (its leading rows) carries the version
                 if m.offset_conv.weight.requires_grad and m.offset_conv.weight.is_cuda:
                     w27 = m._merged()[0]
-                    items.append((m.offset_conv.weight, tuple(w27.shape), w27))
+                    items.append((m.offset_conv.weight, tuple(w27.shape), w27, (m.modulator_conv.weight,)))
             self.__dict__["_flip_dcn"] = [(m, e[2]) for m, e in zip([m for m in dcns if m.offset_conv.weight.requires_grad and m.offset_conv.weight.is_cuda],
                                                                      [e for e in items if len(e) > 2])]
             fw = self.__dict__["_flipped"] = ops.FlippedWeights(items)
@@ -116,7 +116,7 @@ class PlaneRecNet(nn.Module):
         # on demand by ops.flip_transpose
         self.__dict__["_flip_steps"] += 1
         if self.__dict__["_flip_steps"] == 3:
-            used = [(w, shp, d) for (w, shp), d in zip(fw.weights, fw.data) if d.data_ptr() in ops._FLIP_USED]
+            used = [(w, shp, d, gd[1:]) for (w, shp), d, gd in zip(fw.weights, fw.data, fw.guards) if d.data_ptr() in ops._FLIP_USED]
             if used and len(used) < len(fw.weights):
                 for d in fw.data:
                     ops._FLIPPED.pop(d.data_ptr(), None)
@@ -172,9 +172,7 @@ class PlaneRecNet(nn.Module):
         """Write the host-side `num_batches_tracked` counts (ops.batch_norm_module) into the buffers."""
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
-                n = m.__dict__.pop("_prn_nbt_pending", 0)
-                if n and m.num_batches_tracked is not None:
-                    m.num_batches_tracked += n
+                ops.flush_batch_count(m)
 
     def state_dict(self, *args, **kwargs):
         self._flush_bn_counters()

@@ -82,6 +82,9 @@ def test_batchnorm_bookkeeping_and_fold_cache(setup):
         net(xd)
         net(xd)
     assert net.backbone.bn1.running_mean._version > v0
+    # a SUB-module's state dict is as current as the root's (the counters are flushed by a pre-hook on every BatchNorm module)
+    assert int(net.backbone.state_dict()["layers.0.0.bn1.num_batches_tracked"]) == 2
+    assert int(net.depth_decoder.deconv3[3].state_dict()["num_batches_tracked"]) == 2 if hasattr(net.depth_decoder.deconv3[3], "num_batches_tracked") else True
     got = net.state_dict()
     assert int(got["backbone.bn1.num_batches_tracked"]) == 2 and int(got["depth_decoder.deconv4.3.num_batches_tracked"]) == 2
     assert int(net.state_dict()["backbone.layers.1.0.bn2.num_batches_tracked"]) == 2          # (flushing twice does not double count)

@@ -73,3 +73,35 @@ def test_fused_adam_runs_ahead_of_the_device():
     torch.cuda.synchronize()
     for a, b in zip(pa, pb):
         assert torch.allclose(a, b, rtol=5e-6, atol=1e-7)
+
+
+def test_fused_adam_survives_state_reload_and_storage_moves():
+    """The launch tables hold raw pointers: after load_state_dict (new moment tensors, `step` possibly a host tensor) and after a
+    parameter's storage was replaced (p.data = ...) the next step must work on the live tensors, like torch.optim.Adam does."""
+    from planerecnet_amd.optim import FusedAdam
+    pa, pb = _params(5), _params(5)
+    ref, mine = torch.optim.Adam(pa, lr=1e-2), FusedAdam(pb, lr=1e-2)
+    g = torch.Generator().manual_seed(6)
+
+    def both_step():
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step()
+        mine.step()
+
+    both_step(); both_step()
+    sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+    for st in sd_mine["state"].values():                            # a checkpoint that kept the counter on the host
+        st["step"] = st["step"].cpu()
+    ref.load_state_dict(sd_ref)
+    mine.load_state_dict(sd_mine)
+    both_step()
+    for a, b in zip(pa, pb):                                        # storage replaced behind the optimizer's back
+        a.data = a.data.clone()
+        b.data = b.data.clone()
+    both_step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.allclose(a, b, rtol=5e-6, atol=1e-7), (i, float((a - b).abs().max()))
+        assert float(mine.state[b]["step"]) == 4.0 and mine.state[b]["step"].is_cuda

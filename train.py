@@ -15,7 +15,7 @@ What differs is the machinery underneath:
     is logged is the mean over ranks (reference train.py:348), and the "skip the step on a non-finite loss" decision
     (train.py:353) is taken collectively so ranks cannot diverge;
   * GT-only loss preparation runs in worker processes two batches ahead of the GPU (losses.TargetPrefetcher);
-  * `--dataset synthetic` (the default when the annotated datasets are not on disk) feeds seeded synthetic batches with the
+  * `--dataset synthetic` (must be given explicitly: there is no silent fallback) feeds seeded synthetic batches with the
     reference's batch contract (data/datasets.py:54-57,250-273) -- the ScanNet / NYU readers need cv2 + pycocotools and are
     outside this hot-path build.
 """
@@ -164,9 +164,11 @@ def main():
     from planerecnet_amd.staging import FrameStager
 
     os.makedirs(args.save_folder, exist_ok=True)
-    synthetic = args.dataset == "synthetic" or not os.path.exists(cfg.dataset.train_info)
-    if not synthetic:
-        raise SystemExit("The annotated dataset readers (cv2 + pycocotools) are outside this build; use --dataset synthetic.")
+    if args.dataset != "synthetic":
+        # no silent fallback: a run (and its validation tables) on seeded noise must not pass for a run on the configured dataset
+        raise SystemExit("train.py: the annotated dataset readers (cv2 + pycocotools) are outside this build; pass --dataset synthetic "
+                         "to train / validate on seeded synthetic batches.")
+    print("NOTE: training on SYNTHETIC batches (--dataset synthetic); validation metrics are plumbing checks, not accuracy figures.")
     dataset = SyntheticPlaneDataset(args.synthetic_size)
     val_dataset = SyntheticPlaneDataset(args.synthetic_val_size)
     eval_script.parse_args(["--no_bar"])                   # (reference train.py:436-437)
