@@ -33,7 +33,8 @@ Diagnostics (environment, stderr only; none of them changes the timed work excep
   PRN_BENCH_PHASES=1        host time per phase of a step (get / submit / fwd / loss / bwd / adam) and GPU time per step
   PRN_BENCH_GAP=1           GPU time between the end of Adam and the next forward's first kernel, and the compute stream's wait at wgrad_join
   PRN_BENCH_FIXED_TARGETS=1 the same loss targets every step (nothing fetched from the prefetch workers): isolates the boundary work
-  PRN_FORCE_EXCHANGE=1      the gradient exchange (hooks, bucket pack, RCCL all-reduce) with one rank: its overhead before any wire time
+  PRN_FORCE_EXCHANGE=1      the gradient exchange (hooks, bucket pack, RCCL all-reduce) with one rank in the HEADLINE timing (the default
+                            run reports the same probe as `exchange_probe.exchange_overhead_ms` from extra steps)
 """
 import argparse
 import json
@@ -170,6 +171,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exchange-probe", action="store_true", help="skip the extra steps that time the gradient-exchange path on a one-rank group")
     ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
                     "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
     args = ap.parse_args()
@@ -250,6 +252,8 @@ def main():
             from planerecnet_amd.optim import FusedAdam
             opt = FusedAdam(net.parameters(), lr=1e-4)
         exchange = GradAllReduce(list(net.parameters()), force=bool(os.environ.get("PRN_FORCE_EXCHANGE")))    # force: run the bucket / RCCL path with one rank too (overhead probe)
+        if hasattr(opt, "exchange"):
+            opt.exchange = exchange
 
         # --graph: the network's forward and backward are static, so each can be captured as ONE hipGraph
         # (torch.cuda.make_graphed_callables: stream capture of every HIP launch our C ABI issues on torch's current stream).
@@ -363,7 +367,44 @@ def main():
             el = float(t.item())
         return el, out
 
+    n_host0 = len(ph.get("host_ms_per_step", []))
+    cpu0 = time.process_time()
     elapsed, last = timed(args.warmup, args.steps)
+    # host side of the timed steps on this rank: wall time the trainer thread needs to enqueue a step, and CPU time of the whole
+    # process (trainer + autograd + receiver threads; the target workers are separate processes) -- at N ranks per host these add up
+    host = None
+    if train:
+        hs = ph.get("host_ms_per_step", [])[n_host0 + args.warmup:]
+        host = {"enqueue_ms_per_step": (sum(hs) / len(hs)) if hs else None,
+                "process_cpu_ms_per_step": 1e3 * (time.process_time() - cpu0) / max(args.steps + args.warmup, 1),
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "target_workers": getattr(prefetch, "nworkers", None)}
+        if world > 1:                                            # slowest rank
+            t = torch.tensor([host["enqueue_ms_per_step"] or 0.0, host["process_cpu_ms_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            host["enqueue_ms_per_step"], host["process_cpu_ms_per_step"] = float(t[0]), float(t[1])
+    # cost of the gradient-exchange path itself (hooks, bucket pack, one-rank RCCL all-reduce, `.grad` re-pointing) before any wire
+    # time: the same step with the exchange forced on a one-rank group (N = 1 only; with N > 1 it is always on)
+    exch = None
+    if train and world == 1 and rank == 0 and not graphed and not args.no_exchange_probe and not exchange.active:
+        try:
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29534")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            plain = exchange
+            exchange = GradAllReduce(list(net.parameters()), force=True)
+            if hasattr(opt, "exchange"):
+                opt.exchange = exchange
+            n2 = max(args.steps // 2, 5)
+            el2, _ = timed(3, n2)
+            exchange.remove()
+            exchange = plain
+            if hasattr(opt, "exchange"):
+                opt.exchange = plain
+            exch = {"ms_per_step_with_exchange": 1e3 * el2 / n2, "exchange_overhead_ms": 1e3 * el2 / n2 - 1e3 * elapsed / args.steps, "steps": n2,
+                    "buckets": None, "note": "one-rank RCCL group: hooks + pack + all-reduce launch + unpack, no wire time"}
+        except Exception as e:                                   # noqa: BLE001
+            exch = {"error": "%s: %s" % (type(e).__name__, e)}
     if os.environ.get("PRN_EXCHANGE_PROF"):
         from planerecnet_amd import parallel as _par
         n_ = max(_par._PROF.get("steps", 1), 1)
@@ -426,9 +467,23 @@ def main():
             traffic = {"hbm_bytes_per_launch": None if pmc is None else pmc["bytes_per_launch"], "source": None if pmc is None else pmc["source"],
                        "algorithmic_bytes_per_launch": alg,
                        "ratio": (pmc["bytes_per_launch"] / alg) if (pmc is not None and alg) else None}
+        # the same comparison for every MFMA family that logs algorithmic bytes (weight gradients, the fused DCNv2 launches)
+        by_family = {}
+        for f in fams:
+            if f["bound"] == "mfma" and f.get("bytes"):
+                pm = pmc_traffic(f["kernel"])
+                alg_f = f["bytes"] / f["launches"]
+                by_family[f["kernel"]] = {"algorithmic_bytes_per_launch": alg_f, "hbm_bytes_per_launch": None if pm is None else pm["bytes_per_launch"],
+                                          "ratio": None if pm is None else pm["bytes_per_launch"] / alg_f, "source": None if pm is None else pm["source"]}
+        if traffic is not None:
+            traffic["by_family"] = by_family
+        # HBM-bound families are credited with the bytes their kernels EXECUTE (per variant), so none can exceed what the memory
+        # system delivers; a figure above the measured copy rate means the accounting of that family is wrong
+        over = [f["kernel"] for f in fams if f["bound"] == "hbm" and f["achieved"] > 6300.0 and f["time_ms"] > 0.02]
         roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"],
-                "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"]}
+                "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"],
+                "hbm_families_above_copy_rate": over}
         # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation) -- that is the headline
         # figure.  Footnote: the Winograd launches execute a quarter of the multiply-adds of the convolution they evaluate, so the
         # same step is also summarised as FLOPs of the REFERENCE convolutions over the time of every kernel of the convolution
@@ -477,7 +532,8 @@ def main():
                            % (args.workload, args.config, wl[5], args.batch, args.height, args.width, "RGB+depth+planes" if train else "RGB"),
                            "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},
                 "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
-                "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "kernels": kernels}
+                "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "host": host,
+                "exchange_probe": exch, "kernels": kernels}
         print(json.dumps(line), flush=True)
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)

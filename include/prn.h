@@ -253,6 +253,10 @@ int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x, const void
 int64_t prn_dcnv2_bwd_ws_bytes(const prn_dcn_desc* d);
 int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
                         void* stream);
+/* phase 0 = everything; 1 / 2 = the column-gradient GEMM (launch / K-split sum); 3 = the CSR gather of dx from the column
+ * gradient already in ws. */
+int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
+                              void* stream, int phase);
 int prn_dcnv2_bwd_offset_mask(const prn_dcn_desc* d, const float* x, const float* offset, const float* mask, float* d_offset, float* d_mask,
                               void* ws, void* stream);
 
@@ -267,6 +271,9 @@ int prn_bn_apply(const float* x, const float* stats, const float* gamma, const f
                  float* y, int B, int C, int HW, int relu, void* stream);
 /* training forward in two launches (per-channel partial sums, then normalise with the statistics finalised inside the apply
  * kernel): equivalent to prn_bn_stats + prn_bn_apply; stats[2C] receives mean / invstd for the backward. */
+/* 1: training-mode forward / backward of a [B, C, HW] layer run as ONE launch each that reads the activation once (small maps: the
+ * channel lives in a workgroup's registers), 0: statistics pass + apply pass -- lets a profiler credit the bytes actually moved. */
+int prn_bn_kernel_kind(int B, int HW);
 int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
                      float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps, float momentum,
                      int relu, void* stream);
@@ -338,6 +345,10 @@ int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int
 int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, int F);
 int prn_plane_prior_fwd(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws, int B, int E,
                         int h, int w, int NK, int F, void* stream);
+/* phase 0 = the whole block (== prn_plane_prior_fwd); 1 centre gather, 2 the B per-image dynamic convolutions (one batched MFMA
+ * launch), 3 the 2x2 mean, 4 conv1x1 -- so that a profiler can bracket each launch of the block. */
+int prn_plane_prior_fwd_phase(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws, int B, int E,
+                        int h, int w, int NK, int F, void* stream, int phase);
 int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F);
 int prn_plane_prior_wgrad(const float* pooled, const float* d_out, float* dw1, void* ws, int B, int h, int w, int NK, int F, void* stream);
 int64_t prn_fpn_level_ws_bytes(int B, int C, int H, int W, int F, int relu, int has_prev, int have_u);
@@ -455,6 +466,13 @@ int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores,
 int prn_adam_chunk_elems(void);
 int prn_adam_step(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
                   const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps, void* stream);
+/* The same for data-parallel runs: present [any length] (device) holds, per parameter of the gradient exchange, how many ranks
+ * produced a gradient for it (all-reduced); present_idx [ntensors] maps this launch's tensors into it.  A tensor whose count is 0 is
+ * left untouched -- parameter, exp_avg and exp_avg_sq -- exactly as optim.Adam skips a parameter whose .grad is None
+ * (train.py:362), without a device-to-host round trip.  Both NULL: prn_adam_step. */
+int prn_adam_step_masked(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
+                         const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps,
+                         const float* present, const int* present_idx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,9 +93,12 @@ SIGNATURES = {
     "prn_dcnv2_bwd_weight_phase": (c_int, [P] * 7 + [c_int]),
     "prn_dcnv2_bwd_ws_bytes": (c_i64, [P]),
     "prn_dcnv2_bwd_input": (c_int, [P] * 8),
+    "prn_dcnv2_bwd_input_phase": (c_int, [P] * 8 + [c_int]),
+    "prn_bn_kernel_kind": (c_int, [c_int, c_int]),
     "prn_dcnv2_bwd_offset_mask": (c_int, [P] * 8),
     "prn_plane_prior_ws_bytes": (c_i64, [c_int] * 6),
     "prn_plane_prior_fwd": (c_int, [P] * 7 + [c_int] * 6 + [P]),
+    "prn_plane_prior_fwd_phase": (c_int, [P] * 7 + [c_int] * 6 + [P, c_int]),
     "prn_plane_prior_wgrad_ws_bytes": (c_i64, [c_int] * 5),
     "prn_plane_prior_wgrad": (c_int, [P] * 4 + [c_int] * 5 + [P]),
     "prn_fpn_level_ws_bytes": (c_i64, [c_int] * 8),
@@ -118,6 +121,7 @@ SIGNATURES = {
     "prn_rmse_log_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),
     "prn_adam_chunk_elems": (c_int, []),
     "prn_adam_step": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P]),
+    "prn_adam_step_masked": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P, P, P]),
     "prn_pairwise_iou_ws_bytes": (c_i64, [c_int, c_int, c_i64]),
     "prn_pairwise_iou": (c_int, [P, P, P, P, c_int, c_int, c_i64, P, P, P, P]),
     "prn_mask_boxes": (c_int, [P, c_int, c_int, c_int, P, P]),

@@ -49,7 +49,15 @@ extern "C" int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, 
 
 extern "C" int prn_plane_prior_fwd(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws,
                                    int B, int E, int h, int w, int NK, int F, void* stream) {
+  return prn_plane_prior_fwd_phase(seg, kernels, w1, b1, pooled, out, ws, B, E, h, w, NK, F, stream, 0);
+}
+
+// phase 0: the whole block; 1 centre gather, 2 the per-image dynamic convolutions (ONE batched MFMA launch, blockIdx.z = image),
+// 3 the 2x2 mean, 4 conv1x1 NK -> F: the profiler brackets each launch of the block separately (bench.py's roofline leg)
+extern "C" int prn_plane_prior_fwd_phase(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws,
+                                         int B, int E, int h, int w, int NK, int F, void* stream, int phase) {
   PRN_REQUIRE(seg && kernels && w1 && pooled && out && ws, "prn_plane_prior_fwd: null tensor");
+  PRN_REQUIRE(phase >= 0 && phase <= 4, "prn_plane_prior_fwd: bad phase");
   PriorWs l;
   if (int e = prior_layout(B, E, h, w, NK, F, l)) return e;
   char* wsb = (char*)ws;
@@ -58,14 +66,26 @@ extern "C" int prn_plane_prior_fwd(const float* seg, const float* kernels, const
   hipStream_t st = (hipStream_t)stream;
   const int h2 = h / 2, w2 = w / 2;
   const int64_t nc = (int64_t)B * E * h2 * w2;
-  hipLaunchKernelGGL(centre_gather_kernel, dim3(cdiv(nc, 256)), dim3(256), 0, st, seg, centre, nc, h, w);
-  PRN_CHECK_LAUNCH("prn_plane_prior_fwd/centre");
-  for (int b = 0; b < B; ++b)                                  // dynamic 1x1 conv: every image has its own NK kernels (planerecnet.py:589-592)
-    if (int e = prn_conv2d_fwd(&l.d1, centre + (size_t)b * E * h2 * w2, kernels + (size_t)b * NK * E, nullptr, nullptr, sig + (size_t)b * NK * h2 * w2,
-                               wsb + l.gemm1, stream))
-      return e;
-  if (int e = prn_resize_bilinear_fwd(sig, pooled, B * NK, h2, w2, h / 4, w / 4, stream)) return e;      // exact x0.5: 2x2 mean
-  return prn_conv2d_fwd(&l.d2, pooled, w1, b1, nullptr, out, wsb + l.gemm2, stream);
+  if (phase == 0 || phase == 1) {
+    hipLaunchKernelGGL(centre_gather_kernel, dim3(cdiv(nc, 256)), dim3(256), 0, st, seg, centre, nc, h, w);
+    PRN_CHECK_LAUNCH("prn_plane_prior_fwd/centre");
+  }
+  if (phase == 0 || phase == 2) {
+    // dynamic 1x1 conv: every image has its own NK kernels (planerecnet.py:589-592).  One launch over all images when the pixel
+    // count allows the vector staging (it does for every input size that is a multiple of 32); the same k-ordered sums either way.
+    if (((h2 * w2) & 3) == 0 && (E & 3) == 0) {
+      if (int e = prn_gemm_batched_epi(NK, E, h2 * w2, B, kernels, centre, sig, PRN_EPI_SIGMOID, stream)) return e;
+    } else {
+      for (int b = 0; b < B; ++b)
+        if (int e = prn_conv2d_fwd(&l.d1, centre + (size_t)b * E * h2 * w2, kernels + (size_t)b * NK * E, nullptr, nullptr, sig + (size_t)b * NK * h2 * w2,
+                                   wsb + l.gemm1, stream))
+          return e;
+    }
+  }
+  if (phase == 0 || phase == 3)
+    if (int e = prn_resize_bilinear_fwd(sig, pooled, B * NK, h2, w2, h / 4, w / 4, stream)) return e;      // exact x0.5: 2x2 mean
+  if (phase == 0 || phase == 4) return prn_conv2d_fwd(&l.d2, pooled, w1, b1, nullptr, out, wsb + l.gemm2, stream);
+  return 0;
 }
 
 extern "C" int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F) {

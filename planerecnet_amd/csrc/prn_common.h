@@ -54,3 +54,5 @@ int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* 
                                int epi, hipStream_t st);
 int prn_launch_reduce_splits(const float* ws, float* out, int64_t n, int splits, hipStream_t st);
 int prn_quantise_splits(int64_t tiles, int splits);
+//   Y_z[M x P] = epi(U_z[M x C] * V_z[C x P]) for z < nb in one launch (prn_gemm_batched with an activation)
+int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const float* V, float* Y, int epi, void* stream);

@@ -1643,12 +1643,17 @@ extern "C" int prn_weight_flip_transpose(const float* w, float* wt, int M, int C
 // nb independent GEMMs Y_z[M x P] = U_z[M x C] * V_z[C x P] in one launch of the 1x1 (VEC) instances: the product step of
 // the Winograd path (prn_winograd.hip), z = one of the 36 transform-domain positions.
 extern "C" int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const float* V, float* Y, void* stream) {
+  return prn_gemm_batched_epi(M, C, P, nb, U, V, Y, PRN_EPI_NONE, stream);
+}
+
+// (internal, prn_common.h) the same with an activation in the epilogue: the per-image dynamic convolutions of the plane prior
+int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const float* V, float* Y, int epi, void* stream) {
   PRN_REQUIRE(U && V && Y && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched: bad arguments");
   PRN_REQUIRE((P & 3) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0, "prn_gemm_batched: P %% 4 == 0 and 16-byte aligned V required (P=%d)", P);
   PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched: operand larger than a buffer descriptor");
   ConvArgs a;
   a.x = V; a.w = U; a.bias = nullptr; a.addend = nullptr; a.y = Y; a.ws = nullptr;
-  a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P; a.epi = PRN_EPI_NONE;
+  a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P; a.epi = epi;
   a.K = C; a.N = P; a.HoWo = P; a.HW = P; a.xbytes = C * P * 4; a.wbytes = M * C * 4;
   a.ystride = 1; a.yW = P; a.yHW = P;
   a.zx = C * P; a.zw = M * C; a.zy = M * P;

@@ -451,13 +451,22 @@ extern "C" int64_t prn_dcnv2_bwd_ws_bytes(const prn_dcn_desc* d) {
 
 extern "C" int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
                                    void* stream) {
+  return prn_dcnv2_bwd_input_phase(d, dy, wt, offset, mask, dx, ws, stream, 0);
+}
+
+// phase 0: everything; 1 / 2: the column-gradient GEMM W^T dy (launch / its K-split sum); 3: the CSR gather of dx from the column
+// gradient already in ws (profiler brackets: each launch timed on its own, nothing issued twice)
+extern "C" int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx,
+                                         void* ws, void* stream, int phase) {
   if (int e = check_dcn_desc(d, "prn_dcnv2_bwd_input")) return e;
   PRN_REQUIRE(dy && wt && offset && ws, "prn_dcnv2_bwd_input: null tensor");
+  PRN_REQUIRE(phase >= 0 && phase <= 3, "prn_dcnv2_bwd_input: bad phase");
   DataWs l;
   if (int e = data_ws_layout(d, l)) return e;
   char* wsb = (char*)ws;
-  if (int e = prn_conv2d_fwd(&l.g, dy, wt, nullptr, nullptr, (float*)(wsb + l.dcols), wsb + l.gemm, stream)) return e;
-  if (dx == nullptr) return 0;                             // (column gradient only: the caller just wants prn_dcnv2_bwd_offset_mask)
+  if (phase <= 2)
+    if (int e = prn_conv2d_fwd_phase(&l.g, dy, wt, nullptr, nullptr, (float*)(wsb + l.dcols), wsb + l.gemm, stream, phase)) return e;
+  if (dx == nullptr || phase == 1 || phase == 2) return 0;   // (dx == NULL: column gradient only, the caller just wants prn_dcnv2_bwd_offset_mask)
   const BwdWs bl = bwd_ws_layout(d->B, d->C, d->H, d->W, d->Ho, d->Wo);
   return launch_dx(desc_view(d, offset, mask), (const float*)(wsb + l.dcols), dx, wsb + l.rest, bl, d->B, d->C, d->H, d->W, d->Ho, d->Wo, d->stride,
                    (hipStream_t)stream);

@@ -385,6 +385,13 @@ bool bn_small_ok(int B, int HW) {
   if (on < 0) { const char* e = getenv("PRN_BN_SMALL"); on = e ? atoi(e) : 1; }
   return on && (HW & 3) == 0 && (int64_t)B * HW <= BN_SMALL_MAX;
 }
+}  // namespace
+
+// 1: the training-mode forward / backward of a [B, C, HW] BatchNorm run as ONE launch that reads the activation once (the channel
+// lives in a workgroup's registers); 0: two launches (statistics pass + apply pass) -- for profilers that credit executed bytes.
+extern "C" int prn_bn_kernel_kind(int B, int HW) { return bn_small_ok(B, HW) ? 1 : 0; }
+
+namespace {
 
 // ------------------------------------------------------------------------------------------- GroupNorm
 // one block per (b, group): pass 1 statistics, pass 2 normalise + affine + ReLU (second read is L2-resident)

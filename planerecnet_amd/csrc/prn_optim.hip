@@ -11,10 +11,15 @@ constexpr int ADAM_CHUNK = 4096;       // elements per workgroup (256 threads x 
 __global__ __launch_bounds__(256) void adam_kernel(const int2* __restrict__ chunks, float* const* __restrict__ p, const float* const* __restrict__ g,
                                                    float* const* __restrict__ m, float* const* __restrict__ v, const int* __restrict__ numel,
                                                    const float* __restrict__ lr, const float* __restrict__ step, const float* __restrict__ found_inf,
-                                                   const float* __restrict__ grad_scale, double beta1_d, double beta2_d, float eps) {
+                                                   const float* __restrict__ grad_scale, double beta1_d, double beta2_d, float eps,
+                                                   const float* __restrict__ present, const int* __restrict__ present_idx) {
   if (found_inf && *found_inf != 0.f) return;                 // collective "skip this update" (train.py:353), decided on the device
   const int2 c = chunks[blockIdx.x];
   const int t = c.x, off = c.y;
+  // data-parallel runs: a tensor for which NO rank produced a gradient is left alone (parameter and moments), like optim.Adam
+  // leaves a parameter whose .grad is None (train.py:362) -- the exchange zero-fills such gradients so that every rank posts the
+  // same collectives, and hands over the all-reduced presence counts instead of a host-side None
+  if (present && present[present_idx[t]] == 0.f) return;
   const int n = min(ADAM_CHUNK, numel[t] - off);
   // bias corrections of step + 1 (the counter is advanced by adam_advance_kernel after this launch), in double like torch
   const double s = (double)(*step) + 1.0;
@@ -59,10 +64,17 @@ extern "C" int prn_adam_chunk_elems(void) { return ADAM_CHUNK; }
 extern "C" int prn_adam_step(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
                              const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps,
                              void* stream) {
+  return prn_adam_step_masked(chunks, nchunks, p, g, m, v, numel, lr, step, found_inf, grad_scale, beta1, beta2, eps, nullptr, nullptr, stream);
+}
+
+extern "C" int prn_adam_step_masked(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                    const int* numel, const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1,
+                                    double beta2, float eps, const float* present, const int* present_idx, void* stream) {
   PRN_REQUIRE(chunks && p && g && m && v && numel && lr && step && nchunks > 0, "prn_adam_step: bad arguments");
+  PRN_REQUIRE((present == nullptr) == (present_idx == nullptr), "prn_adam_step_masked: present and present_idx come together");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, st, reinterpret_cast<const int2*>(chunks), p, g, m, v, numel, lr, (const float*)step, found_inf,
-                     grad_scale, beta1, beta2, eps);
+                     grad_scale, beta1, beta2, eps, present, present_idx);
   PRN_CHECK_LAUNCH("prn_adam_step");
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, step, found_inf);
   PRN_CHECK_LAUNCH("prn_adam_step/advance");

@@ -357,6 +357,7 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
         direct = M <= 2 and lib.prn_conv2d_kernel_kind(ref) == 1       # (the one- / two-channel 3x3 layers: direct HBM-bound kernel)
         with profiling.span("conv3x3_direct" if direct else "conv_wgrad_kernel", "hbm" if direct else "mfma",
                             4.0 * (x.numel() + dy.numel()) if direct else 2.0 * M * C * K * K * B * Ho * Wo,
+                            nbytes=4.0 * (x.numel() + dy.numel() + dw.numel()),
                             tag=None if direct else ("wgrad", C, H, W, M, K, stride, mode, 1, B)):
             check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_conv2d_wgrad")
         if nbytes:
@@ -850,7 +851,8 @@ def dcn_fwd_raw(x, table, w, bias, stride, pad, raw, max_offset, epi=EPI_NONE):
     y = torch.empty(B, M, d.Ho, d.Wo, device=x.device, dtype=torch.float32)
     ws = _f32(fb, x.device) if fb else None
     if profiling._enabled:
-        with profiling.span("dcnv2_fwd_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo):
+        with profiling.span("dcnv2_fwd_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo,
+                            nbytes=4.0 * (x.numel() + w.numel() + y.numel()) + 32.0 * 9 * B * d.Ho * d.Wo):
             check(lib.prn_dcnv2_fwd_phase(ref, _p(x), _p(table), _p(w), _p(bias), _p(y), _p(ws), _stream(), 1), "prn_dcnv2_fwd")
         if fb:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(fb) + 4.0 * y.numel()):
@@ -866,7 +868,8 @@ def dcn_wgrad_raw(x, table, dy, M, stride, pad, raw, max_offset):
     dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
     ws = _f32(wb, x.device) if wb else None
     if profiling._enabled:
-        with profiling.span("dcnv2_wgrad_kernel", "mfma", 2.0 * M * C * 9 * dy.shape[0] * dy.shape[2] * dy.shape[3]):
+        with profiling.span("dcnv2_wgrad_kernel", "mfma", 2.0 * M * C * 9 * dy.shape[0] * dy.shape[2] * dy.shape[3],
+                            nbytes=4.0 * (x.numel() + dy.numel() + dw.numel()) + 32.0 * 9 * dy.shape[0] * dy.shape[2] * dy.shape[3]):
             check(lib.prn_dcnv2_bwd_weight_phase(ref, _p(x), _p(table), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_dcnv2_bwd_weight")
         if wb:
             with profiling.span("reduce_splits_kernel", "hbm", float(wb) + 4.0 * dw.numel()):
@@ -887,11 +890,15 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
     dx = torch.empty_like(x) if need_x else None
     ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
     if profiling._enabled:
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo, nbytes=4.0 * (dy.numel() + wt.numel()) + ncols):
-            check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), None, _p(ws), _stream()), "prn_dcnv2_bwd_input")
-        if need_x:                                                  # (re-issues the GEMM: profiling runs only)
-            with profiling.span("dcnv2_bwd_input", "hbm", ncols + 8.0 * x.numel()):
-                check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream()), "prn_dcnv2_bwd_input")
+        # every launch bracketed on its own: the column-gradient GEMM, its K-split sum, the CSR gather of dx (phases 1 / 2 / 3)
+        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo, nbytes=4.0 * (dy.numel() + wt.numel()) + ncols,
+                            tag=("dcn-colgrad", M, d.Ho, d.Wo, 9 * C, 1, 1, 0, 1, B)):
+            check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 1), "prn_dcnv2_bwd_input")
+        with profiling.span("reduce_epilogue_kernel", "hbm", 0.0):      # (no-op without a K split: an empty bracket, ~0 us)
+            check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 2), "prn_dcnv2_bwd_input")
+        if need_x:
+            with profiling.span("dcnv2_bwd_input", "hbm", ncols + 4.0 * x.numel() + 8.0 * offset.numel()):
+                check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 3), "prn_dcnv2_bwd_input")
     else:
         check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream()), "prn_dcnv2_bwd_input")
     d_off = d_msk = None
@@ -1052,8 +1059,19 @@ class _PlanePrior(torch.autograd.Function):
         ws = _f32(nb, seg.device)
         pooled = torch.empty(B, NK, h // 4, w // 4, device=seg.device, dtype=torch.float32)
         out = torch.empty(B, F, h // 4, w // 4, device=seg.device, dtype=torch.float32)
-        check(lib.prn_plane_prior_fwd(_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream()),
-              "prn_plane_prior_fwd")
+        if profiling._enabled:
+            args = (_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream())
+            npx = (h // 2) * (w // 2)
+            for ph, (fam, bound, work, nb_, tag) in enumerate((
+                    ("plane_prior_centre_gather", "hbm", 4.0 * 2 * B * E * npx, 0.0, None),
+                    ("conv_igemm_kernel", "mfma", 2.0 * NK * E * B * npx, 4.0 * B * (E * npx + NK * E + NK * npx), ("prior-dynamic", E, h // 2, w // 2, NK, 1, 1, 0, 1, B)),
+                    ("resize_down2", "hbm", 4.0 * B * NK * npx * 1.25, 0.0, None),
+                    ("conv_igemm_kernel", "mfma", 2.0 * F * NK * B * npx / 4, 4.0 * (B * NK * npx / 4 + F * NK + B * F * npx / 4), ("conv", NK, h // 4, w // 4, F, 1, 1, 0, 1, B))), 1):
+                with profiling.span(fam, bound, work, nbytes=nb_, tag=tag):
+                    check(lib.prn_plane_prior_fwd_phase(*args, ph), "prn_plane_prior_fwd")
+        else:
+            check(lib.prn_plane_prior_fwd(_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream()),
+                  "prn_plane_prior_fwd")
         ctx.save_for_backward(pooled, w1)
         ctx.dims = (B, h, w, NK, F, b1 is not None)
         ctx.bias = b1
@@ -1068,7 +1086,9 @@ class _PlanePrior(torch.autograd.Function):
         def wgrad():
             dw = torch.empty(F, NK, 1, 1, device=d_out.device, dtype=torch.float32)
             ws = _f32(lib.prn_plane_prior_wgrad_ws_bytes(B, h, w, NK, F), d_out.device)
-            check(lib.prn_plane_prior_wgrad(_p(pooled), _p(d_out), _p(dw), _p(ws), B, h, w, NK, F, _stream()), "prn_plane_prior_wgrad")
+            with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * F * NK * B * (h // 4) * (w // 4), nbytes=4.0 * (pooled.numel() + d_out.numel() + dw.numel()),
+                                tag=("wgrad", NK, h // 4, w // 4, F, 1, 1, 0, 1, B)):      # (GEMM + split sum in one bracket)
+                check(lib.prn_plane_prior_wgrad(_p(pooled), _p(d_out), _p(dw), _p(ws), B, h, w, NK, F, _stream()), "prn_plane_prior_wgrad")
             return dw
         dw = None
         if _defer(ctx.needs_input_grad[2], w1):
@@ -1118,7 +1138,10 @@ class _BatchNorm(torch.autograd.Function):
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
             if profiling._enabled:
-                with profiling.span("bn_train_fwd", "hbm", 4.0 * x.numel() * (4 if residual is not None else 3)):
+                small = lib.prn_bn_kernel_kind(B, HW) == 1        # one pass (x read once) or statistics pass + apply pass
+                r_ = 1 if residual is not None else 0
+                with profiling.span("bn_small_fwd" if small else "bn_train_fwd", "hbm", 4.0 * x.numel() * ((2 if small else 3) + r_),
+                                    ref=4.0 * x.numel() * (3 + r_)):
                     check(lib.prn_bn_train_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean), _p(rvar), _p(ws),
                                                B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd")
             else:
@@ -1149,7 +1172,12 @@ class _BatchNorm(torch.autograd.Function):
         dg = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
-        with profiling.span("bn_bwd", "hbm", 4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
+        # executed bytes: dy and x (and y, when the ReLU mask comes from the output) are read once by the one-pass kernel, twice by the
+        # two-pass pair; dx (and the residual's gradient) written once.  ref = the reference operator chain (ReLU bwd + BN bwd + add)
+        small = training and lib.prn_bn_kernel_kind(B, H * W) == 1
+        reads = 2 + (1 if y is not None else 0)
+        with profiling.span("bn_small_bwd" if small else "bn_bwd", "hbm", 4.0 * x.numel() * (reads * (1 if small else 2) + 1 + (1 if has_res else 0)),
+                            ref=4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
             check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
                                  B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
         return dx, dg, db, None, None, dres, None, None, None, None

@@ -17,6 +17,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.found_inf = None
         self.grad_scale = None
+        self.exchange = None          # a parallel.GradAllReduce: tensors for which no rank produced a gradient are skipped (see step)
         self._tab = None
 
     def load_state_dict(self, state_dict):
@@ -99,8 +100,19 @@ class FusedAdam(torch.optim.Optimizer):
         fi = self.found_inf.float().reshape(()) if self.found_inf is not None else None
         gs = self.grad_scale.float().reshape(()) if self.grad_scale is not None else None
         stream = ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(tab["dev"].index))
-        check(lib.prn_adam_step(vp(tab["chunks"]), tab["nchunks"], vp(tab["p"]), vp(tab["g"]), vp(tab["m"]), vp(tab["v"]), vp(tab["numel"]), vp(tab["lr"]),
-                                vp(tab["step"]), vp(fi), vp(gs), float(betas[0]), float(betas[1]), float(eps), stream), "prn_adam_step")
+        present = pidx = None
+        ex = self.exchange
+        if ex is not None and getattr(ex, "active", False) and ex.presence is not None:
+            # data-parallel: the exchange zero-fills gradients a rank did not produce (every rank must post the same collectives), so
+            # "no rank had a gradient" arrives as an all-reduced count on the device instead of a host-side None; the kernel leaves such
+            # tensors alone like optim.Adam leaves a parameter whose .grad is None (reference train.py:362)
+            if tab.get("pidx_for") is not ex:
+                tab["pidx"] = torch.tensor([ex.index[p] for p, _ in plist], dtype=torch.int32, device=tab["dev"])
+                tab["pidx_for"] = ex
+            present, pidx = ex.presence, tab["pidx"]
+        check(lib.prn_adam_step_masked(vp(tab["chunks"]), tab["nchunks"], vp(tab["p"]), vp(tab["g"]), vp(tab["m"]), vp(tab["v"]), vp(tab["numel"]),
+                                       vp(tab["lr"]), vp(tab["step"]), vp(fi), vp(gs), float(betas[0]), float(betas[1]), float(eps), vp(present), vp(pidx),
+                                       stream), "prn_adam_step")
         # the kernel wrote through raw pointers: advance the version counters like an in-place torch op would -- the flipped /
         # Winograd-domain / BatchNorm-folded weight caches of this package are keyed on them
         torch.autograd.graph.increment_version([p for p, _ in plist])

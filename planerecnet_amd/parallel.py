@@ -67,6 +67,12 @@ class GradAllReduce:
         self.arrived = [0] * len(self.buckets)
         self.ready = [False] * len(self.buckets)
         self.next = 0
+        # per parameter: how many ranks produced a gradient this step (all-reduced in finish(); optim.FusedAdam skips a tensor whose
+        # count is 0, the way optim.Adam skips a parameter whose .grad is None -- reference train.py:362)
+        self.index = {p: i for i, p in enumerate(self.params)}
+        self.presence = torch.ones(len(self.params), device=dev, dtype=torch.float32)
+        self._ones = torch.ones(len(self.params), device=dev, dtype=torch.float32)
+        self._presence_work = None
 
     # called by autograd on the backward thread, once per parameter per backward
     def _on_grad(self, p):
@@ -144,17 +150,31 @@ class GradAllReduce:
 
     def _finish_impl(self):
         # Buckets held back by a parameter that received no gradient on THIS rank: every rank must still post the same sequence
-        # of collectives, so the missing gradient enters as zeros.  Difference to the reference's single-process training: such
-        # a parameter then has a (zero or other ranks') gradient instead of None, i.e. Adam advances its step count and decays its
-        # moments.  Whether all ranks lacked it is not known without a host round trip; in PlaneRecNet every parameter
-        # receives a gradient in every step (all five loss terms are always active), so the case does not arise on the hot path.
+        # of collectives, so the missing gradient enters as zeros.  Whether ALL ranks lacked it (then the reference's optim.Adam would
+        # skip the parameter: .grad is None, train.py:362) is exchanged as a per-parameter presence count that stays on the device:
+        # optim.FusedAdam (its `exchange` attribute) leaves a tensor with count 0 untouched -- no host round trip.  Only `.grad` itself
+        # differs from the single-process run (a zero tensor instead of None).
+        missing = []
         for bi in range(self.next, len(self.buckets)):
             if any(p.grad is not None for p in self.buckets[bi]) or self.world > 1:
                 for p in self.buckets[bi]:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
+                        missing.append(self.index[p])
                 self._launch(bi)
         self.next = len(self.buckets)
+        # which parameters had a gradient on ANY rank: one more (tiny) all-reduce, posted by every rank in every step
+        ctx = torch.cuda.stream(self.stream) if self.on_gpu else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            self.presence.copy_(self._ones)
+            if missing:
+                self.presence[torch.tensor(missing, device=self.presence.device)] = 0.0
+            self._presence_work = dist.all_reduce(self.presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
         for bi, work in self._pending:
             bucket, flat = self.buckets[bi], self.flat[bi]
             if self.on_gpu:
@@ -172,6 +192,13 @@ class GradAllReduce:
                 # exchange stream issues after waiting for the compute stream, i.e. after the optimizer has read them)
                 for p, v in zip(bucket, self.windows[bi]):
                     p.grad = v
+        if self._presence_work is not None:
+            if self.on_gpu:
+                with torch.cuda.stream(self.stream):
+                    self._presence_work.wait()
+            else:
+                self._presence_work.wait()
+            self._presence_work = None
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending.clear()

@@ -145,6 +145,71 @@ print("EXCHANGE_OK")
     assert "EXCHANGE_OK" in out
 
 
+def test_two_rank_exchange_yields_the_mean_gradient(tmp_path):
+    """Two ranks (gloo, time-sharing the GPU), DIFFERENT data per rank, PlaneRecNet_50 with deferred weight gradients on the side
+    stream: after GradAllReduce.finish() every parameter's .grad must be the mean over ranks of the gradients each rank computed
+    locally -- checked against a plain dist.all_reduce of the locally saved gradients.  (test_train_two_ranks_stay_identical only
+    shows that replicas stay identical, not that what they exchange is the mean.)"""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from planerecnet_amd.config import cfg, set_cfg
+from planerecnet_amd.planerecnet import PlaneRecNet
+from planerecnet_amd.parallel import GradAllReduce
+from planerecnet_amd import ops, timer
+timer.disable_all()
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 2
+set_cfg("PlaneRecNet_50_config")
+torch.manual_seed(0)                                            # identical replicas
+net = PlaneRecNet(cfg); net.init_head_weights(); net = net.cuda().train()
+for m in net.modules():
+    if isinstance(m, torch.nn.BatchNorm2d): m.eval()            # running statistics fixed between the two passes
+x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(100 + rank)).cuda()     # different data per rank
+ops.set_wgrad_async(True)
+def backward(ex):
+    net.zero_grad(set_to_none=True)
+    mask, cate, kern, depth = net(x)
+    (mask.square().mean() + depth.mean() + sum(c.mean() for c in cate) + sum(k.square().mean() for k in kern)).backward()
+    ops.wgrad_join()
+    if ex is not None: ex.finish()
+    torch.cuda.synchronize()
+backward(None)
+local = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+want = {}
+for n in sorted(local):
+    t = local[n].clone()
+    dist.all_reduce(t)
+    want[n] = t / world
+ex = GradAllReduce(list(net.parameters()), bucket_bytes=8 << 20)
+assert ex.active and len(ex.buckets) > 3
+backward(ex)
+worst = 0.0
+for n, p in net.named_parameters():
+    if n not in want: continue
+    s = float(want[n].abs().max()) + 1e-12
+    err = float((p.grad - want[n]).abs().max()) / s
+    worst = max(worst, err)
+    # (not bit-equal: the DCN d-input gather's summation order varies from run to run)
+    assert err <= 1e-3, (n, err)
+    # and it is NOT just the local gradient: the two ranks saw different data
+differs = sum(float((local[n] - want[n]).abs().max()) > 1e-6 * (float(want[n].abs().max()) + 1e-12) for n in want)
+assert differs > 0.9 * len(want), differs
+ops.set_wgrad_async(False)
+dist.barrier()
+if rank == 0: print("MEAN_OK worst %%.2e over %%d tensors" %% (worst, len(want)))
+dist.destroy_process_group()
+''' % ROOT
+    script = os.path.join(str(tmp_path), "mean_check.py")
+    with open(script, "w") as f:
+        f.write(code)
+    cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547", script]
+    r = subprocess.run([sys.executable] + cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=900, env=_two_rank_env())
+    assert r.returncode == 0 and "MEAN_OK" in r.stdout, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+
+
 def test_frame_stager_rotating_pinned_uploads():
     """train.py's input staging (planerecnet_amd/staging.py): batches uploaded from rotating page-locked buffers on a side stream
     arrive intact while the compute stream is busy, buffers are reused only after their previous upload has left them."""

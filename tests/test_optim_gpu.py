@@ -105,3 +105,34 @@ def test_fused_adam_survives_state_reload_and_storage_moves():
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert torch.allclose(a, b, rtol=5e-6, atol=1e-7), (i, float((a - b).abs().max()))
         assert float(mine.state[b]["step"]) == 4.0 and mine.state[b]["step"].is_cuda
+
+
+def test_fused_adam_skips_tensors_no_rank_had_a_gradient_for():
+    """Data-parallel runs: the exchange zero-fills a gradient this rank did not produce; when NO rank produced one (all-reduced
+    presence count 0) the tensor and its moments must stay untouched, like optim.Adam with .grad = None (reference train.py:362)."""
+    from planerecnet_amd.optim import FusedAdam
+    pa, pb = _params(7), _params(7)
+    ref, mine = torch.optim.Adam(pa, lr=1e-2), FusedAdam(pb, lr=1e-2)
+
+    class Exchange:                                               # the two attributes FusedAdam reads from parallel.GradAllReduce
+        active = True
+        index = {p: len(pb) - 1 - i for i, p in enumerate(pb)}    # (a different order than the optimizer's)
+        presence = torch.full((len(pb),), 2.0, device="cuda")
+    mine.exchange = Exchange
+    g = torch.Generator().manual_seed(8)
+    for it in range(3):
+        absent = {2, 5} if it == 1 else set()
+        Exchange.presence.fill_(2.0)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn(a.shape, generator=g).cuda()
+            if i in absent:
+                a.grad, b.grad = None, torch.zeros_like(b)         # what the exchange leaves behind
+                Exchange.presence[Exchange.index[b]] = 0.0
+            else:
+                a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step()
+        mine.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.allclose(a, b, rtol=5e-6, atol=1e-7), i
+        assert torch.allclose(ref.state[a]["exp_avg_sq"], mine.state[b]["exp_avg_sq"], rtol=5e-6, atol=1e-9), i

@@ -26,8 +26,9 @@ def _worker(rank, world, port, bucket_bytes, q):
         net = torch.nn.Sequential(torch.nn.Linear(13, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
                                   torch.nn.Linear(32, 7), torch.nn.Linear(7, 3))
         net[5].weight.requires_grad_(False)                  # a frozen parameter (frozen BN affine in the real model)
-        unused = torch.nn.Parameter(torch.ones(5))           # a parameter that receives no gradient this step
-        params = list(net.parameters()) + [unused]
+        unused = torch.nn.Parameter(torch.ones(5))           # a parameter that receives no gradient on ANY rank
+        half = torch.nn.Parameter(torch.ones(4))             # ... and one that receives a gradient on rank 1 only
+        params = list(net.parameters()) + [unused, half]
         ex = GradAllReduce(params, bucket_bytes=bucket_bytes)
         results = []
         for step in range(2):                                # two steps: bucket counters must reset
@@ -36,11 +37,19 @@ def _worker(rank, world, port, bucket_bytes, q):
             for p in params:
                 p.grad = None
             loss = net(x).square().mean() * (rank + 1)
+            if rank == 1:
+                loss = loss + (half * torch.arange(4.0)).sum()
             loss.backward()
             local = [None if p.grad is None else p.grad.clone() for p in params]
             ex.finish()
+            # how many ranks produced a gradient, per parameter (what optim.FusedAdam uses to skip a tensor like a .grad of None)
+            cnt = {p: float(ex.presence[ex.index[p]]) for p in ex.params}
+            assert cnt[unused] == 0.0 and cnt[half] == 1.0 and all(cnt[p] == float(world) for p in ex.params if p is not unused and p is not half)
+            assert torch.allclose(half.grad, torch.arange(4.0) / world)          # the mean over ranks, zeros entering for rank 0
             # reference: plain all-reduce of the local gradients
             for p, l in zip(params, local):
+                if p is half:
+                    continue
                 if l is None:
                     assert p.grad is None or float(p.grad.abs().max()) == 0
                     continue

@@ -9,8 +9,9 @@ data/config.py:232: dcn_layers [0,4,23,3], interval 3), stage 2 at blocks 0 and 
    the fixture holds, per parameter, how far the reference's own fp32 gradient is from the fp64 gradient of the same
    function (rel-L2 `spread`: 1e-6 for the instance / mask heads, ~2e-2 for backbone and depth-decoder parameters, whose
    training-mode BatchNorm backward subtracts two nearly equal means); the HIP gradient must be within
-   GRAD_K * spread (+ a 5e-4 floor for summation-order noise) of the fp64 oracle.  A second fp32 implementation with
-   independent rounding lands at ~1-1.5 x spread; a wrong term lands far outside.
+   GRAD_K * spread (+ a 5e-4 floor for summation-order noise) of the fp64 oracle, GRAD_K = 2 since round 3 (4 before: the
+   measured worst case is 0.83 of the K = 2 bound, median 0.5; a term that is 3 % wrong now fails).  A second fp32
+   implementation with independent rounding lands at ~1-1.5 x spread; a wrong term lands far outside.
    The step is checked twice: with every 3x3 layer on the direct kernel (ops.WINOGRAD off: EVERY parameter inside the bound)
    and in the default build (Winograd F(4x4,3x3) for the stride-1 3x3 layers).  Winograd's fp32 forward error is ~1e-5 of the
    tensor max where the direct kernel's is ~1e-7 (both far inside the 5e-4 output tolerance); five parameters of the
@@ -31,7 +32,8 @@ pytestmark = pytest.mark.gpu
 
 CN = "PlaneRecNet_101_config"
 SEED_W, SEED_X, SEED_NP = 3, 12, 13          # as in tests/golden/make_golden_r101.py
-GRAD_K, GRAD_FLOOR = 4.0, 5e-4
+GRAD_K, GRAD_FLOOR = 2.0, 5e-4               # direct kernels: the HIP gradient within 2 x the reference's own fp32-vs-fp64 spread (measured max: 0.83 of it)
+GRAD_FLOOR_WINOGRAD = 1e-3                   # default build: F(4x4,3x3)'s ~1e-5 forward error (direct: ~1e-7) through gradients of condition ~100
 WINOGRAD_SENSITIVE = {"inst_head.kernel_tower.0.weight": 2e-2, "inst_head.kernel_tower.1.weight": 2e-2, "inst_head.kernel_tower.1.bias": 2e-2,
                       "inst_head.kernel_tower.3.weight": 2e-2, "inst_head.kernel_tower.4.bias": 2e-2}
 
@@ -137,7 +139,7 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
             assert got.norm().item() <= 1e-4 * g64[wn].norm().item() + 1e-6, (n, got.norm().item())
             continue
         l2 = ((got - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()
-        bound = GRAD_K * spread[n] + GRAD_FLOOR
+        bound = GRAD_K * spread[n] + (GRAD_FLOOR_WINOGRAD if winograd else GRAD_FLOOR)
         if winograd and n in WINOGRAD_SENSITIVE:
             bound = WINOGRAD_SENSITIVE[n]
         worst.append((l2 / bound, n, l2, spread[n]))
@@ -159,8 +161,9 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
             for r, n, l2, sp in sorted(worst, key=lambda t: t[1]):
                 f.write("%-64s err %.2e spread %.2e ratio %.2f\n" % (n, l2, sp, r))
     ratios = np.array([r for r, _, _, _ in worst])
-    print("error / bound percentiles (50, 90, 99, max): %s" % np.round(np.percentile(ratios, [50, 90, 99, 100]), 3))
-    assert not bad, "parameter gradients outside the calibrated bound: %s" % bad[:10]
+    pct = np.round(np.percentile(ratios, [50, 90, 99, 100]), 3)
+    print("error / bound percentiles (50, 90, 99, max): %s" % pct)
+    assert not bad, "parameter gradients outside the calibrated bound (error / bound percentiles 50 / 90 / 99 / max: %s): %s" % (pct, bad[:10])
     # the DCN blocks the interval rule places in the 23-block stage are all among the checked parameters
     for b in range(3, 23, 3):
         for leaf in ("regular_conv.weight", "offset_conv.weight", "offset_conv.bias", "modulator_conv.weight", "modulator_conv.bias"):

@@ -201,6 +201,7 @@ def main():
         {"params": prn_net.inst_head.parameters(), "lr": args.lr}, {"params": prn_net.mask_head.parameters(), "lr": args.lr},
         {"params": prn_net.depth_decoder.parameters(), "lr": 2 * args.lr}], lr=args.lr)      # optim.Adam of train.py:251-256 as one launch
     exchange = GradAllReduce([p for p in prn_net.parameters()])
+    optimizer.exchange = exchange                          # parameters no rank had a gradient for are skipped like a .grad of None (train.py:362)
     ops.set_wgrad_async(True)          # weight gradients on a side stream; joined by ops.wgrad_join() after every backward()
 
     # BN-safe warm-up forward with frozen statistics (reference train.py:270-272)
