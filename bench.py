@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--targets", choices=("device", "workers"), default=os.environ.get("PRN_BENCH_TARGETS", "device"),
+                    help="GT-only loss preparation: HIP kernels one batch ahead on the side stream (planerecnet_amd/targets.py, triplets drawn by the "
+                         "device sampler) or the round-2 host worker processes (losses.TargetPrefetcher, numpy stream)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the extra steps that time the gradient-exchange path on a one-rank group")
     ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
                     "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
@@ -269,7 +272,11 @@ def main():
 
         ops.set_wgrad_async(not args.sync_wgrad)                 # weight gradients on a side stream, joined after backward (ops.py)
         hw = (args.height, args.width)
-        prefetch = TargetPrefetcher(crit)
+        if args.targets == "device":
+            from planerecnet_amd.targets import DeviceTargetBuilder
+            prefetch = DeviceTargetBuilder(crit, seed=rank)
+        else:
+            prefetch = TargetPrefetcher(crit)
         prefetch.submit(inst, hw)                                # two batches in flight: the workers never wait for the trainer
         prefetch.submit(inst, hw)
 
@@ -313,7 +320,7 @@ def main():
                 ev.record()
                 ph.setdefault("_gap_a2", []).append(ev)
             t6 = time.perf_counter()
-            if os.environ.get("PRN_BENCH_PHASES"):                              # how long does `get` wait for the workers' results?
+            if os.environ.get("PRN_BENCH_PHASES") and args.targets == "workers":    # how long does `get` wait for the workers' results?
                 tw = time.perf_counter()
                 prefetch.queue[0][0].result()
                 if prefetch.queue[0][1] is not None:
@@ -377,7 +384,8 @@ def main():
         hs = ph.get("host_ms_per_step", [])[n_host0 + args.warmup:]
         host = {"enqueue_ms_per_step": (sum(hs) / len(hs)) if hs else None,
                 "process_cpu_ms_per_step": 1e3 * (time.process_time() - cpu0) / max(args.steps + args.warmup, 1),
-                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "target_workers": getattr(prefetch, "nworkers", None)}
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "targets": args.targets,
+                "target_prep_host_ms_per_step": (getattr(prefetch, "host_ms", None) / max(args.steps + args.warmup + 3, 1)) if hasattr(prefetch, "host_ms") else None}
         if world > 1:                                            # slowest rank
             t = torch.tensor([host["enqueue_ms_per_step"] or 0.0, host["process_cpu_ms_per_step"]], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -454,23 +454,45 @@ int prn_sigmoid_point_nms(const float* x, float* out, int B, int C, int S, int64
  * ws: n floats. */
 int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores, int n, float sigma, int gaussian, float* out, float* ws, void* stream);
 
+/* ---- GT-only preparation of the loss on the device (csrc/prn_targets.hip) ---------------------------------------------------
+ * The per-instance mask work of SOLOv2's target assignment (models/functions/losses.py:200-286: centre of mass, empty-mask flag,
+ * the 1/4-scale masks) and the virtual-normal triplet sampling (models/functions/vnl.py:43-70,119-140), which the reference runs
+ * on the host per image / per plane.  masks: uint8 [Ntot][H][W], the plane masks of all B images back to back; img_first [B+1]
+ * (device): first mask of every image.  REGIONS: r < Ntot = plane mask r; r = Ntot + b = the pixels of image b no plane covers.
+ *   prn_gt_mask_stats     -> totals [Ntot+B][3] uint64 = (pixels, sum of x, sum of y) per region (exact integers), segcnt
+ *                            [Ntot+B][H*W/64] set pixels per 64-pixel segment, segstart [Ntot+B][H*W/64 + 1] their exclusive prefix
+ *   prn_gt_quarter_masks  -> out [N][H/4][W/4]: cv2 INTER_LINEAR at exactly 1/4 (mean of the 2x2 centre of each 4x4 block, rounded
+ *                            half up) -- imrescale(mask, 0.25) of losses.py:243-247
+ *   prn_gt_sample_triplets: n_tot triplets; triplet t belongs to sampled region list entry trip_seg[t] (seg_region / seg_img: its
+ *                            region and image); its three points are the pixels of RANK r_j in that region (raster order, i.e.
+ *                            np.flatnonzero(mask)[r_j]).  ranks [3][n_tot] != NULL: injected ranks (the reference's numpy stream
+ *                            drawn by the caller: bit-identical to the host path); NULL: drawn on the device (Philox4x32-10, counter
+ *                            = t, key = seed), rank = floor(u * pixels).  gid [3][n_tot] = image * H*W + pixel.              */
+int64_t prn_gt_segments(int H, int W);
+int prn_gt_mask_stats(const unsigned char* masks, const int* img_first, int B, int Ntot, int H, int W, unsigned char* segcnt, int* segstart,
+                      unsigned long long* totals, void* stream);
+int prn_gt_quarter_masks(const unsigned char* masks, unsigned char* out, int N, int H, int W, void* stream);
+int prn_gt_sample_triplets(const unsigned char* masks, const int* img_first, int B, int Ntot, int H, int W, const int* segstart, const int* trip_seg,
+                           const int* seg_region, const int* seg_img, const int* ranks, unsigned long long seed, int64_t n_tot, int* gid, void* stream);
+
 /* ---- optimizer step ------------------------------------------------------------------------------------------------------
  * replaces optimizer.step() of the reference's optim.Adam (train.py:251-256,362; no weight decay, no amsgrad): every
  * parameter tensor of the model in ONE launch.  Tables (device memory, built once by the caller): chunks [nchunks][2] =
  * (tensor index, first element) covering each tensor in pieces of prn_adam_chunk_elems() elements; p / m / v [ntensors]
  * device pointers, numel [ntensors], lr [ntensors] (a group's learning rate, per tensor); g [ntensors] is rewritten every
- * step (gradients are fresh allocations).  step: device scalar, the number of updates applied so far (advanced here).
- * found_inf (device scalar or NULL): non-zero => nothing is updated and step stays (the collective skip of train.py:353).
+ * step (gradients are fresh allocations).  step [ntensors] (device): per tensor, the number of updates applied so far (advanced
+ * here) -- optim.Adam's state['step'].  found_inf (device scalar or NULL): non-zero => nothing is updated and the counters stay
+ * (the collective skip of train.py:353).
  * grad_scale (device scalar or NULL): gradients are divided by it.
  *   m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),  t = step + 1 */
 int prn_adam_chunk_elems(void);
-int prn_adam_step(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
+int prn_adam_step(const int* chunks, int nchunks, int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
                   const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps, void* stream);
 /* The same for data-parallel runs: present [any length] (device) holds, per parameter of the gradient exchange, how many ranks
  * produced a gradient for it (all-reduced); present_idx [ntensors] maps this launch's tensors into it.  A tensor whose count is 0 is
- * left untouched -- parameter, exp_avg and exp_avg_sq -- exactly as optim.Adam skips a parameter whose .grad is None
+ * left untouched -- parameter, exp_avg, exp_avg_sq and its step counter -- exactly as optim.Adam skips a parameter whose .grad is None
  * (train.py:362), without a device-to-host round trip.  Both NULL: prn_adam_step. */
-int prn_adam_step_masked(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
+int prn_adam_step_masked(const int* chunks, int nchunks, int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
                          const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps,
                          const float* present, const int* present_idx, void* stream);
 

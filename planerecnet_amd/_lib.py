@@ -119,9 +119,13 @@ SIGNATURES = {
     "prn_focal_sum_bwd": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
     "prn_rmse_log_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),
     "prn_rmse_log_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),
+    "prn_gt_segments": (c_i64, [c_int, c_int]),
+    "prn_gt_mask_stats": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "prn_gt_quarter_masks": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "prn_gt_sample_triplets": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, ctypes.c_uint64, c_i64, P, P]),
     "prn_adam_chunk_elems": (c_int, []),
-    "prn_adam_step": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P]),
-    "prn_adam_step_masked": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P, P, P]),
+    "prn_adam_step": (c_int, [P, c_int, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P]),
+    "prn_adam_step_masked": (c_int, [P, c_int, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P, P, P]),
     "prn_pairwise_iou_ws_bytes": (c_i64, [c_int, c_int, c_i64]),
     "prn_pairwise_iou": (c_int, [P, P, P, P, c_int, c_int, c_i64, P, P, P, P]),
     "prn_mask_boxes": (c_int, [P, c_int, c_int, c_int, P, P]),

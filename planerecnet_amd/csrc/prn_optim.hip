@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const int2* __restrict__ chun
   if (present && present[present_idx[t]] == 0.f) return;
   const int n = min(ADAM_CHUNK, numel[t] - off);
   // bias corrections of step + 1 (the counter is advanced by adam_advance_kernel after this launch), in double like torch
-  const double s = (double)(*step) + 1.0;
+  const double s = (double)step[t] + 1.0;                     // per tensor, like optim.Adam's state['step']: a skipped tensor does not advance
   const float bc1 = (float)(1.0 - pow(beta1_d, s)), bc2_sqrt = (float)sqrt(1.0 - pow(beta2_d, s));
   // (1 - beta) is formed in double and then rounded, like torch: 1 - 0.999f would be 0.00100005)
   const float beta2 = (float)beta2_d, w1 = (float)(1.0 - beta1_d), w2 = (float)(1.0 - beta2_d);
@@ -54,29 +54,32 @@ __global__ __launch_bounds__(256) void adam_kernel(const int2* __restrict__ chun
   }
 }
 
-__global__ void adam_advance_kernel(float* step, const float* found_inf) {
-  if (!(found_inf && *found_inf != 0.f)) *step += 1.f;
+__global__ void adam_advance_kernel(float* step, int ntensors, const float* found_inf, const float* present, const int* present_idx) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntensors || (found_inf && *found_inf != 0.f)) return;
+  if (present && present[present_idx[t]] == 0.f) return;
+  step[t] += 1.f;
 }
 }  // namespace
 
 extern "C" int prn_adam_chunk_elems(void) { return ADAM_CHUNK; }
 
-extern "C" int prn_adam_step(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v, const int* numel,
-                             const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2, float eps,
-                             void* stream) {
-  return prn_adam_step_masked(chunks, nchunks, p, g, m, v, numel, lr, step, found_inf, grad_scale, beta1, beta2, eps, nullptr, nullptr, stream);
+extern "C" int prn_adam_step(const int* chunks, int nchunks, int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                             const int* numel, const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1, double beta2,
+                             float eps, void* stream) {
+  return prn_adam_step_masked(chunks, nchunks, ntensors, p, g, m, v, numel, lr, step, found_inf, grad_scale, beta1, beta2, eps, nullptr, nullptr, stream);
 }
 
-extern "C" int prn_adam_step_masked(const int* chunks, int nchunks, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                    const int* numel, const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1,
+extern "C" int prn_adam_step_masked(const int* chunks, int nchunks, int ntensors, float* const* p, const float* const* g, float* const* m,
+                                    float* const* v, const int* numel, const float* lr, float* step, const float* found_inf, const float* grad_scale, double beta1,
                                     double beta2, float eps, const float* present, const int* present_idx, void* stream) {
-  PRN_REQUIRE(chunks && p && g && m && v && numel && lr && step && nchunks > 0, "prn_adam_step: bad arguments");
+  PRN_REQUIRE(chunks && p && g && m && v && numel && lr && step && nchunks > 0 && ntensors > 0, "prn_adam_step: bad arguments");
   PRN_REQUIRE((present == nullptr) == (present_idx == nullptr), "prn_adam_step_masked: present and present_idx come together");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, st, reinterpret_cast<const int2*>(chunks), p, g, m, v, numel, lr, (const float*)step, found_inf,
                      grad_scale, beta1, beta2, eps, present, present_idx);
   PRN_CHECK_LAUNCH("prn_adam_step");
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, step, found_inf);
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(cdiv(ntensors, 256)), dim3(256), 0, st, step, ntensors, found_inf, present, present_idx);
   PRN_CHECK_LAUNCH("prn_adam_step/advance");
   return 0;
 }

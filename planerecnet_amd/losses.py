@@ -62,13 +62,31 @@ class PlaneRecNetLoss(nn.Module):
         """losses.py:200-286 for one image, on host tensors. Returns per-level lists
         (ins_label uint8 [n,h,w], cate_label int64 [S,S], ins_ind bool [S*S], grid_order list)."""
         boxes, labels, masks = inst["boxes"].cpu(), inst["classes"].cpu(), inst["masks"].cpu()
-        fh, fw = int(mask_feat_size[0]), int(mask_feat_size[1])
-        up_h, up_w = fh * 4, fw * 4
-        areas = torch.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))
         small_all = quarter_mask_u8(masks.to(torch.uint8))
         cx_all, cy_all = center_of_mass(masks)
         nonempty = masks.flatten(1).sum(1) > 0
-        ins_l, cate_l, ind_l, order_l = [], [], [], []
+        which_l, cate_l, ind_l, order_l = self.assign_cells(boxes, labels, cx_all, cy_all, nonempty, mask_feat_size)
+        fh, fw = int(mask_feat_size[0]), int(mask_feat_size[1])
+        ins_l = []
+        for which in which_l:
+            if which:
+                lab = torch.zeros(len(which), fh, fw, dtype=torch.uint8)
+                sm = small_all[which]
+                lab[:, :sm.shape[1], :sm.shape[2]] = sm
+            else:
+                lab = torch.zeros(0, fh, fw, dtype=torch.uint8)
+            ins_l.append(lab)
+        return ins_l, cate_l, ind_l, order_l
+
+    def assign_cells(self, boxes, labels, cx_all, cy_all, nonempty, mask_feat_size):
+        """The centre-region assignment of losses.py:213-279 given the per-instance mask statistics (centre of mass, empty flag):
+        per level -> (instance index of every positive cell, category map [S,S], positive flags [S*S], cell index of every positive
+        cell).  Shared by the host path (prepare_ground_truth) and the device path (targets.DeviceTargetBuilder, which gets the
+        statistics from prn_gt_mask_stats)."""
+        fh, fw = int(mask_feat_size[0]), int(mask_feat_size[1])
+        up_h, up_w = fh * 4, fw * 4
+        areas = torch.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))
+        which_l, cate_l, ind_l, order_l = [], [], [], []
         for (lo, hi), S in zip(self.scale_ranges, self.num_grids):
             hit = ((areas >= lo) & (areas <= hi)).nonzero().flatten().tolist()
             cate = torch.full((S, S), self.num_classes, dtype=torch.int64)
@@ -92,17 +110,11 @@ class PlaneRecNetLoss(nn.Module):
                         which.append(i)
                         order.append(r * S + c)
                         ind[r * S + c] = True
-            if which:
-                lab = torch.zeros(len(which), fh, fw, dtype=torch.uint8)
-                sm = small_all[which]
-                lab[:, :sm.shape[1], :sm.shape[2]] = sm
-            else:
-                lab = torch.zeros(0, fh, fw, dtype=torch.uint8)
-            ins_l.append(lab)
+            which_l.append(which)
             cate_l.append(cate)
             ind_l.append(ind)
             order_l.append(order)
-        return ins_l, cate_l, ind_l, order_l
+        return which_l, cate_l, ind_l, order_l
 
     # ------------------------------------------------------------------ GT-only work, before the forward
     @torch.no_grad()

@@ -31,8 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
     def _build(self, plist):
         dev = plist[0][0].device
         ce = lib.prn_adam_chunk_elems()
-        chunks, numel = [], []
-        step = None
+        chunks, numel, old_steps = [], [], []
         for i, (p, _) in enumerate(plist):
             if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                 raise RuntimeError("FusedAdam: parameters must be contiguous fp32 device tensors")
@@ -42,17 +41,15 @@ class FusedAdam(torch.optim.Optimizer):
             for k in ("exp_avg", "exp_avg_sq"):
                 if st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous():
                     st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
-            if step is None:
-                # one counter for all tensors (they are always stepped together); every state entry refers to it
-                step = next((self.state[q]["step"] for q, _ in plist if "step" in self.state[q]), None)
-                if step is None:
-                    step = torch.zeros((), device=dev, dtype=torch.float32)
-                elif not (torch.is_tensor(step) and step.device == dev and step.dtype == torch.float32 and step.dim() == 0):
-                    # (a loaded state keeps `step` wherever the checkpoint had it, e.g. on the host: the kernel needs a device scalar)
-                    step = torch.as_tensor(float(step), dtype=torch.float32).to(dev).reshape(())
-            st["step"] = step
+            old_steps.append(st.get("step"))
             numel.append(p.numel())
             chunks += [(i, o) for o in range(0, p.numel(), ce)]
+        # per-tensor update counters (optim.Adam's state['step']) in ONE device array, each state entry a 0-d view of it; values of a
+        # loaded / previous state are carried over without a device-to-host read (a loaded state may keep them on the host)
+        step = torch.stack([torch.zeros((), dtype=torch.float32, device=dev) if t is None else
+                            torch.as_tensor(t, dtype=torch.float32).reshape(()).to(dev, non_blocking=True) for t in old_steps])
+        for i, (p, _) in enumerate(plist):
+            self.state[p]["step"] = step[i]
         ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)      # noqa: E731
         tab = {"ids": [id(p) for p, _ in plist], "pptr": [p.data_ptr() for p, _ in plist], "dev": dev, "step": step, "n": len(plist), "nchunks": len(chunks),
                "chunks": torch.tensor(chunks, dtype=torch.int32, device=dev), "numel": torch.tensor(numel, dtype=torch.int32, device=dev),
@@ -110,7 +107,7 @@ class FusedAdam(torch.optim.Optimizer):
                 tab["pidx"] = torch.tensor([ex.index[p] for p, _ in plist], dtype=torch.int32, device=tab["dev"])
                 tab["pidx_for"] = ex
             present, pidx = ex.presence, tab["pidx"]
-        check(lib.prn_adam_step_masked(vp(tab["chunks"]), tab["nchunks"], vp(tab["p"]), vp(tab["g"]), vp(tab["m"]), vp(tab["v"]), vp(tab["numel"]),
+        check(lib.prn_adam_step_masked(vp(tab["chunks"]), tab["nchunks"], tab["n"], vp(tab["p"]), vp(tab["g"]), vp(tab["m"]), vp(tab["v"]), vp(tab["numel"]),
                                        vp(tab["lr"]), vp(tab["step"]), vp(fi), vp(gs), float(betas[0]), float(betas[1]), float(eps), vp(present), vp(pidx),
                                        stream), "prn_adam_step")
         # the kernel wrote through raw pointers: advance the version counters like an in-place torch op would -- the flipped /

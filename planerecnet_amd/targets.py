@@ -1,0 +1,240 @@
+"""GT-only preparation of the loss ON THE DEVICE -- the alternative to losses.TargetPrefetcher's worker processes.
+
+What the reference does on the host per image and per plane (models/functions/losses.py:200-286: centre of mass, empty-mask flag and
+the cv2 1/4 rescale of every GT mask; models/functions/vnl.py:43-70: np.flatnonzero of every plane region and three index draws per
+region) is pixel work over ~15 MB of uint8 masks per batch of 8.  Here that work runs in four small HIP kernels
+(csrc/prn_targets.hip) on the side stream, one batch ahead of the step that needs it; the host keeps only what is O(instances):
+
+  submit(batch)   upload the packed masks -> prn_gt_mask_stats (pixels / sum x / sum y per region, per-segment counts + prefix),
+                  prn_gt_quarter_masks -> the 56 x 24 bytes of region totals travel back into page-locked memory behind an event;
+  get()           (a step later: the event has long fired) centre of mass and empty flags from the totals -> the reference's
+                  centre-region loop over <= 8 instances x 4 levels (losses.PlaneRecNetLoss.assign_cells, shared with the host
+                  path) -> cell lists / category maps uploaded, instance labels gathered from the 1/4 masks on the device;
+                  per region n = int(0.3 * pixels) triplets -> prn_gt_sample_triplets maps RANKS to pixels.
+
+Triplet ranks: `sampler="numpy"` draws them on the host from numpy's global stream exactly as vnl.py:43-55 does (choice + shuffle,
+three times per region, regions in the reference's order) and injects them: the triplets are then BIT-IDENTICAL to the host path's
+(parity tests).  `sampler="philox"` (default) draws them in the kernel from a counter-based generator: same distribution (uniform
+with replacement per region; the reference's shuffle of i.i.d. draws changes nothing), different stream, no host work at all.
+
+Exactness: pixel counts and coordinate sums are integers (exact); the centre of mass is float32(sum) / float32(count), which equals
+the reference's float32 reductions whenever those are exact (sums < 2^24) and otherwise agrees to the last ulp except for torch's
+summation-order rounding -- a centre would have to sit within an ulp of a grid-cell boundary for a target to differ.
+"""
+import collections
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import cfg
+from .ops import _p, _stream, check, lib
+
+
+class DeviceTargetBuilder:
+    """Drop-in for losses.TargetPrefetcher (submit / get / pending / discard / close); no worker processes."""
+
+    def __init__(self, criterion, sampler=None, seed=0, depth=3):
+        self.criterion = criterion
+        self.sampler = sampler or os.environ.get("PRN_TARGET_SAMPLER", "philox")
+        if self.sampler not in ("philox", "numpy"):
+            raise ValueError("sampler must be 'philox' or 'numpy'")
+        self.seed, self.calls = int(seed), 0
+        self.queue = collections.deque()
+        self._stage = []                                   # rotating page-locked staging buffers for the packed masks
+        self._depth = depth
+        self.nworkers = 0
+        self.host_ms = 0.0                                 # host time spent in submit + get (tools / bench report it per step)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _staging(self, nbytes):
+        for st in self._stage:
+            if st["free"] is None or st["free"].query():
+                if st["buf"].numel() < nbytes:
+                    st["buf"] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8).pin_memory()
+                return st
+        if len(self._stage) < self._depth + 1:
+            st = {"buf": torch.empty(int(nbytes * 1.25), dtype=torch.uint8).pin_memory(), "free": None}
+            self._stage.append(st)
+            return st
+        self._stage[0]["free"].synchronize()               # (more batches in flight than buffers: wait for the oldest upload)
+        return self._stage[0]
+
+    @property
+    def pending(self):
+        return self.queue[0] if self.queue else None
+
+    @torch.no_grad()
+    def submit(self, gt_instances, hw, mask_feat_size=None):
+        import time
+        t0 = time.perf_counter()
+        H, W = hw
+        dev = torch.device("cuda", torch.cuda.current_device())
+        B = len(gt_instances)
+        N_per = [int(g["masks"].shape[0]) for g in gt_instances]
+        Ntot = sum(N_per)
+        img_first = np.concatenate([[0], np.cumsum(N_per)]).astype(np.int32)
+        nbytes = Ntot * H * W
+        st = self._staging(max(nbytes, 16))
+        off = 0
+        for g in gt_instances:                             # pack the uint8 masks of all images back to back (page-locked)
+            m = g["masks"]
+            if m.dtype != torch.uint8:
+                m = m.to(torch.uint8)
+            n = m.numel()
+            if n:
+                st["buf"][off:off + n].copy_(m.reshape(-1))
+            off += n
+        main = torch.cuda.current_stream()
+        side = ops._side_stream(dev, main)
+        side.wait_stream(main)
+        R, nseg = Ntot + B, int(lib.prn_gt_segments(H, W))
+        with torch.cuda.stream(side):
+            masks = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+            masks[:nbytes].copy_(st["buf"][:nbytes], non_blocking=True)
+            st["free"] = torch.cuda.Event()
+            st["free"].record()
+            first_d = torch.from_numpy(img_first).pin_memory().to(dev, non_blocking=True)
+            segcnt = torch.empty(R * nseg, dtype=torch.uint8, device=dev)
+            segstart = torch.empty(R * (nseg + 1), dtype=torch.int32, device=dev)
+            totals = torch.empty(R * 3, dtype=torch.int64, device=dev)
+            check(lib.prn_gt_mask_stats(_p(masks), _p(first_d), B, Ntot, H, W, _p(segcnt), _p(segstart), _p(totals), _stream()), "prn_gt_mask_stats")
+            small = torch.empty(Ntot, H // 4, W // 4, dtype=torch.uint8, device=dev)
+            check(lib.prn_gt_quarter_masks(_p(masks), _p(small), Ntot, H, W, _stream()), "prn_gt_quarter_masks")
+            totals_h = torch.empty(R * 3, dtype=torch.int64).pin_memory()
+            totals_h.copy_(totals, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        small_meta = [{k: (g[k].cpu() if torch.is_tensor(g[k]) else g[k]) for k in ("boxes", "classes", "plane_paras", "k_matrix")} for g in gt_instances]
+        self.queue.append({"hw": (H, W), "feat": mask_feat_size, "B": B, "N_per": N_per, "Ntot": Ntot, "img_first": img_first, "first_d": first_d,
+                           "masks": masks, "segstart": segstart, "segcnt": segcnt, "small": small, "totals_h": totals_h, "done": done, "meta": small_meta})
+        self.host_ms += (time.perf_counter() - t0) * 1e3
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _finish(self, job, gt_depths, device):
+        """Host: O(instances) bookkeeping from the region totals; device: label gather, triplet sampling, the loss's own uploads."""
+        crit = self.criterion
+        H, W = job["hw"]
+        fh, fw = job["feat"] if job["feat"] is not None else (H // 4, W // 4)
+        B, N_per, Ntot, first = job["B"], job["N_per"], job["Ntot"], job["img_first"]
+        job["done"].synchronize()                          # recorded a step ago: no wait in steady state
+        tot = job["totals_h"].view(-1, 3)
+        cnt_t, sx_t, sy_t = tot[:, 0], tot[:, 1], tot[:, 2]
+        m00 = cnt_t.to(torch.float32).clamp(min=1e-6)
+        cx_all, cy_all = sx_t.to(torch.float32) / m00, sy_t.to(torch.float32) / m00
+        L = len(crit.num_grids)
+        level_start = np.concatenate([[0], np.cumsum([g * g for g in crit.num_grids])])
+        cell_ids, which_all, cate_rows, n_pos, num_ins = [], [], [[] for _ in range(L)], [], 0
+        for b in range(B):
+            lo, hi = int(first[b]), int(first[b + 1])
+            meta = job["meta"][b]
+            which_l, cate_l, ind_l, order_l = crit.assign_cells(meta["boxes"], meta["classes"], cx_all[lo:hi], cy_all[lo:hi], cnt_t[lo:hi] > 0, (fh, fw))
+            cell_ids.append(np.concatenate([level_start[lv] + np.asarray(order_l[lv], dtype=np.int64) for lv in range(L)]))
+            which_all.append(np.concatenate([np.asarray(w, dtype=np.int64) for w in which_l]) + lo)
+            n_pos.append(int(cell_ids[-1].shape[0]))
+            num_ins += sum(int(i.sum()) for i in ind_l)
+            for lv in range(L):
+                cate_rows[lv].append(cate_l[lv].flatten())
+        pin = lambda x: x.pin_memory()                      # noqa: E731
+        n_cells = int(level_start[-1])
+        cell_gidx = np.concatenate([b * n_cells + cell_ids[b] for b in range(B)]) if B else np.zeros(0, np.int64)
+        cell_u, cell_inv, cell_cnt = np.unique(cell_gidx, return_inverse=True, return_counts=True)
+        cell_mult = int(cell_cnt.max()) if cell_cnt.size else 1
+        which_d = pin(torch.from_numpy(np.concatenate(which_all) if which_all else np.zeros(0, np.int64))).to(device, non_blocking=True)
+        small = job["small"]
+        if small.shape[1] != fh or small.shape[2] != fw:     # (mask features of another size than H/4 x W/4: place like losses.py:268-270)
+            pad = torch.zeros(small.shape[0], fh, fw, dtype=torch.uint8, device=device)
+            pad[:, :min(fh, small.shape[1]), :min(fw, small.shape[2])] = small[:, :fh, :fw]
+            small = pad
+        ins_labels = small.index_select(0, which_d)
+        h = {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
+             "n_pos_f": pin(torch.as_tensor(n_pos, dtype=torch.float32)),
+             "cell_gidx": pin(torch.from_numpy(cell_u if cell_mult > 1 else cell_gidx)),
+             "cell_inv": pin(torch.from_numpy(cell_inv)) if cell_mult > 1 else None,
+             "cells_unique": cell_mult <= 2,
+             "cell_ids": pin(torch.from_numpy(np.concatenate(cell_ids))), "pos_img": pin(torch.from_numpy(np.repeat(np.arange(B), n_pos))),
+             "ins_labels": ins_labels,
+             "cate_labels": pin(torch.cat([r for lv in range(L) for r in cate_rows[lv]])),
+             "vnl": self._vnl(job, cnt_t, device) if cfg.use_plane_loss else None}
+        return crit.upload(h, gt_depths, device)
+
+    def _vnl(self, job, cnt_t, device):
+        """Segment bookkeeping of vnl.py:119-140 from the region pixel counts + the device sampler."""
+        H, W = job["hw"]
+        B, N_per, Ntot, first = job["B"], job["N_per"], job["Ntot"], job["img_first"]
+        ratio = self.criterion.vnl.sample_ratio
+        cnt = cnt_t.numpy()
+        seg_len, seg_img, seg_plane, seg_region, normals, fx, fy, ranks = [], [], [], [], [], [], [], []
+        for b in range(B):
+            meta = job["meta"][b]
+            K = meta["k_matrix"].numpy()
+            fx.append(K[0, 0]); fy.append(K[1, 1])
+            planes = meta["plane_paras"].numpy()[:, :3]
+            regions = [(int(first[b]) + i, True, planes[i]) for i in range(N_per[b])]
+            if int(cnt[Ntot + b]) > 0:                       # the pixels no plane covers (vnl.py:127-131)
+                regions.append((Ntot + b, False, np.zeros(3)))
+            for r, is_plane, nrm in regions:
+                num = int(cnt[r])
+                if not num <= W * H:
+                    raise AssertionError()
+                n = int(num * ratio)
+                if self.sampler == "numpy":                  # vnl.py:43-55: three (choice, shuffle) pairs from numpy's global stream
+                    trio = []
+                    for _ in range(3):
+                        p = np.random.choice(num, n, replace=True)
+                        np.random.shuffle(p)
+                        trio.append(p)
+                    ranks.append(np.stack(trio, 0))
+                seg_len.append(n); seg_img.append(b); seg_plane.append(is_plane); seg_region.append(r); normals.append(nrm)
+        seg_len = np.asarray(seg_len, dtype=np.int64)
+        n_seg, n_tot = len(seg_len), int(seg_len.sum())
+        pin = lambda x: x.pin_memory()                      # noqa: E731
+        up = lambda a, dt: pin(torch.from_numpy(np.ascontiguousarray(a)).to(dt)).to(device, non_blocking=True)      # noqa: E731
+        seg_len_d = up(seg_len, torch.int64)
+        seg = torch.repeat_interleave(torch.arange(n_seg, device=device, dtype=torch.int32), seg_len_d, output_size=n_tot) if n_tot else \
+            torch.zeros(0, dtype=torch.int32, device=device)
+        seg_region_d, seg_img_d = up(np.asarray(seg_region, np.int32), torch.int32), up(np.asarray(seg_img, np.int32), torch.int32)
+        gid = torch.empty(3, n_tot, dtype=torch.int32, device=device)
+        ranks_d = None
+        if self.sampler == "numpy" and n_tot:
+            ranks_d = up(np.concatenate(ranks, 1).astype(np.int32), torch.int32)
+        self.calls += 1
+        if n_tot:
+            check(lib.prn_gt_sample_triplets(_p(job["masks"]), _p(job["first_d"]), B, Ntot, H, W, _p(job["segstart"]), _p(seg), _p(seg_region_d), _p(seg_img_d),
+                                             _p(ranks_d), ctypes.c_uint64((self.seed << 20) ^ self.calls), n_tot, _p(gid), _stream()), "prn_gt_sample_triplets")
+        return {"B": B, "n_seg": n_seg, "n_tot": n_tot, "npts": B * H * W,
+                "N": pin(torch.as_tensor(N_per, dtype=torch.float64)), "fx": pin(torch.as_tensor(np.asarray(fx), dtype=torch.float64)),
+                "fy": pin(torch.as_tensor(np.asarray(fy), dtype=torch.float64)),
+                "gid": gid, "seg": seg,
+                "seg_start": pin(torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64))),
+                "seg_img": pin(torch.as_tensor(seg_img, dtype=torch.int64)), "seg_is_plane": pin(torch.as_tensor(seg_plane, dtype=torch.bool)),
+                "seg_normal": pin(torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3)))}
+
+    def get(self, gt_depths, device, overlap=False):
+        """Targets of the OLDEST submitted batch.  overlap: issue the device work on the weight-gradient side stream (idle during
+        the forward pass); the loss waits for `ready`."""
+        import time
+        t0 = time.perf_counter()
+        job = self.queue.popleft()
+        main = torch.cuda.current_stream()
+        side = ops._side_stream(torch.device(device), main)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            t = self._finish(job, gt_depths, device)
+            if overlap:
+                t.ready = torch.cuda.Event()
+                t.ready.record()
+        if not overlap:
+            main.wait_stream(side)
+        self.host_ms += (time.perf_counter() - t0) * 1e3
+        return t
+
+    def discard(self):
+        while self.queue:
+            self.queue.popleft()["done"].synchronize()
+
+    def close(self):
+        self.discard()

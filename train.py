@@ -14,7 +14,9 @@ What differs is the machinery underneath:
     are mean-all-reduced over RCCL on a side stream overlapped with backward (planerecnet_amd/parallel.py), the loss that
     is logged is the mean over ranks (reference train.py:348), and the "skip the step on a non-finite loss" decision
     (train.py:353) is taken collectively so ranks cannot diverge;
-  * GT-only loss preparation runs in worker processes two batches ahead of the GPU (losses.TargetPrefetcher);
+  * GT-only loss preparation (SOLOv2 target assignment, virtual-normal triplet sampling) runs on the device one batch ahead of the
+    step (planerecnet_amd/targets.py; `--target_prep workers`: the host worker processes of losses.TargetPrefetcher, which draw the
+    triplets from numpy's global stream like the reference);
   * `--dataset synthetic` (must be given explicitly: there is no silent fallback) feeds seeded synthetic batches with the
     reference's batch contract (data/datasets.py:54-57,250-273) -- the ScanNet / NYU readers need cv2 + pycocotools and are
     outside this hot-path build.
@@ -64,6 +66,10 @@ parser.add_argument("--no_interrupt", dest="interrupt", action="store_false")
 parser.add_argument("--batch_alloc", default=None, type=str, help="Accepted for CLI compatibility; ranks always take equal shares.")
 parser.add_argument("--max_iter", default=None, type=int, help="(extension) stop after this many iterations.")
 parser.add_argument("--synthetic_size", default=64, type=int, help="(extension) samples per synthetic epoch.")
+parser.add_argument("--target_prep", default="device", choices=("device", "workers"),
+                    help="(extension) where the GT-only part of the loss is prepared: HIP kernels a batch ahead, or host worker processes.")
+parser.add_argument("--triplet_sampler", default="philox", choices=("philox", "numpy"),
+                    help="(extension, --target_prep device) virtual-normal triplet ranks: drawn on the device, or from numpy's global stream like the reference.")
 parser.add_argument("--synthetic_val_size", default=8, type=int, help="(extension) frames in the synthetic validation set.")
 parser.set_defaults(keep_latest=False, interrupt=True, autoscale=True)
 
@@ -221,7 +227,11 @@ def main():
     step_index, last_time = 0, time.time()
     time_avg, loss_avgs = MovingAverage(), {k: MovingAverage(100) for k in LOSS_TYPES}
     save_path = lambda epoch, it: SavePath(cfg.name, epoch, it).get_path(root=args.save_folder)
-    prefetch = TargetPrefetcher(criterion)
+    if args.target_prep == "device":
+        from planerecnet_amd.targets import DeviceTargetBuilder
+        prefetch = DeviceTargetBuilder(criterion, sampler=args.triplet_sampler, seed=rank)
+    else:
+        prefetch = TargetPrefetcher(criterion)
     stager = FrameStager(dev)
     # device-side "skip the update on a non-finite loss": needs an optimizer whose step takes `found_inf` (fused Adam does)
     device_skip = bool(getattr(optimizer, "_step_supports_amp_scaling", False)) and dev.type == "cuda" and not os.environ.get("PRN_TRAIN_SYNC_LOSS")
