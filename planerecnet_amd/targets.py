@@ -33,6 +33,46 @@ from .config import cfg
 from .ops import _p, _stream, check, lib
 
 
+class _Arena:
+    """Small host arrays of one batch -> ONE page-locked buffer -> ONE asynchronous upload -> device views.  (A pin_memory() call per
+    array costs ~0.1 ms of host time each, a pageable upload blocks the trainer until the side stream has caught up.)"""
+
+    def __init__(self, nbytes=4 << 20):
+        self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.np = self.host.numpy()
+        self.free = None                                   # event after which the buffer may be rewritten
+
+    def upload(self, arrays, device):
+        """arrays: dict name -> numpy array (or None).  Returns dict name -> device tensor (same dtype / shape) or None."""
+        if self.free is not None:
+            self.free.synchronize()
+        plan, off = {}, 0
+        for k, a in arrays.items():
+            if a is None:
+                continue
+            a = np.ascontiguousarray(a)
+            n = a.nbytes
+            if off + n + 16 > self.np.shape[0]:
+                grow = torch.empty(max(2 * self.np.shape[0], off + n + 16), dtype=torch.uint8).pin_memory()
+                grow.numpy()[:off] = self.np[:off]
+                self.host, self.np = grow, grow.numpy()
+            self.np[off:off + n] = a.reshape(-1).view(np.uint8)
+            plan[k] = (off, n, a.dtype, a.shape)
+            off += (n + 15) & ~15
+        dev = torch.empty(max(off, 16), dtype=torch.uint8, device=device)
+        dev[:off].copy_(self.host[:off], non_blocking=True)
+        self.free = torch.cuda.Event()
+        self.free.record()
+        out = {k: None for k in arrays}
+        for k, (o, n, dt, shp) in plan.items():
+            out[k] = dev[o:o + n].view(_TORCH_DT[np.dtype(dt)]).view(shp) if n else torch.empty(shp, dtype=_TORCH_DT[np.dtype(dt)], device=device)
+        return out
+
+
+_TORCH_DT = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+             np.dtype(np.bool_): torch.bool, np.dtype(np.uint8): torch.uint8}
+
+
 class DeviceTargetBuilder:
     """Drop-in for losses.TargetPrefetcher (submit / get / pending / discard / close); no worker processes."""
 
@@ -45,6 +85,9 @@ class DeviceTargetBuilder:
         self.queue = collections.deque()
         self._stage = []                                   # rotating page-locked staging buffers for the packed masks
         self._depth = depth
+        self._arenas, self._arena_i = [_Arena() for _ in range(2 * (depth + 1))], 0
+        self._totals = [torch.empty(4096, dtype=torch.int64).pin_memory() for _ in range(depth + 2)]
+        self._totals_i = 0
         self.nworkers = 0
         self.host_ms = 0.0                                 # host time spent in submit + get (tools / bench report it per step)
 
@@ -61,6 +104,10 @@ class DeviceTargetBuilder:
             return st
         self._stage[0]["free"].synchronize()               # (more batches in flight than buffers: wait for the oldest upload)
         return self._stage[0]
+
+    def _arena(self):
+        self._arena_i = (self._arena_i + 1) % len(self._arenas)
+        return self._arenas[self._arena_i]
 
     @property
     def pending(self):
@@ -96,14 +143,17 @@ class DeviceTargetBuilder:
             masks[:nbytes].copy_(st["buf"][:nbytes], non_blocking=True)
             st["free"] = torch.cuda.Event()
             st["free"].record()
-            first_d = torch.from_numpy(img_first).pin_memory().to(dev, non_blocking=True)
+            first_d = self._arena().upload({"first": img_first}, dev)["first"]
             segcnt = torch.empty(R * nseg, dtype=torch.uint8, device=dev)
             segstart = torch.empty(R * (nseg + 1), dtype=torch.int32, device=dev)
             totals = torch.empty(R * 3, dtype=torch.int64, device=dev)
             check(lib.prn_gt_mask_stats(_p(masks), _p(first_d), B, Ntot, H, W, _p(segcnt), _p(segstart), _p(totals), _stream()), "prn_gt_mask_stats")
             small = torch.empty(Ntot, H // 4, W // 4, dtype=torch.uint8, device=dev)
             check(lib.prn_gt_quarter_masks(_p(masks), _p(small), Ntot, H, W, _stream()), "prn_gt_quarter_masks")
-            totals_h = torch.empty(R * 3, dtype=torch.int64).pin_memory()
+            self._totals_i = (self._totals_i + 1) % len(self._totals)
+            if self._totals[self._totals_i].numel() < R * 3:
+                self._totals[self._totals_i] = torch.empty(R * 3 * 2, dtype=torch.int64).pin_memory()
+            totals_h = self._totals[self._totals_i][:R * 3]
             totals_h.copy_(totals, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
@@ -138,31 +188,35 @@ class DeviceTargetBuilder:
             num_ins += sum(int(i.sum()) for i in ind_l)
             for lv in range(L):
                 cate_rows[lv].append(cate_l[lv].flatten())
-        pin = lambda x: x.pin_memory()                      # noqa: E731
         n_cells = int(level_start[-1])
         cell_gidx = np.concatenate([b * n_cells + cell_ids[b] for b in range(B)]) if B else np.zeros(0, np.int64)
         cell_u, cell_inv, cell_cnt = np.unique(cell_gidx, return_inverse=True, return_counts=True)
         cell_mult = int(cell_cnt.max()) if cell_cnt.size else 1
-        which_d = pin(torch.from_numpy(np.concatenate(which_all) if which_all else np.zeros(0, np.int64))).to(device, non_blocking=True)
+        vnl_np, vnl_meta = self._vnl_host(job, cnt_t) if cfg.use_plane_loss else ({}, None)
+        arrays = {"which": np.concatenate(which_all) if which_all else np.zeros(0, np.int64),
+                  "n_pos_f": np.asarray(n_pos, dtype=np.float32),
+                  "cell_gidx": cell_u if cell_mult > 1 else cell_gidx,
+                  "cell_inv": cell_inv.astype(np.int64) if cell_mult > 1 else None,
+                  "cell_ids": np.concatenate(cell_ids) if cell_ids else np.zeros(0, np.int64),
+                  "pos_img": np.repeat(np.arange(B), n_pos),
+                  # level-major, image-minor flattening == the reference's cat order (losses.py:121-131)
+                  "cate_labels": torch.cat([r for lv in range(L) for r in cate_rows[lv]]).numpy()}
+        arrays.update({"vnl_" + k: v for k, v in vnl_np.items()})
+        d = self._arena().upload(arrays, device)
         small = job["small"]
         if small.shape[1] != fh or small.shape[2] != fw:     # (mask features of another size than H/4 x W/4: place like losses.py:268-270)
             pad = torch.zeros(small.shape[0], fh, fw, dtype=torch.uint8, device=device)
             pad[:, :min(fh, small.shape[1]), :min(fw, small.shape[2])] = small[:, :fh, :fw]
             small = pad
-        ins_labels = small.index_select(0, which_d)
-        h = {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins,
-             "n_pos_f": pin(torch.as_tensor(n_pos, dtype=torch.float32)),
-             "cell_gidx": pin(torch.from_numpy(cell_u if cell_mult > 1 else cell_gidx)),
-             "cell_inv": pin(torch.from_numpy(cell_inv)) if cell_mult > 1 else None,
-             "cells_unique": cell_mult <= 2,
-             "cell_ids": pin(torch.from_numpy(np.concatenate(cell_ids))), "pos_img": pin(torch.from_numpy(np.repeat(np.arange(B), n_pos))),
-             "ins_labels": ins_labels,
-             "cate_labels": pin(torch.cat([r for lv in range(L) for r in cate_rows[lv]])),
-             "vnl": self._vnl(job, cnt_t, device) if cfg.use_plane_loss else None}
+        h = {"B": B, "hw": (H, W), "feat": (fh, fw), "n_pos": n_pos, "num_ins": num_ins, "n_pos_f": d["n_pos_f"],
+             "cell_gidx": d["cell_gidx"], "cell_inv": d["cell_inv"], "cells_unique": cell_mult <= 2,
+             "cell_ids": d["cell_ids"], "pos_img": d["pos_img"], "ins_labels": small.index_select(0, d["which"]),
+             "cate_labels": d["cate_labels"],
+             "vnl": self._vnl_device(job, vnl_meta, {k[4:]: v for k, v in d.items() if k.startswith("vnl_")}, device) if cfg.use_plane_loss else None}
         return crit.upload(h, gt_depths, device)
 
-    def _vnl(self, job, cnt_t, device):
-        """Segment bookkeeping of vnl.py:119-140 from the region pixel counts + the device sampler."""
+    def _vnl_host(self, job, cnt_t):
+        """Segment bookkeeping of vnl.py:119-140 from the region pixel counts -> (arrays to upload, host-side meta)."""
         H, W = job["hw"]
         B, N_per, Ntot, first = job["B"], job["N_per"], job["Ntot"], job["img_first"]
         ratio = self.criterion.vnl.sample_ratio
@@ -191,27 +245,27 @@ class DeviceTargetBuilder:
                 seg_len.append(n); seg_img.append(b); seg_plane.append(is_plane); seg_region.append(r); normals.append(nrm)
         seg_len = np.asarray(seg_len, dtype=np.int64)
         n_seg, n_tot = len(seg_len), int(seg_len.sum())
-        pin = lambda x: x.pin_memory()                      # noqa: E731
-        up = lambda a, dt: pin(torch.from_numpy(np.ascontiguousarray(a)).to(dt)).to(device, non_blocking=True)      # noqa: E731
-        seg_len_d = up(seg_len, torch.int64)
-        seg = torch.repeat_interleave(torch.arange(n_seg, device=device, dtype=torch.int32), seg_len_d, output_size=n_tot) if n_tot else \
+        arrays = {"seg_len": seg_len, "seg_region": np.asarray(seg_region, np.int32), "seg_img32": np.asarray(seg_img, np.int32),
+                  "N": np.asarray(N_per, dtype=np.float64), "fx": np.asarray(fx, dtype=np.float64), "fy": np.asarray(fy, dtype=np.float64),
+                  "seg_start": (np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64)).astype(np.int64),
+                  "seg_img": np.asarray(seg_img, dtype=np.int64), "seg_is_plane": np.asarray(seg_plane, dtype=np.bool_),
+                  "seg_normal": np.asarray(normals, dtype=np.float64).reshape(-1, 3),
+                  "ranks": np.concatenate(ranks, 1).astype(np.int32) if (self.sampler == "numpy" and n_tot) else None}
+        return arrays, {"n_seg": n_seg, "n_tot": n_tot}
+
+    def _vnl_device(self, job, meta, d, device):
+        H, W = job["hw"]
+        B, Ntot = job["B"], job["Ntot"]
+        n_seg, n_tot = meta["n_seg"], meta["n_tot"]
+        seg = torch.repeat_interleave(torch.arange(n_seg, device=device, dtype=torch.int32), d["seg_len"], output_size=n_tot) if n_tot else \
             torch.zeros(0, dtype=torch.int32, device=device)
-        seg_region_d, seg_img_d = up(np.asarray(seg_region, np.int32), torch.int32), up(np.asarray(seg_img, np.int32), torch.int32)
         gid = torch.empty(3, n_tot, dtype=torch.int32, device=device)
-        ranks_d = None
-        if self.sampler == "numpy" and n_tot:
-            ranks_d = up(np.concatenate(ranks, 1).astype(np.int32), torch.int32)
         self.calls += 1
         if n_tot:
-            check(lib.prn_gt_sample_triplets(_p(job["masks"]), _p(job["first_d"]), B, Ntot, H, W, _p(job["segstart"]), _p(seg), _p(seg_region_d), _p(seg_img_d),
-                                             _p(ranks_d), ctypes.c_uint64((self.seed << 20) ^ self.calls), n_tot, _p(gid), _stream()), "prn_gt_sample_triplets")
-        return {"B": B, "n_seg": n_seg, "n_tot": n_tot, "npts": B * H * W,
-                "N": pin(torch.as_tensor(N_per, dtype=torch.float64)), "fx": pin(torch.as_tensor(np.asarray(fx), dtype=torch.float64)),
-                "fy": pin(torch.as_tensor(np.asarray(fy), dtype=torch.float64)),
-                "gid": gid, "seg": seg,
-                "seg_start": pin(torch.from_numpy(np.concatenate([[0], np.cumsum(seg_len)[:-1]]) if n_seg else np.zeros(0, np.int64))),
-                "seg_img": pin(torch.as_tensor(seg_img, dtype=torch.int64)), "seg_is_plane": pin(torch.as_tensor(seg_plane, dtype=torch.bool)),
-                "seg_normal": pin(torch.from_numpy(np.asarray(normals, dtype=np.float64).reshape(-1, 3)))}
+            check(lib.prn_gt_sample_triplets(_p(job["masks"]), _p(job["first_d"]), B, Ntot, H, W, _p(job["segstart"]), _p(seg), _p(d["seg_region"]), _p(d["seg_img32"]),
+                                             _p(d["ranks"]), ctypes.c_uint64((self.seed << 20) ^ self.calls), n_tot, _p(gid), _stream()), "prn_gt_sample_triplets")
+        return {"B": B, "n_seg": n_seg, "n_tot": n_tot, "npts": B * H * W, "N": d["N"], "fx": d["fx"], "fy": d["fy"], "gid": gid, "seg": seg,
+                "seg_start": d["seg_start"], "seg_img": d["seg_img"], "seg_is_plane": d["seg_is_plane"], "seg_normal": d["seg_normal"]}
 
     def get(self, gt_depths, device, overlap=False):
         """Targets of the OLDEST submitted batch.  overlap: issue the device work on the weight-gradient side stream (idle during
