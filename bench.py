@@ -44,7 +44,15 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime initialises: see planerecnet_amd/__init__.py
+# Hardware queues the HIP runtime multiplexes this process's streams onto (compute stream, weight-gradient / exchange side stream, RCCL's
+# own streams with N > 1).  3 is the measured optimum with ONE rank; with N > 1 it is unmeasured, hence an explicit
+# knob: `--hw-queues K` (or GPU_MAX_HW_QUEUES in the environment) -- read here because it must be set before the runtime initialises.
+for _i, _a in enumerate(sys.argv):
+    if _a == "--hw-queues" and _i + 1 < len(sys.argv):
+        os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[_i + 1]
+    elif _a.startswith("--hw-queues="):
+        os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=", 1)[1]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -174,6 +182,7 @@ def main():
     ap.add_argument("--targets", choices=("device", "workers"), default=os.environ.get("PRN_BENCH_TARGETS", "device"),
                     help="GT-only loss preparation: HIP kernels one batch ahead on the side stream (planerecnet_amd/targets.py, triplets drawn by the "
                          "device sampler) or the round-2 host worker processes (losses.TargetPrefetcher, numpy stream)")
+    ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this run (default 3; applied before the HIP runtime starts)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the extra steps that time the gradient-exchange path on a one-rank group")
     ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
                     "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
@@ -385,7 +394,8 @@ def main():
         host = {"enqueue_ms_per_step": (sum(hs) / len(hs)) if hs else None,
                 "process_cpu_ms_per_step": 1e3 * (time.process_time() - cpu0) / max(args.steps + args.warmup, 1),
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "targets": args.targets,
-                "target_prep_host_ms_per_step": (getattr(prefetch, "host_ms", None) / max(args.steps + args.warmup + 3, 1)) if hasattr(prefetch, "host_ms") else None}
+                "target_prep_host_cpu_ms_per_step": (prefetch.host_cpu_ms / max(getattr(prefetch, "calls", 1), 1)) if hasattr(prefetch, "host_cpu_ms") else None,
+                "target_prep_host_wall_ms_per_step": (prefetch.host_ms / max(getattr(prefetch, "calls", 1), 1)) if hasattr(prefetch, "host_ms") else None}
         if world > 1:                                            # slowest rank
             t = torch.tensor([host["enqueue_ms_per_step"] or 0.0, host["process_cpu_ms_per_step"]], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -89,7 +89,8 @@ class DeviceTargetBuilder:
         self._totals = [torch.empty(4096, dtype=torch.int64).pin_memory() for _ in range(depth + 2)]
         self._totals_i = 0
         self.nworkers = 0
-        self.host_ms = 0.0                                 # host time spent in submit + get (tools / bench report it per step)
+        self.host_ms = 0.0                                 # host WALL time spent in submit + get (includes waiting for the device when the host runs ahead)
+        self.host_cpu_ms = 0.0                             # CPU time of the calling thread inside submit + get: the host WORK of the preparation
 
     # ------------------------------------------------------------------------------------------------------------------
     def _staging(self, nbytes):
@@ -116,7 +117,7 @@ class DeviceTargetBuilder:
     @torch.no_grad()
     def submit(self, gt_instances, hw, mask_feat_size=None):
         import time
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.thread_time()
         H, W = hw
         dev = torch.device("cuda", torch.cuda.current_device())
         B = len(gt_instances)
@@ -161,6 +162,7 @@ class DeviceTargetBuilder:
         self.queue.append({"hw": (H, W), "feat": mask_feat_size, "B": B, "N_per": N_per, "Ntot": Ntot, "img_first": img_first, "first_d": first_d,
                            "masks": masks, "segstart": segstart, "segcnt": segcnt, "small": small, "totals_h": totals_h, "done": done, "meta": small_meta})
         self.host_ms += (time.perf_counter() - t0) * 1e3
+        self.host_cpu_ms += (time.thread_time() - c0) * 1e3
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -260,7 +262,6 @@ class DeviceTargetBuilder:
         seg = torch.repeat_interleave(torch.arange(n_seg, device=device, dtype=torch.int32), d["seg_len"], output_size=n_tot) if n_tot else \
             torch.zeros(0, dtype=torch.int32, device=device)
         gid = torch.empty(3, n_tot, dtype=torch.int32, device=device)
-        self.calls += 1
         if n_tot:
             check(lib.prn_gt_sample_triplets(_p(job["masks"]), _p(job["first_d"]), B, Ntot, H, W, _p(job["segstart"]), _p(seg), _p(d["seg_region"]), _p(d["seg_img32"]),
                                              _p(d["ranks"]), ctypes.c_uint64((self.seed << 20) ^ self.calls), n_tot, _p(gid), _stream()), "prn_gt_sample_triplets")
@@ -271,8 +272,9 @@ class DeviceTargetBuilder:
         """Targets of the OLDEST submitted batch.  overlap: issue the device work on the weight-gradient side stream (idle during
         the forward pass); the loss waits for `ready`."""
         import time
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.thread_time()
         job = self.queue.popleft()
+        self.calls += 1                                    # (also the stream position of the device sampler)
         main = torch.cuda.current_stream()
         side = ops._side_stream(torch.device(device), main)
         side.wait_stream(main)
@@ -284,6 +286,7 @@ class DeviceTargetBuilder:
         if not overlap:
             main.wait_stream(side)
         self.host_ms += (time.perf_counter() - t0) * 1e3
+        self.host_cpu_ms += (time.thread_time() - c0) * 1e3
         return t
 
     def discard(self):

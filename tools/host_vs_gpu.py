@@ -27,7 +27,11 @@ net = net.to(dev).train()
 crit = PlaneRecNetLoss().to(dev)
 opt = __import__("planerecnet_amd.optim", fromlist=["FusedAdam"]).FusedAdam(net.parameters(), lr=1e-4)
 images, inst, depths = bench.synth_batch(B, 480, 640, 1000, dev)
-pf = TargetPrefetcher(crit)
+if os.environ.get("TARGETS", "device") == "device":      # GT-only loss preparation: device kernels (default) or the host workers
+    from planerecnet_amd.targets import DeviceTargetBuilder
+    pf = DeviceTargetBuilder(crit)
+else:
+    pf = TargetPrefetcher(crit)
 pf.submit(inst, (480, 640))
 pf.submit(inst, (480, 640))
 ops.set_wgrad_async(True)
@@ -75,4 +79,6 @@ for _ in range(6):
 print("free-running step S = %.1f ms" % S)
 print("host enqueue H (GPU parked): " + " ".join("%.1f" % h for h in Hs))
 print("GPU drain    G (no host dep): " + " ".join("%.1f" % g for g in Gs))
+if hasattr(pf, "host_ms"):
+    print("target preparation, host side (submit + get): %.1f ms wall / %.1f ms CPU per step (mode %s)" % (pf.host_ms / pf.calls, pf.host_cpu_ms / pf.calls, os.environ.get("TARGETS", "device")))
 pf.close()

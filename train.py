@@ -27,11 +27,20 @@ import collections
 import math
 import os
 import random
+import sys
 import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       # before the HIP runtime initialises: see planerecnet_amd/__init__.py
+# Hardware queues the HIP runtime multiplexes this process's streams onto (compute stream, weight-gradient / exchange side stream, RCCL's
+# own streams with N > 1).  3 is the measured optimum with ONE rank; with N > 1 it is unmeasured, hence an explicit
+# knob: `--hw-queues K` (or GPU_MAX_HW_QUEUES in the environment) -- read here because it must be set before the runtime initialises.
+for _i, _a in enumerate(sys.argv):
+    if _a == "--hw-queues" and _i + 1 < len(sys.argv):
+        os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[_i + 1]
+    elif _a.startswith("--hw-queues="):
+        os.environ["GPU_MAX_HW_QUEUES"] = _a.split("=", 1)[1]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 import torch  # noqa: E402
 import torch.distributed as dist
 
@@ -66,6 +75,8 @@ parser.add_argument("--no_interrupt", dest="interrupt", action="store_false")
 parser.add_argument("--batch_alloc", default=None, type=str, help="Accepted for CLI compatibility; ranks always take equal shares.")
 parser.add_argument("--max_iter", default=None, type=int, help="(extension) stop after this many iterations.")
 parser.add_argument("--synthetic_size", default=64, type=int, help="(extension) samples per synthetic epoch.")
+parser.add_argument("--hw-queues", dest="hw_queues", default=None, type=int,
+                    help="(extension) GPU_MAX_HW_QUEUES for this run (default 3; applied before the HIP runtime starts).")
 parser.add_argument("--target_prep", default="device", choices=("device", "workers"),
                     help="(extension) where the GT-only part of the loss is prepared: HIP kernels a batch ahead, or host worker processes.")
 parser.add_argument("--triplet_sampler", default="philox", choices=("philox", "numpy"),
