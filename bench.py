@@ -232,7 +232,7 @@ def main():
     from planerecnet_amd.parallel import GradAllReduce, all_reduce_mean_scalars
     from planerecnet_amd.planerecnet import PlaneRecNet
 
-    torch.set_num_threads(4)                           # host-side tensor ops are small: a wide OpenMP team only adds fork/join latency
+    torch.set_num_threads(int(os.environ.get("PRN_HOST_THREADS", "4")))   # host-side tensor ops are small: a wide OpenMP team only adds fork/join latency
     timer.disable_all()                                # like the reference's train.py:233 (enabled timers synchronise per stage)
     set_cfg(args.config)
     if args.workload == "c5":
