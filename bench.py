@@ -60,6 +60,13 @@ sys.path.insert(0, ROOT)
 
 METRIC = "img/s fwd+bwd @480×640 ResNet101-DCN, 1/2/4/8 MI355X + roofline %"
 PEAK_FP32_MFMA_TFLOPS = 157.3
+# dense bf16 MFMA peak: 256 CUs x 4 SIMDs x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16: 32768 FLOPs in 8 passes of 4 clk) x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 256 * 4 * 1024 * 2.4e9 / 1e12
+
+
+def mfma_peak(kernel):
+    """Peak of the matrix pipe a kernel family issues on: the split GEMM runs bf16 piece products, everything else fp32 MFMA."""
+    return PEAK_BF16_MFMA_TFLOPS if kernel == "split_gemm_kernel" else PEAK_FP32_MFMA_TFLOPS
 PEAK_HBM_GBS = 8000.0
 
 
@@ -498,15 +505,25 @@ def main():
         # HBM-bound families are credited with the bytes their kernels EXECUTE (per variant), so none can exceed what the memory
         # system delivers; a figure above the measured copy rate means the accounting of that family is wrong
         over = [f["kernel"] for f in fams if f["bound"] == "hbm" and f["achieved"] > 6300.0 and f["time_ms"] > 0.02]
-        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"],
+        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": mfma_peak(dom["kernel"]), "unit": "TFLOP/s",
+                "frac": dom["achieved"] / mfma_peak(dom["kernel"]), "traffic": traffic, "launches": dom["launches"],
                 "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"],
                 "hbm_families_above_copy_rate": over}
         # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation) -- that is the headline
         # figure.  Footnote: the Winograd launches execute a quarter of the multiply-adds of the convolution they evaluate, so the
         # same step is also summarised as FLOPs of the REFERENCE convolutions over the time of every kernel of the convolution
         # family, transforms and reductions included.
-        conv = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "reduce_epilogue_kernel", "winograd_input_kernel", "winograd_output_kernel",
+        # The plain-GEMM launches that run on the bf16 matrix pipe by exact operand splitting (csrc/prn_gemm_split.hip): `achieved` /
+        # `frac` price the six bf16 piece products each fp32 multiply-add costs against the bf16 peak; `fp32_equivalent` is the fp32
+        # GEMM rate the launches deliver (2*M*N*K over their time), next to the fp32 MFMA peak it would otherwise be bounded by.
+        sp = [f for f in fams if f["kernel"] == "split_gemm_kernel"]
+        if sp:
+            f = sp[0]
+            eq = f["work"] / 6.0 / (f["time_ms"] * 1e-3) / 1e12          # 2*M*N*K of the GEMMs the launches evaluate (six piece products per MAC)
+            roof["split_gemm"] = {"launches": f["launches"], "time_ms": f["time_ms"], "achieved": f["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": f["achieved"] / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent": eq, "fp32_equivalent_over_fp32_mfma_peak": eq / PEAK_FP32_MFMA_TFLOPS,
+                                  "pieces": "3 x bf16 per fp32 operand (exact), 6 of 9 products, fp32 accumulate"}
+        conv = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "split_gemm_kernel", "reduce_epilogue_kernel", "winograd_input_kernel", "winograd_output_kernel",
                                                     "conv3x3_winograd_ragged", "conv_wgrad_kernel", "reduce_splits_kernel", "winograd_wgrad_transforms",
                                                     "winograd_dw_kernel", "conv3x3_winograd_wgrad_ragged", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel")]
         ref_flops = sum(f["ref_work"] for f in conv if f["bound"] == "mfma")

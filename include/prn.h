@@ -61,9 +61,20 @@ typedef struct prn_conv_desc {
  * along K: `ws` is a caller-owned workspace of prn_conv2d_fwd_ws_bytes(d) bytes (0 => may be NULL); the split partials
  * are summed in a fixed order, so results are deterministic. */
 int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
-/* 0: the descriptor's forward runs on the MFMA implicit-GEMM kernel; 1: on the direct HBM-bound kernels (3x3 layers with one or two
- * output channels, or one input channel, over large maps: the depth head) -- for profilers that attribute launches to a roofline. */
+/* 0: the descriptor's forward runs on the fp32-MFMA implicit-GEMM kernel; 1: on the direct HBM-bound kernels (3x3 layers with one or two
+ * output channels, or one input channel, over large maps: the depth head); 2 / 3: on the bf16-split GEMM kernel (prn_gemm_pipe below)
+ * without / with a K split (3: a reduce launch follows, as for a split fp32 launch) -- for profilers that attribute launches to a roofline. */
 int prn_conv2d_kernel_kind(const prn_conv_desc* d);
+/* Which matrix pipe the plain GEMM y[z][b][m][p] = sum_k w[z][m][k] x[z][b][k][p] (a stride-1 1x1 convolution: nz = 1, HW = H*W; a
+ * prn_gemm_batched call: B = 1, HW = P, nz = nb) runs on.  0: the fp32 MFMA kernel (v_mfma_f32_32x32x2_f32).  s >= 1: the split kernel
+ * with s K splits -- both operands are cut EXACTLY into three bf16 pieces (the 8-bit slices of the 24-bit significand), six of the nine
+ * piece products (each exact in fp32) are issued as v_mfma_f32_32x32x16_bf16 with fp32 accumulation and the three dropped ones are
+ * <= 2^-23 of the product: an fp32 GEMM whose error against fp64 is no larger than the fp32 MFMA's (tests/test_ops_gpu.py), in 3/8 of its
+ * matrix-pipe time.  PRN_SPLIT_GEMM=0 in the environment keeps every launch on the fp32 kernel; =2 takes the split kernel wherever it applies. */
+int prn_gemm_pipe(int M, int K, int B, int HW, int nz);
+/* Sets PRN_SPLIT_GEMM's value for this process (0 / 1 / 2 as above; < 0: query only) and returns the previous one.  Workspace sizes
+ * (prn_conv2d_fwd_ws_bytes and the block-level *_ws_bytes) depend on it: query them again after a change. */
+int prn_split_gemm_mode(int mode);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
 /* The same with the K-split sum folded into the GEMM launch (no second kernel, one launch less per split layer): `counters` is

@@ -40,6 +40,8 @@ SIGNATURES = {
     "prn_last_error": (ctypes.c_char_p, []),
     "prn_conv2d_fwd_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_kernel_kind": (c_int, [_DP]),
+    "prn_gemm_pipe": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "prn_split_gemm_mode": (c_int, [c_int]),
     "prn_conv2d_fwd": (c_int, [_DP, P, P, P, P, P, P, P]),
     "prn_conv2d_fwd_ragged": (c_int, [_DP, P, P, P, P, P, P, P]),
     "prn_conv2d_wgrad_ragged_ws_bytes": (c_i64, [_DP, P]),

@@ -56,3 +56,13 @@ int prn_launch_reduce_splits(const float* ws, float* out, int64_t n, int splits,
 int prn_quantise_splits(int64_t tiles, int splits);
 //   Y_z[M x P] = epi(U_z[M x C] * V_z[C x P]) for z < nb in one launch (prn_gemm_batched with an activation)
 int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const float* V, float* Y, int epi, void* stream);
+
+// fp32 GEMM on the bf16 matrix pipe by exact three-way operand splitting (prn_gemm_split.hip):
+//   y[z][b][m][p] = epi(sum_k w[z][m][k] * x[z][b][k][p] + bias[m] + addend)   for z < nz, b < B  (a (z, b) image of x is [K][HW], of y [M][HW])
+// prn_split_gemm_plan: 0 = keep the fp32 MFMA kernel, else the number of K splits to run it with.
+int prn_split_gemm_plan(int M, int K, int B, int HW, int nz);
+int64_t prn_split_gemm_image_bytes(int M, int K, int nz);
+int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits);
+int prn_split_gemm(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images, float* partial, int M, int K, int B, int HW,
+                   int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, hipStream_t st, int phase);
+void* prn_split_scratch(hipStream_t st, int64_t bytes);

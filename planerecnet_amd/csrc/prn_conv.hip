@@ -1291,6 +1291,15 @@ int tail_of(const prn_conv_desc* d, const Geo& g, const FwdPlan& p, int* pieces)
   return plan_tail(p, (int64_t)tilesM * cdiv(N, 32 * p.wn * p.tn), tilesM, d->C * d->KH * d->KW, N, g.gH * g.gW, pieces);
 }
 
+// Plain-GEMM 1x1 convolutions may run on the bf16-split kernel (prn_gemm_split.hip): number of K splits, 0 = no
+int split_plan_of(const prn_conv_desc* d) {
+  if (!(d->KH == 1 && d->in_mode == PRN_IN_ZERO && d->stride == 1 && d->pad == 0 && d->ystride <= 1 && d->Ho == d->H && d->Wo == d->W)) return 0;
+  return prn_split_gemm_plan(d->M, d->C, d->B, d->H * d->W, 1);
+}
+int64_t split_ws_bytes(const prn_conv_desc* d, int splits) {
+  return ((prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->H * d->W, 1, splits);
+}
+
 }  // namespace
 
 int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* addend, float* y, int64_t total, int M, int HoWo, int splits,
@@ -1309,6 +1318,7 @@ int prn_quantise_splits(int64_t tiles, int splits) { return quantise_splits(tile
 extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
   if (direct_small_m(d) || direct_one_c(d)) return 0;
+  if (const int ss = split_plan_of(d)) return split_ws_bytes(d, ss);
   const Geo g = geo_of(d);
   const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
                              wide_ks(d->KH, d->in_mode));
@@ -1360,7 +1370,9 @@ int conv_wgrad_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x
 // pixel, HBM-bound) kernels for one- or two-channel 3x3 layers -- so that a profiler can attribute a launch to the right roofline
 extern "C" int prn_conv2d_kernel_kind(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_kernel_kind")) return -1;
-  return (direct_small_m(d) || direct_one_c(d)) ? 1 : 0;
+  if (direct_small_m(d) || direct_one_c(d)) return 1;
+  const int ss = split_plan_of(d);
+  return ss == 0 ? 0 : (ss == 1 ? 2 : 3);
 }
 
 extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -1405,6 +1417,12 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
     }
     PRN_CHECK_LAUNCH("prn_conv2d_fwd/direct");
     return 0;
+  }
+  if (rg == nullptr && ws != nullptr) {
+    if (const int ss = split_plan_of(d)) {
+      const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL;
+      return prn_split_gemm(w, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H * d->W, 1, 0, 0, 0, d->epilogue, ss, (hipStream_t)stream, phase);
+    }
   }
   ConvArgs a;
   a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.y = y; a.ws = (float*)ws;
@@ -1651,6 +1669,10 @@ int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const floa
   PRN_REQUIRE(U && V && Y && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched: bad arguments");
   PRN_REQUIRE((P & 3) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0, "prn_gemm_batched: P %% 4 == 0 and 16-byte aligned V required (P=%d)", P);
   PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched: operand larger than a buffer descriptor");
+  if (prn_split_gemm_plan(M, C, 1, P, nb) == 1) {
+    if (void* images = prn_split_scratch((hipStream_t)stream, prn_split_gemm_image_bytes(M, C, nb)))
+      return prn_split_gemm(U, V, nullptr, nullptr, Y, images, nullptr, M, C, 1, P, nb, (int64_t)M * C, (int64_t)C * P, (int64_t)M * P, epi, 1, (hipStream_t)stream, 0);
+  }
   ConvArgs a;
   a.x = V; a.w = U; a.bias = nullptr; a.addend = nullptr; a.y = Y; a.ws = nullptr;
   a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P; a.epi = epi;

@@ -1,0 +1,275 @@
+// fp32 GEMM on the bf16 matrix pipe by EXACT three-way operand splitting -- the 1x1 convolutions (reference models/backbone.py:56-66,
+// models/fpn.py:46-57) and the batched transform-domain products of the Winograd path, i.e. the plain-GEMM launches of conv_igemm_kernel.
+//
+//   x = h + m + l,  h / m / l = the three consecutive 8-bit slices of x's 24-bit significand (truncation, not rounding): every piece is
+//   exactly a bf16 and the three add up to x exactly.  a*b is then the sum of nine piece products, each EXACT in fp32 (8 x 8 bits);
+//   the kernel issues six of them as v_mfma_f32_32x32x16_bf16 (fp32 accumulate) and drops m*l, l*m, l*l, which are <= 2^-23 |a*b| --
+//   below one rounding of the fp32 accumulation.  Measured against fp64 on the step's shapes the result is as close as the fp32 MFMA's
+//   (max 2.2e-7 / rms 1.8e-8 of sum|a||b| against 2.7e-7 / 2.2e-8; tools/native/gemm_split_lab, tests/test_ops_gpu.py), so the launch
+//   is an fp32 GEMM in every sense the parity tests check, at 6 x 1/16 = 3/8 of the fp32 pipe's issue time per MAC.
+//
+// Layout.  y[z][b][m][p] = sum_k w[z][m][k] * x[z][b][k][p]; one workgroup = 128 rows x 128 pixels of one (z, b) image, four waves of
+// 128 rows x 32 pixels.  The weight side is split ONCE per launch by split_prepare_kernel into "images" [m tile][k slice][piece][k group]
+// [row][8 x bf16] that are exactly the LDS image a workgroup needs per 32-deep K slice (24 KB), so the A stream is buffer_load ... lds
+// (no registers, no ds_write) into a two-stage ring.  The activation side never touches LDS: a lane of the 32x32x16 MFMA holds eight
+// consecutive k of ONE pixel, and with NCHW activations lanes = pixels is the coalesced direction, so every wave fetches its own B
+// operand with 16 dword buffer loads per slice (rows beyond K read 0: the row is part of the VGPR offset, which the descriptor's range check sees), splits it in registers (5.5 VALU
+// per element, under the MFMAs of the slice before) and feeds the pieces straight to the matrix pipe.  One barrier per slice.
+#include "prn_common.h"
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BK = 32;
+constexpr int IMG_U4 = 1536;      // uint4 per image: 3 pieces x 4 k-groups x 128 rows x 16 B = 24 KB
+
+// three exact bf16 pieces of two consecutive-k values, packed (low half = first value)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// w[z][m][k] (row stride K, z stride zw) -> images [z][m tile][k slice][piece][k group][row][8 x bf16], zero padded in M and K
+__global__ void split_prepare_kernel(const float* __restrict__ w, uint4* __restrict__ img, int M, int K, long long zw, int mtiles, int kslices, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per (z, m tile, k slice, k group, row)
+  if (i >= total) return;
+  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
+  const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (m < M && k0 + j < K) ? w[z * zw + (long long)m * K + k0 + j] : 0.f;
+  uint4 h, mm, l;
+  split2(v[0], v[1], h.x, mm.x, l.x); split2(v[2], v[3], h.y, mm.y, l.y); split2(v[4], v[5], h.z, mm.z, l.z); split2(v[6], v[7], h.w, mm.w, l.w);
+  uint4* o = img + t * IMG_U4;
+  o[(0 * 4 + g) * 128 + r] = h; o[(1 * 4 + g) * 128 + r] = mm; o[(2 * 4 + g) * 128 + r] = l;
+}
+
+__device__ __forceinline__ i32x4_t make_desc(const void* p, unsigned bytes) {
+  const unsigned long long q = (unsigned long long)p;
+  i32x4_t d;
+  d.x = __builtin_amdgcn_readfirstlane((int)(unsigned)q);
+  d.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32) & 0xffff);
+  d.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  d.w = 0x00020000;
+  return d;
+}
+// LDS-DMA: 64 lanes x 16 bytes from (descriptor, lane offset + scalar offset) to LDS [lds_byte_addr + 16 * lane].  An asm statement on
+// purpose: hipcc neither has to model M0 nor counts it in its own vmcnt bookkeeping; it is ordered by the buffer loads issued after it
+// (vmcnt retires in order) and the workgroup barrier.
+__device__ __forceinline__ void lds_dma16(unsigned lds_byte_addr, i32x4_t desc, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_byte_addr)), "v"(voff), "s"(desc),
+               "s"(__builtin_amdgcn_readfirstlane(soff))
+               : "memory");
+}
+
+struct SplitArgs {
+  const uint4* img; const float* x; const float* bias; const float* addend; float* y; float* partial;
+  int M, K, B, HW, epi, mtiles, kslices, ptiles, total, splits;
+  long long zx, zy;               // element strides of x / y per z (a (z, b) image is K*HW / M*HW elements)
+  long long slice;                // elements of one partial slice (splits > 1): nz * B * M * HW
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void split_gemm_kernel(const SplitArgs a) {
+  __shared__ uint4 lds[2 * IMG_U4];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int id = prn_xcd_remap(blockIdx.x, a.total);            // the m tiles of one pixel tile share an XCD's L2
+  const int mt = id % a.mtiles; const int rest = id / a.mtiles;
+  const int pt = rest % a.ptiles; const int zb = rest / a.ptiles; const int b = zb % a.B, z = zb / a.B;
+  const int sp = blockIdx.y;
+  const int ks0 = (int)((long long)a.kslices * sp / a.splits), ks1 = (int)((long long)a.kslices * (sp + 1) / a.splits);
+  const int HW = a.HW, M = a.M;
+  const int r = lane & 31, gs = lane >> 5;
+  const int px = pt * 128 + wave * 32 + r;
+  const int pxc = px < HW ? px : HW - 1;
+  const float* xb = a.x + (long long)z * a.zx + (long long)b * a.K * HW;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.K * HW * 4, 0x00020000);
+  const int xoff = (pxc + gs * 8 * HW) * 4;                      // this lane's byte offset inside a 16-row group
+  const uint4* ag = a.img + ((long long)(z * a.mtiles + mt) * a.kslices) * IMG_U4;
+  const i32x4_t adesc = make_desc(ag, (unsigned)a.kslices * IMG_U4 * 16u);
+  const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
+  float rn[16];
+  bf16x8_t bp[2][3];
+#define SPLIT_DMA(ks_, st_) do { \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) \
+      lds_dma16(lds0 + (unsigned)(st_) * (IMG_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG_U4 + (i * 4 + wave) * 64) * 16); \
+  } while (0)
+#define SPLIT_LOADB(ks_) do { \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) \
+        rn[s2 * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff + ((ks_) * BK + s2 * 16 + j) * HW * 4, 0, 0)); \
+  } while (0)
+#define SPLIT_PIECES() do { \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) { \
+      uint4 h, m, l; \
+      split2(rn[s2 * 8 + 0], rn[s2 * 8 + 1], h.x, m.x, l.x); split2(rn[s2 * 8 + 2], rn[s2 * 8 + 3], h.y, m.y, l.y); \
+      split2(rn[s2 * 8 + 4], rn[s2 * 8 + 5], h.z, m.z, l.z); split2(rn[s2 * 8 + 6], rn[s2 * 8 + 7], h.w, m.w, l.w); \
+      bp[s2][0] = __builtin_bit_cast(bf16x8_t, h); bp[s2][1] = __builtin_bit_cast(bf16x8_t, m); bp[s2][2] = __builtin_bit_cast(bf16x8_t, l); \
+    } } while (0)
+  // products smallest first: l*h, h*l, m*m, m*h, h*m, h*h
+#define SPLIT_STEP(s2_) do { \
+    const int kg = 2 * (s2_) + gs; \
+    const bf16x8_t bh = bp[s2_][0], bm = bp[s2_][1], bl = bp[s2_][2]; \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+      const uint4* ap = lds + st * IMG_U4 + kg * 128 + i * 32 + r; \
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, ap[0]), am = __builtin_bit_cast(bf16x8_t, ap[512]), al = __builtin_bit_cast(bf16x8_t, ap[1024]); \
+      f32x16_t c = acc[i]; \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0); \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0); \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0); \
+      acc[i] = c; \
+    } } while (0)
+  f32x16_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  SPLIT_DMA(ks0, 0);
+  SPLIT_LOADB(ks0);
+  SPLIT_PIECES();
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int st = (ks - ks0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (already true: the pieces above waited for loads younger than the DMA)
+    __syncthreads();
+    const bool more = ks + 1 < ks1;
+    const int kn = more ? ks + 1 : ks;
+    if (more) SPLIT_DMA(ks + 1, st ^ 1);
+    SPLIT_LOADB(kn);
+    __builtin_amdgcn_sched_barrier(0);                           // keep the loads up here: hipcc otherwise sinks them next to their first use
+    SPLIT_STEP(0);
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STEP(1);
+    SPLIT_PIECES();                                              // next slice's pieces, interleaved with the second step's MFMAs
+  }
+#undef SPLIT_DMA
+#undef SPLIT_LOADB
+#undef SPLIT_PIECES
+#undef SPLIT_STEP
+  const bool cok = px < HW;
+  if (a.splits > 1) {                                            // K split: raw partial sums, summed in fixed order by reduce_epilogue_kernel
+    float* pb = a.partial + (long long)sp * a.slice + ((long long)z * a.B + b) * (long long)M * HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = mt * BM + i * 32 + gs * 4 + (e >> 2) * 8 + (e & 3);
+        if (cok && row < M) pb[(long long)row * HW + px] = acc[i][e];
+      }
+    return;
+  }
+  float* yb = a.y + (long long)z * a.zy + (long long)b * M * HW;
+  const float* ab = a.addend ? a.addend + (long long)z * a.zy + (long long)b * M * HW : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rbase = mt * BM + i * 32 + gs * 4;
+    float bv[16], av[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = rbase + (e >> 2) * 8 + (e & 3); const int rc = row < M ? row : M - 1;
+      bv[e] = a.bias ? a.bias[rc] : 0.f; av[e] = ab ? ab[(long long)rc * HW + pxc] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = rbase + (e >> 2) * 8 + (e & 3);
+      float v = acc[i][e] + bv[e] + av[e];
+      if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+      else if (a.epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
+      if (cok && row < M) yb[(long long)row * HW + px] = v;
+    }
+  }
+}
+
+int g_mode = -1;       // PRN_SPLIT_GEMM: 0 = off (fp32 MFMA everywhere), 1 = where the plan says so (default), 2 = wherever the kernel applies
+int mode() {
+  if (g_mode < 0) { const char* e = getenv("PRN_SPLIT_GEMM"); g_mode = e ? atoi(e) : 1; }
+  return g_mode;
+}
+
+}  // namespace
+
+// ---- internal interface (prn_common.h) ------------------------------------------------------------------------------------------------
+// Should y[nz][B][M][HW] = w[nz][M][K] * x[nz][B][K][HW] run on the split kernel, and with how many K splits?  0 = no.
+// Plan (tools/native/gemm_split_lab on the step's shapes): the kernel wins where at least ~300 of its 128 x 128 tiles exist and the last
+// m tile is more than half full; short of tiles, a K split of 2 .. 4 fills the GPU as long as every split keeps >= 8 slices.
+int prn_split_gemm_plan(int M, int K, int B, int HW, int nz) {
+  const int md = mode();
+  if (md == 0) return 0;
+  if ((int64_t)K * HW >= (1LL << 29) || (int64_t)M * HW >= (1LL << 29)) return 0;
+  const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32);
+  const int64_t tiles = (int64_t)mtiles * cdiv(HW, 128) * B * nz;
+  int splits = 1;
+  if (tiles < 300) {
+    splits = (int)(640 / (tiles > 0 ? tiles : 1));
+    if (splits > kslices / 8) splits = kslices / 8;
+    if (splits > 4) splits = 4;
+    if (splits < 1) splits = 1;
+  }
+  if (md == 2) return splits;
+  if (M % 128 != 0 && M % 128 <= 64) return 0;
+  if (tiles * splits < 300) return 0;
+  return splits;
+}
+extern "C" int prn_split_gemm_mode(int m) {
+  const int old = mode();
+  if (m >= 0) g_mode = m;
+  return old;
+}
+extern "C" int prn_gemm_pipe(int M, int K, int B, int HW, int nz) {
+  if (M <= 0 || K <= 0 || B <= 0 || HW <= 0 || nz <= 0) return 0;
+  return prn_split_gemm_plan(M, K, B, HW, nz);
+}
+int64_t prn_split_gemm_image_bytes(int M, int K, int nz) { return (int64_t)nz * cdiv(M, 128) * cdiv(K, 32) * IMG_U4 * 16; }
+int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits) { return splits > 1 ? (int64_t)splits * nz * B * M * HW * 4 : 0; }
+
+// images: prn_split_gemm_image_bytes; partial: prn_split_gemm_partial_bytes (splits > 1).  zw / zx / zy: element strides per z.
+// phase: 0 = everything, 1 = the split + GEMM launches only, 2 = the K-split sum only (profiler brackets, like prn_conv2d_fwd_phase).
+int prn_split_gemm(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images, float* partial, int M, int K, int B, int HW,
+                   int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, hipStream_t st, int phase) {
+  PRN_REQUIRE(w && x && y && images && (splits == 1 || partial), "prn_split_gemm: null operand");
+  PRN_REQUIRE((reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_gemm: images must be 16-byte aligned");
+  const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32), ptiles = cdiv(HW, 128);
+  PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)K * HW < (1LL << 29), "prn_split_gemm: operand larger than a buffer descriptor");
+  const long long ptotal = (long long)nz * mtiles * kslices * 512;
+  if (phase != 2) {
+  hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, (long long)zw, mtiles, kslices, ptotal);
+  PRN_CHECK_LAUNCH("prn_split_gemm/prepare");
+  SplitArgs a;
+  a.img = (const uint4*)images; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
+  a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
+  a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
+  hipLaunchKernelGGL(split_gemm_kernel, dim3(a.total, splits), dim3(256), 0, st, a);
+  PRN_CHECK_LAUNCH("prn_split_gemm");
+  }
+  if (splits > 1 && phase != 1) {
+    PRN_REQUIRE(nz == 1 || (zy == (int64_t)B * M * HW), "prn_split_gemm: K splits need a dense output");
+    return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)nz * B * M * HW, M, HW, splits, epi, st);
+  }
+  return 0;
+}
+
+// Device scratch for callers whose entry point has no workspace argument (prn_gemm_batched): one grow-only buffer per stream, so that
+// launches queued on different streams never share images.  nullptr on allocation failure (the caller keeps the fp32 MFMA kernel).
+void* prn_split_scratch(hipStream_t st, int64_t bytes) {
+  struct Buf { void* p; int64_t cap; };
+  static std::map<hipStream_t, Buf> bufs;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  Buf& b = bufs[st];
+  if (b.cap >= bytes) return b.p;
+  if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const int64_t cap = (bytes + (8 << 20) - 1) & ~(int64_t)((8 << 20) - 1);
+  if (hipMalloc(&b.p, cap) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
+  b.cap = cap;
+  return b.p;
+}

@@ -314,6 +314,17 @@ def _counters(dev):
     return c
 
 
+SPLIT_PRODUCTS = 6.0     # bf16 MFMA products the split GEMM kernel issues per fp32 multiply-add (csrc/prn_gemm_split.hip)
+
+
+def _gemm_family(M, K, B, HW, nz, flops):
+    """(family, executed FLOPs, reference FLOPs) of a plain GEMM launch for the profiler: on the split kernel the launch executes six
+    bf16 products per fp32 multiply-add on the bf16 matrix pipe; `flops` (2*M*K*N) stays the reference operator's work."""
+    if lib.prn_gemm_pipe(int(M), int(K), int(B), int(HW), int(nz)) >= 1:
+        return "split_gemm_kernel", SPLIT_PRODUCTS * flops, flops
+    return "conv_igemm_kernel", flops, flops
+
+
 # ------------------------------------------------------------------------------------------ raw launches
 def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None):
     """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor."""
@@ -329,13 +340,16 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
         # FLOPs of the strided forward conv it differentiates: a quarter of the MACs the kernel issues)
-        direct = lib.prn_conv2d_kernel_kind(ref) == 1       # the one- / two-channel 3x3 layers run on HBM-bound direct kernels, not on the GEMM
+        kind = lib.prn_conv2d_kernel_kind(ref)
+        direct = kind == 1       # the one- / two-channel 3x3 layers run on HBM-bound direct kernels, not on the GEMM
+        split = kind >= 2        # plain GEMM on the bf16-split kernel (3: with a K split)
         nb_ = 4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0))
-        with profiling.span("conv3x3_direct" if direct else "conv_igemm_kernel", "hbm" if direct else "mfma",
-                            nb_ if direct else 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil), nbytes=nb_,
+        fl = 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)
+        with profiling.span("conv3x3_direct" if direct else ("split_gemm_kernel" if split else "conv_igemm_kernel"), "hbm" if direct else "mfma",
+                            nb_ if direct else (SPLIT_PRODUCTS * fl if split else fl), ref=None if direct else fl, nbytes=nb_,
                             tag=None if direct else ("conv", C, H, W, M, K, stride, mode, dil, B)):
             check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 1), "prn_conv2d_fwd")
-        if nbytes:
+        if nbytes and kind != 2:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
                 check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 2), "prn_conv2d_fwd")
     else:
@@ -565,7 +579,8 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
             check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P),
+        fam, ex, _ = _gemm_family(M, C, 1, P, 36, 2.0 * 36 * M * C * P)
+        with profiling.span(fam, "mfma", ex, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P),
                             tag=("wino-products", C, H, W, M, 3, 1, mode, 1, B)):
             check(lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()), "prn_gemm_batched")
         with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1), 0.0):
@@ -891,7 +906,8 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
     ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
     if profiling._enabled:
         # every launch bracketed on its own: the column-gradient GEMM, its K-split sum, the CSR gather of dx (phases 1 / 2 / 3)
-        with profiling.span("conv_igemm_kernel", "mfma", 2.0 * M * C * 9 * B * d.Ho * d.Wo, nbytes=4.0 * (dy.numel() + wt.numel()) + ncols,
+        fam, ex, fl = _gemm_family(9 * C, M, B, d.Ho * d.Wo, 1, 2.0 * M * C * 9 * B * d.Ho * d.Wo)
+        with profiling.span(fam, "mfma", ex, fl, nbytes=4.0 * (dy.numel() + wt.numel()) + ncols,
                             tag=("dcn-colgrad", M, d.Ho, d.Wo, 9 * C, 1, 1, 0, 1, B)):
             check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 1), "prn_dcnv2_bwd_input")
         with profiling.span("reduce_epilogue_kernel", "hbm", 0.0):      # (no-op without a K split: an empty bracket, ~0 us)
@@ -1062,12 +1078,14 @@ class _PlanePrior(torch.autograd.Function):
         if profiling._enabled:
             args = (_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream())
             npx = (h // 2) * (w // 2)
-            for ph, (fam, bound, work, nb_, tag) in enumerate((
-                    ("plane_prior_centre_gather", "hbm", 4.0 * 2 * B * E * npx, 0.0, None),
-                    ("conv_igemm_kernel", "mfma", 2.0 * NK * E * B * npx, 4.0 * B * (E * npx + NK * E + NK * npx), ("prior-dynamic", E, h // 2, w // 2, NK, 1, 1, 0, 1, B)),
-                    ("resize_down2", "hbm", 4.0 * B * NK * npx * 1.25, 0.0, None),
-                    ("conv_igemm_kernel", "mfma", 2.0 * F * NK * B * npx / 4, 4.0 * (B * NK * npx / 4 + F * NK + B * F * npx / 4), ("conv", NK, h // 4, w // 4, F, 1, 1, 0, 1, B))), 1):
-                with profiling.span(fam, bound, work, nbytes=nb_, tag=tag):
+            g1 = _gemm_family(NK, E, 1, npx, B, 2.0 * NK * E * B * npx)
+            g2 = _gemm_family(F, NK, B, npx // 4, 1, 2.0 * F * NK * B * npx / 4)
+            for ph, (fam, bound, work, rf, nb_, tag) in enumerate((
+                    ("plane_prior_centre_gather", "hbm", 4.0 * 2 * B * E * npx, None, 0.0, None),
+                    (g1[0], "mfma", g1[1], g1[2], 4.0 * B * (E * npx + NK * E + NK * npx), ("prior-dynamic", E, h // 2, w // 2, NK, 1, 1, 0, 1, B)),
+                    ("resize_down2", "hbm", 4.0 * B * NK * npx * 1.25, None, 0.0, None),
+                    (g2[0], "mfma", g2[1], g2[2], 4.0 * (B * NK * npx / 4 + F * NK + B * F * npx / 4), ("conv", NK, h // 4, w // 4, F, 1, 1, 0, 1, B))), 1):
+                with profiling.span(fam, bound, work, rf, nbytes=nb_, tag=tag):
                     check(lib.prn_plane_prior_fwd_phase(*args, ph), "prn_plane_prior_fwd")
         else:
             check(lib.prn_plane_prior_fwd(_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream()),

@@ -864,3 +864,87 @@ def test_fpn_level_block_equals_operator_sequence(B, C, H, W, with_prev):
                                bo.float().to(d), True)
     close(lat, lat_ref, "fpn lateral")
     close(p, p_ref, "fpn output")
+
+
+@pytest.fixture
+def split_everywhere():
+    """PRN_SPLIT_GEMM=2 for one test: every plain GEMM the split kernel can take runs on it (workspace sizes are re-queried)."""
+    from planerecnet_amd import ops
+    old = ops.lib.prn_split_gemm_mode(2)
+    ops._DESC.clear()
+    yield ops
+    ops.lib.prn_split_gemm_mode(old)
+    ops._DESC.clear()
+
+
+def _gemm_errors(y, w, x, bias, add, epi):
+    """(max, rms) of (y - fp64 reference) / (sum_k |w||x| + |bias| + |addend|) per element."""
+    wd, xd = w.double().cpu(), x.double().cpu()
+    ref = torch.einsum("mk,bkp->bmp", wd, xd)
+    mag = torch.einsum("mk,bkp->bmp", wd.abs(), xd.abs())
+    if bias is not None:
+        ref = ref + bias.double().cpu()[None, :, None]; mag = mag + bias.double().cpu().abs()[None, :, None]
+    if add is not None:
+        ref = ref + add.double().cpu(); mag = mag + add.double().cpu().abs()
+    if epi == 1:
+        ref = torch.relu(ref)
+    e = (y.double().cpu() - ref) / (mag + 1e-30)
+    return float(e.abs().max()), float(e.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("M,K,B,HW,bias,add,epi", [
+    (1024, 256, 2, 1200, False, False, 0),      # stage-3 expand
+    (256, 1024, 2, 1200, True, True, 1),        # stage-3 reduce: K split (few tiles), bias + residual + ReLU through the reduce kernel
+    (200, 72, 3, 1205, True, True, 1),          # tails in M, K (72 = 2 slices + 8) and pixels (odd plane)
+    (128, 32, 1, 100, False, False, 0),         # one tile, one slice
+    (512, 2048, 8, 300, False, False, 0),       # stage-4 reduce: 4 K splits
+    (64, 256, 1, 19200, True, False, 0),        # half-empty row tile
+])
+def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywhere):
+    """csrc/prn_gemm_split.hip (three exact bf16 pieces per operand, six bf16 MFMA products, fp32 accumulate) against fp64, next to the
+    fp32 MFMA kernel on the same operands: its error is fp32 ROUNDING error -- at every element below 4e-7 of sum|w||x| (or twice the
+    fp32 kernel's maximum on that shape; that kernel's own maximum is 1e-7 .. 3.7e-7 depending on its K split), rms below 2.5e-8 (or
+    1.5x the fp32 kernel's 1.2e-8 .. 2.2e-8) -- four orders of magnitude from a bf16 or TF32 product's 1e-3."""
+    ops = split_everywhere
+    lib, _p, _stream, check = ops.lib, ops._p, ops._stream, ops.check
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.rand(B, K, HW, generator=g) * 2 - 1).cuda()
+    w = ((torch.rand(M, K, generator=g) * 2 - 1) * K ** -0.5).cuda()
+    bv = torch.randn(M, generator=g).cuda() if bias else None
+    av = torch.randn(B, M, HW, generator=g).cuda() if add else None
+    assert lib.prn_gemm_pipe(M, K, B, HW, 1) >= 1
+    out = {}
+    for mode in (2, 0):
+        lib.prn_split_gemm_mode(mode)
+        ops._DESC.clear()
+        _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, epi)
+        assert lib.prn_conv2d_kernel_kind(ref) == (0 if mode == 0 else (3 if lib.prn_gemm_pipe(M, K, B, HW, 1) > 1 else 2))
+        ws = torch.full((max(nbytes, 16) // 4,), float("nan"), device="cuda")
+        y = torch.full((B, M, HW), float("nan"), device="cuda")
+        check(lib.prn_conv2d_fwd(ref, _p(x), _p(w), _p(bv), _p(av), _p(y), _p(ws), _stream()), "conv")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y).all())
+        out[mode] = _gemm_errors(y, w, x, bv, av, epi)
+    (smax, srms), (fmax, frms) = out[2], out[0]
+    assert smax <= max(2.0 * fmax, 4e-7) and srms <= max(1.5 * frms, 2.5e-8), (out,)
+
+
+def test_split_gemm_batched_and_special_values(split_everywhere):
+    """prn_gemm_batched on the split kernel (the Winograd products: z = 36 independent GEMMs), and operand values the split must
+    survive: exact zeros, powers of two, denormal-range and large magnitudes, negative numbers (pieces carry the operand's sign)."""
+    ops = split_everywhere
+    lib, _p, _stream, check = ops.lib, ops._p, ops._stream, ops.check
+    M, C, P, nb = 256, 96, 640, 5
+    assert lib.prn_gemm_pipe(M, C, 1, P, nb) == 1
+    g = torch.Generator().manual_seed(3)
+    U = torch.randn(nb, M, C, generator=g)
+    V = torch.randn(nb, C, P, generator=g)
+    U[0, :, :8] = 0.0; U[1, :, 8:16] = 2.0 ** -20; U[2, 3] = 1.0; V[0, :4] = 0.0; V[3] *= 1e18; U[3] *= 1e-18; V[4, :, ::7] = -4096.0
+    V[2, 5] = 1e-38                                                            # below bf16's / fp32's normal range after the second slice
+    Y = torch.empty(nb, M, P, device="cuda")
+    check(lib.prn_gemm_batched(M, C, P, nb, _p(U.cuda()), _p(V.cuda()), _p(Y), _stream()), "batched")
+    torch.cuda.synchronize()
+    ref = torch.bmm(U.double(), V.double())
+    mag = torch.bmm(U.double().abs(), V.double().abs())
+    e = ((Y.double().cpu() - ref) / (mag + 1e-300)).abs().max()
+    assert bool(torch.isfinite(Y).all()) and float(e) <= 6e-7, float(e)
