@@ -430,6 +430,8 @@ def main():
                     "buckets": None, "note": "one-rank RCCL group: hooks + pack + all-reduce launch + unpack, no wire time"}
         except Exception as e:                                   # noqa: BLE001
             exch = {"error": "%s: %s" % (type(e).__name__, e)}
+    if os.environ.get("PRN_SPLIT_STATS"):
+        print("split-GEMM weight images: %s, %d cached operands" % (ops.SPLIT_STATS, len(ops._SPLIT_IMG)), file=sys.stderr)
     if os.environ.get("PRN_EXCHANGE_PROF"):
         from planerecnet_amd import parallel as _par
         n_ = max(_par._PROF.get("steps", 1), 1)

@@ -75,6 +75,20 @@ int prn_gemm_pipe(int M, int K, int B, int HW, int nz);
 /* Sets PRN_SPLIT_GEMM's value for this process (0 / 1 / 2 as above; < 0: query only) and returns the previous one.  Workspace sizes
  * (prn_conv2d_fwd_ws_bytes and the block-level *_ws_bytes) depend on it: query them again after a change. */
 int prn_split_gemm_mode(int mode);
+/* Mode 1 takes the split kernel for launches of at least this many 128 x 128 output tiles (PRN_SPLIT_MIN_TILES, default 2500; < 0: query
+ * only); returns the previous value.  The threshold is a BOARD-level trade, see prn_gemm_split.hip: broad use of the bf16 pipe makes the
+ * firmware lower the shader clock for everything else. */
+int prn_split_gemm_min_tiles(int n);
+/* The weight side of the split kernel ("images": [z][m tile of 128][k slice of 32][piece][k group][row][8 x bf16], zero padded) is cut
+ * inside every launch unless the caller keeps it: prn_split_images_bytes = size of the images of w[nz][M][K]; prn_split_prepare_batched =
+ * ONE launch that cuts many weights (items_dev: device array of {const float* src; void* dst; int32 M, K, nz, pad; int64 z stride of src
+ * in elements; int64 first} -- `first` = the item's first 256-thread block, an item has ceil(nz * ceil(M/128) * ceil(K/32) * 512 / 256)
+ * blocks, total_blocks = their sum); prn_split_images_register(w, images, M, K, nz) tells the library that launches whose weight operand
+ * is exactly `w` (same M, K, nz, dense z stride) read `images` instead of cutting w again -- the caller re-runs the prepare whenever w's
+ * contents change; images == NULL removes the entry.  (planerecnet_amd.ops.SplitImages: one prepare launch per training step.) */
+int64_t prn_split_images_bytes(int M, int K, int nz);
+int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, void* stream);
+int prn_split_images_register(const float* w, const void* images, int M, int K, int nz);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
 /* The same with the K-split sum folded into the GEMM launch (no second kernel, one launch less per split layer): `counters` is

@@ -190,6 +190,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// one launch for many weights: item i covers blocks [first_i, first_{i+1}) of 256 threads = 256 (z, m tile, k slice, k group, row) tuples
+struct PrepItem { const float* src; uint4* dst; int M, K, nz, pad; long long zw; long long first; };
+__global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;
+  const long long blk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].first <= blk) lo = mid; else hi = mid - 1; }
+  const PrepItem it = items[lo];
+  const int mtiles = (it.M + 127) / 128, kslices = (it.K + 31) / 32;
+  const long long total = (long long)it.nz * mtiles * kslices * 512;
+  const long long i = (blk - it.first) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
+  const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (m < it.M && k0 + j < it.K) ? it.src[z * it.zw + (long long)m * it.K + k0 + j] : 0.f;
+  uint4 h, mm, l;
+  split2(v[0], v[1], h.x, mm.x, l.x); split2(v[2], v[3], h.y, mm.y, l.y); split2(v[4], v[5], h.z, mm.z, l.z); split2(v[6], v[7], h.w, mm.w, l.w);
+  uint4* o = it.dst + t * IMG_U4;
+  o[(0 * 4 + g) * 128 + r] = h; o[(1 * 4 + g) * 128 + r] = mm; o[(2 * 4 + g) * 128 + r] = l;
+}
+
+// weight pointer -> images the caller keeps current (prn_split_images_register): launches on such a weight skip the per-call split
+struct RegEntry { const void* images; int M, K, nz; };
+std::map<const void*, RegEntry> g_registry;
+std::mutex g_registry_mu;
+const void* registered_images(const float* w, int M, int K, int nz) {
+  std::lock_guard<std::mutex> lock(g_registry_mu);
+  auto it = g_registry.find((const void*)w);
+  if (it == g_registry.end() || it->second.M != M || it->second.K != K || it->second.nz != nz) return nullptr;
+  return it->second.images;
+}
+
+// Launches with fewer 128 x 128 tiles than this keep the fp32 kernel.  300 is where the split kernel starts to win launch by launch; the
+// DEFAULT is 2500 because of what the board does, not the kernel: with the split kernel on every launch it wins (214 of 296 plain-GEMM
+// launches of a PlaneRecNet_101 training step) the firmware lowers the shader clock from 2.35 to 2.17-2.20 GHz for the WHOLE step (socket
+// power falls 1.2 -> 1.05-1.1 kW at the same time: a current / di-dt limit of the bf16 matrix pipe, not the 1.4 kW cap), and every other
+// kernel pays 7 %: 50.5 -> 51.5 ms per step on three boxes (tools/smi_ab.sh, profiles/r03_c_*).  Restricted to the big launches the clock
+// stays (2.33-2.34 GHz) and the step gains 0.3 %; at inference (no weight-gradient stream beside it, 0.85-1.05 kW) the low threshold is
+// the better one (high-resolution workload +4 %) -- planerecnet_amd.ops.split_gemm_policy() switches it with the model's train() / eval().
+int g_min_tiles = -1;
+int min_tiles() {
+  if (g_min_tiles < 0) { const char* e = getenv("PRN_SPLIT_MIN_TILES"); g_min_tiles = e ? atoi(e) : 2500; }
+  return g_min_tiles;
+}
 int g_mode = -1;       // PRN_SPLIT_GEMM: 0 = off (fp32 MFMA everywhere), 1 = where the plan says so (default), 2 = wherever the kernel applies
 int mode() {
   if (g_mode < 0) { const char* e = getenv("PRN_SPLIT_GEMM"); g_mode = e ? atoi(e) : 1; }
@@ -217,8 +263,32 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz) {
   }
   if (md == 2) return splits;
   if (M % 128 != 0 && M % 128 <= 64) return 0;
-  if (tiles * splits < 300) return 0;
+  if (2.0 * M * K * (double)HW * B * nz < 2e9) return 0;         // small launches are all launch latency: one kernel beats split + GEMM (+ sum)
+  if (tiles * splits < min_tiles()) return 0;
   return splits;
+}
+extern "C" int64_t prn_split_images_bytes(int M, int K, int nz) {
+  if (M <= 0 || K <= 0 || nz <= 0) return -1;
+  return prn_split_gemm_image_bytes(M, K, nz);
+}
+extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, void* stream) {
+  PRN_REQUIRE(items_dev && n_items > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "prn_split_prepare_batched: bad arguments");
+  hipLaunchKernelGGL(split_prepare_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n_items);
+  PRN_CHECK_LAUNCH("prn_split_prepare_batched");
+  return 0;
+}
+extern "C" int prn_split_images_register(const float* w, const void* images, int M, int K, int nz) {
+  PRN_REQUIRE(w != nullptr, "prn_split_images_register: null weight");
+  std::lock_guard<std::mutex> lock(g_registry_mu);
+  if (images == nullptr) { g_registry.erase((const void*)w); return 0; }
+  PRN_REQUIRE(M > 0 && K > 0 && nz > 0 && (reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_images_register: bad arguments");
+  g_registry[(const void*)w] = RegEntry{images, M, K, nz};
+  return 0;
+}
+extern "C" int prn_split_gemm_min_tiles(int n) {
+  const int old = min_tiles();
+  if (n >= 0) g_min_tiles = n;
+  return old;
 }
 extern "C" int prn_split_gemm_mode(int m) {
   const int old = mode();
@@ -236,14 +306,18 @@ int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits) {
 // phase: 0 = everything, 1 = the split + GEMM launches only, 2 = the K-split sum only (profiler brackets, like prn_conv2d_fwd_phase).
 int prn_split_gemm(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images, float* partial, int M, int K, int B, int HW,
                    int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, hipStream_t st, int phase) {
-  PRN_REQUIRE(w && x && y && images && (splits == 1 || partial), "prn_split_gemm: null operand");
+  PRN_REQUIRE(w && x && y && (splits == 1 || partial), "prn_split_gemm: null operand");
   PRN_REQUIRE((reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_gemm: images must be 16-byte aligned");
   const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32), ptiles = cdiv(HW, 128);
   PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)K * HW < (1LL << 29), "prn_split_gemm: operand larger than a buffer descriptor");
   const long long ptotal = (long long)nz * mtiles * kslices * 512;
   if (phase != 2) {
-  hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, (long long)zw, mtiles, kslices, ptotal);
-  PRN_CHECK_LAUNCH("prn_split_gemm/prepare");
+  if (const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz) : nullptr) {
+    images = const_cast<void*>(reg);                               // split by the caller since the weight last changed
+  } else {
+    hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, (long long)zw, mtiles, kslices, ptotal);
+    PRN_CHECK_LAUNCH("prn_split_gemm/prepare");
+  }
   SplitArgs a;
   a.img = (const uint4*)images; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
   a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;

@@ -288,6 +288,7 @@ def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NO
         wb = lib.prn_conv2d_wgrad_ws_bytes(ref) if (mode != IN_DILATED and K != 4 and ystride <= 1) else 0
         if fb < 0 or wb < 0:
             raise RuntimeError(lib.prn_last_error().decode())
+        d.kind = lib.prn_conv2d_kernel_kind(ref)             # 2 / 3: plain GEMM on the bf16-split kernel
         e = _DESC[key] = (d, ref, fb, wb)
     return e
 
@@ -320,9 +321,149 @@ SPLIT_PRODUCTS = 6.0     # bf16 MFMA products the split GEMM kernel issues per f
 def _gemm_family(M, K, B, HW, nz, flops):
     """(family, executed FLOPs, reference FLOPs) of a plain GEMM launch for the profiler: on the split kernel the launch executes six
     bf16 products per fp32 multiply-add on the bf16 matrix pipe; `flops` (2*M*K*N) stays the reference operator's work."""
-    if lib.prn_gemm_pipe(int(M), int(K), int(B), int(HW), int(nz)) >= 1:
+    if gemm_pipe(M, K, B, HW, nz) >= 1:
         return "split_gemm_kernel", SPLIT_PRODUCTS * flops, flops
     return "conv_igemm_kernel", flops, flops
+
+
+
+# ------------------------------------------------------------------------------------------ split-GEMM weight images
+# The bf16-split GEMM kernel (csrc/prn_gemm_split.hip) reads its weight operand as pre-cut "images".  Left alone the library cuts the
+# weight inside every launch (one more small kernel in front of each GEMM); for operands that persist -- parameters, the per-step flipped
+# dgrad layouts, the Winograd transform-domain weights -- this cache keeps the images, registers them with the library
+# (prn_split_images_register) and re-cuts ALL of them with one launch per training step (split_refresh_all, called by the model next to
+# FlippedWeights / WinogradWeights); at inference they are cut once.  Every launch site checks its operand's entry against the version
+# counter of the parameter (or the generation stamp of the derived buffer) first, so a stale image is never read.
+# OFF by default (PRN_SPLIT_CACHE=1 turns it on): measured on the PlaneRecNet_101 training step the per-launch cut is FASTER than reading
+# images cut at the start of the step (48.5 vs 51.5 ms per step, same box; fp32 kernel: 50.4) -- the cut leaves the 0.2 .. 14 MB of
+# images in L2 / Infinity Cache right in front of the GEMM whose 80 .. 600 workgroups each stream them, whereas images written 20 ms
+# earlier come from HBM; at inference (static weights, nothing to re-cut) the cache is a small gain on the high-resolution workload.
+SPLIT_CACHE = bool(int(os.environ.get("PRN_SPLIT_CACHE", "0")))
+_SPLIT_IMG = {}    # operand data_ptr -> _SplitEntry
+_STAMP = {}        # data_ptr of a derived persistent operand (flipped weight view, Winograd U / Ut) -> generation of its contents
+_SPLIT_ITEMS = [None, None, 0]     # [item table on the device, the entry set it was built for, total blocks]
+_PIPE = {}
+SPLIT_STATS = {"hits": 0, "cuts": 0, "uncached": 0, "refreshes": 0}     # launches on current images / single re-cuts / temporaries / batched refreshes
+
+
+_SPLIT_POLICY = {"train": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_TRAIN", "2500"))),
+                 "eval": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_EVAL", "300")))}
+
+
+def split_gemm_policy(which):
+    """'train' / 'eval': how small a plain GEMM may be and still take the bf16-split kernel (csrc/prn_gemm_split.hip: g_min_tiles has the
+    measurements).  A model calls this from train() / eval(); the cached launch plans and workspace sizes are dropped on a change."""
+    n = _SPLIT_POLICY[which]
+    if _SPLIT_POLICY.get("current") != n:
+        _SPLIT_POLICY["current"] = n
+        lib.prn_split_gemm_min_tiles(n)
+        _DESC.clear()
+        _PIPE.clear()
+        _DCN.clear()
+
+
+def gemm_pipe(M, K, B, HW, nz):
+    key = (M, K, B, HW, nz)
+    v = _PIPE.get(key)
+    if v is None:
+        v = _PIPE[key] = lib.prn_gemm_pipe(int(M), int(K), int(B), int(HW), int(nz))
+    return v
+
+
+class _SplitEntry:
+    __slots__ = ("owner", "tensor", "stamp", "images", "dims", "ptr")
+
+
+def _stamp(t):
+    """A derived persistent operand (one the caches below keep and rewrite in place) got new contents."""
+    p = t.data_ptr()
+    _STAMP[p] = _STAMP.get(p, 0) + 1
+
+
+def _split_drop(ptr, stamp=True):
+    if stamp:
+        _STAMP.pop(ptr, None)
+    if _SPLIT_IMG.pop(ptr, None) is not None:
+        lib.prn_split_images_register(ctypes.c_void_p(ptr), None, 0, 0, 0)
+        _SPLIT_ITEMS[0] = None
+
+
+def _split_state(e):
+    """Current content stamp of an entry's operand, or None when its owner is gone."""
+    if e.owner is not None:
+        o = e.owner()
+        return None if o is None else o._version
+    return _STAMP.get(e.ptr)
+
+
+def _prep_items(entries, dev):
+    import numpy as np
+    items = np.zeros(len(entries), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("M", "i4"), ("K", "i4"), ("nz", "i4"), ("pad", "i4"), ("zw", "i8"), ("first", "i8")]))
+    blocks = 0
+    for i, e in enumerate(entries):
+        M, K, nz = e.dims
+        items[i] = (e.ptr, e.images.data_ptr(), M, K, nz, 0, M * K, blocks)
+        blocks += (nz * ((M + 127) // 128) * ((K + 31) // 32) * 512 + 255) // 256
+    return torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev), blocks
+
+
+def split_images(t, M, K, nz):
+    """Call in front of a launch that takes the split kernel with weight operand t [nz, M, K] (dense): makes sure the library holds
+    current images of t when t persists (a parameter / a view of one / a stamped derived buffer); otherwise the launch cuts t itself."""
+    if not SPLIT_CACHE:
+        return
+    ptr = t.data_ptr()
+    e = _SPLIT_IMG.get(ptr)
+    if e is not None:
+        cur = _split_state(e)
+        if cur is not None and cur == e.stamp and e.dims == (M, K, nz):
+            SPLIT_STATS["hits"] += 1
+            return                                              # registered and current
+        if cur is None or e.dims != (M, K, nz):                 # owner gone (address reused) or another view of the storage: start over
+            _split_drop(ptr, stamp=False)
+            e = None
+    if e is None:
+        owner = t if isinstance(t, torch.nn.Parameter) else (t._base if isinstance(t._base, torch.nn.Parameter) else None)
+        if owner is None and ptr not in _STAMP:
+            SPLIT_STATS["uncached"] += 1
+            return                                              # a temporary: the launch cuts it
+        if owner is not None and owner.data_ptr() != ptr:
+            return                                              # a view that does not start at the parameter's first element
+        e = _SplitEntry()
+        e.owner = weakref.ref(owner) if owner is not None else None
+        e.tensor = None if owner is not None else t              # derived buffers are kept alive by the entry (no address reuse)
+        e.ptr, e.dims = ptr, (M, K, nz)
+        nb = lib.prn_split_images_bytes(M, K, nz)
+        e.images = torch.empty(nb, device=t.device, dtype=torch.uint8)
+        _SPLIT_IMG[ptr] = e
+        _SPLIT_ITEMS[0] = None
+        if owner is not None:
+            weakref.finalize(owner, lambda p=ptr, r=e: _split_drop(p) if _SPLIT_IMG.get(p) is r else None)
+        check(lib.prn_split_images_register(ctypes.c_void_p(ptr), _p(e.images), M, K, nz), "prn_split_images_register")
+    items, blocks = _prep_items([e], t.device)
+    check(lib.prn_split_prepare_batched(_p(items), 1, blocks, _stream()), "prn_split_prepare_batched")
+    e.stamp = _split_state(e)
+    SPLIT_STATS["cuts"] += 1
+    if os.environ.get("PRN_SPLIT_DEBUG"):
+        SPLIT_STATS.setdefault("who", {}).setdefault((M, K, nz, "param" if e.owner is not None else "derived"), []).append(SPLIT_STATS["refreshes"])
+
+
+def split_refresh_all():
+    """Re-cut every cached operand with ONE launch (a model calls this once per training step, after the optimizer changed the weights
+    and after the flipped / transform-domain layouts were refreshed)."""
+    dead = [p for p, e in _SPLIT_IMG.items() if _split_state(e) is None]
+    for p in dead:
+        _split_drop(p)
+    if not _SPLIT_IMG:
+        return
+    entries = list(_SPLIT_IMG.values())
+    if _SPLIT_ITEMS[0] is None or _SPLIT_ITEMS[1] != [id(e) for e in entries]:
+        items, blocks = _prep_items(entries, entries[0].images.device)
+        _SPLIT_ITEMS[0], _SPLIT_ITEMS[1], _SPLIT_ITEMS[2] = items, [id(e) for e in entries], blocks
+    check(lib.prn_split_prepare_batched(_p(_SPLIT_ITEMS[0]), len(entries), _SPLIT_ITEMS[2], _stream()), "prn_split_prepare_batched")
+    for e in entries:
+        e.stamp = _split_state(e)
+    SPLIT_STATS["refreshes"] += 1
 
 
 # ------------------------------------------------------------------------------------------ raw launches
@@ -331,7 +472,9 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     B, C, H, W = x.shape
     if scatter2 is None:
         y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
-        _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+        d_, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+        if d_.kind >= 2:
+            split_images(w2d, M, C, 1)
     else:
         y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
         _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
@@ -460,10 +603,13 @@ class FlippedWeights:
         if self.ptrs is None or any(w.data_ptr() != p for w, p in zip(self.data, self.ptrs)):
             for p in (self.ptrs or []):
                 _FLIPPED.pop(p, None)
+            for v in (getattr(self, "views", None) or []):
+                _split_drop(v.data_ptr())
             self._build()
         check(lib.prn_weight_flip_transpose_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_weight_flip_transpose_batched")
         for gd, d, v in zip(self.guards, self.data, self.views):
             _FLIPPED[d.data_ptr()] = (gd, tuple(t._version for t in gd), v)
+            _stamp(v)
 
 
 # ------------------------------------------------------------------------------------------ Winograd F(4x4, 3x3)
@@ -496,9 +642,19 @@ def _wino_store(w, U, Ut):
     weight's size -- a dead model must not pin them)."""
     ptr = w.data_ptr()
     new = ptr not in _WINO or _WINO[ptr][0]() is not w
+    old = _WINO.get(ptr)
+    if old is not None and (old[2] is not U or old[3] is not Ut):
+        _split_drop(old[2].data_ptr()); _split_drop(old[3].data_ptr())
     _WINO[ptr] = (weakref.ref(w), w._version, U, Ut)
+    _stamp(U); _stamp(Ut)
     if new:
-        weakref.finalize(w, lambda p=ptr, r=_WINO[ptr][0]: _WINO.pop(p, None) if (_WINO.get(p) or (None,))[0] is r else None)
+        weakref.finalize(w, lambda p=ptr, r=_WINO[ptr][0]: _wino_pop(p) if (_WINO.get(p) or (None,))[0] is r else None)
+
+
+def _wino_pop(ptr):
+    e = _WINO.pop(ptr, None)
+    if e is not None:
+        _split_drop(e[2].data_ptr()); _split_drop(e[3].data_ptr())
 
 
 def winograd_weights(w):
@@ -555,7 +711,7 @@ class WinogradWeights:
             return
         if self.ptrs is None or any(w.data_ptr() != p for w, p in zip(self.weights, self.ptrs)):
             for p in (self.ptrs or []):
-                _WINO.pop(p, None)
+                _wino_pop(p)
             self._build()
         check(lib.prn_winograd_weights_batched(_p(self.items), len(self.weights), self.total, _stream()), "prn_winograd_weights_batched")
         for w, (U, Ut) in zip(self.weights, self.views):
@@ -575,6 +731,8 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
     P = lib.prn_winograd_tiles(B, H, W)
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
     ws = torch.empty(36 * (C + M) * P, device=x.device, dtype=torch.float32)
+    if gemm_pipe(M, C, 1, P, 36) >= 1:
+        split_images(U, M, C, 36)
     if profiling._enabled:
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
@@ -902,6 +1060,8 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
     d, ref, _, _, _, db = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset)
     wt = flip_transpose(w.view(M, C * 9, 1, 1))                   # [9C, M, 1, 1]
     ws = _f32(db, x.device)
+    if gemm_pipe(9 * C, M, B, d.Ho * d.Wo, 1) >= 1:
+        split_images(wt, 9 * C, M, 1)                            # the column-gradient GEMM's weight operand
     dx = torch.empty_like(x) if need_x else None
     ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
     if profiling._enabled:

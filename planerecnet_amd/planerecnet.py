@@ -132,8 +132,13 @@ class PlaneRecNet(nn.Module):
             ww = self.__dict__["_wino"] = ops.WinogradWeights(seen)
         if ww is not None:
             ww.refresh()
+        ops.split_refresh_all()          # weight images of the bf16-split GEMM launches (parameters, flipped and transform-domain layouts): one launch
 
     def forward(self, x):
+        if x.is_cuda:
+            # which plain GEMMs take the bf16-split kernel is a board-level trade that differs between training and inference
+            # (ops.split_gemm_policy, csrc/prn_gemm_split.hip)
+            ops.split_gemm_policy("train" if self.training else "eval")
         if self.training and torch.is_grad_enabled() and x.is_cuda:
             self._refresh_dgrad_weights()
         with timer.env("backbone"):

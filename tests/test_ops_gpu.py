@@ -871,10 +871,10 @@ def split_everywhere():
     """PRN_SPLIT_GEMM=2 for one test: every plain GEMM the split kernel can take runs on it (workspace sizes are re-queried)."""
     from planerecnet_amd import ops
     old = ops.lib.prn_split_gemm_mode(2)
-    ops._DESC.clear()
+    ops._DESC.clear(); ops._PIPE.clear()
     yield ops
     ops.lib.prn_split_gemm_mode(old)
-    ops._DESC.clear()
+    ops._DESC.clear(); ops._PIPE.clear()
 
 
 def _gemm_errors(y, w, x, bias, add, epi):
@@ -916,7 +916,7 @@ def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywher
     out = {}
     for mode in (2, 0):
         lib.prn_split_gemm_mode(mode)
-        ops._DESC.clear()
+        ops._DESC.clear(); ops._PIPE.clear()
         _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, epi)
         assert lib.prn_conv2d_kernel_kind(ref) == (0 if mode == 0 else (3 if lib.prn_gemm_pipe(M, K, B, HW, 1) > 1 else 2))
         ws = torch.full((max(nbytes, 16) // 4,), float("nan"), device="cuda")
@@ -948,3 +948,45 @@ def test_split_gemm_batched_and_special_values(split_everywhere):
     mag = torch.bmm(U.double().abs(), V.double().abs())
     e = ((Y.double().cpu() - ref) / (mag + 1e-300)).abs().max()
     assert bool(torch.isfinite(Y).all()) and float(e) <= 6e-7, float(e)
+
+
+def test_split_gemm_weight_images_follow_the_weight(split_everywhere, monkeypatch):
+    """ops.split_images: a parameter's images are cut once, reused while its version counter stands still, re-cut after an in-place
+    update (by the launch itself when nobody called split_refresh_all, by ONE batched launch when the model does), and dropped with
+    the parameter; a temporary weight tensor is cut inside its launch and never cached."""
+    ops = split_everywhere
+    monkeypatch.setattr(ops, "SPLIT_CACHE", True)
+    M, C, B, H, W = 256, 128, 2, 24, 32
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = torch.nn.Parameter((torch.randn(M, C, 1, 1, generator=g) * C ** -0.5).cuda())
+
+    def run(wt):
+        return ops.conv_fwd_raw(x, wt.view(M, C), None, None, M, 1, 1, 0, H, W)
+
+    def ref(wt):
+        return F.conv2d(x.double().cpu(), wt.detach().double().cpu())
+    n0 = len(ops._SPLIT_IMG)
+    with torch.no_grad():
+        close(run(w), ref(w), "first use")
+        assert len(ops._SPLIT_IMG) == n0 + 1 and w.data_ptr() in ops._SPLIT_IMG
+        img = ops._SPLIT_IMG[w.data_ptr()].images
+        before = img.clone()
+        close(run(w), ref(w), "cached")
+        assert torch.equal(img, before)
+        w.mul_(-3.0)                                            # version bump, no refresh: the launch site notices
+        close(run(w), ref(w), "after an in-place update")
+        assert not torch.equal(img, before)
+        w.add_(0.25)
+        ops.split_refresh_all()                                 # the per-step batch
+        after = img.clone()
+        close(run(w), ref(w), "after the batched refresh")
+        assert torch.equal(img, after)
+        tmp = (torch.randn(M, C, generator=g) * C ** -0.5).cuda()          # not a parameter: cut per launch, not cached
+        close(run(tmp), ref(tmp.view(M, C, 1, 1)), "temporary weight")
+        assert tmp.data_ptr() not in ops._SPLIT_IMG
+    ptr = w.data_ptr()
+    del w
+    import gc
+    gc.collect()
+    assert ptr not in ops._SPLIT_IMG

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <chrono>
 #include "../../../include/prn.h"
 #include "split_gemm.h"
 
@@ -92,14 +93,19 @@ int main(int argc, char** argv) {
       fn(); CK(hipStreamSynchronize(st));
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       CK(hipEventRecord(e0, st));
+      const auto w0 = std::chrono::steady_clock::now();
       for (int i = 0; i < reps; ++i) fn();
       CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+      const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (getenv("LAB_WALL")) printf("    [events %.1f us/launch, host wall %.1f us/launch over %d launches]\n", ms / reps * 1e3, wall / reps * 1e6, reps);
       return ms / reps * 1e3f;
     };
-    const float tpre = timeit(run_presplit);
-    const float tsp = timeit(run_split);
-    const float told = old_ok ? timeit(run_old) : 0.f;
+    const char* only = getenv("LAB_ONLY");                       // "split" / "old": time (and keep the GPU busy with) one kernel only
+    run_presplit();
+    const float tpre = only ? 0.f : timeit(run_presplit);
+    const float tsp = (only && strcmp(only, "split")) ? 0.f : timeit(run_split);
+    const float told = (old_ok && !(only && strcmp(only, "old"))) ? timeit(run_old) : 0.f;
     const double gf = 2.0 * s.M * s.K * (double)N * s.Z / 1e9;
     char msg[160] = "-";
     if (ny <= (48ll << 20)) {
