@@ -565,6 +565,9 @@ def main():
         line = {"metric": METRIC, "value": gb * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "arithmetic": "fp32 tensors, fp32 accumulation, fp32 MFMA; plain GEMMs of >= %d output tiles run on the bf16 pipe with every fp32 operand cut "
+                              "exactly into three bf16 pieces (error vs fp64 no larger than the fp32 MFMA's; DESIGN.md 9.1b; PRN_SPLIT_GEMM=0 turns it off)"
+                              % ops.lib.prn_split_gemm_min_tiles(-1),
                 "config": {"workload": "%s: %s %s, per-GPU batch %d, %dx%d synthetic %s, random-init weights"
                            % (args.workload, args.config, wl[5], args.batch, args.height, args.width, "RGB+depth+planes" if train else "RGB"),
                            "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},
