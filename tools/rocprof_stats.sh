@@ -17,7 +17,9 @@ python3 - <<PY
 import csv
 for mode in ("serial", "default"):
     rows = list(csv.DictReader(open("$R/gpurun_out/prof/${TAG}_kernel_stats_%s.csv" % mode)))
-    steps = 11
+    # steps actually executed (warm-up, timed, the exchange probe and the roofline-free extras): the one-launch Adam runs once per step
+    adam = [int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"]]
+    steps = adam[0] if adam else 11
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
     n = sum(int(r["Calls"]) for r in rows) / steps
     ours = [r for r in rows if "anonymous namespace" in r["Name"] and "at::" not in r["Name"]]
