@@ -83,7 +83,7 @@ def test_bench_inference_workloads(tmp_path, workload, batch, hw):
     assert line["config"]["workload"].startswith(workload + ":") and hw in line["config"]["workload"]
     assert line["config"]["global_batch"] == batch and line["unit"] == "img/s" and line["value"] > 0 and line["losses_finite"]
     roof = line["roofline"]
-    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["kernel"] == "conv_igemm_kernel"
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["kernel"] in ("conv_igemm_kernel", "split_gemm_kernel")
     assert roof["traffic"]["algorithmic_bytes_per_launch"] > 0
 
 
