@@ -190,6 +190,9 @@ def main():
                     help="GT-only loss preparation: HIP kernels one batch ahead on the side stream (planerecnet_amd/targets.py, triplets drawn by the "
                          "device sampler) or the round-2 host worker processes (losses.TargetPrefetcher, numpy stream)")
     ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this run (default 3; applied before the HIP runtime starts)")
+    ap.add_argument("--autotune", action="store_true", help="time the default launch-size threshold of the bf16-split GEMM kernel against the alternative on "
+                    "this board before the warm-up (ops.autotune_split_policy).  Off by default: the board's clock answers over seconds, blocks of ten "
+                    "steps under-estimate the penalty of the broad setting (50.4 vs 50.2 ms in-process where separate runs give 51.4 vs 50.1)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the extra steps that time the gradient-exchange path on a one-rank group")
     ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
                     "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
@@ -390,6 +393,19 @@ def main():
             el = float(t.item())
         return el, out
 
+    # which plain GEMMs take the bf16-split kernel is a trade against this board's clock management: time the alternative (untimed steps,
+    # before the warm-up proper; every rank decides on the slowest rank's times)
+    tune = None
+    if args.autotune and not graphed:
+        def rmax(v):
+            if world == 1:
+                return v
+            t = torch.tensor(v, device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.tolist()
+        for _ in range(3):
+            step()
+        tune = ops.autotune_split_policy(step, "train" if train else "eval", reduce_max=rmax)
     n_host0 = len(ph.get("host_ms_per_step", []))
     cpu0 = time.process_time()
     elapsed, last = timed(args.warmup, args.steps)
@@ -583,7 +599,7 @@ def main():
                            "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},
                 "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
                 "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "host": host,
-                "exchange_probe": exch, "kernels": kernels}
+                "exchange_probe": exch, "split_gemm_policy": tune, "kernels": kernels}
         print(json.dumps(line), flush=True)
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)

@@ -362,6 +362,43 @@ def split_gemm_policy(which):
         _DCN.clear()
 
 
+def autotune_split_policy(run_step, which, alternatives=None, steps=10, skip=3, rounds=2, margin=0.015, reduce_max=None):
+    """The threshold of split_gemm_policy is a trade against the BOARD's clock management, and boards differ (one box of
+    five ran the training step 3.6 % faster with the split kernel on every launch it wins alone, the others 2 % slower).  Times `run_step`
+    under the default threshold and under each alternative (A B A B ..., `skip` untimed steps after every switch) and keeps an alternative
+    only if its SLOWEST block beats the default's FASTEST by `margin`.  reduce_max: callable(list of floats) -> list, the maximum over ranks
+    (so that every rank of a job decides alike).  Returns a dict for the log.
+    CAVEAT (measured): the firmware lowers the clock over SECONDS; with ten-step blocks the broad setting looks 0.2 ms slower where
+    separate half-minute runs say 1.3 ms -- use steps >= 60 for a decision that holds, or trust the defaults."""
+    import time
+    base = _SPLIT_POLICY[which]
+    alts = [a for a in (alternatives if alternatives is not None else ((300,) if which == "train" else (10 ** 9,))) if a != base]
+    if lib.prn_split_gemm_mode(-1) != 1 or "PRN_SPLIT_MIN_TILES" in os.environ or not alts:
+        return {"tuned": False, "min_tiles": base}
+    times = {n: [] for n in [base] + alts}
+    for _ in range(rounds):
+        for n in [base] + alts:
+            _SPLIT_POLICY[which] = n
+            for _ in range(skip):
+                run_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_step()
+            torch.cuda.synchronize()
+            times[n].append((time.perf_counter() - t0) / steps)
+    if reduce_max is not None:
+        flat = reduce_max([t for n in [base] + alts for t in times[n]])
+        for i, n in enumerate([base] + alts):
+            times[n] = flat[i * rounds:(i + 1) * rounds]
+    best = base
+    for n in alts:
+        if max(times[n]) < (1.0 - margin) * min(times[best]):
+            best = n
+    _SPLIT_POLICY[which] = best
+    return {"tuned": True, "min_tiles": best, "default": base, "ms_per_step": {str(n): [round(1e3 * t, 2) for t in v] for n, v in times.items()}}
+
+
 def gemm_pipe(M, K, B, HW, nz):
     key = (M, K, B, HW, nz)
     v = _PIPE.get(key)
