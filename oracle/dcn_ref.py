@@ -16,7 +16,9 @@ it.  The restatement follows the published algorithm:
   out[b,co,ho,wo] = sum_{c,k} weight[co,c,k] * col[...] + bias[co]
 
 and is pinned by tests/test_oracle_dcn.py (zero offsets == conv2d; integer offsets == shifted conv;
-linear-ramp analytic value; out-of-bounds rule; fp64 gradcheck).  It is written with differentiable
+linear-ramp analytic value; out-of-bounds rule; fp64 gradcheck; for fractional offsets that cross and
+leave the image: equal to 1e-10 to ATen's grid sampler evaluated at the same pixel coordinates -- an
+implementation of the same published rule that shares no code with this file).  It is written with differentiable
 torch ops so autograd provides d-input / d-offset / d-mask / d-weight / d-bias (floor() has zero
 gradient, which reproduces torchvision's one-sided coordinate derivative).
 

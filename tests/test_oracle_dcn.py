@@ -78,3 +78,32 @@ def test_gradcheck_fp64():
     assert ((frac > 1e-3) & (frac < 1 - 1e-3)).all()
     assert torch.autograd.gradcheck(lambda *a: deform_conv2d_ref(a[0], a[1], a[2], a[3], a[4], 1, 1), (x, off, m, w, b),
                                     eps=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("stride,pad,with_mask", [(1, 1, True), (2, 1, True), (1, 0, False)])
+def test_matches_atens_grid_sampler_for_fractional_offsets(stride, pad, with_mask):
+    """A second, independent implementation of the sampling rule: torchvision's bilinear_interpolate (zero outside (-1, H) x (-1, W),
+    corners outside the image contribute 0) is F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True) at the pixel
+    coordinates (ho*stride - pad + ki + dy, wo*stride - pad + kj + dx) -- ATen's grid sampler shares no code with oracle/dcn_ref.py.
+    Offsets up to +-3 px, so that samples cross the border and leave the image; offset channel order (dy, dx) per tap, taps row-major,
+    weight columns (c, ki, kj): torchvision.ops.deform_conv2d's layout."""
+    B, C, H, W, M = 2, 5, 11, 13, 7
+    x, w, b = rnd(B, C, H, W), rnd(M, C, 3, 3, seed=1), rnd(M, seed=2)
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    off = rnd(B, 18, Ho, Wo, seed=3) * 1.5
+    off[:, :, 0, 0] = 3.0                                             # far outside for the corner pixel
+    m = torch.sigmoid(rnd(B, 9, Ho, Wo, seed=4)) * 2 if with_mask else None
+    y = deform_conv2d_ref(x, off, m, w, b, stride, pad)
+    ho = torch.arange(Ho, dtype=torch.float64).view(1, Ho, 1) * stride - pad
+    wo = torch.arange(Wo, dtype=torch.float64).view(1, 1, Wo) * stride - pad
+    ref = b.view(1, M, 1, 1).expand(B, M, Ho, Wo).clone()
+    for t in range(9):
+        ki, kj = divmod(t, 3)
+        py = ho + ki + off[:, 2 * t]                                   # [B, Ho, Wo] pixel coordinates
+        px = wo + kj + off[:, 2 * t + 1]
+        grid = torch.stack([2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1], dim=-1)      # (x, y) in [-1, 1], align_corners=True
+        s = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True)      # [B, C, Ho, Wo]
+        if m is not None:
+            s = s * m[:, t:t + 1]
+        ref = ref + torch.einsum("mc,bchw->bmhw", w[:, :, ki, kj], s)
+    assert torch.allclose(y, ref, atol=1e-10), float((y - ref).abs().max())
