@@ -75,6 +75,10 @@ int prn_gemm_pipe(int M, int K, int B, int HW, int nz);
 /* Sets PRN_SPLIT_GEMM's value for this process (0 / 1 / 2 as above; < 0: query only) and returns the previous one.  Workspace sizes
  * (prn_conv2d_fwd_ws_bytes and the block-level *_ws_bytes) depend on it: query them again after a change. */
 int prn_split_gemm_mode(int mode);
+/* Piece format of the split kernel: 16 = two fp16 pieces per operand and three products, operands scaled by exact powers of two per weight row
+ * / activation column (default, PRN_SPLIT_KIND=f16); 0 = three bf16 pieces and six products, no scaling (PRN_SPLIT_KIND=bf16).  Any other value
+ * queries.  Returns the previous kind.  Workspace sizes do not depend on it. */
+int prn_split_gemm_kind(int kind);
 /* Mode 1 takes the split kernel for launches of at least this many 128 x 128 output tiles (PRN_SPLIT_MIN_TILES, default 2500; < 0: query
  * only); returns the previous value.  The threshold is a BOARD-level trade, see prn_gemm_split.hip: broad use of the bf16 pipe makes the
  * firmware lower the shader clock for everything else. */

@@ -42,6 +42,7 @@ SIGNATURES = {
     "prn_conv2d_kernel_kind": (c_int, [_DP]),
     "prn_gemm_pipe": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "prn_split_gemm_mode": (c_int, [c_int]),
+    "prn_split_gemm_kind": (c_int, [c_int]),
     "prn_split_gemm_min_tiles": (c_int, [c_int]),
     "prn_split_images_bytes": (c_i64, [c_int, c_int, c_int]),
     "prn_split_prepare_batched": (c_int, [P, c_int, c_i64, P]),

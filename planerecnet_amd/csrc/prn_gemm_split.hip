@@ -17,6 +17,7 @@
 // per element, under the MFMAs of the slice before) and feeds the pieces straight to the matrix pipe.  One barrier per slice.
 #include "prn_common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <map>
 #include <mutex>
 
@@ -190,6 +191,189 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// ---- the same idea on the fp16 pipe: TWO pieces and THREE products per multiply-add ---------------------------------------------------------
+// fp16 carries 11 significand bits, so two pieces hold 22 of fp32's 24 -- if the operand sits inside fp16's narrow exponent range.  Both
+// operands are therefore scaled by exact powers of two first: a weight row by 2^(14 - E_a[m]) (E_a = exponent of the row's largest element,
+// found by split16_rowmax_kernel), an activation column by 2^(14 - E_b[n]) where E_b is the RUNNING exponent of the column's largest element
+// so far -- when a later K slice raises it, the lane's accumulators are rescaled (exact) before the next MFMA; the epilogue undoes both
+// scalings.  Per element: h = fp16(x), l = fp16(x - h) (round to nearest: |x - h - l| <= 2^-23 |x|, unbiased; elements more than 2^17 below
+// their row's / column's maximum lose relative precision, at an absolute error of 2^-39 of that maximum); products l*h, h*l, h*h -- the
+// dropped l*l is <= 2^-22 of the product.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+constexpr int IMG16_U4 = 1024;    // uint4 per fp16 image: 2 pieces x 4 k-groups x 128 rows x 16 B = 16 KB
+
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+  f16x2_t hv, lv;
+  hv[0] = h0; hv[1] = h1; lv[0] = (_Float16)r0; lv[1] = (_Float16)r1;
+  h = __builtin_bit_cast(unsigned, hv); l = __builtin_bit_cast(unsigned, lv);
+}
+
+// ex[z * Mpad + m] = frexp exponent of max_k |w[z][m][k]| (0 for an all-zero or padding row): one wave per row
+__global__ __launch_bounds__(256) void split16_rowmax_kernel(const float* __restrict__ w, int* __restrict__ ex, int M, int K, long long zw, int Mpad, long long rows) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long z = row / Mpad; const int m = (int)(row - z * Mpad);
+  float mx = 0.f;
+  if (m < M) {
+    const float* wr = w + z * zw + (long long)m * K;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(wr[k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) ex[row] = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : 0;
+}
+
+__global__ void split16_prepare_kernel(const float* __restrict__ w, uint4* __restrict__ img, const int* __restrict__ ex, int M, int K, long long zw, int mtiles, int kslices,
+                                       long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per (z, m tile, k slice, k group, row)
+  if (i >= total) return;
+  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
+  const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
+  const int sh = 14 - ex[z * (mtiles * 128) + m];
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (m < M && k0 + j < K) ? ldexpf(w[z * zw + (long long)m * K + k0 + j], sh) : 0.f;
+  uint4 h, l;
+  split2_f16(v[0], v[1], h.x, l.x); split2_f16(v[2], v[3], h.y, l.y); split2_f16(v[4], v[5], h.z, l.z); split2_f16(v[6], v[7], h.w, l.w);
+  uint4* o = img + t * IMG16_U4;
+  o[g * 128 + r] = h; o[(4 + g) * 128 + r] = l;
+}
+
+struct Split16Args {
+  const uint4* img; const int* ex; const float* x; const float* bias; const float* addend; float* y; float* partial;
+  int M, K, B, HW, epi, mtiles, kslices, ptiles, total, splits;
+  long long zx, zy, slice;
+};
+
+template <int NP>      // 3: l*h, h*l, h*h   4: + l*l
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void split16_gemm_kernel(const Split16Args a) {
+  __shared__ uint4 lds[2 * IMG16_U4];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int id = prn_xcd_remap(blockIdx.x, a.total);
+  const int mt = id % a.mtiles; const int rest = id / a.mtiles;
+  const int pt = rest % a.ptiles; const int zb = rest / a.ptiles; const int b = zb % a.B, z = zb / a.B;
+  const int sp = blockIdx.y;
+  const int ks0 = (int)((long long)a.kslices * sp / a.splits), ks1 = (int)((long long)a.kslices * (sp + 1) / a.splits);
+  const int HW = a.HW, M = a.M;
+  const int r = lane & 31, gs = lane >> 5;
+  const int px = pt * 128 + wave * 32 + r;
+  const int pxc = px < HW ? px : HW - 1;
+  const float* xb = a.x + (long long)z * a.zx + (long long)b * a.K * HW;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.K * HW * 4, 0x00020000);
+  const int xoff = (pxc + gs * 8 * HW) * 4;
+  const uint4* ag = a.img + ((long long)(z * a.mtiles + mt) * a.kslices) * IMG16_U4;
+  const i32x4_t adesc = make_desc(ag, (unsigned)a.kslices * IMG16_U4 * 16u);
+  const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
+  float rn[16];
+  f16x8_t bp[2][2];
+  int erun = -1000, de = 0;        // running exponent of this column's largest element; pending rescale of the accumulators
+#define S16_DMA(ks_, st_) do { \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+      lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \
+  } while (0)
+#define S16_LOADB(ks_) do { \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) \
+        rn[s2 * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff + ((ks_) * BK + s2 * 16 + j) * HW * 4, 0, 0)); \
+  } while (0)
+#define S16_PIECES() do { \
+    float mx = 0.f; \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) mx = fmaxf(mx, fabsf(rn[j])); \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                       /* the two lanes of a column hold different k */ \
+    const int en = max(erun, mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : -200); \
+    de = erun - en; erun = en; \
+    const int sh = 14 - en; \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) { \
+      uint4 h, l; \
+      split2_f16(ldexpf(rn[s2 * 8 + 0], sh), ldexpf(rn[s2 * 8 + 1], sh), h.x, l.x); split2_f16(ldexpf(rn[s2 * 8 + 2], sh), ldexpf(rn[s2 * 8 + 3], sh), h.y, l.y); \
+      split2_f16(ldexpf(rn[s2 * 8 + 4], sh), ldexpf(rn[s2 * 8 + 5], sh), h.z, l.z); split2_f16(ldexpf(rn[s2 * 8 + 6], sh), ldexpf(rn[s2 * 8 + 7], sh), h.w, l.w); \
+      bp[s2][0] = __builtin_bit_cast(f16x8_t, h); bp[s2][1] = __builtin_bit_cast(f16x8_t, l); \
+    } } while (0)
+#define S16_STEP(s2_) do { \
+    const int kg = 2 * (s2_) + gs; \
+    const f16x8_t bh = bp[s2_][0], bl = bp[s2_][1]; \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+      const uint4* ap = lds + st * IMG16_U4 + kg * 128 + i * 32 + r; \
+      const f16x8_t ah = __builtin_bit_cast(f16x8_t, ap[0]), al = __builtin_bit_cast(f16x8_t, ap[512]); \
+      f32x16_t c = acc[i]; \
+      if (NP >= 4) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, c, 0, 0, 0); \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0); \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0); \
+      acc[i] = c; \
+    } } while (0)
+  f32x16_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  S16_DMA(ks0, 0);
+  S16_LOADB(ks0);
+  S16_PIECES();
+  de = 0;                                                        // nothing accumulated yet
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int st = (ks - ks0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(de != 0) != 0ull) {          // a column's maximum grew: bring its partial sums to the new scale (exact)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = ldexpf(acc[i][e], de);
+    }
+    const bool more = ks + 1 < ks1;
+    const int kn = more ? ks + 1 : ks;
+    if (more) S16_DMA(ks + 1, st ^ 1);
+    S16_LOADB(kn);
+    __builtin_amdgcn_sched_barrier(0);
+    S16_STEP(0);
+    __builtin_amdgcn_sched_barrier(0);
+    S16_STEP(1);
+    if (more) S16_PIECES(); else de = 0;                        // (the last slice was loaded twice: its pieces are not needed again)
+  }
+#undef S16_DMA
+#undef S16_LOADB
+#undef S16_PIECES
+#undef S16_STEP
+  const bool cok = px < HW;
+  const int* exm = a.ex + (long long)z * a.mtiles * 128 + mt * 128;
+  if (a.splits > 1) {
+    float* pb = a.partial + (long long)sp * a.slice + ((long long)z * a.B + b) * (long long)M * HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = i * 32 + gs * 4 + (e >> 2) * 8 + (e & 3), row = mt * BM + rl;
+        if (cok && row < M) pb[(long long)row * HW + px] = ldexpf(acc[i][e], erun + exm[rl] - 28);
+      }
+    return;
+  }
+  float* yb = a.y + (long long)z * a.zy + (long long)b * M * HW;
+  const float* ab = a.addend ? a.addend + (long long)z * a.zy + (long long)b * M * HW : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl0 = i * 32 + gs * 4, rbase = mt * BM + rl0;
+    float bv[16], av[16]; int ev[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ro = (e >> 2) * 8 + (e & 3), row = rbase + ro; const int rc = row < M ? row : M - 1;
+      bv[e] = a.bias ? a.bias[rc] : 0.f; av[e] = ab ? ab[(long long)rc * HW + pxc] : 0.f; ev[e] = exm[rl0 + ro];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = rbase + (e >> 2) * 8 + (e & 3);
+      float v = ldexpf(acc[i][e], erun + ev[e] - 28) + bv[e] + av[e];
+      if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+      else if (a.epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
+      if (cok && row < M) yb[(long long)row * HW + px] = v;
+    }
+  }
+}
+
 // one launch for many weights: item i covers blocks [first_i, first_{i+1}) of 256 threads = 256 (z, m tile, k slice, k group, row) tuples
 struct PrepItem { const float* src; uint4* dst; int M, K, nz, pad; long long zw; long long first; };
 __global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items, int n) {
@@ -235,6 +419,17 @@ int g_min_tiles = -1;
 int min_tiles() {
   if (g_min_tiles < 0) { const char* e = getenv("PRN_SPLIT_MIN_TILES"); g_min_tiles = e ? atoi(e) : 2500; }
   return g_min_tiles;
+}
+// PRN_SPLIT_KIND: "f16" (default) = fp16 pieces, two per operand, three products, operands scaled into fp16's range by exact powers of two;
+// "bf16" = bf16 pieces, three per operand, six products, no scaling needed (bf16 has fp32's exponent range).  Same error on the network's
+// tensors (both at the fp32 MFMA's level); the bf16 form keeps it for ANY operands, the fp16 form loses relative precision on elements more
+// than 2^17 below their row's / column's largest (max error 1e-5 instead of 1e-6 of sum|a||b| on log-normal operands spanning 12 decades).
+// Half the matrix-pipe work buys little per launch (the kernel is bound by its L2 stream, not by the pipe: 48 vs 49 us on 256->1024
+// @30x40) but the firmware takes less clock for it: the 960-pixel inference workload 236 (f16) / 228 (bf16) / 221 (fp32 only) img/s.
+int g_kind = -1;
+int kind() {
+  if (g_kind < 0) { const char* e = getenv("PRN_SPLIT_KIND"); g_kind = (e && !strcmp(e, "bf16")) ? 0 : 16; }
+  return g_kind;
 }
 int g_mode = -1;       // PRN_SPLIT_GEMM: 0 = off (fp32 MFMA everywhere), 1 = where the plan says so (default), 2 = wherever the kernel applies
 int mode() {
@@ -290,6 +485,11 @@ extern "C" int prn_split_gemm_min_tiles(int n) {
   if (n >= 0) g_min_tiles = n;
   return old;
 }
+extern "C" int prn_split_gemm_kind(int k) {
+  const int old = kind();
+  if (k == 0 || k == 16) g_kind = k;
+  return old;
+}
 extern "C" int prn_split_gemm_mode(int m) {
   const int old = mode();
   if (m >= 0) g_mode = m;
@@ -299,7 +499,8 @@ extern "C" int prn_gemm_pipe(int M, int K, int B, int HW, int nz) {
   if (M <= 0 || K <= 0 || B <= 0 || HW <= 0 || nz <= 0) return 0;
   return prn_split_gemm_plan(M, K, B, HW, nz);
 }
-int64_t prn_split_gemm_image_bytes(int M, int K, int nz) { return (int64_t)nz * cdiv(M, 128) * cdiv(K, 32) * IMG_U4 * 16; }
+// (the larger of the two kinds' images, plus the fp16 kind's row exponents behind them)
+int64_t prn_split_gemm_image_bytes(int M, int K, int nz) { return (int64_t)nz * cdiv(M, 128) * cdiv(K, 32) * IMG_U4 * 16 + (int64_t)nz * cdiv(M, 128) * 128 * 4; }
 int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits) { return splits > 1 ? (int64_t)splits * nz * B * M * HW * 4 : 0; }
 
 // images: prn_split_gemm_image_bytes; partial: prn_split_gemm_partial_bytes (splits > 1).  zw / zx / zy: element strides per z.
@@ -311,6 +512,29 @@ int prn_split_gemm(const float* w, const float* x, const float* bias, const floa
   const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32), ptiles = cdiv(HW, 128);
   PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)K * HW < (1LL << 29), "prn_split_gemm: operand larger than a buffer descriptor");
   const long long ptotal = (long long)nz * mtiles * kslices * 512;
+  if (kind() == 16) {
+    if (phase != 2) {
+      int* ex = (int*)((char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
+      const long long rows = (long long)nz * mtiles * 128;
+      hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, (long long)zw, mtiles * 128, rows);
+      hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, (long long)zw, mtiles, kslices, ptotal);
+      PRN_CHECK_LAUNCH("prn_split_gemm/prepare16");
+      Split16Args a;
+      a.img = (const uint4*)images; a.ex = ex; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
+      a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
+      a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
+      static int np = -1;
+      if (np < 0) { const char* e = getenv("PRN_SPLIT16_PRODUCTS"); np = e ? atoi(e) : 3; }
+      if (np >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(split16_gemm_kernel<3>, dim3(a.total, splits), dim3(256), 0, st, a);
+      PRN_CHECK_LAUNCH("prn_split_gemm/f16");
+    }
+    if (splits > 1 && phase != 1) {
+      PRN_REQUIRE(nz == 1 || (zy == (int64_t)B * M * HW), "prn_split_gemm: K splits need a dense output");
+      return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)nz * B * M * HW, M, HW, splits, epi, st);
+    }
+    return 0;
+  }
   if (phase != 2) {
   if (const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz) : nullptr) {
     images = const_cast<void*>(reg);                               // split by the caller since the weight last changed

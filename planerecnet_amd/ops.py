@@ -447,7 +447,7 @@ def _prep_items(entries, dev):
 def split_images(t, M, K, nz):
     """Call in front of a launch that takes the split kernel with weight operand t [nz, M, K] (dense): makes sure the library holds
     current images of t when t persists (a parameter / a view of one / a stamped derived buffer); otherwise the launch cuts t itself."""
-    if not SPLIT_CACHE:
+    if not SPLIT_CACHE or lib.prn_split_gemm_kind(-1) != 0:       # (kept images exist for the bf16 piece format only)
         return
     ptr = t.data_ptr()
     e = _SPLIT_IMG.get(ptr)

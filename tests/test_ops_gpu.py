@@ -892,6 +892,15 @@ def _gemm_errors(y, w, x, bias, add, epi):
     return float(e.abs().max()), float(e.pow(2).mean().sqrt())
 
 
+@pytest.fixture(params=["f16", "bf16"])
+def split_kind(request):
+    """Both piece formats of csrc/prn_gemm_split.hip: two fp16 pieces / three products (default) and three bf16 pieces / six products."""
+    from planerecnet_amd import ops
+    old = ops.lib.prn_split_gemm_kind(16 if request.param == "f16" else 0)
+    yield request.param
+    ops.lib.prn_split_gemm_kind(old)
+
+
 @pytest.mark.parametrize("M,K,B,HW,bias,add,epi", [
     (1024, 256, 2, 1200, False, False, 0),      # stage-3 expand
     (256, 1024, 2, 1200, True, True, 1),        # stage-3 reduce: K split (few tiles), bias + residual + ReLU through the reduce kernel
@@ -900,8 +909,9 @@ def _gemm_errors(y, w, x, bias, add, epi):
     (512, 2048, 8, 300, False, False, 0),       # stage-4 reduce: 4 K splits
     (64, 256, 1, 19200, True, False, 0),        # half-empty row tile
 ])
-def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywhere):
-    """csrc/prn_gemm_split.hip (three exact bf16 pieces per operand, six bf16 MFMA products, fp32 accumulate) against fp64, next to the
+def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywhere, split_kind):
+    """csrc/prn_gemm_split.hip (two fp16 pieces per operand scaled into range by exact powers of two, three fp16 MFMA products -- or three exact
+    bf16 pieces, six bf16 MFMA products --, fp32 accumulate) against fp64, next to the
     fp32 MFMA kernel on the same operands: its error is fp32 ROUNDING error -- at every element below 4e-7 of sum|w||x| (or twice the
     fp32 kernel's maximum on that shape; that kernel's own maximum is 1e-7 .. 3.7e-7 depending on its K split), rms below 2.5e-8 (or
     1.5x the fp32 kernel's 1.2e-8 .. 2.2e-8) -- four orders of magnitude from a bf16 or TF32 product's 1e-3."""
@@ -929,7 +939,7 @@ def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywher
     assert smax <= max(2.0 * fmax, 4e-7) and srms <= max(1.5 * frms, 2.5e-8), (out,)
 
 
-def test_split_gemm_batched_and_special_values(split_everywhere):
+def test_split_gemm_batched_and_special_values(split_everywhere, split_kind):
     """prn_gemm_batched on the split kernel (the Winograd products: z = 36 independent GEMMs), and operand values the split must
     survive: exact zeros, powers of two, denormal-range and large magnitudes, negative numbers (pieces carry the operand's sign)."""
     ops = split_everywhere
@@ -950,12 +960,40 @@ def test_split_gemm_batched_and_special_values(split_everywhere):
     assert bool(torch.isfinite(Y).all()) and float(e) <= 6e-7, float(e)
 
 
+def test_split_gemm_on_operands_spanning_twelve_decades(split_everywhere, split_kind):
+    """Where the two piece formats differ: log-normal operands whose rows / columns AND elements within them span ~12 decades.  The bf16
+    pieces cover fp32's exponent range element by element and stay at the fp32 kernel's error; the fp16 pieces are scaled per weight row /
+    activation column, so elements more than 2^17 below their row's / column's largest lose relative precision: the rms error is unchanged,
+    the maximum (at outputs whose sum|a||b| is carried by such elements) grows to ~1e-5 of sum|a||b| -- still ten times below ONE bf16 product."""
+    ops = split_everywhere
+    lib, _p, _stream, check = ops.lib, ops._p, ops._stream, ops.check
+    M, K, B, HW = 1024, 256, 2, 1200
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, K, HW, generator=g) * torch.exp(torch.randn(B, K, HW, generator=g) * 3) * torch.exp(torch.randn(B, 1, HW, generator=g) * 6)).cuda()
+    w = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 3) * torch.exp(torch.randn(M, 1, generator=g) * 6)).cuda()
+    out = {}
+    for mode in (2, 0):
+        lib.prn_split_gemm_mode(mode)
+        ops._DESC.clear(); ops._PIPE.clear()
+        _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
+        ws = torch.empty(max(nbytes, 16) // 4, device="cuda")
+        y = torch.empty(B, M, HW, device="cuda")
+        check(lib.prn_conv2d_fwd(ref, _p(x), _p(w), None, None, _p(y), _p(ws), _stream()), "conv")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y).all())
+        out[mode] = _gemm_errors(y, w, x, None, None, 0)
+    (smax, srms), (fmax, frms) = out[2], out[0]
+    assert srms <= 1.5 * frms, out
+    assert smax <= (5e-5 if split_kind == "f16" else 3.0 * fmax), out
+
+
 def test_split_gemm_weight_images_follow_the_weight(split_everywhere, monkeypatch):
     """ops.split_images: a parameter's images are cut once, reused while its version counter stands still, re-cut after an in-place
     update (by the launch itself when nobody called split_refresh_all, by ONE batched launch when the model does), and dropped with
     the parameter; a temporary weight tensor is cut inside its launch and never cached."""
     ops = split_everywhere
     monkeypatch.setattr(ops, "SPLIT_CACHE", True)
+    old_kind = ops.lib.prn_split_gemm_kind(0)                    # kept images exist for the bf16 piece format
     M, C, B, H, W = 256, 128, 2, 24, 32
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, C, H, W, generator=g).cuda()
@@ -990,3 +1028,4 @@ def test_split_gemm_weight_images_follow_the_weight(split_everywhere, monkeypatc
     import gc
     gc.collect()
     assert ptr not in ops._SPLIT_IMG
+    ops.lib.prn_split_gemm_kind(old_kind)
