@@ -91,6 +91,7 @@ int prn_split_gemm_min_tiles(int n);
  * is exactly `w` (same M, K, nz, dense z stride) read `images` instead of cutting w again -- the caller re-runs the prepare whenever w's
  * contents change; images == NULL removes the entry.  (planerecnet_amd.ops.SplitImages: one prepare launch per training step.) */
 int64_t prn_split_images_bytes(int M, int K, int nz);
+int prn_split_prepare(const float* w, void* images, int M, int K, int nz, void* stream);   /* one weight, current piece format */
 int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, void* stream);
 int prn_split_images_register(const float* w, const void* images, int M, int K, int nz);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,

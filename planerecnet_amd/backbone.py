@@ -28,7 +28,10 @@ def folded_bn(conv_w, conv_b, m):
             scale = m.weight * torch.rsqrt(m.running_var + m.eps)
             w = (conv_w * scale.view(-1, 1, 1, 1)).contiguous()
             b = m.bias - m.running_mean * scale if conv_b is None else (conv_b - m.running_mean) * scale + m.bias
+        if c is not None:
+            ops._split_drop(c[1].data_ptr())                   # (kept split-GEMM images of the weights this replaces)
         c = m.__dict__["_prn_folded"] = (key, w, b.contiguous())
+        ops._stamp(w)                                          # a derived operand that persists: its cut images may be kept (ops.split_images)
     return c[1], c[2]
 
 

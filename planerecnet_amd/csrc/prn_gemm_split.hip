@@ -398,13 +398,13 @@ __global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items,
 }
 
 // weight pointer -> images the caller keeps current (prn_split_images_register): launches on such a weight skip the per-call split
-struct RegEntry { const void* images; int M, K, nz; };
+struct RegEntry { const void* images; int M, K, nz, kind; };
 std::map<const void*, RegEntry> g_registry;
 std::mutex g_registry_mu;
-const void* registered_images(const float* w, int M, int K, int nz) {
+const void* registered_images(const float* w, int M, int K, int nz, int knd) {
   std::lock_guard<std::mutex> lock(g_registry_mu);
   auto it = g_registry.find((const void*)w);
-  if (it == g_registry.end() || it->second.M != M || it->second.K != K || it->second.nz != nz) return nullptr;
+  if (it == g_registry.end() || it->second.M != M || it->second.K != K || it->second.nz != nz || it->second.kind != knd) return nullptr;
   return it->second.images;
 }
 
@@ -472,12 +472,29 @@ extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int
   PRN_CHECK_LAUNCH("prn_split_prepare_batched");
   return 0;
 }
+// cuts ONE dense weight [nz][M][K] into images of the current piece format (prn_split_images_bytes bytes)
+extern "C" int prn_split_prepare(const float* w, void* images, int M, int K, int nz, void* stream) {
+  PRN_REQUIRE(w && images && M > 0 && K > 0 && nz > 0 && (reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_prepare: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32);
+  const long long ptotal = (long long)nz * mtiles * kslices * 512, zw = (long long)M * K;
+  if (kind() == 16) {
+    int* ex = (int*)((char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
+    const long long rows = (long long)nz * mtiles * 128;
+    hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, zw, mtiles * 128, rows);
+    hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, zw, mtiles, kslices, ptotal);
+  } else {
+    hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, zw, mtiles, kslices, ptotal);
+  }
+  PRN_CHECK_LAUNCH("prn_split_prepare");
+  return 0;
+}
 extern "C" int prn_split_images_register(const float* w, const void* images, int M, int K, int nz) {
   PRN_REQUIRE(w != nullptr, "prn_split_images_register: null weight");
   std::lock_guard<std::mutex> lock(g_registry_mu);
   if (images == nullptr) { g_registry.erase((const void*)w); return 0; }
   PRN_REQUIRE(M > 0 && K > 0 && nz > 0 && (reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_images_register: bad arguments");
-  g_registry[(const void*)w] = RegEntry{images, M, K, nz};
+  g_registry[(const void*)w] = RegEntry{images, M, K, nz, kind()};
   return 0;
 }
 extern "C" int prn_split_gemm_min_tiles(int n) {
@@ -514,11 +531,16 @@ int prn_split_gemm(const float* w, const float* x, const float* bias, const floa
   const long long ptotal = (long long)nz * mtiles * kslices * 512;
   if (kind() == 16) {
     if (phase != 2) {
+      const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz, 16) : nullptr;
+      if (reg) images = const_cast<void*>(reg);                    // cut by the caller since the weight last changed
+      PRN_REQUIRE(images != nullptr, "prn_split_gemm: no workspace for the weight images");
       int* ex = (int*)((char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
-      const long long rows = (long long)nz * mtiles * 128;
-      hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, (long long)zw, mtiles * 128, rows);
-      hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, (long long)zw, mtiles, kslices, ptotal);
-      PRN_CHECK_LAUNCH("prn_split_gemm/prepare16");
+      if (!reg) {
+        const long long rows = (long long)nz * mtiles * 128;
+        hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, (long long)zw, mtiles * 128, rows);
+        hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, (long long)zw, mtiles, kslices, ptotal);
+        PRN_CHECK_LAUNCH("prn_split_gemm/prepare16");
+      }
       Split16Args a;
       a.img = (const uint4*)images; a.ex = ex; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
       a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
@@ -536,7 +558,7 @@ int prn_split_gemm(const float* w, const float* x, const float* bias, const floa
     return 0;
   }
   if (phase != 2) {
-  if (const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz) : nullptr) {
+  if (const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz, 0) : nullptr) {
     images = const_cast<void*>(reg);                               // split by the caller since the weight last changed
   } else {
     hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, (long long)zw, mtiles, kslices, ptotal);

@@ -338,7 +338,13 @@ def _gemm_family(M, K, B, HW, nz, flops):
 # images cut at the start of the step (48.5 vs 51.5 ms per step, same box; fp32 kernel: 50.4) -- the cut leaves the 0.2 .. 14 MB of
 # images in L2 / Infinity Cache right in front of the GEMM whose 80 .. 600 workgroups each stream them, whereas images written 20 ms
 # earlier come from HBM; at inference (static weights, nothing to re-cut) the cache is a small gain on the high-resolution workload.
-SPLIT_CACHE = bool(int(os.environ.get("PRN_SPLIT_CACHE", "0")))
+# "eval" (default): keep images only while autograd is off -- inference, where the weights (BatchNorm folded in, Winograd-transformed) do not
+# change and every launch saves its one or two cutting kernels; "1": always; "0": never.
+SPLIT_CACHE = os.environ.get("PRN_SPLIT_CACHE", "eval")
+# ... and only for launches of at least this many output tiles: below it the cutting kernels pay for themselves by leaving the images in L2 /
+# Infinity Cache in front of the GEMM that streams them (PlaneRecNet_50 B = 8 at 480x640: 580 img/s cutting per launch, 571 with kept images;
+# PlaneRecNet_101 B = 4 at 736x960: 246 against 253)
+SPLIT_CACHE_MIN_TILES = int(os.environ.get("PRN_SPLIT_CACHE_MIN_TILES", "2500"))
 _SPLIT_IMG = {}    # operand data_ptr -> _SplitEntry
 _STAMP = {}        # data_ptr of a derived persistent operand (flipped weight view, Winograd U / Ut) -> generation of its contents
 _SPLIT_ITEMS = [None, None, 0]     # [item table on the device, the entry set it was built for, total blocks]
@@ -438,25 +444,31 @@ def _prep_items(entries, dev):
     items = np.zeros(len(entries), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("M", "i4"), ("K", "i4"), ("nz", "i4"), ("pad", "i4"), ("zw", "i8"), ("first", "i8")]))
     blocks = 0
     for i, e in enumerate(entries):
-        M, K, nz = e.dims
+        M, K, nz, _ = e.dims
         items[i] = (e.ptr, e.images.data_ptr(), M, K, nz, 0, M * K, blocks)
         blocks += (nz * ((M + 127) // 128) * ((K + 31) // 32) * 512 + 255) // 256
     return torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev), blocks
 
 
-def split_images(t, M, K, nz):
+def split_images(t, M, K, nz, cols=None):
     """Call in front of a launch that takes the split kernel with weight operand t [nz, M, K] (dense): makes sure the library holds
-    current images of t when t persists (a parameter / a view of one / a stamped derived buffer); otherwise the launch cuts t itself."""
-    if not SPLIT_CACHE or lib.prn_split_gemm_kind(-1) != 0:       # (kept images exist for the bf16 piece format only)
+    current images of t when t persists (a parameter / a view of one / a stamped derived buffer); otherwise the launch cuts t itself.
+    cols = (B, HW) of the activation side: small launches keep cutting per launch (SPLIT_CACHE_MIN_TILES)."""
+    if SPLIT_CACHE in ("0", False) or (SPLIT_CACHE == "eval" and torch.is_grad_enabled()):
         return
+    if cols is not None and ((M + 127) // 128) * ((cols[1] + 127) // 128) * cols[0] * nz < SPLIT_CACHE_MIN_TILES:
+        if t.data_ptr() in _SPLIT_IMG:
+            _split_drop(t.data_ptr(), stamp=False)               # (the same weight seen earlier with a larger batch)
+        return
+    kind = lib.prn_split_gemm_kind(-1)
     ptr = t.data_ptr()
     e = _SPLIT_IMG.get(ptr)
     if e is not None:
         cur = _split_state(e)
-        if cur is not None and cur == e.stamp and e.dims == (M, K, nz):
+        if cur is not None and cur == e.stamp and e.dims == (M, K, nz, kind):
             SPLIT_STATS["hits"] += 1
             return                                              # registered and current
-        if cur is None or e.dims != (M, K, nz):                 # owner gone (address reused) or another view of the storage: start over
+        if cur is None or e.dims != (M, K, nz, kind):           # owner gone (address reused), another view of the storage, other piece format
             _split_drop(ptr, stamp=False)
             e = None
     if e is None:
@@ -469,7 +481,7 @@ def split_images(t, M, K, nz):
         e = _SplitEntry()
         e.owner = weakref.ref(owner) if owner is not None else None
         e.tensor = None if owner is not None else t              # derived buffers are kept alive by the entry (no address reuse)
-        e.ptr, e.dims = ptr, (M, K, nz)
+        e.ptr, e.dims = ptr, (M, K, nz, kind)
         nb = lib.prn_split_images_bytes(M, K, nz)
         e.images = torch.empty(nb, device=t.device, dtype=torch.uint8)
         _SPLIT_IMG[ptr] = e
@@ -477,8 +489,7 @@ def split_images(t, M, K, nz):
         if owner is not None:
             weakref.finalize(owner, lambda p=ptr, r=e: _split_drop(p) if _SPLIT_IMG.get(p) is r else None)
         check(lib.prn_split_images_register(ctypes.c_void_p(ptr), _p(e.images), M, K, nz), "prn_split_images_register")
-    items, blocks = _prep_items([e], t.device)
-    check(lib.prn_split_prepare_batched(_p(items), 1, blocks, _stream()), "prn_split_prepare_batched")
+    check(lib.prn_split_prepare(ctypes.c_void_p(ptr), _p(e.images), M, K, nz, _stream()), "prn_split_prepare")
     e.stamp = _split_state(e)
     SPLIT_STATS["cuts"] += 1
     if os.environ.get("PRN_SPLIT_DEBUG"):
@@ -488,12 +499,20 @@ def split_images(t, M, K, nz):
 def split_refresh_all():
     """Re-cut every cached operand with ONE launch (a model calls this once per training step, after the optimizer changed the weights
     and after the flipped / transform-domain layouts were refreshed)."""
+    if SPLIT_CACHE == "eval" or SPLIT_CACHE in ("0", False):     # (inference-only images are validated launch by launch, never refreshed)
+        return
     dead = [p for p, e in _SPLIT_IMG.items() if _split_state(e) is None]
     for p in dead:
         _split_drop(p)
     if not _SPLIT_IMG:
         return
     entries = list(_SPLIT_IMG.values())
+    if any(e.dims[3] != 0 for e in entries):                    # the batched cut exists for the bf16 pieces; others one by one
+        for e in entries:
+            check(lib.prn_split_prepare(ctypes.c_void_p(e.ptr), _p(e.images), e.dims[0], e.dims[1], e.dims[2], _stream()), "prn_split_prepare")
+            e.stamp = _split_state(e)
+        SPLIT_STATS["refreshes"] += 1
+        return
     if _SPLIT_ITEMS[0] is None or _SPLIT_ITEMS[1] != [id(e) for e in entries]:
         items, blocks = _prep_items(entries, entries[0].images.device)
         _SPLIT_ITEMS[0], _SPLIT_ITEMS[1], _SPLIT_ITEMS[2] = items, [id(e) for e in entries], blocks
@@ -511,7 +530,7 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
         d_, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
         if d_.kind >= 2:
-            split_images(w2d, M, C, 1)
+            split_images(w2d, M, C, 1, (B, Ho * Wo))
     else:
         y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
         _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
@@ -769,7 +788,7 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
     ws = torch.empty(36 * (C + M) * P, device=x.device, dtype=torch.float32)
     if gemm_pipe(M, C, 1, P, 36) >= 1:
-        split_images(U, M, C, 36)
+        split_images(U, M, C, 36, (1, P))
     if profiling._enabled:
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
@@ -1098,7 +1117,7 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
     wt = flip_transpose(w.view(M, C * 9, 1, 1))                   # [9C, M, 1, 1]
     ws = _f32(db, x.device)
     if gemm_pipe(9 * C, M, B, d.Ho * d.Wo, 1) >= 1:
-        split_images(wt, 9 * C, M, 1)                            # the column-gradient GEMM's weight operand
+        split_images(wt, 9 * C, M, 1, (B, d.Ho * d.Wo))          # the column-gradient GEMM's weight operand
     dx = torch.empty_like(x) if need_x else None
     ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
     if profiling._enabled:

@@ -987,13 +987,13 @@ def test_split_gemm_on_operands_spanning_twelve_decades(split_everywhere, split_
     assert smax <= (5e-5 if split_kind == "f16" else 3.0 * fmax), out
 
 
-def test_split_gemm_weight_images_follow_the_weight(split_everywhere, monkeypatch):
+def test_split_gemm_weight_images_follow_the_weight(split_everywhere, split_kind, monkeypatch):
     """ops.split_images: a parameter's images are cut once, reused while its version counter stands still, re-cut after an in-place
     update (by the launch itself when nobody called split_refresh_all, by ONE batched launch when the model does), and dropped with
     the parameter; a temporary weight tensor is cut inside its launch and never cached."""
     ops = split_everywhere
-    monkeypatch.setattr(ops, "SPLIT_CACHE", True)
-    old_kind = ops.lib.prn_split_gemm_kind(0)                    # kept images exist for the bf16 piece format
+    monkeypatch.setattr(ops, "SPLIT_CACHE", "1")
+    monkeypatch.setattr(ops, "SPLIT_CACHE_MIN_TILES", 0)
     M, C, B, H, W = 256, 128, 2, 24, 32
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, C, H, W, generator=g).cuda()
@@ -1028,4 +1028,3 @@ def test_split_gemm_weight_images_follow_the_weight(split_everywhere, monkeypatc
     import gc
     gc.collect()
     assert ptr not in ops._SPLIT_IMG
-    ops.lib.prn_split_gemm_kind(old_kind)
