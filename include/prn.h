@@ -85,14 +85,15 @@ int prn_split_gemm_kind(int kind);
 int prn_split_gemm_min_tiles(int n);
 /* The weight side of the split kernel ("images": [z][m tile of 128][k slice of 32][piece][k group][row][8 x bf16], zero padded) is cut
  * inside every launch unless the caller keeps it: prn_split_images_bytes = size of the images of w[nz][M][K]; prn_split_prepare_batched =
- * ONE launch that cuts many weights (items_dev: device array of {const float* src; void* dst; int32 M, K, nz, pad; int64 z stride of src
- * in elements; int64 first} -- `first` = the item's first 256-thread block, an item has ceil(nz * ceil(M/128) * ceil(K/32) * 512 / 256)
+ * ONE launch (two for the fp16 pieces) that cuts many DENSE weights (items_dev: device array of {const float* src; void* dst; int32 M, K, nz, pad;
+ * int64 first_row_block -- the item's first block of FOUR rows of nz * ceil(M/128)*128 rows, total_row_blocks = their sum (fp16 pieces' row
+ * exponents); int64 first} -- `first` = the item's first 256-thread block, an item has ceil(nz * ceil(M/128) * ceil(K/32) * 512 / 256)
  * blocks, total_blocks = their sum); prn_split_images_register(w, images, M, K, nz) tells the library that launches whose weight operand
  * is exactly `w` (same M, K, nz, dense z stride) read `images` instead of cutting w again -- the caller re-runs the prepare whenever w's
  * contents change; images == NULL removes the entry.  (planerecnet_amd.ops.SplitImages: one prepare launch per training step.) */
 int64_t prn_split_images_bytes(int M, int K, int nz);
 int prn_split_prepare(const float* w, void* images, int M, int K, int nz, void* stream);   /* one weight, current piece format */
-int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, void* stream);
+int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, int64_t total_row_blocks, void* stream);
 int prn_split_images_register(const float* w, const void* images, int M, int K, int nz);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);

@@ -46,7 +46,7 @@ SIGNATURES = {
     "prn_split_gemm_min_tiles": (c_int, [c_int]),
     "prn_split_images_bytes": (c_i64, [c_int, c_int, c_int]),
     "prn_split_prepare": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "prn_split_prepare_batched": (c_int, [P, c_int, c_i64, P]),
+    "prn_split_prepare_batched": (c_int, [P, c_int, c_i64, c_i64, P]),
     "prn_split_images_register": (c_int, [P, P, c_int, c_int, c_int]),
     "prn_conv2d_fwd": (c_int, [_DP, P, P, P, P, P, P, P]),
     "prn_conv2d_fwd_ragged": (c_int, [_DP, P, P, P, P, P, P, P]),

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // one launch for many weights: item i covers blocks [first_i, first_{i+1}) of 256 threads = 256 (z, m tile, k slice, k group, row) tuples
-struct PrepItem { const float* src; uint4* dst; int M, K, nz, pad; long long zw; long long first; };
+struct PrepItem { const float* src; uint4* dst; int M, K, nz, pad; long long zw; long long first; };   // zw: first block of four rows (fp16 row pass); weights are dense
 __global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items, int n) {
   int lo = 0, hi = n - 1;
   const long long blk = blockIdx.x;
@@ -390,11 +390,57 @@ __global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items,
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (m < it.M && k0 + j < it.K) ? it.src[z * it.zw + (long long)m * it.K + k0 + j] : 0.f;
+  for (int j = 0; j < 8; ++j) v[j] = (m < it.M && k0 + j < it.K) ? it.src[z * (long long)it.M * it.K + (long long)m * it.K + k0 + j] : 0.f;
   uint4 h, mm, l;
   split2(v[0], v[1], h.x, mm.x, l.x); split2(v[2], v[3], h.y, mm.y, l.y); split2(v[4], v[5], h.z, mm.z, l.z); split2(v[6], v[7], h.w, mm.w, l.w);
   uint4* o = it.dst + t * IMG_U4;
   o[(0 * 4 + g) * 128 + r] = h; o[(1 * 4 + g) * 128 + r] = mm; o[(2 * 4 + g) * 128 + r] = l;
+}
+
+// the fp16 piece format of the same batch: row exponents first (one wave per row of every item), then the images
+__device__ __forceinline__ PrepItem find_item(const PrepItem* items, int n, long long blk, bool rows) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((rows ? items[mid].zw : items[mid].first) <= blk) lo = mid; else hi = mid - 1; }
+  return items[lo];
+}
+// (rows pass: the item's `zw` field holds its first block of FOUR rows -- a second table, see prn_split_prepare_batched)
+__global__ __launch_bounds__(256) void split16_rowmax_batched_kernel(const PrepItem* __restrict__ items, int n) {
+  const PrepItem it = find_item(items, n, blockIdx.x, true);
+  const int mtiles = (it.M + 127) / 128, Mpad = mtiles * 128;
+  const long long rows = (long long)it.nz * Mpad;
+  const long long row = ((long long)blockIdx.x - it.zw) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int kslices = (it.K + 31) / 32;
+  int* ex = (int*)((char*)it.dst + (long long)it.nz * mtiles * kslices * IMG16_U4 * 16);
+  const int lane = threadIdx.x & 63;
+  const long long z = row / Mpad; const int m = (int)(row - z * Mpad);
+  float mx = 0.f;
+  if (m < it.M) {
+    const float* wr = it.src + z * (long long)it.M * it.K + (long long)m * it.K;
+    for (int k = lane; k < it.K; k += 64) mx = fmaxf(mx, fabsf(wr[k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) ex[row] = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : 0;
+}
+__global__ void split16_prepare_batched_kernel(const PrepItem* __restrict__ items, int n) {
+  const PrepItem it = find_item(items, n, blockIdx.x, false);
+  const int mtiles = (it.M + 127) / 128, kslices = (it.K + 31) / 32;
+  const long long total = (long long)it.nz * mtiles * kslices * 512;
+  const long long i = ((long long)blockIdx.x - it.first) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int* ex = (const int*)((const char*)it.dst + (long long)it.nz * mtiles * kslices * IMG16_U4 * 16);
+  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
+  const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
+  const int sh = 14 - ex[z * (mtiles * 128) + m];
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (m < it.M && k0 + j < it.K) ? ldexpf(it.src[z * (long long)it.M * it.K + (long long)m * it.K + k0 + j], sh) : 0.f;
+  uint4 h, l;
+  split2_f16(v[0], v[1], h.x, l.x); split2_f16(v[2], v[3], h.y, l.y); split2_f16(v[4], v[5], h.z, l.z); split2_f16(v[6], v[7], h.w, l.w);
+  uint4* o = it.dst + t * IMG16_U4;
+  o[g * 128 + r] = h; o[(4 + g) * 128 + r] = l;
 }
 
 // weight pointer -> images the caller keeps current (prn_split_images_register): launches on such a weight skip the per-call split
@@ -466,8 +512,15 @@ extern "C" int64_t prn_split_images_bytes(int M, int K, int nz) {
   if (M <= 0 || K <= 0 || nz <= 0) return -1;
   return prn_split_gemm_image_bytes(M, K, nz);
 }
-extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, void* stream) {
+extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, int64_t total_row_blocks, void* stream) {
   PRN_REQUIRE(items_dev && n_items > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "prn_split_prepare_batched: bad arguments");
+  if (kind() == 16) {
+    PRN_REQUIRE(total_row_blocks > 0 && total_row_blocks < (1LL << 31), "prn_split_prepare_batched: the fp16 piece format needs the row-block count");
+    hipLaunchKernelGGL(split16_rowmax_batched_kernel, dim3((unsigned)total_row_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n_items);
+    hipLaunchKernelGGL(split16_prepare_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n_items);
+    PRN_CHECK_LAUNCH("prn_split_prepare_batched/f16");
+    return 0;
+  }
   hipLaunchKernelGGL(split_prepare_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n_items);
   PRN_CHECK_LAUNCH("prn_split_prepare_batched");
   return 0;

@@ -338,9 +338,11 @@ def _gemm_family(M, K, B, HW, nz, flops):
 # images cut at the start of the step (48.5 vs 51.5 ms per step, same box; fp32 kernel: 50.4) -- the cut leaves the 0.2 .. 14 MB of
 # images in L2 / Infinity Cache right in front of the GEMM whose 80 .. 600 workgroups each stream them, whereas images written 20 ms
 # earlier come from HBM; at inference (static weights, nothing to re-cut) the cache is a small gain on the high-resolution workload.
-# "eval" (default): keep images only while autograd is off -- inference, where the weights (BatchNorm folded in, Winograd-transformed) do not
-# change and every launch saves its one or two cutting kernels; "1": always; "0": never.
-SPLIT_CACHE = os.environ.get("PRN_SPLIT_CACHE", "eval")
+# "auto" (default): while training every operand's images are kept and re-cut by ONE batched pass per step (two launches) -- the launches then
+# run without their two cutting kernels, i.e. without two dependent-launch gaps each (~6 us of a 45 us launch: 50.5 -> 49.3 ms per step with the
+# fp16 pieces; that the first measurement of this cache, with the bf16 pieces, read slower was a comparison across boxes); at inference images
+# are kept for the large launches only (SPLIT_CACHE_MIN_TILES).  "1": always, every launch; "eval": only while autograd is off; "0": never.
+SPLIT_CACHE = os.environ.get("PRN_SPLIT_CACHE", "auto")
 # ... and only for launches of at least this many output tiles: below it the cutting kernels pay for themselves by leaving the images in L2 /
 # Infinity Cache in front of the GEMM that streams them (PlaneRecNet_50 B = 8 at 480x640: 580 img/s cutting per launch, 571 with kept images;
 # PlaneRecNet_101 B = 4 at 736x960: 246 against 253)
@@ -352,7 +354,7 @@ _PIPE = {}
 SPLIT_STATS = {"hits": 0, "cuts": 0, "uncached": 0, "refreshes": 0}     # launches on current images / single re-cuts / temporaries / batched refreshes
 
 
-_SPLIT_POLICY = {"train": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_TRAIN", "2500"))),
+_SPLIT_POLICY = {"train": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_TRAIN", "300"))),
                  "eval": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_EVAL", "300")))}
 
 
@@ -442,12 +444,13 @@ def _split_state(e):
 def _prep_items(entries, dev):
     import numpy as np
     items = np.zeros(len(entries), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("M", "i4"), ("K", "i4"), ("nz", "i4"), ("pad", "i4"), ("zw", "i8"), ("first", "i8")]))
-    blocks = 0
+    blocks = rblocks = 0
     for i, e in enumerate(entries):
         M, K, nz, _ = e.dims
-        items[i] = (e.ptr, e.images.data_ptr(), M, K, nz, 0, M * K, blocks)
+        items[i] = (e.ptr, e.images.data_ptr(), M, K, nz, 0, rblocks, blocks)      # ("zw" slot: first block of four rows, weights are dense)
         blocks += (nz * ((M + 127) // 128) * ((K + 31) // 32) * 512 + 255) // 256
-    return torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev), blocks
+        rblocks += (nz * ((M + 127) // 128) * 128 + 3) // 4
+    return torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev), blocks, rblocks
 
 
 def split_images(t, M, K, nz, cols=None):
@@ -456,7 +459,8 @@ def split_images(t, M, K, nz, cols=None):
     cols = (B, HW) of the activation side: small launches keep cutting per launch (SPLIT_CACHE_MIN_TILES)."""
     if SPLIT_CACHE in ("0", False) or (SPLIT_CACHE == "eval" and torch.is_grad_enabled()):
         return
-    if cols is not None and ((M + 127) // 128) * ((cols[1] + 127) // 128) * cols[0] * nz < SPLIT_CACHE_MIN_TILES:
+    floor = SPLIT_CACHE_MIN_TILES if (SPLIT_CACHE == "eval" or (SPLIT_CACHE == "auto" and not torch.is_grad_enabled())) else 0
+    if cols is not None and ((M + 127) // 128) * ((cols[1] + 127) // 128) * cols[0] * nz < floor:
         if t.data_ptr() in _SPLIT_IMG:
             _split_drop(t.data_ptr(), stamp=False)               # (the same weight seen earlier with a larger batch)
         return
@@ -506,17 +510,16 @@ def split_refresh_all():
         _split_drop(p)
     if not _SPLIT_IMG:
         return
+    kind = lib.prn_split_gemm_kind(-1)
+    for e in [e for e in _SPLIT_IMG.values() if e.dims[3] != kind]:          # images of the other piece format: start over at their next launch
+        _split_drop(e.ptr, stamp=False)
     entries = list(_SPLIT_IMG.values())
-    if any(e.dims[3] != 0 for e in entries):                    # the batched cut exists for the bf16 pieces; others one by one
-        for e in entries:
-            check(lib.prn_split_prepare(ctypes.c_void_p(e.ptr), _p(e.images), e.dims[0], e.dims[1], e.dims[2], _stream()), "prn_split_prepare")
-            e.stamp = _split_state(e)
-        SPLIT_STATS["refreshes"] += 1
+    if not entries:
         return
     if _SPLIT_ITEMS[0] is None or _SPLIT_ITEMS[1] != [id(e) for e in entries]:
-        items, blocks = _prep_items(entries, entries[0].images.device)
-        _SPLIT_ITEMS[0], _SPLIT_ITEMS[1], _SPLIT_ITEMS[2] = items, [id(e) for e in entries], blocks
-    check(lib.prn_split_prepare_batched(_p(_SPLIT_ITEMS[0]), len(entries), _SPLIT_ITEMS[2], _stream()), "prn_split_prepare_batched")
+        items, blocks, rblocks = _prep_items(entries, entries[0].images.device)
+        _SPLIT_ITEMS[0], _SPLIT_ITEMS[1], _SPLIT_ITEMS[2] = items, [id(e) for e in entries], (blocks, rblocks)
+    check(lib.prn_split_prepare_batched(_p(_SPLIT_ITEMS[0]), len(entries), _SPLIT_ITEMS[2][0], _SPLIT_ITEMS[2][1], _stream()), "prn_split_prepare_batched")
     for e in entries:
         e.stamp = _split_state(e)
     SPLIT_STATS["refreshes"] += 1
