@@ -523,9 +523,14 @@ def main():
         # HBM-bound families are credited with the bytes their kernels EXECUTE (per variant), so none can exceed what the memory
         # system delivers; a figure above the measured copy rate means the accounting of that family is wrong
         over = [f["kernel"] for f in fams if f["bound"] == "hbm" and f["achieved"] > 6300.0 and f["time_ms"] > 0.02]
-        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": mfma_peak(dom["kernel"]), "unit": "TFLOP/s",
-                "frac": dom["achieved"] / mfma_peak(dom["kernel"]), "traffic": traffic, "launches": dom["launches"],
-                "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"], "flops_per_launch": dom["work"] / dom["launches"],
+        # ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMMs a launch evaluates) over the launch time, against the dense matrix peak of the dtype the
+        # path computes in (fp32: 157.3 TFLOP/s).  For the fp32 MFMA kernels that is also what they execute; the split kernel executes three
+        # (fp16 pieces) or six (bf16 pieces) products per multiply-add on the 16-bit pipe -- its pipe-side view is in `split_gemm` below.
+        dom_alg = dom["achieved"] / (ops.split_products() if dom["kernel"] == "split_gemm_kernel" else 1.0)
+        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom_alg, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom_alg / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"],
+                "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"],
+                "flops_per_launch": dom["work"] / dom["launches"] / (ops.split_products() if dom["kernel"] == "split_gemm_kernel" else 1.0),
                 "hbm_families_above_copy_rate": over}
         # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation) -- that is the headline
         # figure.  Footnote: the Winograd launches execute a quarter of the multiply-adds of the convolution they evaluate, so the
@@ -537,16 +542,17 @@ def main():
         sp = [f for f in fams if f["kernel"] == "split_gemm_kernel"]
         if sp:
             f = sp[0]
-            eq = f["work"] / 6.0 / (f["time_ms"] * 1e-3) / 1e12          # 2*M*N*K of the GEMMs the launches evaluate (six piece products per MAC)
+            eq = f["work"] / ops.split_products() / (f["time_ms"] * 1e-3) / 1e12     # 2*M*N*K of the GEMMs the launches evaluate
             roof["split_gemm"] = {"launches": f["launches"], "time_ms": f["time_ms"], "achieved": f["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": f["achieved"] / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent": eq, "fp32_equivalent_over_fp32_mfma_peak": eq / PEAK_FP32_MFMA_TFLOPS,
-                                  "pieces": "3 x bf16 per fp32 operand (exact), 6 of 9 products, fp32 accumulate"}
+                                  "pieces": ("2 x fp16 per fp32 operand (scaled by exact powers of two per weight row / activation column), 3 of 4 products, fp32 accumulate"
+                                             if ops.split_products() == 3.0 else "3 x bf16 per fp32 operand (exact), 6 of 9 products, fp32 accumulate")}
         # The forward / input-gradient GEMM launches as ONE family, whichever pipe a launch took: 2*M*N*K of the GEMMs they evaluate over
         # their time, against the fp32 MFMA peak -- comparable with the conv_igemm figure of the rounds before the split kernel existed (the
         # launches that moved to it were conv_igemm's most efficient ones, so that family's own `frac` falls when they leave).
         gm = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "split_gemm_kernel")]
         if len(gm) == 2:
-            fl = sum(f["work"] / (6.0 if f["kernel"] == "split_gemm_kernel" else 1.0) for f in gm)
+            fl = sum(f["work"] / (ops.split_products() if f["kernel"] == "split_gemm_kernel" else 1.0) for f in gm)
             ms = sum(f["time_ms"] for f in gm)
             roof["gemm_launches_fp32_equivalent"] = {"kernels": [f["kernel"] for f in gm], "launches": sum(f["launches"] for f in gm), "time_ms": ms,
                                                      "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -591,9 +597,9 @@ def main():
         line = {"metric": METRIC, "value": gb * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "arithmetic": "fp32 tensors, fp32 accumulation, fp32 MFMA; plain GEMMs of >= %d output tiles run on the bf16 pipe with every fp32 operand cut "
-                              "exactly into three bf16 pieces (error vs fp64 no larger than the fp32 MFMA's; DESIGN.md 9.1b; PRN_SPLIT_GEMM=0 turns it off)"
-                              % ops.lib.prn_split_gemm_min_tiles(-1),
+                "arithmetic": "fp32 tensors, fp32 accumulation, fp32 MFMA; plain GEMMs of >= %d output tiles run on the 16-bit matrix pipe with every fp32 operand cut "
+                              "into %s (error vs fp64 at the fp32 MFMA's level; DESIGN.md 9.1b / 9.1c; PRN_SPLIT_GEMM=0 turns it off)"
+                              % (ops.lib.prn_split_gemm_min_tiles(-1), "two fp16 pieces after an exact power-of-two scaling" if ops.split_products() == 3.0 else "three exact bf16 pieces"),
                 "config": {"workload": "%s: %s %s, per-GPU batch %d, %dx%d synthetic %s, random-init weights"
                            % (args.workload, args.config, wl[5], args.batch, args.height, args.width, "RGB+depth+planes" if train else "RGB"),
                            "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},

@@ -315,14 +315,16 @@ def _counters(dev):
     return c
 
 
-SPLIT_PRODUCTS = 6.0     # bf16 MFMA products the split GEMM kernel issues per fp32 multiply-add (csrc/prn_gemm_split.hip)
+def split_products():
+    """Piece products the split GEMM kernel issues per fp32 multiply-add (csrc/prn_gemm_split.hip): 3 with the fp16 pieces, 6 with the bf16 ones."""
+    return 3.0 if lib.prn_split_gemm_kind(-1) == 16 else 6.0
 
 
 def _gemm_family(M, K, B, HW, nz, flops):
     """(family, executed FLOPs, reference FLOPs) of a plain GEMM launch for the profiler: on the split kernel the launch executes six
     bf16 products per fp32 multiply-add on the bf16 matrix pipe; `flops` (2*M*K*N) stays the reference operator's work."""
     if gemm_pipe(M, K, B, HW, nz) >= 1:
-        return "split_gemm_kernel", SPLIT_PRODUCTS * flops, flops
+        return "split_gemm_kernel", split_products() * flops, flops
     return "conv_igemm_kernel", flops, flops
 
 
@@ -548,7 +550,7 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         nb_ = 4.0 * (x.numel() + w2d.numel() + y.numel() + (addend.numel() if addend is not None else 0))
         fl = 2.0 * M * C * K * K * B * Ho * Wo / (dil * dil)
         with profiling.span("conv3x3_direct" if direct else ("split_gemm_kernel" if split else "conv_igemm_kernel"), "hbm" if direct else "mfma",
-                            nb_ if direct else (SPLIT_PRODUCTS * fl if split else fl), ref=None if direct else fl, nbytes=nb_,
+                            nb_ if direct else (split_products() * fl if split else fl), ref=None if direct else fl, nbytes=nb_,
                             tag=None if direct else ("conv", C, H, W, M, K, stride, mode, dil, B)):
             check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 1), "prn_conv2d_fwd")
         if nbytes and kind != 2:
