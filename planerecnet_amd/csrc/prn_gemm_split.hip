@@ -504,7 +504,9 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz) {
   }
   if (md == 2) return splits;
   if (M % 128 != 0 && M % 128 <= 64) return 0;
-  if (2.0 * M * K * (double)HW * B * nz < 4e9) return 0;         // small launches are all launch latency: one kernel beats split + GEMM (+ sum)
+  static double min_flops = -1.;                                 // PRN_SPLIT_MIN_GFLOP (tuning)
+  if (min_flops < 0.) { const char* e = getenv("PRN_SPLIT_MIN_GFLOP"); min_flops = (e ? atof(e) : 4.0) * 1e9; }
+  if (2.0 * M * K * (double)HW * B * nz < min_flops) return 0;   // small launches are all launch latency: one kernel beats split + GEMM (+ sum)
   if (tiles * splits < min_tiles()) return 0;
   return splits;
 }

@@ -38,6 +38,7 @@ __global__ void fill_kernel(float* p, long long n, unsigned seed, float scale) {
   unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   p[i] = ((h & 0xffffff) / 16777216.0f - 0.5f) * 2.f * scale;
 }
+__global__ void flush_kernel(float* p, long long n, float v) { const long long i = (long long)blockIdx.x * 256 + threadIdx.x; if (i < n) p[i] = v; }
 static float* dalloc(long long n) { float* p; CK(hipMalloc(&p, n * 4)); return p; }
 static void fill(float* p, long long n, unsigned seed, float scale) { fill_kernel<<<(unsigned)((n + 255) / 256), 256>>>(p, n, seed, scale); }
 
@@ -65,6 +66,9 @@ int main(int argc, char** argv) {
       {"gemm 4096^2 x 16384", 4096, 4096, 1, 16384, 1, 0, false, false},
   };
   hipStream_t st; CK(hipStreamCreate(&st));
+  const bool cold = getenv("LAB_COLD") && atoi(getenv("LAB_COLD"));
+  float* flushbuf = nullptr;
+  if (cold) CK(hipMalloc(&flushbuf, 512ll << 20));
   printf("NPROD = %d\n%-26s %8s | %8s %7s %7s | %8s %7s | %s\n", nprod, "shape", "GFLOP", "split us", "TF/s eq", "presplit", "old us", "TF/s", "error / sum|a||b| : split max, rms | fp32 MFMA max, rms");
   for (const Shape& s : shapes) {
     if (filter && !strstr(s.name, filter)) continue;
@@ -92,6 +96,15 @@ int main(int argc, char** argv) {
     auto timeit = [&](auto fn) {
       fn(); CK(hipStreamSynchronize(st));
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      if (cold) {                                            // LAB_COLD=1: 512 MB written between launches (operands come from HBM, as inside a training step)
+        float tot = 0.f; const int n = reps < 12 ? reps : 12;
+        for (int i = 0; i < n; ++i) {
+          flush_kernel<<<(512 << 20) / 4 / 256, 256, 0, st>>>(flushbuf, (512ll << 20) / 4, (float)i);
+          CK(hipEventRecord(e0, st)); fn(); CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
+        }
+        return tot / n * 1e3f;
+      }
       CK(hipEventRecord(e0, st));
       const auto w0 = std::chrono::steady_clock::now();
       for (int i = 0; i < reps; ++i) fn();
