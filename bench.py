@@ -605,7 +605,9 @@ def main():
                            "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},
                 "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
                 "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "host": host,
-                "exchange_probe": exch, "split_gemm_policy": tune, "kernels": kernels}
+                "exchange_probe": exch, "split_gemm_policy": tune,
+                "device": {"name": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", None))},   # boxes differ by +-2 %
+                "kernels": kernels}
         print(json.dumps(line), flush=True)
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)

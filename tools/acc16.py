@@ -8,6 +8,7 @@ def errs(y, w, x):
     e = (y.double().cpu() - ref) / (mag + 1e-300)
     return float(e.abs().max()), float(e.pow(2).mean().sqrt()), float(e.mean())
 lib.prn_split_gemm_mode(2)
+print("piece format:", "fp16 x 2, three products" if lib.prn_split_gemm_kind(-1) == 16 else "bf16 x 3, six products")
 for (M, K, B, HW, dist) in [(1024,256,2,1200,"uniform"),(256,1024,2,1200,"uniform"),(200,72,3,1205,"uniform"),(512,2048,8,300,"uniform"),(1024,256,2,1200,"normal"),(1024,256,2,1200,"wide"),(256,256,2,4800,"relu")]:
     g = torch.Generator().manual_seed(M+K)
     if dist == "uniform":

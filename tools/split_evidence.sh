@@ -13,4 +13,15 @@ tools/native/mfma_peak/mfma_peak.bin 2 > $O/${TAG}_mfma_peak.txt 2>&1
   echo "# inference, 960-pixel workload (c5)"
   BENCH_ARGS="--workload c5" STEPS=40 bash tools/smi_ab.sh "PRN_SPLIT_GEMM=0" "PRN_SPLIT_GEMM=1" "PRN_SPLIT_GEMM=1 PRN_SPLIT_MIN_TILES=2500"
 } > $O/${TAG}_split_gemm_step_ab.txt 2>&1
-tail -3 $O/${TAG}_split_gemm_step_ab.txt
+# the fp16 piece format (default): production path (prn_conv2d_fwd / prn_gemm_batched incl. the cutting kernels) against the fp32 kernel, warm and cold
+{ for cfg in "PRN_SPLIT_GEMM=0" "PRN_SPLIT_GEMM=2 PRN_SPLIT_KIND=bf16" "PRN_SPLIT_GEMM=2 PRN_SPLIT_KIND=f16"; do
+    echo "## $cfg, 300 back-to-back launches"; env $cfg LAB_ONLY=old LAB_REPS=300 timeout 300 $L | cut -c1-28,64-84 | grep -v "^shape\|NPROD"
+    echo "## $cfg, 512 MB written between launches (operands from HBM, as inside a step)"; env $cfg LAB_ONLY=old LAB_COLD=1 timeout 300 $L | cut -c1-28,64-84 | grep -v "^shape\|NPROD"
+  done; } > $O/${TAG}_split16_lab_production_path.txt 2>&1
+python tools/acc16.py > $O/${TAG}_split16_accuracy_f16.txt 2>&1
+PRN_SPLIT_KIND=bf16 python tools/acc16.py > $O/${TAG}_split16_accuracy_bf16.txt 2>&1
+{ echo "# training step (c3): fp32 only / default (fp16 pieces, 300 tiles, kept images) / bf16 pieces / default without kept images / 2500 tiles"
+  STEPS=60 bash tools/smi_ab.sh "PRN_SPLIT_GEMM=0" "DEFAULT=1" "PRN_SPLIT_KIND=bf16" "PRN_SPLIT_CACHE=0" "PRN_SPLIT_MIN_TILES=2500" "PRN_SPLIT_GEMM=0" "DEFAULT=1"
+  for wl in c2 c5; do echo "# inference $wl"; BENCH_ARGS="--workload $wl" STEPS=40 bash tools/smi_ab.sh "PRN_SPLIT_GEMM=0" "DEFAULT=1" "PRN_SPLIT_KIND=bf16" "PRN_SPLIT_GEMM=0" "DEFAULT=1"; done
+} > $O/${TAG}_split16_step_ab.txt 2>&1
+tail -3 $O/${TAG}_split16_step_ab.txt
