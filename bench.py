@@ -112,7 +112,10 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None
-    fam = json.load(open(files[-1])).get("families", {}).get(kernel)
+    fams = json.load(open(files[-1])).get("families", {})
+    fam = fams.get(kernel)
+    if fam is None and kernel == "split_gemm_kernel":           # (the profiler family of both piece formats; the fp16 one's kernel is split16_gemm_kernel)
+        fam = fams.get("split16_gemm_kernel")
     return None if fam is None else {"bytes_per_launch": fam["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
 
 

@@ -364,6 +364,7 @@ def split_gemm_policy(which):
     """'train' / 'eval': how small a plain GEMM may be and still take the bf16-split kernel (csrc/prn_gemm_split.hip: g_min_tiles has the
     measurements).  A model calls this from train() / eval(); the cached launch plans and workspace sizes are dropped on a change."""
     n = _SPLIT_POLICY[which]
+    _SPLIT_POLICY["mode"] = which                                # (autograd functions run with grad mode off: this, not torch.is_grad_enabled(), tells training from inference)
     if _SPLIT_POLICY.get("current") != n:
         _SPLIT_POLICY["current"] = n
         lib.prn_split_gemm_min_tiles(n)
@@ -459,9 +460,10 @@ def split_images(t, M, K, nz, cols=None):
     """Call in front of a launch that takes the split kernel with weight operand t [nz, M, K] (dense): makes sure the library holds
     current images of t when t persists (a parameter / a view of one / a stamped derived buffer); otherwise the launch cuts t itself.
     cols = (B, HW) of the activation side: small launches keep cutting per launch (SPLIT_CACHE_MIN_TILES)."""
-    if SPLIT_CACHE in ("0", False) or (SPLIT_CACHE == "eval" and torch.is_grad_enabled()):
+    training = _SPLIT_POLICY.get("mode", "eval") == "train"
+    if SPLIT_CACHE in ("0", False) or (SPLIT_CACHE == "eval" and training):
         return
-    floor = SPLIT_CACHE_MIN_TILES if (SPLIT_CACHE == "eval" or (SPLIT_CACHE == "auto" and not torch.is_grad_enabled())) else 0
+    floor = SPLIT_CACHE_MIN_TILES if (SPLIT_CACHE == "eval" or (SPLIT_CACHE == "auto" and not training)) else 0
     if cols is not None and ((M + 127) // 128) * ((cols[1] + 127) // 128) * cols[0] * nz < floor:
         if t.data_ptr() in _SPLIT_IMG:
             _split_drop(t.data_ptr(), stamp=False)               # (the same weight seen earlier with a larger batch)
@@ -506,6 +508,8 @@ def split_refresh_all():
     """Re-cut every cached operand with ONE launch (a model calls this once per training step, after the optimizer changed the weights
     and after the flipped / transform-domain layouts were refreshed)."""
     if SPLIT_CACHE == "eval" or SPLIT_CACHE in ("0", False):     # (inference-only images are validated launch by launch, never refreshed)
+        return
+    if _SPLIT_POLICY.get("mode", "eval") != "train":
         return
     dead = [p for p, e in _SPLIT_IMG.items() if _split_state(e) is None]
     for p in dead:
