@@ -330,16 +330,12 @@ def _gemm_family(M, K, B, HW, nz, flops):
 
 
 # ------------------------------------------------------------------------------------------ split-GEMM weight images
-# The bf16-split GEMM kernel (csrc/prn_gemm_split.hip) reads its weight operand as pre-cut "images".  Left alone the library cuts the
+# The split GEMM kernel (csrc/prn_gemm_split.hip, both piece formats) reads its weight operand as pre-cut "images".  Left alone the library cuts the
 # weight inside every launch (one more small kernel in front of each GEMM); for operands that persist -- parameters, the per-step flipped
 # dgrad layouts, the Winograd transform-domain weights -- this cache keeps the images, registers them with the library
 # (prn_split_images_register) and re-cuts ALL of them with one launch per training step (split_refresh_all, called by the model next to
 # FlippedWeights / WinogradWeights); at inference they are cut once.  Every launch site checks its operand's entry against the version
 # counter of the parameter (or the generation stamp of the derived buffer) first, so a stale image is never read.
-# OFF by default (PRN_SPLIT_CACHE=1 turns it on): measured on the PlaneRecNet_101 training step the per-launch cut is FASTER than reading
-# images cut at the start of the step (48.5 vs 51.5 ms per step, same box; fp32 kernel: 50.4) -- the cut leaves the 0.2 .. 14 MB of
-# images in L2 / Infinity Cache right in front of the GEMM whose 80 .. 600 workgroups each stream them, whereas images written 20 ms
-# earlier come from HBM; at inference (static weights, nothing to re-cut) the cache is a small gain on the high-resolution workload.
 # "auto" (default): while training every operand's images are kept and re-cut by ONE batched pass per step (two launches) -- the launches then
 # run without their two cutting kernels, i.e. without two dependent-launch gaps each (~6 us of a 45 us launch: 50.5 -> 49.3 ms per step with the
 # fp16 pieces; that the first measurement of this cache, with the bf16 pieces, read slower was a comparison across boxes); at inference images
