@@ -574,6 +574,21 @@ def main():
             roof["dcnv2"] = {f["kernel"]: {"achieved": f["achieved"], "unit": f["unit"], "frac": f["achieved"] / PEAK_FP32_MFMA_TFLOPS,
                                            "launches": f["launches"], "avg_launch_us": 1e3 * f["time_ms"] / f["launches"]} for f in dcn}
 
+        # north star: ">= 60 % of the relevant roofline on the DCNv2 + conv kernels" -- one line per kernel group, all as ALGORITHMIC fp32 FLOPs
+        # over launch time against the fp32 MFMA peak (the dominant-kernel object above is one of these rows, whichever is largest by time)
+        def _alg(f):
+            return f["achieved"] / (ops.split_products() if f["kernel"] == "split_gemm_kernel" else 1.0)
+        groups = {"forward_and_input_gradient_gemms": ("conv_igemm_kernel", "split_gemm_kernel"), "weight_gradient_gemms": ("conv_wgrad_kernel",),
+                  "dcnv2_forward": ("dcnv2_fwd_kernel",), "dcnv2_weight_gradient": ("dcnv2_wgrad_kernel",)}
+        view = {}
+        for name, ks in groups.items():
+            fs = [f for f in fams if f["kernel"] in ks and f["time_ms"] > 0]
+            if fs:
+                ms = sum(f["time_ms"] for f in fs)
+                tf = sum(_alg(f) * f["time_ms"] for f in fs) / ms
+                view[name] = {"time_ms": ms, "launches": sum(f["launches"] for f in fs), "achieved": tf, "frac": tf / PEAK_FP32_MFMA_TFLOPS}
+        roof["conv_kernel_groups"] = view
+
     # the same step with non-trivial deformable offsets (after the headline timing; the weights change)
     dcn_run = None
     if train and args.dcn_offsets > 0 and not graphed:
