@@ -66,3 +66,8 @@ int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits);
 int prn_split_gemm(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images, float* partial, int M, int K, int B, int HW,
                    int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, hipStream_t st, int phase);
 void* prn_split_scratch(hipStream_t st, int64_t bytes);
+// DCNv2 forward on the fp16-piece split kernel (prn_gemm_split.hip): plan = K splits (0: keep the fp32 kernel), workspace, launch
+int prn_split_dcn_plan(int M, int K, int N);
+int64_t prn_split_dcn_ws_bytes(int M, int K, int B, int HoWo, int splits);
+int prn_split_dcn_fwd(const float* w, const float* x, const void* table, const float* bias, float* y, void* ws, int B, int C, int HW, int M, int HoWo, int nchunks,
+                      int epi, int splits, hipStream_t st, int phase);

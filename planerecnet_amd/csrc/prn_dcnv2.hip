@@ -501,6 +501,7 @@ extern "C" int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const
 
 extern "C" int64_t prn_dcnv2_fwd_ws_bytes(const prn_dcn_desc* d) {
   if (check_dcn(d, "prn_dcnv2_fwd_ws_bytes")) return -1;
+  if (const int ss = prn_split_dcn_plan(d->M, d->C * 9, d->B * d->Ho * d->Wo)) return prn_split_dcn_ws_bytes(d->M, d->C * 9, d->B, d->Ho * d->Wo, ss);
   const FPlan p = plan_dcn_fwd(d->M, d->B * d->Ho * d->Wo, d->C * 9);
   return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
@@ -509,6 +510,10 @@ extern "C" int prn_dcnv2_fwd_phase(const prn_dcn_desc* d, const float* x, const 
                                    void* stream, int phase) {
   if (int e = check_dcn(d, "prn_dcnv2_fwd")) return e;
   PRN_REQUIRE(x && table && w && y, "prn_dcnv2_fwd: null tensor");
+  if (ws != nullptr) {                                       // the sampler as operand loader of the fp16-piece split GEMM (prn_gemm_split.hip)
+    if (const int ss = prn_split_dcn_plan(d->M, d->C * 9, d->B * d->Ho * d->Wo))
+      return prn_split_dcn_fwd(w, x, table, bias, y, ws, d->B, d->C, d->H * d->W, d->M, d->Ho * d->Wo, npad(d) / 16, d->epilogue, ss, (hipStream_t)stream, phase);
+  }
   FwdArgs a;
   a.x = x; a.w = w; a.bias = bias; a.tab = (const float4*)table; a.y = y; a.ws = (float*)ws;
   a.B = d->B; a.C = d->C; a.HW = d->H * d->W; a.M = d->M; a.K = d->C * 9; a.HoWo = d->Ho * d->Wo; a.N = d->B * a.HoWo;

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // dropped l*l is <= 2^-22 of the product.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int IMG16_U4 = 1024;    // uint4 per fp16 image: 2 pieces x 4 k-groups x 128 rows x 16 B = 16 KB
 
 __device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
@@ -372,6 +373,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (cok && row < M) yb[(long long)row * HW + px] = v;
     }
   }
+}
+
+// ---- DCNv2 forward on the fp16 pieces: the bilinear 4-corner gather of torchvision.ops.deform_conv2d IS the activation-side operand loader --------
+// Y[M x N] = W[M x 9C] * cols[9C x N], cols[(c, t), n] = sum_q wt[t, n, q] * x[c, off[t, n, q]] (prn_dcnv2.hip has the gather table: per (pixel, tap) two
+// byte offsets of horizontal pixel pairs and four weights).  Same skeleton as split16_gemm_kernel: weight images by LDS-DMA, a lane owns one output
+// pixel and eight consecutive k = (c, t) of it per MFMA step; instead of loading x[k][n] it gathers the two pixel pairs of (c, t) -- the table rows of the
+// workgroup's 128 pixels live in LDS (27 KB) --, blends them, and cuts the sample into two fp16 pieces under the column's running scale.  Gathers of the
+// next MFMA step are in flight during the current one (two register sets).  K = 9C must be a multiple of 32.
+struct Dcn16Args {
+  const uint4* img; const int* ex; const float* x; const float4* tab; const float* bias; float* y; float* partial;
+  int M, K, HW, HoWo, N, nchunks, epi, mtiles, kslices, ntiles, total, splits, xbytes;
+  long long slice;                // elements of one partial slice: B * M * HoWo
+};
+constexpr int DCN_TAB_CHUNK4 = 9 * 2 * 16;     // float4 per 16-pixel chunk of the gather table (prn_dcnv2.hip: TAB_CHUNK4)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void split16_dcn_kernel(const Dcn16Args a) {
+  __shared__ uint4 lds[2 * IMG16_U4];
+  __shared__ uint2 toff[9 * 128];
+  __shared__ float4 twt[9 * 128];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int id = prn_xcd_remap(blockIdx.x, a.total);
+  const int mt = id % a.mtiles, nt = id / a.mtiles;
+  const int sp = blockIdx.y;
+  const int ks0 = (int)((long long)a.kslices * sp / a.splits), ks1 = (int)((long long)a.kslices * (sp + 1) / a.splits);
+  const int M = a.M, HW4 = a.HW * 4;
+  const int r = lane & 31, gs = lane >> 5;
+  const int pxl = wave * 32 + r;                                 // this lane's pixel inside the tile
+  const int n = nt * 128 + pxl;
+  {  // gather-table rows of the tile's 128 pixels: eight 16-pixel chunks, [tap][pixel] in LDS
+    const float4* tg = a.tab + (size_t)(nt * 8) * DCN_TAB_CHUNK4;
+    for (int i = t; i < 8 * DCN_TAB_CHUNK4; i += 256) {
+      const int cl = i / DCN_TAB_CHUNK4, q = i - cl * DCN_TAB_CHUNK4, tp = q >> 5, sx = (q >> 4) & 1, pp = q & 15;
+      const bool ok = nt * 8 + cl < a.nchunks;
+      const float4 v = ok ? tg[i] : make_float4(__uint_as_float(0x80000000u), __uint_as_float(0x80000000u), 0.f, 0.f);
+      if (sx) twt[tp * 128 + cl * 16 + pp] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      else toff[tp * 128 + cl * 16 + pp] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.xbytes, 0x00020000);
+  const uint4* ag = a.img + ((long long)mt * a.kslices) * IMG16_U4;
+  const i32x4_t adesc = make_desc(ag, (unsigned)a.kslices * IMG16_U4 * 16u);
+  const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
+  float2 ga[8][2], gb[8][2];       // gathered pixel pairs of the next two MFMA steps
+  f16x8_t p0[2], p1[2];            // pieces (h, l) of MFMA step 0 / 1
+  int erun = -1000, de = 0;
+#define D16_DMA(ks_, st_) do { \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+      lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \
+  } while (0)
+  // the eight k of MFMA step u of slice ks: k = ks * 32 + (2u + gs) * 8 + j = 9 c + tp
+#define D16_GATHER(g_, ks_, u_) do { \
+    const int kb = (ks_) * BK + (2 * (u_) + gs) * 8; \
+    int c = kb / 9, tp = kb - 9 * c; \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
+      const uint2 o = toff[tp * 128 + pxl]; \
+      const unsigned co = (unsigned)(c * HW4); \
+      const f32x2_t q0 = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(o.x + co), 0, 0)); \
+      const f32x2_t q1 = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(o.y + co), 0, 0)); \
+      g_[j][0] = make_float2(q0.x, q0.y); g_[j][1] = make_float2(q1.x, q1.y); \
+      ++tp; if (tp == 9) { tp = 0; ++c; } \
+    } } while (0)
+#define D16_PIECES(pc_, g_, ks_, u_) do { \
+    const int kb = (ks_) * BK + (2 * (u_) + gs) * 8; \
+    int tp = kb % 9; \
+    float v[8]; float mx = 0.f; \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
+      const float4 w4 = twt[tp * 128 + pxl]; \
+      v[j] = (w4.x * g_[j][0].x + w4.y * g_[j][0].y) + (w4.z * g_[j][1].x + w4.w * g_[j][1].y); \
+      mx = fmaxf(mx, fabsf(v[j])); \
+      ++tp; if (tp == 9) tp = 0; \
+    } \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); \
+    const int en = max(erun, mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : -200); \
+    de += erun - en; erun = en; \
+    const int sh = 14 - en; \
+    uint4 h, l; \
+    split2_f16(ldexpf(v[0], sh), ldexpf(v[1], sh), h.x, l.x); split2_f16(ldexpf(v[2], sh), ldexpf(v[3], sh), h.y, l.y); \
+    split2_f16(ldexpf(v[4], sh), ldexpf(v[5], sh), h.z, l.z); split2_f16(ldexpf(v[6], sh), ldexpf(v[7], sh), h.w, l.w); \
+    pc_[0] = __builtin_bit_cast(f16x8_t, h); pc_[1] = __builtin_bit_cast(f16x8_t, l); \
+  } while (0)
+#define D16_RESCALE() do { \
+    if (__builtin_amdgcn_ballot_w64(de != 0) != 0ull) { \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][e] = ldexpf(acc[i][e], de); \
+    } \
+    de = 0; } while (0)
+#define D16_STEP(pc_, u_) do { \
+    const int kg = 2 * (u_) + gs; \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+      const uint4* ap = lds + st * IMG16_U4 + kg * 128 + i * 32 + r; \
+      const f16x8_t ah = __builtin_bit_cast(f16x8_t, ap[0]), al = __builtin_bit_cast(f16x8_t, ap[512]); \
+      f32x16_t c = acc[i]; \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, pc_[0], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pc_[1], c, 0, 0, 0); \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pc_[0], c, 0, 0, 0); \
+      acc[i] = c; \
+    } } while (0)
+  f32x16_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  __syncthreads();                                               // the table is in LDS
+  D16_DMA(ks0, 0);
+  D16_GATHER(ga, ks0, 0);
+  D16_GATHER(gb, ks0, 1);
+  D16_PIECES(p0, ga, ks0, 0);
+  de = 0;                                                        // nothing accumulated yet
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int st = (ks - ks0) & 1;
+    const bool more = ks + 1 < ks1;
+    const int kn = more ? ks + 1 : ks;
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // this slice's LDS-DMA is older than the 16 gathers of `gb` that may still be in flight
+    __syncthreads();
+    D16_RESCALE();
+    if (more) D16_DMA(ks + 1, st ^ 1);
+    D16_GATHER(ga, kn, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    D16_STEP(p0, 0);
+    D16_PIECES(p1, gb, ks, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    D16_RESCALE();
+    D16_GATHER(gb, kn, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    D16_STEP(p1, 1);
+    if (more) D16_PIECES(p0, ga, ks + 1, 0);
+  }
+#undef D16_DMA
+#undef D16_GATHER
+#undef D16_PIECES
+#undef D16_RESCALE
+#undef D16_STEP
+  if (n >= a.N) return;
+  const int bb = n / a.HoWo, pp = n - bb * a.HoWo;
+  const int* exm = a.ex + mt * 128;
+  float* ob = (a.splits > 1 ? a.partial + (long long)sp * a.slice : a.y) + (long long)bb * M * a.HoWo + pp;
+  const bool fin = a.splits == 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = i * 32 + gs * 4 + (e >> 2) * 8 + (e & 3), row = mt * BM + rl;
+      if (row >= M) continue;
+      float v = ldexpf(acc[i][e], erun + exm[rl] - 28);
+      if (fin) {
+        if (a.bias) v += a.bias[row];
+        if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+      }
+      ob[(long long)row * a.HoWo] = v;
+    }
 }
 
 // one launch for many weights: item i covers blocks [first_i, first_{i+1}) of 256 threads = 256 (z, m tile, k slice, k group, row) tuples
@@ -647,4 +797,55 @@ void* prn_split_scratch(hipStream_t st, int64_t bytes) {
   if (hipMalloc(&b.p, cap) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
   b.cap = cap;
   return b.p;
+}
+
+// ---- DCNv2 forward on the split kernel (internal, prn_common.h): plan = number of K splits, 0 = keep the fp32 kernel ---------------------------------
+int prn_split_dcn_plan(int M, int K, int N) {
+  if (mode() == 0 || kind() != 16) return 0;
+  // OFF by default (PRN_SPLIT_DCN=1): the launch is bound by the sampler, not by the matrix pipe -- 131 against 141 us on 256 ch @30x40, and two
+  // row tiles sample every pixel twice -- and with it the R101 gradient test (direct-kernel build, K = 2) leaves its bound; kept as an experiment.
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("PRN_SPLIT_DCN"); on = e ? atoi(e) : 0; }
+  if (!on || (K & 31) != 0 || M < 96) return 0;
+  const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+  const int kslices = K / 32;
+  int splits = 1;
+  if (tiles < 400) {
+    splits = (int)(512 / (tiles > 0 ? tiles : 1));
+    if (splits > kslices / 8) splits = kslices / 8;
+    if (splits > 8) splits = 8;
+    if (splits < 1) splits = 1;
+  }
+  return splits;
+}
+int64_t prn_split_dcn_ws_bytes(int M, int K, int B, int HoWo, int splits) {
+  return ((prn_split_gemm_image_bytes(M, K, 1) + 255) & ~255LL) + (splits > 1 ? (int64_t)splits * B * M * HoWo * 4 : 0);
+}
+// table: prn_dcnv2_table's output (nchunks 16-pixel chunks); ws: prn_split_dcn_ws_bytes
+int prn_split_dcn_fwd(const float* w, const float* x, const void* table, const float* bias, float* y, void* ws, int B, int C, int HW, int M, int HoWo, int nchunks,
+                      int epi, int splits, hipStream_t st, int phase) {
+  const int K = C * 9, N = B * HoWo;
+  PRN_REQUIRE(w && x && table && y && ws && (K & 31) == 0, "prn_split_dcn_fwd: bad arguments");
+  const int mtiles = cdiv(M, 128), kslices = K / 32, ntiles = cdiv(N, 128);
+  const int64_t ib = (prn_split_gemm_image_bytes(M, K, 1) + 255) & ~255LL;
+  float* partial = (float*)((char*)ws + ib);
+  if (phase != 2) {
+    const void* reg = registered_images(w, M, K, 1, 16);
+    void* images = reg ? const_cast<void*>(reg) : ws;
+    int* ex = (int*)((char*)images + (int64_t)mtiles * kslices * IMG16_U4 * 16);
+    if (!reg) {
+      const long long rows = (long long)mtiles * 128, ptotal = (long long)mtiles * kslices * 512;
+      hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, (long long)M * K, mtiles * 128, rows);
+      hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, (long long)M * K, mtiles, kslices, ptotal);
+      PRN_CHECK_LAUNCH("prn_split_dcn_fwd/prepare");
+    }
+    Dcn16Args a;
+    a.img = (const uint4*)images; a.ex = ex; a.x = x; a.tab = (const float4*)table; a.bias = bias; a.y = y; a.partial = partial;
+    a.M = M; a.K = K; a.HW = HW; a.HoWo = HoWo; a.N = N; a.nchunks = nchunks; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ntiles = ntiles;
+    a.total = mtiles * ntiles; a.splits = splits; a.xbytes = B * C * HW * 4; a.slice = (long long)B * M * HoWo;
+    hipLaunchKernelGGL(split16_dcn_kernel, dim3(a.total, splits), dim3(256), 0, st, a);
+    PRN_CHECK_LAUNCH("prn_split_dcn_fwd");
+  }
+  if (splits > 1 && phase != 1) return prn_launch_reduce_epilogue(partial, bias, nullptr, y, (int64_t)B * M * HoWo, M, HoWo, splits, epi, st);
+  return 0;
 }
