@@ -994,6 +994,7 @@ def test_split_gemm_weight_images_follow_the_weight(split_everywhere, split_kind
     ops = split_everywhere
     monkeypatch.setattr(ops, "SPLIT_CACHE", "1")
     monkeypatch.setattr(ops, "SPLIT_CACHE_MIN_TILES", 0)
+    monkeypatch.setitem(ops._SPLIT_POLICY, "mode", "train")     # (what a model's training forward sets: split_refresh_all is a training-step pass)
     M, C, B, H, W = 256, 128, 2, 24, 32
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, C, H, W, generator=g).cuda()
