@@ -18,13 +18,21 @@ For the inference workloads a step is one batch through net.eval() (BatchNorm fo
 post-process, list[dict] result) and `value` is images / s.
 
 Extra objects:
-  roofline     -- the dominant kernel family (implicit-GEMM conv on fp32 MFMA: forward + dgrad launches).  Every launch of
-                  one extra, untimed step is bracketed by HIP events on the launch stream; achieved = sum of EXECUTED
-                  FLOPs / sum of event durations.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  `traffic` puts
+  roofline     -- the dominant MFMA kernel family BY TIME of the bracketed step, whichever that is (since round 3: the weight-gradient
+                  GEMMs, conv_wgrad_kernel; `roofline.kernel` names it, `conv_kernel_groups` has every group).  Every launch of
+                  one extra, untimed step is bracketed by HIP events on the launch stream; achieved = sum of ALGORITHMIC fp32
+                  FLOPs (2*M*N*K of the GEMMs the launches evaluate) / sum of event durations.  peak = 157.3 TFLOP/s (fp32 MFMA,
+                  MI355X_MICROARCH.md); launches on the 16-bit pipe (split kernels) are priced against their own peak in
+                  `roofline.split_gemm`.  `traffic` puts
                   the PMC bytes per launch (profiles/*pmc_traffic.json) next to the algorithmic bytes per launch logged live
                   (4 B x operand + result elements of every launch).  `kernels` lists the other families the same way.
   cpu_baseline -- the oracle (CPU restatement proven equal to the reference) timed on the host cores on a bounded sample:
                   ONE image of the same workload; 1 warm-up + 3 timed iterations, median.  kind = "port".
+  fp32_only_run -- the same step re-timed with every contraction on the fp32 MFMA kernels (prn_gemm_opts.split_mode = 0, what
+                  PRN_SPLIT_GEMM=0 selects): the default sends the large plain GEMMs through the 16-bit matrix pipe as fp16-piece products
+                  (`dtype` says so); this is the step's rate in the reference's arithmetic class, in the same process on the same board.
+  conditioned_run (c1 / c2 / c5) -- the same batch re-timed after shifting inst_head.cate_pred.bias until every image keeps >= 5 detections
+                  through matrix NMS: at the init state the post-process runs on (almost) empty candidate sets.
   dcn_offsets_run (c3) -- the same step re-timed after giving the DCN offset / modulator convs non-zero weights (~0.6 px r.m.s.
                   offsets): the headline runs at the reference's init state (offset convs zero, models/dcn.py:32-43), where
                   every deformable gather is a regular 3x3 pattern -- the best case for locality.
@@ -549,7 +557,7 @@ def main():
             roof["split_gemm"] = {"launches": f["launches"], "time_ms": f["time_ms"], "achieved": f["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": f["achieved"] / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent": eq, "fp32_equivalent_over_fp32_mfma_peak": eq / PEAK_FP32_MFMA_TFLOPS,
                                   "pieces": ("2 x fp16 per fp32 operand (scaled by exact powers of two per weight row / activation column), 3 of 4 products, fp32 accumulate"
-                                             if ops.split_products() == 3.0 else "3 x bf16 per fp32 operand (exact), 6 of 9 products, fp32 accumulate")}
+                                             if ops.split_products() <= 4.0 else "3 x bf16 per fp32 operand (exact), 6 of 9 products, fp32 accumulate")}
         # The forward / input-gradient GEMM launches as ONE family, whichever pipe a launch took: 2*M*N*K of the GEMMs they evaluate over
         # their time, against the fp32 MFMA peak -- comparable with the conv_igemm figure of the rounds before the split kernel existed (the
         # launches that moved to it were conv_igemm's most efficient ones, so that family's own `frac` falls when they leave).
@@ -589,6 +597,37 @@ def main():
                 view[name] = {"time_ms": ms, "launches": sum(f["launches"] for f in fs), "achieved": tf, "frac": tf / PEAK_FP32_MFMA_TFLOPS}
         roof["conv_kernel_groups"] = view
 
+    # the same step with every contraction on the fp32 MFMA kernels (same weights, same process, after the headline timing)
+    fp32_run = None
+    if not graphed and ops.split_mode() != 0 and not os.environ.get("PRN_BENCH_NO_FP32_RUN"):
+        old_pol = ops.set_split_gemm(mode=0)
+        n2 = max(args.steps // 2, 5)
+        el2, _ = timed(3, n2)
+        ops.set_split_gemm(**old_pol)
+        fp32_run = {"steps": n2, "ms_per_step": 1e3 * el2 / n2, "value": args.batch * world * n2 / el2,
+                    "arithmetic": "every contraction on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate); nothing on the 16-bit pipe"}
+        timed(2, 0)                                              # (back on the default plan before the legs below)
+
+    # inference workloads: the timed post-process at the init state sees (almost) no candidates.  Shift the category bias until every image
+    # keeps >= 5 detections and time the same batch again (the product's own forward picks the shift: no oracle on this path).
+    cond_run = None
+    if not train and rank == 0 and not os.environ.get("PRN_BENCH_NO_CONDITIONED_RUN"):
+        bias = net.inst_head.cate_pred.bias
+        b0 = bias.detach().clone()
+        for shift in (0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0):
+            with torch.no_grad():
+                bias.copy_(b0 + shift)
+            res = step()                                         # (in-place copy_: version counters move, cached derived weights follow)
+            counts = [0 if r["pred_scores"] is None else len(r["pred_scores"]) for r in res]
+            if min(counts) >= 5:
+                n2 = max(args.steps // 2, 5)
+                el2, res = timed(2, n2)
+                cond_run = {"cate_bias_shift": shift, "detections_per_image": [0 if r["pred_scores"] is None else len(r["pred_scores"]) for r in res],
+                            "steps": n2, "ms_per_step": 1e3 * el2 / n2, "value": args.batch * world * n2 / el2}
+                break
+        with torch.no_grad():
+            bias.copy_(b0)
+
     # the same step with non-trivial deformable offsets (after the headline timing; the weights change)
     dcn_run = None
     if train and args.dcn_offsets > 0 and not graphed:
@@ -614,15 +653,20 @@ def main():
         gb = args.batch * world
         line = {"metric": METRIC, "value": gb * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None,
+                "dtype": ("f32" if ops.split_mode() == 0 else
+                          "f32 (tensors and accumulation fp32; plain GEMMs >= %d tiles: %s split MFMA, fp32 accumulate; fp32-only rate in fp32_only_run)"
+                          % (ops._POLICY["min_tiles"], "2xfp16-piece" if ops.split_products() <= 4.0 else "3xbf16-piece")),
+                "data": "synthetic",
                 "arithmetic": "fp32 tensors, fp32 accumulation, fp32 MFMA; plain GEMMs of >= %d output tiles run on the 16-bit matrix pipe with every fp32 operand cut "
                               "into %s (error vs fp64 at the fp32 MFMA's level; DESIGN.md 9.1b / 9.1c; PRN_SPLIT_GEMM=0 turns it off)"
-                              % (ops.lib.prn_split_gemm_min_tiles(-1), "two fp16 pieces after an exact power-of-two scaling" if ops.split_products() == 3.0 else "three exact bf16 pieces"),
+                              % (ops._POLICY["min_tiles"], "two fp16 pieces after an exact power-of-two scaling" if ops.split_products() <= 4.0 else "three exact bf16 pieces"),
                 "config": {"workload": "%s: %s %s, per-GPU batch %d, %dx%d synthetic %s, random-init weights"
                            % (args.workload, args.config, wl[5], args.batch, args.height, args.width, "RGB+depth+planes" if train else "RGB"),
                            "global_batch": gb, "parallelism": ("dp%d" % world) if train else ("replicas%d" % world)},
                 "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
-                "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "dcn_offsets_run": dcn_run, "host": host,
+                "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "fp32_only_run": fp32_run, "conditioned_run": cond_run,
+                "dcn_offsets_run": dcn_run, "host": host,
                 "exchange_probe": exch, "split_gemm_policy": tune,
                 "device": {"name": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", None))},   # boxes differ by +-2 %
                 "kernels": kernels}

@@ -6,11 +6,16 @@
  *
  * Conventions (all entry points):
  *   - tensors are fp32, NCHW, contiguous, device pointers; the caller owns every buffer (outputs and
- *     workspaces come from the host framework's allocator -- nothing is allocated inside);
+ *     workspaces come from the host framework's allocator -- nothing is allocated, freed or synchronised
+ *     inside: the library makes no hipMalloc / hipFree / hip*Synchronize call, tests/test_abi_cpu.py greps for it);
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
  *   - the return value is 0 on success, non-zero on error (message: prn_last_error()); nothing throws;
- *   - no global mutable state except the thread-local error string; re-entrant; callable from any host
- *     thread (PyTorch's autograd worker threads call the backward entry points).
+ *   - no global mutable state except the thread-local error string: everything that selects a kernel
+ *     (matrix pipe, piece format, thresholds, launch sizes) travels with the call in a prn_gemm_opts value,
+ *     pre-cut weight images are passed in by the caller who vouches for them; re-entrant; callable from any host
+ *     thread (PyTorch's autograd worker threads call the backward entry points) with different options
+ *     per thread.  (The environment is read for tuning overrides only -- PRN_CONV_FORCE and friends, listed
+ *     in DESIGN.md -- once, never written.)
  */
 #ifndef PRN_H
 #define PRN_H
@@ -43,6 +48,34 @@ enum { PRN_IN_ZERO = 0, PRN_IN_REFLECT = 1, PRN_IN_UP2_REFLECT = 2, PRN_IN_DILAT
        PRN_IN_EMBED1 = 5 /* Winograd calls only, see prn_conv3x3_winograd */ };
 enum { PRN_EPI_NONE = 0, PRN_EPI_RELU = 1, PRN_EPI_SIGMOID = 2 };
 
+/* ---- per-call execution options of the GEMM-shaped operators -------------------------------------------------------------
+ * A plain value the caller fills (or zeroes) per call / per descriptor; the library keeps nothing between calls.
+ *   split_mode      PRN_SPLIT_OFF: every contraction on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).  PRN_SPLIT_PLAN: plain GEMMs
+ *                   (stride-1 1x1 convolutions, the 36 transform-domain products of the Winograd path, the DCNv2 column gradient) of at
+ *                   least split_min_tiles 128 x 128 output tiles and split_min_gflop GFLOP take the split kernel of prn_gemm_pipe below.
+ *                   PRN_SPLIT_ALWAYS: wherever that kernel applies (tests: small batches then exercise what batch 8 runs).
+ *   split_kind      PRN_PIECES_F16: two fp16 pieces per operand element after an exact power-of-two scaling per weight row / activation
+ *                   column, split_products = 3 (l*h, h*l, h*h) or 4 (+ l*l) v_mfma_f32_32x32x16_f16 per multiply-add.  PRN_PIECES_BF16:
+ *                   three exact bf16 pieces, six v_mfma_f32_32x32x16_bf16, no scaling.  Both accumulate in fp32.
+ *   wgrad_wgs       weight-gradient launches are planned for this many workgroups instead of a full residency round (0): a weight
+ *                   gradient that shares the GPU with the main chain should not fill every CU's registers.  wgrad_target: workgroups a
+ *                   many-tile launch splits up to (0 = 2048).
+ * An all-zero value means "fp32 MFMA kernels, full-round weight gradients"; prn_gemm_opts_default() fills the shipping defaults
+ * (PRN_SPLIT_PLAN, fp16 pieces, three products, 300 tiles, 4 GFLOP).  A NULL `opts` argument means the all-zero value. */
+enum { PRN_SPLIT_OFF = 0, PRN_SPLIT_PLAN = 1, PRN_SPLIT_ALWAYS = 2 };
+enum { PRN_PIECES_BF16 = 0, PRN_PIECES_F16 = 16 };
+typedef struct prn_gemm_opts {
+  int32_t split_mode;       /* PRN_SPLIT_*  */
+  int32_t split_kind;       /* PRN_PIECES_* */
+  int32_t split_products;   /* fp16 pieces: 3 (0 means 3) or 4 */
+  int32_t split_min_tiles;  /* PRN_SPLIT_PLAN */
+  float split_min_gflop;    /* PRN_SPLIT_PLAN */
+  int32_t wgrad_wgs;
+  int32_t wgrad_target;
+  int32_t reserved;
+} prn_gemm_opts;
+void prn_gemm_opts_default(prn_gemm_opts* o);
+
 typedef struct prn_conv_desc {
   int32_t B, C, H, W;      /* input tensor [B,C,H,W] as stored                                        */
   int32_t M;               /* output channels                                                          */
@@ -54,6 +87,8 @@ typedef struct prn_conv_desc {
   int32_t epilogue;        /* PRN_EPI_* (fwd only)                                                     */
   int32_t ystride;         /* 0/1: dense output.  2 (fwd only): output pixel (oh,ow) is stored at (2*oh, 2*ow) of  */
   int32_t yH, yW;          /*    a caller-zeroed [B,M,yH,yW] tensor (input gradient of a stride-2 1x1 conv)    */
+  int32_t reserved;
+  prn_gemm_opts opts;      /* which kernels this descriptor's calls (and its workspace sizes) are planned for  */
 } prn_conv_desc;
 
 /* y[b,m,oh,ow] = epi( sum_{c,r,s} w[m,c,r,s] * gather(x)[b,c,oh*stride-pad+r, ow*stride-pad+s] + bias[m] + addend[b,m,oh,ow] )
@@ -62,39 +97,32 @@ typedef struct prn_conv_desc {
  * are summed in a fixed order, so results are deterministic. */
 int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
 /* 0: the descriptor's forward runs on the fp32-MFMA implicit-GEMM kernel; 1: on the direct HBM-bound kernels (3x3 layers with one or two
- * output channels, or one input channel, over large maps: the depth head); 2 / 3: on the bf16-split GEMM kernel (prn_gemm_pipe below)
+ * output channels, or one input channel, over large maps: the depth head); 2 / 3: on the split GEMM kernel (prn_gemm_pipe below, per d->opts)
  * without / with a K split (3: a reduce launch follows, as for a split fp32 launch) -- for profilers that attribute launches to a roofline. */
 int prn_conv2d_kernel_kind(const prn_conv_desc* d);
 /* Which matrix pipe the plain GEMM y[z][b][m][p] = sum_k w[z][m][k] x[z][b][k][p] (a stride-1 1x1 convolution: nz = 1, HW = H*W; a
- * prn_gemm_batched call: B = 1, HW = P, nz = nb) runs on.  0: the fp32 MFMA kernel (v_mfma_f32_32x32x2_f32).  s >= 1: the split kernel
- * with s K splits -- both operands are cut EXACTLY into three bf16 pieces (the 8-bit slices of the 24-bit significand), six of the nine
- * piece products (each exact in fp32) are issued as v_mfma_f32_32x32x16_bf16 with fp32 accumulation and the three dropped ones are
- * <= 2^-23 of the product: an fp32 GEMM whose error against fp64 is no larger than the fp32 MFMA's (tests/test_ops_gpu.py), in 3/8 of its
- * matrix-pipe time.  PRN_SPLIT_GEMM=0 in the environment keeps every launch on the fp32 kernel; =2 takes the split kernel wherever it applies. */
-int prn_gemm_pipe(int M, int K, int B, int HW, int nz);
-/* Sets PRN_SPLIT_GEMM's value for this process (0 / 1 / 2 as above; < 0: query only) and returns the previous one.  Workspace sizes
- * (prn_conv2d_fwd_ws_bytes and the block-level *_ws_bytes) depend on it: query them again after a change. */
-int prn_split_gemm_mode(int mode);
-/* Piece format of the split kernel: 16 = two fp16 pieces per operand and three products, operands scaled by exact powers of two per weight row
- * / activation column (default, PRN_SPLIT_KIND=f16); 0 = three bf16 pieces and six products, no scaling (PRN_SPLIT_KIND=bf16).  Any other value
- * queries.  Returns the previous kind.  Workspace sizes do not depend on it. */
-int prn_split_gemm_kind(int kind);
-/* Mode 1 takes the split kernel for launches of at least this many 128 x 128 output tiles (PRN_SPLIT_MIN_TILES, default 2500; < 0: query
- * only); returns the previous value.  The threshold is a BOARD-level trade, see prn_gemm_split.hip: broad use of the bf16 pipe makes the
- * firmware lower the shader clock for everything else. */
-int prn_split_gemm_min_tiles(int n);
-/* The weight side of the split kernel ("images": [z][m tile of 128][k slice of 32][piece][k group][row][8 x bf16], zero padded) is cut
- * inside every launch unless the caller keeps it: prn_split_images_bytes = size of the images of w[nz][M][K]; prn_split_prepare_batched =
- * ONE launch (two for the fp16 pieces) that cuts many DENSE weights (items_dev: device array of {const float* src; void* dst; int32 M, K, nz, pad;
- * int64 first_row_block -- the item's first block of FOUR rows of nz * ceil(M/128)*128 rows, total_row_blocks = their sum (fp16 pieces' row
- * exponents); int64 first} -- `first` = the item's first 256-thread block, an item has ceil(nz * ceil(M/128) * ceil(K/32) * 512 / 256)
- * blocks, total_blocks = their sum); prn_split_images_register(w, images, M, K, nz) tells the library that launches whose weight operand
- * is exactly `w` (same M, K, nz, dense z stride) read `images` instead of cutting w again -- the caller re-runs the prepare whenever w's
- * contents change; images == NULL removes the entry.  (planerecnet_amd.ops.SplitImages: one prepare launch per training step.) */
+ * prn_gemm_batched call: B = 1, HW = P, nz = nb) runs on under `opts`.  0: the fp32 MFMA kernel (v_mfma_f32_32x32x2_f32).  s >= 1: the
+ * split kernel with s K splits -- fp32 operands cut into 16-bit pieces whose products are exact in fp32 and accumulated in fp32:
+ *   PRN_PIECES_F16 : each weight row / activation column is scaled by an exact power of two into fp16's range, then h = fp16(x),
+ *                    l = fp16(x - h) (22 of 24 significand bits); products l*h, h*l, h*h (+ l*l with split_products = 4) as
+ *                    v_mfma_f32_32x32x16_f16.  Error against fp64 at the fp32 MFMA kernel's level on this network's tensors; on operands
+ *                    spanning > 2^17 inside one row / column the smallest elements lose relative precision (tests/test_ops_gpu.py).
+ *   PRN_PIECES_BF16: the three 8-bit slices of the 24-bit significand (exact), six of the nine products as v_mfma_f32_32x32x16_bf16;
+ *                    the dropped three are <= 2^-23 of the product.
+ * This is NOT the reference's fp32 FMA chain bit for bit (neither is any other summation order); bench.py reports it in `dtype`. */
+int prn_gemm_pipe(int M, int K, int B, int HW, int nz, const prn_gemm_opts* opts);
+/* The weight side of the split kernel ("images": [z][m tile of 128][k slice of 32][piece][k group][row][8 x 16 bit], zero padded; the fp16
+ * kind's row exponents behind them) is cut inside every launch -- into the call's workspace -- unless the caller passes `*_images`: images
+ * of EXACTLY that call's weight operand, of the call's piece format, cut since the weight last changed (the caller vouches for it; the
+ * library keeps no table of them).  prn_split_images_bytes = size of the images of w[nz][M][K] (either kind); prn_split_prepare cuts one
+ * dense weight; prn_split_prepare_batched = ONE launch (two for the fp16 pieces) that cuts many DENSE weights (items_dev: device array of
+ * {const float* src; void* dst; int32 M, K, nz, pad; int64 first_row_block -- the item's first block of FOUR rows of nz * ceil(M/128)*128
+ * rows, total_row_blocks = their sum (fp16 pieces' row exponents); int64 first} -- `first` = the item's first 256-thread block, an item
+ * has ceil(nz * ceil(M/128) * ceil(K/32) * 512 / 256) blocks, total_blocks = their sum).  kind: PRN_PIECES_*.
+ * (planerecnet_amd.ops.split_images / split_refresh_all: one prepare launch per training step, validity by version counters.) */
 int64_t prn_split_images_bytes(int M, int K, int nz);
-int prn_split_prepare(const float* w, void* images, int M, int K, int nz, void* stream);   /* one weight, current piece format */
-int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, int64_t total_row_blocks, void* stream);
-int prn_split_images_register(const float* w, const void* images, int M, int K, int nz);
+int prn_split_prepare(const float* w, void* images, int M, int K, int nz, int kind, void* stream);
+int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, int64_t total_row_blocks, int kind, void* stream);
 int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* addend, float* y, void* ws, void* stream);
 /* The same with the K-split sum folded into the GEMM launch (no second kernel, one launch less per split layer): `counters` is
@@ -106,8 +134,9 @@ int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const
  * opt-in (environment PRN_CONV_FUSED_REDUCE=1, read per call): measured faster per layer, neutral on the training step.
  * phase: 0 = whole operator, 1 = GEMM launch only, 2 = the separate sum only (a no-op when the fold was used).  */
 #define PRN_TILE_COUNTERS 4096
-int prn_conv2d_fwd_counted(const prn_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y, void* ws,
-                           unsigned* counters, void* stream, int phase);
+/* w_images: NULL, or current split-kernel images of w (see prn_split_prepare) -- used when the descriptor's plan is the split kernel. */
+int prn_conv2d_fwd_counted(const prn_conv_desc* d, const float* x, const float* w, const void* w_images, const float* bias, const float* addend, float* y,
+                           void* ws, unsigned* counters, void* stream, int phase);
 /* Ragged batch: `nseg` dense tensors [B, C, H[s], W[s]] stored back to back, convolved with the SAME weights as one
  * GEMM over all their pixels (SOLOv2 applies its instance-head towers to five grid sizes, planerecnet.py:337-360).  Output
  * and addend are packed the same way with M channels.  Stride-1 "same" 1x1 / 3x3 convolutions with zero padding; desc->H,
@@ -151,7 +180,8 @@ int prn_weight_flip_transpose_batched(const prn_flip_item* items_dev, int n_item
  *   prn_winograd_input : x [B][C][H][W] -> V [36][C][P]     (in_mode PRN_IN_ZERO or PRN_IN_REFLECT, pad 1)
  *   prn_gemm_batched   : Y_z [M][P] = U_z [M][C] * V_z [C][P] for z < nb, one launch of the MFMA kernel
  *   prn_winograd_output: Y' [36][M][P] -> y [B][M][H][W]  (+ bias[m], + addend, epilogue PRN_EPI_NONE / PRN_EPI_RELU)
- *   prn_conv3x3_winograd: the three in sequence; ws holds 36 * (C + M) * P floats.
+ *   prn_conv3x3_winograd: the three in sequence; ws: prn_conv3x3_winograd_ws_bytes (36 * (C + M) * P floats: V first, then Y'; behind
+ *                        them whatever prn_gemm_batched needs under `opts`).
  *   in_mode PRN_IN_EMBED1: H, W describe a VIRTUAL zero tensor of which x [B][C][H-2][W-4] is the block starting at (1, 1);
  *   with pad 1 the output [B][M][H][W] then holds, in its columns 0 .. W-3, the FULL correlation of x (output (H-2)+2 by
  *   (W-4)+2) -- the gradient w.r.t. a reflect-padded tensor, folded onto the unpadded one by prn_pad_fold_pitched.
@@ -168,7 +198,11 @@ typedef struct prn_winograd_item {
 } prn_winograd_item;
 int prn_winograd_weights_batched(const prn_winograd_item* items_dev, int n_items, int64_t total_blocks, void* stream);
 int prn_winograd_input(const float* x, float* V, int B, int C, int H, int W, int in_mode, void* stream);
-int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const float* V, float* Y, void* stream);
+/* ws: prn_gemm_batched_ws_bytes(M, C, nb, opts) bytes (0 => may be NULL; non-zero only where the split kernel cuts U itself);
+ * u_images: NULL or current images of U (then no workspace is needed). */
+int64_t prn_gemm_batched_ws_bytes(int M, int C, int P, int nb, const prn_gemm_opts* opts);
+int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const void* u_images, const float* V, float* Y, void* ws, const prn_gemm_opts* opts,
+                     void* stream);
 int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream);
 /* Weight gradient on the same path: dw = G^T [ sum over tiles (A dy A^T) .* (B^T x B) ] G.
  *   prn_winograd_dy    : dy [B][M][H][W] -> dY' [36][M][P]
@@ -177,24 +211,28 @@ int prn_winograd_output(const float* Y, const float* bias, const float* addend, 
  *   prn_winograd_dw    : partials -> dw [M][C][3][3] (sums the splits in fixed order, then G^T . G)
  *   prn_conv3x3_winograd_wgrad: all of it; ws of prn_winograd_wgrad_ws_bytes; phase 0 = everything, 1 / 2 / 3 = transforms /
  *                        products / reduction only (profiler brackets). */
-int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M);
+int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M, const prn_gemm_opts* opts);
 int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream);
-int prn_gemm_batched_nt_splits(int M, int C, int P, int nb);
-int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, void* stream);
+int prn_gemm_batched_nt_splits(int M, int C, int P, int nb, const prn_gemm_opts* opts);
+int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, const prn_gemm_opts* opts, void* stream);
 int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream);
-int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase);
+int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, const prn_gemm_opts* opts,
+                               void* stream, int phase);
 /* The same with V = B^T x B supplied by the caller: the first 36 * C * P floats of the workspace of the forward call of the
  * same layer, kept alive until the backward pass (same ws size as above; its V part is then unused). */
-int prn_conv3x3_winograd_wgrad_v(const float* V, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, void* stream);
+int prn_conv3x3_winograd_wgrad_v(const float* V, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, const prn_gemm_opts* opts, void* stream);
 /* Ragged batches (prn_ragged; zero padding; every segment with W % 4 == 0, H >= 5): the tiles of all segments share the 36
  * products, only the transforms look at the segment table.  P = prn_winograd_tiles_ragged(rg, B). */
 int64_t prn_winograd_tiles_ragged(const prn_ragged* rg, int B);
-int prn_conv3x3_winograd_ragged(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B, int C,
-                                int M, int epilogue, void* stream);
-int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M);
-int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M, void* stream);
-int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
-                         int in_mode, int epilogue, void* stream);
+int64_t prn_conv3x3_winograd_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M, const prn_gemm_opts* opts);
+int prn_conv3x3_winograd_ragged(const float* x, const float* U, const void* u_images, const float* bias, const float* addend, float* y, void* ws,
+                                const prn_ragged* rg, int B, int C, int M, int epilogue, const prn_gemm_opts* opts, void* stream);
+int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M, const prn_gemm_opts* opts);
+int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M, const prn_gemm_opts* opts,
+                                      void* stream);
+int64_t prn_conv3x3_winograd_ws_bytes(int B, int C, int H, int W, int M, const prn_gemm_opts* opts);
+int prn_conv3x3_winograd(const float* x, const float* U, const void* u_images, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H,
+                         int W, int M, int in_mode, int epilogue, const prn_gemm_opts* opts, void* stream);
 
 /* dw[m, c*KH*KW + r*KW + s] = sum_{b,oh,ow} dy[b,m,oh,ow] * gather(x)[b,c,oh*stride-pad+r,ow*stride-pad+s]
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
@@ -271,6 +309,7 @@ typedef struct prn_dcn_desc {
   int32_t raw;             /* see above                                         */
   float max_offset;        /* raw = 1 only                                      */
   int32_t epilogue;        /* forward: PRN_EPI_NONE / PRN_EPI_RELU              */
+  prn_gemm_opts opts;      /* column-gradient GEMM (split kernel or not), weight-gradient launch size */
 } prn_dcn_desc;
 int64_t prn_dcnv2_table_bytes(const prn_dcn_desc* d);
 int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const float* mask, void* table, void* stream);
@@ -282,12 +321,13 @@ int64_t prn_dcnv2_bwd_weight_ws_bytes(const prn_dcn_desc* d);
 int prn_dcnv2_bwd_weight(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream);
 int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream, int phase);
 int64_t prn_dcnv2_bwd_ws_bytes(const prn_dcn_desc* d);
-int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
-                        void* stream);
+/* wt_images: NULL or current split-kernel images of wt [9C, M] (used when d->opts plans the column-gradient GEMM on the split kernel) */
+int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const void* wt_images, const float* offset, const float* mask, float* dx,
+                        void* ws, void* stream);
 /* phase 0 = everything; 1 / 2 = the column-gradient GEMM (launch / K-split sum); 3 = the CSR gather of dx from the column
  * gradient already in ws. */
-int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
-                              void* stream, int phase);
+int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy, const float* wt, const void* wt_images, const float* offset, const float* mask,
+                              float* dx, void* ws, void* stream, int phase);
 int prn_dcnv2_bwd_offset_mask(const prn_dcn_desc* d, const float* x, const float* offset, const float* mask, float* d_offset, float* d_mask,
                               void* ws, void* stream);
 
@@ -373,18 +413,21 @@ int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int
  *   FINER level's lateral or NULL: the reference accumulates bottom-up), p_out = [relu](conv3x3(lateral) + b_out).  u_out: the
  *   3x3 weights in the Winograd domain ([36][F][F], prn_winograd_weights_batched) or NULL -- with them, qualifying shapes take
  *   the F(4x4,3x3) path.                                                                                                  */
-int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, int F);
+int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, int F, const prn_gemm_opts* opts);
 int prn_plane_prior_fwd(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws, int B, int E,
-                        int h, int w, int NK, int F, void* stream);
+                        int h, int w, int NK, int F, const prn_gemm_opts* opts, void* stream);
 /* phase 0 = the whole block (== prn_plane_prior_fwd); 1 centre gather, 2 the B per-image dynamic convolutions (one batched MFMA
  * launch), 3 the 2x2 mean, 4 conv1x1 -- so that a profiler can bracket each launch of the block. */
 int prn_plane_prior_fwd_phase(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws, int B, int E,
-                        int h, int w, int NK, int F, void* stream, int phase);
-int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F);
-int prn_plane_prior_wgrad(const float* pooled, const float* d_out, float* dw1, void* ws, int B, int h, int w, int NK, int F, void* stream);
-int64_t prn_fpn_level_ws_bytes(int B, int C, int H, int W, int F, int relu, int has_prev, int have_u);
+                        int h, int w, int NK, int F, const prn_gemm_opts* opts, void* stream, int phase);
+int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F, const prn_gemm_opts* opts);
+int prn_plane_prior_wgrad(const float* pooled, const float* d_out, float* dw1, void* ws, int B, int h, int w, int NK, int F, const prn_gemm_opts* opts,
+                          void* stream);
+/* (the split-kernel launches of these two blocks cut their weights per call, into ws) */
+int64_t prn_fpn_level_ws_bytes(int B, int C, int H, int W, int F, int relu, int has_prev, int have_u, const prn_gemm_opts* opts);
 int prn_fpn_level_fwd(const float* x, const float* w_lat, const float* b_lat, const float* prev, int Hp, int Wp, const float* w_out, const float* u_out,
-                      const float* b_out, float* lateral, float* p_out, void* ws, int B, int C, int H, int W, int F, int relu, void* stream);
+                      const float* b_out, float* lateral, float* p_out, void* ws, int B, int C, int H, int W, int F, int relu, const prn_gemm_opts* opts,
+                      void* stream);
 
 /* prn_frame_to_input -- input staging of the inference entry point in ONE launch (simple_inference.py:143-152): src = the decoded
  *   uint8 BGR frame [Hs][Ws][3] on the device (uploaded as bytes); cv2.resize(INTER_LINEAR) to Hr x Wr in OpenCV's fixed-point
@@ -498,13 +541,16 @@ int prn_matrix_nms(const float* iou, const int64_t* labels, const float* scores,
  *                            region and image); its three points are the pixels of RANK r_j in that region (raster order, i.e.
  *                            np.flatnonzero(mask)[r_j]).  ranks [3][n_tot] != NULL: injected ranks (the reference's numpy stream
  *                            drawn by the caller: bit-identical to the host path); NULL: drawn on the device (Philox4x32-10, counter
- *                            = t, key = seed), rank = floor(u * pixels).  gid [3][n_tot] = image * H*W + pixel.              */
+ *                            = (t, call), key = seed: `seed` identifies the run and the rank, `call` the batch -- the global
+ *                            iteration, so a resumed run continues the stream), rank = floor(u * pixels).
+ *                            gid [3][n_tot] = image * H*W + pixel.                                                           */
 int64_t prn_gt_segments(int H, int W);
 int prn_gt_mask_stats(const unsigned char* masks, const int* img_first, int B, int Ntot, int H, int W, unsigned char* segcnt, int* segstart,
                       unsigned long long* totals, void* stream);
 int prn_gt_quarter_masks(const unsigned char* masks, unsigned char* out, int N, int H, int W, void* stream);
 int prn_gt_sample_triplets(const unsigned char* masks, const int* img_first, int B, int Ntot, int H, int W, const int* segstart, const int* trip_seg,
-                           const int* seg_region, const int* seg_img, const int* ranks, unsigned long long seed, int64_t n_tot, int* gid, void* stream);
+                           const int* seg_region, const int* seg_img, const int* ranks, unsigned long long seed, unsigned long long call, int64_t n_tot, int* gid,
+                           void* stream);
 
 /* ---- optimizer step ------------------------------------------------------------------------------------------------------
  * replaces optimizer.step() of the reference's optim.Adam (train.py:251-256,362; no weight decay, no amsgrad): every

@@ -12,10 +12,25 @@ LIB_PATH = os.environ.get("PRN_LIB") or os.path.join(_HERE, "libprn_hip.so")   #
 c_int, c_float, c_void_p, c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 
 
+class GemmOpts(ctypes.Structure):
+    """mirror of prn_gemm_opts: per-call execution options (which matrix pipe, piece format, thresholds, weight-gradient launch size).
+    The library keeps no such state; this value travels inside every descriptor / as an argument."""
+    _fields_ = [("split_mode", ctypes.c_int32), ("split_kind", ctypes.c_int32), ("split_products", ctypes.c_int32), ("split_min_tiles", ctypes.c_int32),
+                ("split_min_gflop", ctypes.c_float), ("wgrad_wgs", ctypes.c_int32), ("wgrad_target", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+    def key(self):
+        return (self.split_mode, self.split_kind, self.split_products, self.split_min_tiles, self.split_min_gflop, self.wgrad_wgs, self.wgrad_target)
+
+
+SPLIT_OFF, SPLIT_PLAN, SPLIT_ALWAYS = 0, 1, 2
+PIECES_BF16, PIECES_F16 = 0, 16
+
+
 class ConvDesc(ctypes.Structure):
     """mirror of prn_conv_desc"""
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("B", "C", "H", "W", "M", "KH", "KW", "stride", "pad", "Ho", "Wo", "in_mode", "dil", "epilogue", "ystride", "yH", "yW")]
+                ("B", "C", "H", "W", "M", "KH", "KW", "stride", "pad", "Ho", "Wo", "in_mode", "dil", "epilogue", "ystride", "yH", "yW", "reserved")] + [
+                    ("opts", GemmOpts)]
 
 
 class Ragged(ctypes.Structure):
@@ -26,7 +41,8 @@ class Ragged(ctypes.Structure):
 class DcnDesc(ctypes.Structure):
     """mirror of prn_dcn_desc"""
     _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "H", "W", "M", "stride", "pad", "Ho", "Wo", "raw")] + [("max_offset", ctypes.c_float),
-                                                                                                              ("epilogue", ctypes.c_int32)]
+                                                                                                              ("epilogue", ctypes.c_int32),
+                                                                                                              ("opts", GemmOpts)]
 
 
 IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1 = 0, 1, 2, 3, 4, 5
@@ -35,19 +51,17 @@ BN_SPLITS = 32
 
 P = c_void_p
 _DP = ctypes.POINTER(ConvDesc)
+_OP = ctypes.POINTER(GemmOpts)
 SIGNATURES = {
     "prn_version": (c_int, []),
     "prn_last_error": (ctypes.c_char_p, []),
     "prn_conv2d_fwd_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_kernel_kind": (c_int, [_DP]),
-    "prn_gemm_pipe": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "prn_split_gemm_mode": (c_int, [c_int]),
-    "prn_split_gemm_kind": (c_int, [c_int]),
-    "prn_split_gemm_min_tiles": (c_int, [c_int]),
+    "prn_gemm_opts_default": (None, [_OP]),
+    "prn_gemm_pipe": (c_int, [c_int, c_int, c_int, c_int, c_int, _OP]),
     "prn_split_images_bytes": (c_i64, [c_int, c_int, c_int]),
-    "prn_split_prepare": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "prn_split_prepare_batched": (c_int, [P, c_int, c_i64, c_i64, P]),
-    "prn_split_images_register": (c_int, [P, P, c_int, c_int, c_int]),
+    "prn_split_prepare": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "prn_split_prepare_batched": (c_int, [P, c_int, c_i64, c_i64, c_int, P]),
     "prn_conv2d_fwd": (c_int, [_DP, P, P, P, P, P, P, P]),
     "prn_conv2d_fwd_ragged": (c_int, [_DP, P, P, P, P, P, P, P]),
     "prn_conv2d_wgrad_ragged_ws_bytes": (c_i64, [_DP, P]),
@@ -55,27 +69,30 @@ SIGNATURES = {
     "prn_gn_relu_fwd_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, c_int, c_float, P]),
     "prn_gn_relu_bwd_ragged": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P]),
     "prn_conv2d_fwd_phase": (c_int, [_DP, P, P, P, P, P, P, P, c_int]),
-    "prn_conv2d_fwd_counted": (c_int, [_DP, P, P, P, P, P, P, P, P, c_int]),
+    "prn_conv2d_fwd_counted": (c_int, [_DP, P, P, P, P, P, P, P, P, P, c_int]),
     "prn_conv2d_wgrad_phase": (c_int, [_DP, P, P, P, P, P, c_int]),
     "prn_weight_flip_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_weight_flip_transpose_batched": (c_int, [P, c_int, c_i64, P]),
     "prn_winograd_tiles": (c_i64, [c_int, c_int, c_int]),
     "prn_winograd_weights_batched": (c_int, [P, c_int, c_i64, P]),
     "prn_winograd_input": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "prn_gemm_batched": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    "prn_gemm_batched_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, _OP]),
+    "prn_gemm_batched": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, _OP, P]),
     "prn_winograd_output": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "prn_winograd_wgrad_ws_bytes": (c_i64, [c_int] * 5),
+    "prn_winograd_wgrad_ws_bytes": (c_i64, [c_int] * 5 + [_OP]),
     "prn_winograd_dy": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "prn_gemm_batched_nt_splits": (c_int, [c_int] * 4),
-    "prn_gemm_batched_nt": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    "prn_gemm_batched_nt_splits": (c_int, [c_int] * 4 + [_OP]),
+    "prn_gemm_batched_nt": (c_int, [c_int, c_int, c_int, c_int, P, P, P, _OP, P]),
     "prn_winograd_dw": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "prn_conv3x3_winograd_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int]),
+    "prn_conv3x3_winograd_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, _OP, P, c_int]),
     "prn_winograd_tiles_ragged": (c_i64, [P, c_int]),
-    "prn_conv3x3_winograd_ragged": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "prn_winograd_wgrad_ragged_ws_bytes": (c_i64, [P, c_int, c_int, c_int]),
-    "prn_conv3x3_winograd_wgrad_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
-    "prn_conv3x3_winograd_wgrad_v": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_conv3x3_winograd_ragged_ws_bytes": (c_i64, [P, c_int, c_int, c_int, _OP]),
+    "prn_conv3x3_winograd_ragged": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, _OP, P]),
+    "prn_winograd_wgrad_ragged_ws_bytes": (c_i64, [P, c_int, c_int, c_int, _OP]),
+    "prn_conv3x3_winograd_wgrad_ragged": (c_int, [P, P, P, P, P, c_int, c_int, c_int, _OP, P]),
+    "prn_conv3x3_winograd_wgrad_v": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, _OP, P]),
+    "prn_conv3x3_winograd_ws_bytes": (c_i64, [c_int] * 5 + [_OP]),
+    "prn_conv3x3_winograd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _OP, P]),
     "prn_conv2d_wgrad_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_wgrad_grouped_ws_bytes": (c_i64, [_DP, c_int]),
     "prn_conv2d_wgrad_grouped": (c_int, [_DP, c_int, P, P, P, P, P]),
@@ -100,17 +117,17 @@ SIGNATURES = {
     "prn_dcnv2_bwd_weight": (c_int, [P] * 7),
     "prn_dcnv2_bwd_weight_phase": (c_int, [P] * 7 + [c_int]),
     "prn_dcnv2_bwd_ws_bytes": (c_i64, [P]),
-    "prn_dcnv2_bwd_input": (c_int, [P] * 8),
-    "prn_dcnv2_bwd_input_phase": (c_int, [P] * 8 + [c_int]),
+    "prn_dcnv2_bwd_input": (c_int, [P] * 9),
+    "prn_dcnv2_bwd_input_phase": (c_int, [P] * 9 + [c_int]),
     "prn_bn_kernel_kind": (c_int, [c_int, c_int]),
     "prn_dcnv2_bwd_offset_mask": (c_int, [P] * 8),
-    "prn_plane_prior_ws_bytes": (c_i64, [c_int] * 6),
-    "prn_plane_prior_fwd": (c_int, [P] * 7 + [c_int] * 6 + [P]),
-    "prn_plane_prior_fwd_phase": (c_int, [P] * 7 + [c_int] * 6 + [P, c_int]),
-    "prn_plane_prior_wgrad_ws_bytes": (c_i64, [c_int] * 5),
-    "prn_plane_prior_wgrad": (c_int, [P] * 4 + [c_int] * 5 + [P]),
-    "prn_fpn_level_ws_bytes": (c_i64, [c_int] * 8),
-    "prn_fpn_level_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P] + [c_int] * 6 + [P]),
+    "prn_plane_prior_ws_bytes": (c_i64, [c_int] * 6 + [_OP]),
+    "prn_plane_prior_fwd": (c_int, [P] * 7 + [c_int] * 6 + [_OP, P]),
+    "prn_plane_prior_fwd_phase": (c_int, [P] * 7 + [c_int] * 6 + [_OP, P, c_int]),
+    "prn_plane_prior_wgrad_ws_bytes": (c_i64, [c_int] * 5 + [_OP]),
+    "prn_plane_prior_wgrad": (c_int, [P] * 4 + [c_int] * 5 + [_OP, P]),
+    "prn_fpn_level_ws_bytes": (c_i64, [c_int] * 8 + [_OP]),
+    "prn_fpn_level_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P] + [c_int] * 6 + [_OP, P]),
     "prn_frame_to_input": (c_int, [P] + [c_int] * 6 + [P, P, c_int, P, P, P]),
     "prn_mask_loss_ws_floats": (c_int, [c_int]),
     "prn_mask_loss_fwd": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_float, P]),
@@ -130,7 +147,7 @@ SIGNATURES = {
     "prn_gt_segments": (c_i64, [c_int, c_int]),
     "prn_gt_mask_stats": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
     "prn_gt_quarter_masks": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "prn_gt_sample_triplets": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, ctypes.c_uint64, c_i64, P, P]),
+    "prn_gt_sample_triplets": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, ctypes.c_uint64, ctypes.c_uint64, c_i64, P, P]),
     "prn_adam_chunk_elems": (c_int, []),
     "prn_adam_step": (c_int, [P, c_int, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P]),
     "prn_adam_step_masked": (c_int, [P, c_int, c_int, P, P, P, P, P, P, P, P, P, ctypes.c_double, ctypes.c_double, c_float, P, P, P]),

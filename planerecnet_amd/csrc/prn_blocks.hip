@@ -16,20 +16,25 @@ __global__ __launch_bounds__(256) void centre_gather_kernel(const float* __restr
   out[i] = seg[(be * h + 4 * (iy >> 1) + 1 + (iy & 1)) * w + 4 * (jx >> 1) + 1 + (jx & 1)];
 }
 
-prn_conv_desc desc1x1(int B, int C, int H, int W, int M, int epi) {
+prn_conv_desc desc1x1(int B, int C, int H, int W, int M, int epi, const prn_gemm_opts* opts) {
   prn_conv_desc d;
   d.B = B; d.C = C; d.H = H; d.W = W; d.M = M; d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.Ho = H; d.Wo = W;
-  d.in_mode = PRN_IN_ZERO; d.dil = 1; d.epilogue = epi; d.ystride = 0; d.yH = d.yW = 0;
+  d.in_mode = PRN_IN_ZERO; d.dil = 1; d.epilogue = epi; d.ystride = 0; d.yH = d.yW = 0; d.reserved = 0;
+  d.opts = prn_opts_or_zero(opts);
   return d;
 }
 inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
-struct PriorWs { int64_t centre, sig, gemm1, gemm2, total; prn_conv_desc d1, d2; };
-int prior_layout(int B, int E, int h, int w, int NK, int F, PriorWs& l) {
+struct PriorWs { int64_t centre, sig, gemm1, gemm2, total; prn_conv_desc d1, d2; bool batched; };
+int prior_layout(int B, int E, int h, int w, int NK, int F, const prn_gemm_opts* opts, PriorWs& l) {
   PRN_REQUIRE(B > 0 && E > 0 && NK > 0 && F > 0 && h >= 4 && w >= 4 && h % 4 == 0 && w % 4 == 0, "prn_plane_prior: the mask feature size must be a multiple of 4 (got %dx%d)", h, w);
-  l.d1 = desc1x1(1, E, h / 2, w / 2, NK, PRN_EPI_SIGMOID);      // per image: sigmoid(kernels [NK x E] * centre [E x pixels])
-  l.d2 = desc1x1(B, NK, h / 4, w / 4, F, PRN_EPI_NONE);          // conv1x1 NK -> F over the pooled maps
-  const int64_t g1 = prn_conv2d_fwd_ws_bytes(&l.d1), g2 = prn_conv2d_fwd_ws_bytes(&l.d2);
+  l.d1 = desc1x1(1, E, h / 2, w / 2, NK, PRN_EPI_SIGMOID, opts);      // per image: sigmoid(kernels [NK x E] * centre [E x pixels])
+  l.d2 = desc1x1(B, NK, h / 4, w / 4, F, PRN_EPI_NONE, opts);          // conv1x1 NK -> F over the pooled maps
+  // dynamic 1x1 conv: every image has its own NK kernels (planerecnet.py:589-592).  One launch over all images when the pixel count allows
+  // the vector staging (it does for every input size that is a multiple of 32); the same k-ordered sums either way.
+  l.batched = (((h / 2) * (w / 2)) & 3) == 0 && (E & 3) == 0;
+  const int64_t g1 = l.batched ? prn_gemm_batched_ws_bytes(NK, E, (h / 2) * (w / 2), B, opts) : prn_conv2d_fwd_ws_bytes(&l.d1);
+  const int64_t g2 = prn_conv2d_fwd_ws_bytes(&l.d2);
   if (g1 < 0 || g2 < 0) return 2;
   l.centre = 0;
   l.sig = up256((int64_t)B * E * (h / 2) * (w / 2) * 4);
@@ -41,25 +46,25 @@ int prior_layout(int B, int E, int h, int w, int NK, int F, PriorWs& l) {
 
 }  // namespace
 
-extern "C" int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, int F) {
+extern "C" int64_t prn_plane_prior_ws_bytes(int B, int E, int h, int w, int NK, int F, const prn_gemm_opts* opts) {
   PriorWs l;
-  if (prior_layout(B, E, h, w, NK, F, l)) return -1;
+  if (prior_layout(B, E, h, w, NK, F, opts, l)) return -1;
   return l.total;
 }
 
 extern "C" int prn_plane_prior_fwd(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws,
-                                   int B, int E, int h, int w, int NK, int F, void* stream) {
-  return prn_plane_prior_fwd_phase(seg, kernels, w1, b1, pooled, out, ws, B, E, h, w, NK, F, stream, 0);
+                                   int B, int E, int h, int w, int NK, int F, const prn_gemm_opts* opts, void* stream) {
+  return prn_plane_prior_fwd_phase(seg, kernels, w1, b1, pooled, out, ws, B, E, h, w, NK, F, opts, stream, 0);
 }
 
 // phase 0: the whole block; 1 centre gather, 2 the per-image dynamic convolutions (ONE batched MFMA launch, blockIdx.z = image),
 // 3 the 2x2 mean, 4 conv1x1 NK -> F: the profiler brackets each launch of the block separately (bench.py's roofline leg)
 extern "C" int prn_plane_prior_fwd_phase(const float* seg, const float* kernels, const float* w1, const float* b1, float* pooled, float* out, void* ws,
-                                         int B, int E, int h, int w, int NK, int F, void* stream, int phase) {
+                                         int B, int E, int h, int w, int NK, int F, const prn_gemm_opts* opts, void* stream, int phase) {
   PRN_REQUIRE(seg && kernels && w1 && pooled && out && ws, "prn_plane_prior_fwd: null tensor");
   PRN_REQUIRE(phase >= 0 && phase <= 4, "prn_plane_prior_fwd: bad phase");
   PriorWs l;
-  if (int e = prior_layout(B, E, h, w, NK, F, l)) return e;
+  if (int e = prior_layout(B, E, h, w, NK, F, opts, l)) return e;
   char* wsb = (char*)ws;
   float* centre = (float*)(wsb + l.centre);
   float* sig = (float*)(wsb + l.sig);
@@ -71,10 +76,9 @@ extern "C" int prn_plane_prior_fwd_phase(const float* seg, const float* kernels,
     PRN_CHECK_LAUNCH("prn_plane_prior_fwd/centre");
   }
   if (phase == 0 || phase == 2) {
-    // dynamic 1x1 conv: every image has its own NK kernels (planerecnet.py:589-592).  One launch over all images when the pixel
-    // count allows the vector staging (it does for every input size that is a multiple of 32); the same k-ordered sums either way.
-    if (((h2 * w2) & 3) == 0 && (E & 3) == 0) {
-      if (int e = prn_gemm_batched_epi(NK, E, h2 * w2, B, kernels, centre, sig, PRN_EPI_SIGMOID, stream)) return e;
+    if (l.batched) {
+      if (int e = prn_gemm_batched_epi(NK, E, h2 * w2, B, kernels, nullptr, centre, sig, l.gemm2 > l.gemm1 ? wsb + l.gemm1 : nullptr, opts, PRN_EPI_SIGMOID, stream))
+        return e;
     } else {
       for (int b = 0; b < B; ++b)
         if (int e = prn_conv2d_fwd(&l.d1, centre + (size_t)b * E * h2 * w2, kernels + (size_t)b * NK * E, nullptr, nullptr, sig + (size_t)b * NK * h2 * w2,
@@ -88,31 +92,32 @@ extern "C" int prn_plane_prior_fwd_phase(const float* seg, const float* kernels,
   return 0;
 }
 
-extern "C" int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F) {
+extern "C" int64_t prn_plane_prior_wgrad_ws_bytes(int B, int h, int w, int NK, int F, const prn_gemm_opts* opts) {
   if (B <= 0 || h < 4 || w < 4 || NK <= 0 || F <= 0) return -1;
-  prn_conv_desc d = desc1x1(B, NK, h / 4, w / 4, F, PRN_EPI_NONE);
+  prn_conv_desc d = desc1x1(B, NK, h / 4, w / 4, F, PRN_EPI_NONE, opts);
   return prn_conv2d_wgrad_ws_bytes(&d);
 }
 
-extern "C" int prn_plane_prior_wgrad(const float* pooled, const float* d_out, float* dw1, void* ws, int B, int h, int w, int NK, int F, void* stream) {
+extern "C" int prn_plane_prior_wgrad(const float* pooled, const float* d_out, float* dw1, void* ws, int B, int h, int w, int NK, int F, const prn_gemm_opts* opts,
+                                     void* stream) {
   PRN_REQUIRE(pooled && d_out && dw1 && B > 0 && h >= 4 && w >= 4, "prn_plane_prior_wgrad: bad arguments");
-  prn_conv_desc d = desc1x1(B, NK, h / 4, w / 4, F, PRN_EPI_NONE);
+  prn_conv_desc d = desc1x1(B, NK, h / 4, w / 4, F, PRN_EPI_NONE, opts);
   return prn_conv2d_wgrad(&d, pooled, d_out, dw1, ws, stream);
 }
 
 // ---- one FPN level (models/fpn.py:51-63) ---------------------------------------------------------------------------------
 namespace {
 struct FpnWs { int64_t up, gemm1, gemm2, total; prn_conv_desc d1, d2; bool wino; };
-int fpn_layout(int B, int C, int H, int W, int F, int relu, bool has_prev, bool have_u, FpnWs& l) {
+int fpn_layout(int B, int C, int H, int W, int F, int relu, bool has_prev, bool have_u, const prn_gemm_opts* opts, FpnWs& l) {
   PRN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && F > 0, "prn_fpn_level_fwd: empty dimension");
-  l.d1 = desc1x1(B, C, H, W, F, PRN_EPI_NONE);
-  l.d2 = desc1x1(B, F, H, W, F, relu ? PRN_EPI_RELU : PRN_EPI_NONE);
+  l.d1 = desc1x1(B, C, H, W, F, PRN_EPI_NONE, opts);
+  l.d2 = desc1x1(B, F, H, W, F, relu ? PRN_EPI_RELU : PRN_EPI_NONE, opts);
   l.d2.KH = l.d2.KW = 3; l.d2.pad = 1;
   // the 3x3 output conv takes the Winograd path (prn_conv3x3_winograd) when the caller hands in the transform-domain weights
   // and the shape qualifies (W % 4 == 0, H >= 8, F >= 64, >= 128 tiles: the rule of the operator layer)
   l.wino = have_u && (W % 4) == 0 && H >= 8 && F >= 64 && (int64_t)B * ((H + 3) / 4) * (W / 4) >= 128;
   const int64_t g1 = prn_conv2d_fwd_ws_bytes(&l.d1);
-  const int64_t g2 = l.wino ? (int64_t)36 * 2 * F * prn_winograd_tiles(B, H, W) * 4 : prn_conv2d_fwd_ws_bytes(&l.d2);
+  const int64_t g2 = l.wino ? prn_conv3x3_winograd_ws_bytes(B, F, H, W, F, opts) : prn_conv2d_fwd_ws_bytes(&l.d2);
   if (g1 < 0 || g2 < 0) return 2;
   l.up = 0;
   l.gemm1 = has_prev ? up256((int64_t)B * F * H * W * 4) : 0;
@@ -122,18 +127,18 @@ int fpn_layout(int B, int C, int H, int W, int F, int relu, bool has_prev, bool 
 }
 }  // namespace
 
-extern "C" int64_t prn_fpn_level_ws_bytes(int B, int C, int H, int W, int F, int relu, int has_prev, int have_u) {
+extern "C" int64_t prn_fpn_level_ws_bytes(int B, int C, int H, int W, int F, int relu, int has_prev, int have_u, const prn_gemm_opts* opts) {
   FpnWs l;
-  if (fpn_layout(B, C, H, W, F, relu, has_prev != 0, have_u != 0, l)) return -1;
+  if (fpn_layout(B, C, H, W, F, relu, has_prev != 0, have_u != 0, opts, l)) return -1;
   return l.total;
 }
 
 extern "C" int prn_fpn_level_fwd(const float* x, const float* w_lat, const float* b_lat, const float* prev, int Hp, int Wp, const float* w_out,
                                  const float* u_out, const float* b_out, float* lateral, float* p_out, void* ws, int B, int C, int H, int W, int F,
-                                 int relu, void* stream) {
+                                 int relu, const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(x && w_lat && w_out && lateral && p_out, "prn_fpn_level_fwd: null tensor");
   FpnWs l;
-  if (int e = fpn_layout(B, C, H, W, F, relu, prev != nullptr, u_out != nullptr, l)) return e;
+  if (int e = fpn_layout(B, C, H, W, F, relu, prev != nullptr, u_out != nullptr, opts, l)) return e;
   PRN_REQUIRE(ws != nullptr || l.total == 0, "prn_fpn_level_fwd: workspace required");
   char* wsb = (char*)ws;
   const float* addend = nullptr;
@@ -144,7 +149,7 @@ extern "C" int prn_fpn_level_fwd(const float* x, const float* w_lat, const float
   }
   if (int e = prn_conv2d_fwd(&l.d1, x, w_lat, b_lat, addend, lateral, wsb + l.gemm1, stream)) return e;      // 1x1 lateral (+ bias, + addend in the epilogue)
   if (l.wino)                                                                                                 // 3x3 output conv (+ ReLU in the epilogue)
-    return prn_conv3x3_winograd(lateral, u_out, b_out, nullptr, p_out, wsb + l.gemm2, B, F, H, W, F, PRN_IN_ZERO, relu ? PRN_EPI_RELU : PRN_EPI_NONE, stream);
+    return prn_conv3x3_winograd(lateral, u_out, nullptr, b_out, nullptr, p_out, wsb + l.gemm2, B, F, H, W, F, PRN_IN_ZERO, relu ? PRN_EPI_RELU : PRN_EPI_NONE, opts, stream);
   return prn_conv2d_fwd(&l.d2, lateral, w_out, b_out, nullptr, p_out, wsb + l.gemm2, stream);
 }
 

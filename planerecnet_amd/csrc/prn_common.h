@@ -55,19 +55,22 @@ int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* 
 int prn_launch_reduce_splits(const float* ws, float* out, int64_t n, int splits, hipStream_t st);
 int prn_quantise_splits(int64_t tiles, int splits);
 //   Y_z[M x P] = epi(U_z[M x C] * V_z[C x P]) for z < nb in one launch (prn_gemm_batched with an activation)
-int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const float* V, float* Y, int epi, void* stream);
+int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const void* u_images, const float* V, float* Y, void* ws, const prn_gemm_opts* opts, int epi,
+                         void* stream);
 
-// fp32 GEMM on the bf16 matrix pipe by exact three-way operand splitting (prn_gemm_split.hip):
+// fp32 GEMM on the 16-bit matrix pipe by operand splitting (prn_gemm_split.hip):
 //   y[z][b][m][p] = epi(sum_k w[z][m][k] * x[z][b][k][p] + bias[m] + addend)   for z < nz, b < B  (a (z, b) image of x is [K][HW], of y [M][HW])
-// prn_split_gemm_plan: 0 = keep the fp32 MFMA kernel, else the number of K splits to run it with.
-int prn_split_gemm_plan(int M, int K, int B, int HW, int nz);
+// prn_split_gemm_plan: 0 = keep the fp32 MFMA kernel, else the number of K splits to run it with (opts == NULL: 0).
+int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts* opts);
 int64_t prn_split_gemm_image_bytes(int M, int K, int nz);
 int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits);
-int prn_split_gemm(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images, float* partial, int M, int K, int B, int HW,
-                   int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, hipStream_t st, int phase);
-void* prn_split_scratch(hipStream_t st, int64_t bytes);
-// DCNv2 forward on the fp16-piece split kernel (prn_gemm_split.hip): plan = K splits (0: keep the fp32 kernel), workspace, launch
-int prn_split_dcn_plan(int M, int K, int N);
-int64_t prn_split_dcn_ws_bytes(int M, int K, int B, int HoWo, int splits);
-int prn_split_dcn_fwd(const float* w, const float* x, const void* table, const float* bias, float* y, void* ws, int B, int C, int HW, int M, int HoWo, int nchunks,
-                      int epi, int splits, hipStream_t st, int phase);
+// w_images: the caller's current images of w, or NULL: w is cut into `images_ws` (prn_split_gemm_image_bytes) by this call.
+int prn_split_gemm(const float* w, const void* w_images, const float* x, const float* bias, const float* addend, float* y, void* images_ws, float* partial, int M,
+                   int K, int B, int HW, int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, const prn_gemm_opts* opts, hipStream_t st, int phase);
+// weight-gradient plan knobs of a call (NULL opts: zeros)
+static inline prn_gemm_opts prn_opts_or_zero(const prn_gemm_opts* o) {
+  prn_gemm_opts z;
+  if (o) return *o;
+  z.split_mode = 0; z.split_kind = 0; z.split_products = 0; z.split_min_tiles = 0; z.split_min_gflop = 0.f; z.wgrad_wgs = 0; z.wgrad_target = 0; z.reserved = 0;
+  return z;
+}

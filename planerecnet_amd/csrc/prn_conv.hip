@@ -1159,7 +1159,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
 }
 
 struct WgPlan { int tm, tj, tilesM, tilesJ, splits, chunks, wm; };
-WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false, bool small = false) {
+WgPlan plan_wgrad(const prn_gemm_opts& o, int M, int K, int64_t N, int phases = 1, bool ragged = false, bool small = false) {
   WgPlan p;
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
@@ -1183,18 +1183,16 @@ WgPlan plan_wgrad(int M, int K, int64_t N, int phases = 1, bool ragged = false, 
   // fill one round; when the bounds below cut that short, land on a whole number of workgroups per CU instead.
   // Bounds: the workspace round trip (2 * splits * M*K*4 bytes) stays a fraction of the MFMA time (splits <= 0.0035 *
   // pixels) and every split keeps at least 128 pixels.  Layers with more tiles than slots only split to ~2048 workgroups.
-  const char* tenv = getenv("PRN_WGRAD_TARGET");   // (read per call: planerecnet_amd.ops lowers it while weight gradients are deferred, like PRN_WGRAD_WGS)
-  const int target = tenv ? atoi(tenv) : 2048;
+  const int target = o.wgrad_target > 0 ? o.wgrad_target : 2048;   // (opts: planerecnet_amd.ops lowers it while weight gradients are deferred, like wgrad_wgs)
   static int forced = -1;          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
   if (forced < 0) { const char* e = getenv("PRN_WGRAD_SPLITS"); forced = e ? atoi(e) : 0; }
   int R = (p.tm == 2 && p.tj == 2) ? 3 : ((p.tm + p.tj == 3 || p.wm == 1) ? 4 : 6);
-  // PRN_WGRAD_WGS (read per call; planerecnet_amd.ops sets it while weight gradients are deferred to the side stream): plan a
+  // opts.wgrad_wgs (planerecnet_amd.ops sets it while weight gradients are deferred to the side stream): plan a
   // launch whose tiles are fewer for THIS many workgroups instead of a full residency round.  A weight gradient that shares the GPU
   // with the main chain should not fill every CU's registers (3 resident workgroups of 152 VGPRs leave no room for a 128-VGPR wave
   // of the main stream's GEMMs): 512 workgroups per launch gave the shortest training step (52.6 -> 52.2 ms; 448: 52.3, 640: 52.4,
   // 768: 52.45, 1024: 52.8), although the launch alone is fastest with the full round.
-  const char* wenv = getenv("PRN_WGRAD_WGS");
-  const int wtot = wenv ? atoi(wenv) : 0;
+  const int wtot = o.wgrad_wgs;
   int slots = 256 * R;
   if (wtot > 0) { slots = wtot; R = 3; }
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;
@@ -1294,7 +1292,7 @@ int tail_of(const prn_conv_desc* d, const Geo& g, const FwdPlan& p, int* pieces)
 // Plain-GEMM 1x1 convolutions may run on the bf16-split kernel (prn_gemm_split.hip): number of K splits, 0 = no
 int split_plan_of(const prn_conv_desc* d) {
   if (!(d->KH == 1 && d->in_mode == PRN_IN_ZERO && d->stride == 1 && d->pad == 0 && d->ystride <= 1 && d->Ho == d->H && d->Wo == d->W)) return 0;
-  return prn_split_gemm_plan(d->M, d->C, d->B, d->H * d->W, 1);
+  return prn_split_gemm_plan(d->M, d->C, d->B, d->H * d->W, 1, &d->opts);
 }
 int64_t split_ws_bytes(const prn_conv_desc* d, int splits) {
   return ((prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->H * d->W, 1, splits);
@@ -1362,7 +1360,7 @@ int64_t seg_pixels(const prn_ragged* rg, int B) {
   return n;
 }
 int conv_fwd_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias, const float* addend, float* y,
-                  void* ws, void* stream, int phase, unsigned* counters = nullptr);
+                  void* ws, void* stream, int phase, unsigned* counters = nullptr, const void* w_images = nullptr);
 int conv_wgrad_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* dy, float* dw, void* ws, void* stream, int phase);
 }  // namespace
 
@@ -1380,9 +1378,9 @@ extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, cons
   return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase);
 }
 
-extern "C" int prn_conv2d_fwd_counted(const prn_conv_desc* d, const float* x, const float* w, const float* bias, const float* addend, float* y, void* ws,
-                                      unsigned* counters, void* stream, int phase) {
-  return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase, counters);
+extern "C" int prn_conv2d_fwd_counted(const prn_conv_desc* d, const float* x, const float* w, const void* w_images, const float* bias, const float* addend,
+                                      float* y, void* ws, unsigned* counters, void* stream, int phase) {
+  return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase, counters, w_images);
 }
 
 extern "C" int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* rg, const float* x, const float* w, const float* bias,
@@ -1393,7 +1391,7 @@ extern "C" int prn_conv2d_fwd_ragged(const prn_conv_desc* d, const prn_ragged* r
 
 namespace {
 int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x, const float* w, const float* bias, const float* addend, float* y,
-                  void* ws, void* stream, int phase, unsigned* counters) {
+                  void* ws, void* stream, int phase, unsigned* counters, const void* w_images) {
   prn_conv_desc dd;
   const prn_conv_desc* d = d0;
   if (rg && d0) {                                       // geometry fields of the descriptor are per segment: validate with the first one
@@ -1421,7 +1419,8 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
   if (rg == nullptr && ws != nullptr) {
     if (const int ss = split_plan_of(d)) {
       const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL;
-      return prn_split_gemm(w, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H * d->W, 1, 0, 0, 0, d->epilogue, ss, (hipStream_t)stream, phase);
+      return prn_split_gemm(w, w_images, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H * d->W, 1, 0, 0, 0, d->epilogue, ss, &d->opts,
+                            (hipStream_t)stream, phase);
     }
   }
   ConvArgs a;
@@ -1498,7 +1497,7 @@ extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
   const int K = d->C * d->KH * d->KW;
   if (direct_small_m(d)) return (int64_t)direct_wgrad_splits(d) * d->M * K * 4;
   const Geo g = geo_of(d);
-  WgPlan p = plan_wgrad(d->M, K, (int64_t)d->B * g.gH * g.gW, g.phases);
+  WgPlan p = plan_wgrad(d->opts, d->M, K, (int64_t)d->B * g.gH * g.gW, g.phases);
   return p.splits > 1 ? (int64_t)p.splits * g.phases * d->M * K * 4 : 0;
 }
 
@@ -1517,7 +1516,7 @@ extern "C" int64_t prn_conv2d_wgrad_grouped_ws_bytes(const prn_conv_desc* d, int
   if (check_desc(d, "prn_conv2d_wgrad_grouped_ws_bytes")) return -1;
   if (G < 1 || G > PRN_WGRAD_GROUP_MAX || geo_of(d).phases != 1 || direct_small_m(d)) { prn_set_error("prn_conv2d_wgrad_grouped_ws_bytes: unsupported group"); return -1; }
   const int K = d->C * d->KH * d->KW;
-  const WgPlan p = plan_wgrad(d->M, K, (int64_t)d->B * d->Ho * d->Wo, G);
+  const WgPlan p = plan_wgrad(d->opts, d->M, K, (int64_t)d->B * d->Ho * d->Wo, G);
   return p.splits > 1 ? (int64_t)p.splits * G * d->M * K * 4 : 0;
 }
 
@@ -1541,7 +1540,7 @@ extern "C" int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const flo
     a.gx[i] = x[i < G ? i : 0]; a.gdy[i] = dy[i < G ? i : 0];
     PRN_REQUIRE(a.gx[i] && a.gdy[i], "prn_conv2d_wgrad_grouped: null tensor in the group");
   }
-  const WgPlan p = plan_wgrad(a.M, a.K, a.N, G);
+  const WgPlan p = plan_wgrad(d->opts, a.M, a.K, a.N, G);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad_grouped: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;
@@ -1569,7 +1568,7 @@ extern "C" int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const flo
 extern "C" int64_t prn_conv2d_wgrad_ragged_ws_bytes(const prn_conv_desc* d, const prn_ragged* rg) {
   if (d == nullptr || rg == nullptr || rg->nseg < 1 || rg->nseg > MAX_SEG) return -1;
   const int K = d->C * d->KH * d->KW;
-  WgPlan p = plan_wgrad(d->M, K, seg_pixels(rg, d->B), 1, true);
+  WgPlan p = plan_wgrad(d->opts, d->M, K, seg_pixels(rg, d->B), 1, true);
   return p.splits > 1 ? (int64_t)p.splits * d->M * K * 4 : 0;
 }
 
@@ -1619,7 +1618,7 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
     if (int e = fill_seg(a.seg, rg, d, 16, "prn_conv2d_wgrad_ragged")) return e;
     for (int sI = 0; sI < rg->nseg; ++sI) PRN_REQUIRE((rg->H[sI] * rg->W[sI]) % 4 == 0, "prn_conv2d_wgrad_ragged: segment planes must be multiples of 4 pixels");
   }
-  WgPlan p = plan_wgrad(a.M, a.K, a.N, g.phases, rg != nullptr);
+  WgPlan p = plan_wgrad(d->opts, a.M, a.K, a.N, g.phases, rg != nullptr);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;
@@ -1660,19 +1659,24 @@ extern "C" int prn_weight_flip_transpose(const float* w, float* wt, int M, int C
 
 // nb independent GEMMs Y_z[M x P] = U_z[M x C] * V_z[C x P] in one launch of the 1x1 (VEC) instances: the product step of
 // the Winograd path (prn_winograd.hip), z = one of the 36 transform-domain positions.
-extern "C" int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const float* V, float* Y, void* stream) {
-  return prn_gemm_batched_epi(M, C, P, nb, U, V, Y, PRN_EPI_NONE, stream);
+extern "C" int64_t prn_gemm_batched_ws_bytes(int M, int C, int P, int nb, const prn_gemm_opts* opts) {
+  if (M <= 0 || C <= 0 || P <= 0 || nb <= 0) return -1;
+  return prn_split_gemm_plan(M, C, 1, P, nb, opts) == 1 ? prn_split_gemm_image_bytes(M, C, nb) : 0;
+}
+extern "C" int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const void* u_images, const float* V, float* Y, void* ws, const prn_gemm_opts* opts,
+                                void* stream) {
+  return prn_gemm_batched_epi(M, C, P, nb, U, u_images, V, Y, ws, opts, PRN_EPI_NONE, stream);
 }
 
 // (internal, prn_common.h) the same with an activation in the epilogue: the per-image dynamic convolutions of the plane prior
-int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const float* V, float* Y, int epi, void* stream) {
+int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const void* u_images, const float* V, float* Y, void* ws, const prn_gemm_opts* opts, int epi,
+                         void* stream) {
   PRN_REQUIRE(U && V && Y && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched: bad arguments");
   PRN_REQUIRE((P & 3) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0, "prn_gemm_batched: P %% 4 == 0 and 16-byte aligned V required (P=%d)", P);
   PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched: operand larger than a buffer descriptor");
-  if (prn_split_gemm_plan(M, C, 1, P, nb) == 1) {
-    if (void* images = prn_split_scratch((hipStream_t)stream, prn_split_gemm_image_bytes(M, C, nb)))
-      return prn_split_gemm(U, V, nullptr, nullptr, Y, images, nullptr, M, C, 1, P, nb, (int64_t)M * C, (int64_t)C * P, (int64_t)M * P, epi, 1, (hipStream_t)stream, 0);
-  }
+  if ((u_images != nullptr || ws != nullptr) && prn_split_gemm_plan(M, C, 1, P, nb, opts) == 1)      // (neither images nor a workspace to cut into: the fp32 kernel)
+    return prn_split_gemm(U, u_images, V, nullptr, nullptr, Y, ws, nullptr, M, C, 1, P, nb, (int64_t)M * C, (int64_t)C * P, (int64_t)M * P, epi, 1, opts,
+                          (hipStream_t)stream, 0);
   ConvArgs a;
   a.x = V; a.w = U; a.bias = nullptr; a.addend = nullptr; a.y = Y; a.ws = nullptr;
   a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P; a.epi = epi;
@@ -1699,16 +1703,17 @@ int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const floa
 namespace {
 // 64 x 64 tiles when the 128 x 128 plan leaves most of the GPU empty (short reductions cap the split count): 54 -> 39 us for
 // 36 x [256 x 256 x 640] (tools/winograd_bench.py)
-WgPlan plan_batched_nt(int M, int C, int P, int nb) {
-  WgPlan p = plan_wgrad(M, C, P, nb);
-  if (p.tm == 2 && p.tj == 2 && (int64_t)p.tilesM * p.tilesJ * nb * p.splits < 400) p = plan_wgrad(M, C, P, nb, false, true);
+WgPlan plan_batched_nt(const prn_gemm_opts* opts, int M, int C, int P, int nb) {
+  const prn_gemm_opts o = prn_opts_or_zero(opts);
+  WgPlan p = plan_wgrad(o, M, C, P, nb);
+  if (p.tm == 2 && p.tj == 2 && (int64_t)p.tilesM * p.tilesJ * nb * p.splits < 400) p = plan_wgrad(o, M, C, P, nb, false, true);
   return p;
 }
 }  // namespace
-extern "C" int prn_gemm_batched_nt_splits(int M, int C, int P, int nb) {
-  return plan_batched_nt(M, C, P, nb).splits;
+extern "C" int prn_gemm_batched_nt_splits(int M, int C, int P, int nb, const prn_gemm_opts* opts) {
+  return plan_batched_nt(opts, M, C, P, nb).splits;
 }
-extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, void* stream) {
+extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(A && Bm && ws && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched_nt: bad arguments");
   PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched_nt: operand larger than a buffer descriptor");
   WgArgs a;
@@ -1717,7 +1722,7 @@ extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, 
   a.K = C; a.N = P; a.HoWo = P; a.HW = P; a.xbytes = C * P * 4; a.dybytes = M * P * 4; a.xz = C * P;
   a.ngroup = 0;
   a.seg.nseg = 0;
-  const WgPlan p = plan_batched_nt(M, C, P, nb);
+  const WgPlan p = plan_batched_nt(opts, M, C, P, nb);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   launch_wgrad<1, PRN_IN_ZERO>(a, p, (hipStream_t)stream, nb);
   PRN_CHECK_LAUNCH("prn_gemm_batched_nt");

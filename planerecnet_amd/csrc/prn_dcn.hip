@@ -424,7 +424,8 @@ int data_ws_layout(const prn_dcn_desc* d, DataWs& l) {
   auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
   prn_conv_desc& g = l.g;                                  // dcols[9C x N] = wt[9C x M] * dy[M x N]: a 1x1 convolution of dy
   g.B = d->B; g.C = d->M; g.H = d->Ho; g.W = d->Wo; g.M = d->C * 9; g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.Ho = d->Ho; g.Wo = d->Wo;
-  g.in_mode = PRN_IN_ZERO; g.dil = 1; g.epilogue = PRN_EPI_NONE; g.ystride = 0; g.yH = g.yW = 0;
+  g.in_mode = PRN_IN_ZERO; g.dil = 1; g.epilogue = PRN_EPI_NONE; g.ystride = 0; g.yH = g.yW = 0; g.reserved = 0;
+  g.opts = d->opts;
   const int64_t gb = prn_conv2d_fwd_ws_bytes(&g);
   if (gb < 0) return 2;
   if ((int64_t)d->B * 9 * d->H * d->W >= (1LL << 31) || (int64_t)d->B * 36 * d->Ho * d->Wo >= (1LL << 31)) { prn_set_error("prn_dcnv2_bwd: map too large"); return 2; }
@@ -449,15 +450,15 @@ extern "C" int64_t prn_dcnv2_bwd_ws_bytes(const prn_dcn_desc* d) {
   return l.total;
 }
 
-extern "C" int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx, void* ws,
-                                   void* stream) {
-  return prn_dcnv2_bwd_input_phase(d, dy, wt, offset, mask, dx, ws, stream, 0);
+extern "C" int prn_dcnv2_bwd_input(const prn_dcn_desc* d, const float* dy, const float* wt, const void* wt_images, const float* offset, const float* mask,
+                                   float* dx, void* ws, void* stream) {
+  return prn_dcnv2_bwd_input_phase(d, dy, wt, wt_images, offset, mask, dx, ws, stream, 0);
 }
 
 // phase 0: everything; 1 / 2: the column-gradient GEMM W^T dy (launch / its K-split sum); 3: the CSR gather of dx from the column
 // gradient already in ws (profiler brackets: each launch timed on its own, nothing issued twice)
-extern "C" int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy, const float* wt, const float* offset, const float* mask, float* dx,
-                                         void* ws, void* stream, int phase) {
+extern "C" int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy, const float* wt, const void* wt_images, const float* offset, const float* mask,
+                                         float* dx, void* ws, void* stream, int phase) {
   if (int e = check_dcn_desc(d, "prn_dcnv2_bwd_input")) return e;
   PRN_REQUIRE(dy && wt && offset && ws, "prn_dcnv2_bwd_input: null tensor");
   PRN_REQUIRE(phase >= 0 && phase <= 3, "prn_dcnv2_bwd_input: bad phase");
@@ -465,7 +466,7 @@ extern "C" int prn_dcnv2_bwd_input_phase(const prn_dcn_desc* d, const float* dy,
   if (int e = data_ws_layout(d, l)) return e;
   char* wsb = (char*)ws;
   if (phase <= 2)
-    if (int e = prn_conv2d_fwd_phase(&l.g, dy, wt, nullptr, nullptr, (float*)(wsb + l.dcols), wsb + l.gemm, stream, phase)) return e;
+    if (int e = prn_conv2d_fwd_counted(&l.g, dy, wt, wt_images, nullptr, nullptr, (float*)(wsb + l.dcols), wsb + l.gemm, nullptr, stream, phase)) return e;
   if (dx == nullptr || phase == 1 || phase == 2) return 0;   // (dx == NULL: column gradient only, the caller just wants prn_dcnv2_bwd_offset_mask)
   const BwdWs bl = bwd_ws_layout(d->B, d->C, d->H, d->W, d->Ho, d->Wo);
   return launch_dx(desc_view(d, offset, mask), (const float*)(wsb + l.dcols), dx, wsb + l.rest, bl, d->B, d->C, d->H, d->W, d->Ho, d->Wo, d->stride,

@@ -452,7 +452,7 @@ FPlan plan_dcn_fwd(int M, int N, int K) {
 }
 
 struct WPlan { int tm, tilesM, tilesJ, splits, chunks; };
-WPlan plan_dcn_wgrad(int M, int K, int N) {
+WPlan plan_dcn_wgrad(const prn_gemm_opts& o, int M, int K, int N) {
   static int forced[2] = {-1, 0};                        // PRN_DCN_WGRAD="tm,splits"
   if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_WGRAD")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
   WPlan p;
@@ -463,10 +463,7 @@ WPlan plan_dcn_wgrad(int M, int K, int N) {
   const int tiles = p.tilesM * p.tilesJ;
   const int slots = 256 * (p.tm == 1 ? 4 : (p.tm == 2 ? 3 : 2));
   int s = tiles < slots ? 2 * slots / tiles : 1;
-  if (const char* wenv = getenv("PRN_WGRAD_WGS")) {         // deferred to the side stream: see plan_wgrad in prn_conv.hip
-    const int wtot = atoi(wenv);
-    if (wtot > 0) s = tiles < wtot ? wtot / tiles : 1;
-  }
+  if (o.wgrad_wgs > 0) s = tiles < o.wgrad_wgs ? o.wgrad_wgs / tiles : 1;     // deferred to the side stream: see plan_wgrad in prn_conv.hip
   int cap = p.chunks / 8 > 0 ? p.chunks / 8 : 1;          // at least 128 pixels per split
   const int sbw = (int)(0.0035 * (double)N) > 1 ? (int)(0.0035 * (double)N) : 1;   // workspace round trip stays small
   if (sbw < cap) cap = sbw;
@@ -501,7 +498,6 @@ extern "C" int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const
 
 extern "C" int64_t prn_dcnv2_fwd_ws_bytes(const prn_dcn_desc* d) {
   if (check_dcn(d, "prn_dcnv2_fwd_ws_bytes")) return -1;
-  if (const int ss = prn_split_dcn_plan(d->M, d->C * 9, d->B * d->Ho * d->Wo)) return prn_split_dcn_ws_bytes(d->M, d->C * 9, d->B, d->Ho * d->Wo, ss);
   const FPlan p = plan_dcn_fwd(d->M, d->B * d->Ho * d->Wo, d->C * 9);
   return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
@@ -510,10 +506,6 @@ extern "C" int prn_dcnv2_fwd_phase(const prn_dcn_desc* d, const float* x, const 
                                    void* stream, int phase) {
   if (int e = check_dcn(d, "prn_dcnv2_fwd")) return e;
   PRN_REQUIRE(x && table && w && y, "prn_dcnv2_fwd: null tensor");
-  if (ws != nullptr) {                                       // the sampler as operand loader of the fp16-piece split GEMM (prn_gemm_split.hip)
-    if (const int ss = prn_split_dcn_plan(d->M, d->C * 9, d->B * d->Ho * d->Wo))
-      return prn_split_dcn_fwd(w, x, table, bias, y, ws, d->B, d->C, d->H * d->W, d->M, d->Ho * d->Wo, npad(d) / 16, d->epilogue, ss, (hipStream_t)stream, phase);
-  }
   FwdArgs a;
   a.x = x; a.w = w; a.bias = bias; a.tab = (const float4*)table; a.y = y; a.ws = (float*)ws;
   a.B = d->B; a.C = d->C; a.HW = d->H * d->W; a.M = d->M; a.K = d->C * 9; a.HoWo = d->Ho * d->Wo; a.N = d->B * a.HoWo;
@@ -547,7 +539,7 @@ extern "C" int prn_dcnv2_fwd(const prn_dcn_desc* d, const float* x, const void* 
 
 extern "C" int64_t prn_dcnv2_bwd_weight_ws_bytes(const prn_dcn_desc* d) {
   if (check_dcn(d, "prn_dcnv2_bwd_weight_ws_bytes")) return -1;
-  const WPlan p = plan_dcn_wgrad(d->M, d->C * 9, d->B * d->Ho * d->Wo);
+  const WPlan p = plan_dcn_wgrad(d->opts, d->M, d->C * 9, d->B * d->Ho * d->Wo);
   return p.splits > 1 ? (int64_t)p.splits * d->M * d->C * 9 * 4 : 0;
 }
 
@@ -559,7 +551,7 @@ extern "C" int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x,
   a.x = x; a.dy = dy; a.tab = (const float4*)table;
   a.B = d->B; a.C = d->C; a.HW = d->H * d->W; a.M = d->M; a.K = d->C * 9; a.HoWo = d->Ho * d->Wo; a.N = d->B * a.HoWo;
   a.xbytes = d->B * d->C * a.HW * 4; a.dybytes = d->B * d->M * a.HoWo * 4; a.tabbytes = (int)((int64_t)npad(d) * 9 * 32);
-  const WPlan p = plan_dcn_wgrad(a.M, a.K, a.N);
+  const WPlan p = plan_dcn_wgrad(d->opts, a.M, a.K, a.N);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_dcnv2_bwd_weight: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;

@@ -16,10 +16,6 @@
 // operand with 16 dword buffer loads per slice (rows beyond K read 0: the row is part of the VGPR offset, which the descriptor's range check sees), splits it in registers (5.5 VALU
 // per element, under the MFMAs of the slice before) and feeds the pieces straight to the matrix pipe.  One barrier per slice.
 #include "prn_common.h"
-#include <stdlib.h>
-#include <string.h>
-#include <map>
-#include <mutex>
 
 namespace {
 
@@ -375,155 +371,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
-// ---- DCNv2 forward on the fp16 pieces: the bilinear 4-corner gather of torchvision.ops.deform_conv2d IS the activation-side operand loader --------
-// Y[M x N] = W[M x 9C] * cols[9C x N], cols[(c, t), n] = sum_q wt[t, n, q] * x[c, off[t, n, q]] (prn_dcnv2.hip has the gather table: per (pixel, tap) two
-// byte offsets of horizontal pixel pairs and four weights).  Same skeleton as split16_gemm_kernel: weight images by LDS-DMA, a lane owns one output
-// pixel and eight consecutive k = (c, t) of it per MFMA step; instead of loading x[k][n] it gathers the two pixel pairs of (c, t) -- the table rows of the
-// workgroup's 128 pixels live in LDS (27 KB) --, blends them, and cuts the sample into two fp16 pieces under the column's running scale.  Gathers of the
-// next MFMA step are in flight during the current one (two register sets).  K = 9C must be a multiple of 32.
-struct Dcn16Args {
-  const uint4* img; const int* ex; const float* x; const float4* tab; const float* bias; float* y; float* partial;
-  int M, K, HW, HoWo, N, nchunks, epi, mtiles, kslices, ntiles, total, splits, xbytes;
-  long long slice;                // elements of one partial slice: B * M * HoWo
-};
-constexpr int DCN_TAB_CHUNK4 = 9 * 2 * 16;     // float4 per 16-pixel chunk of the gather table (prn_dcnv2.hip: TAB_CHUNK4)
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void split16_dcn_kernel(const Dcn16Args a) {
-  __shared__ uint4 lds[2 * IMG16_U4];
-  __shared__ uint2 toff[9 * 128];
-  __shared__ float4 twt[9 * 128];
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int id = prn_xcd_remap(blockIdx.x, a.total);
-  const int mt = id % a.mtiles, nt = id / a.mtiles;
-  const int sp = blockIdx.y;
-  const int ks0 = (int)((long long)a.kslices * sp / a.splits), ks1 = (int)((long long)a.kslices * (sp + 1) / a.splits);
-  const int M = a.M, HW4 = a.HW * 4;
-  const int r = lane & 31, gs = lane >> 5;
-  const int pxl = wave * 32 + r;                                 // this lane's pixel inside the tile
-  const int n = nt * 128 + pxl;
-  {  // gather-table rows of the tile's 128 pixels: eight 16-pixel chunks, [tap][pixel] in LDS
-    const float4* tg = a.tab + (size_t)(nt * 8) * DCN_TAB_CHUNK4;
-    for (int i = t; i < 8 * DCN_TAB_CHUNK4; i += 256) {
-      const int cl = i / DCN_TAB_CHUNK4, q = i - cl * DCN_TAB_CHUNK4, tp = q >> 5, sx = (q >> 4) & 1, pp = q & 15;
-      const bool ok = nt * 8 + cl < a.nchunks;
-      const float4 v = ok ? tg[i] : make_float4(__uint_as_float(0x80000000u), __uint_as_float(0x80000000u), 0.f, 0.f);
-      if (sx) twt[tp * 128 + cl * 16 + pp] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      else toff[tp * 128 + cl * 16 + pp] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
-    }
-  }
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.xbytes, 0x00020000);
-  const uint4* ag = a.img + ((long long)mt * a.kslices) * IMG16_U4;
-  const i32x4_t adesc = make_desc(ag, (unsigned)a.kslices * IMG16_U4 * 16u);
-  const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
-  float2 ga[8][2], gb[8][2];       // gathered pixel pairs of the next two MFMA steps
-  f16x8_t p0[2], p1[2];            // pieces (h, l) of MFMA step 0 / 1
-  int erun = -1000, de = 0;
-#define D16_DMA(ks_, st_) do { \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-      lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \
-  } while (0)
-  // the eight k of MFMA step u of slice ks: k = ks * 32 + (2u + gs) * 8 + j = 9 c + tp
-#define D16_GATHER(g_, ks_, u_) do { \
-    const int kb = (ks_) * BK + (2 * (u_) + gs) * 8; \
-    int c = kb / 9, tp = kb - 9 * c; \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
-      const uint2 o = toff[tp * 128 + pxl]; \
-      const unsigned co = (unsigned)(c * HW4); \
-      const f32x2_t q0 = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(o.x + co), 0, 0)); \
-      const f32x2_t q1 = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(o.y + co), 0, 0)); \
-      g_[j][0] = make_float2(q0.x, q0.y); g_[j][1] = make_float2(q1.x, q1.y); \
-      ++tp; if (tp == 9) { tp = 0; ++c; } \
-    } } while (0)
-#define D16_PIECES(pc_, g_, ks_, u_) do { \
-    const int kb = (ks_) * BK + (2 * (u_) + gs) * 8; \
-    int tp = kb % 9; \
-    float v[8]; float mx = 0.f; \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
-      const float4 w4 = twt[tp * 128 + pxl]; \
-      v[j] = (w4.x * g_[j][0].x + w4.y * g_[j][0].y) + (w4.z * g_[j][1].x + w4.w * g_[j][1].y); \
-      mx = fmaxf(mx, fabsf(v[j])); \
-      ++tp; if (tp == 9) tp = 0; \
-    } \
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); \
-    const int en = max(erun, mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : -200); \
-    de += erun - en; erun = en; \
-    const int sh = 14 - en; \
-    uint4 h, l; \
-    split2_f16(ldexpf(v[0], sh), ldexpf(v[1], sh), h.x, l.x); split2_f16(ldexpf(v[2], sh), ldexpf(v[3], sh), h.y, l.y); \
-    split2_f16(ldexpf(v[4], sh), ldexpf(v[5], sh), h.z, l.z); split2_f16(ldexpf(v[6], sh), ldexpf(v[7], sh), h.w, l.w); \
-    pc_[0] = __builtin_bit_cast(f16x8_t, h); pc_[1] = __builtin_bit_cast(f16x8_t, l); \
-  } while (0)
-#define D16_RESCALE() do { \
-    if (__builtin_amdgcn_ballot_w64(de != 0) != 0ull) { \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][e] = ldexpf(acc[i][e], de); \
-    } \
-    de = 0; } while (0)
-#define D16_STEP(pc_, u_) do { \
-    const int kg = 2 * (u_) + gs; \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
-      const uint4* ap = lds + st * IMG16_U4 + kg * 128 + i * 32 + r; \
-      const f16x8_t ah = __builtin_bit_cast(f16x8_t, ap[0]), al = __builtin_bit_cast(f16x8_t, ap[512]); \
-      f32x16_t c = acc[i]; \
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, pc_[0], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pc_[1], c, 0, 0, 0); \
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pc_[0], c, 0, 0, 0); \
-      acc[i] = c; \
-    } } while (0)
-  f32x16_t acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-  __syncthreads();                                               // the table is in LDS
-  D16_DMA(ks0, 0);
-  D16_GATHER(ga, ks0, 0);
-  D16_GATHER(gb, ks0, 1);
-  D16_PIECES(p0, ga, ks0, 0);
-  de = 0;                                                        // nothing accumulated yet
-  for (int ks = ks0; ks < ks1; ++ks) {
-    const int st = (ks - ks0) & 1;
-    const bool more = ks + 1 < ks1;
-    const int kn = more ? ks + 1 : ks;
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // this slice's LDS-DMA is older than the 16 gathers of `gb` that may still be in flight
-    __syncthreads();
-    D16_RESCALE();
-    if (more) D16_DMA(ks + 1, st ^ 1);
-    D16_GATHER(ga, kn, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    D16_STEP(p0, 0);
-    D16_PIECES(p1, gb, ks, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    D16_RESCALE();
-    D16_GATHER(gb, kn, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    D16_STEP(p1, 1);
-    if (more) D16_PIECES(p0, ga, ks + 1, 0);
-  }
-#undef D16_DMA
-#undef D16_GATHER
-#undef D16_PIECES
-#undef D16_RESCALE
-#undef D16_STEP
-  if (n >= a.N) return;
-  const int bb = n / a.HoWo, pp = n - bb * a.HoWo;
-  const int* exm = a.ex + mt * 128;
-  float* ob = (a.splits > 1 ? a.partial + (long long)sp * a.slice : a.y) + (long long)bb * M * a.HoWo + pp;
-  const bool fin = a.splits == 1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rl = i * 32 + gs * 4 + (e >> 2) * 8 + (e & 3), row = mt * BM + rl;
-      if (row >= M) continue;
-      float v = ldexpf(acc[i][e], erun + exm[rl] - 28);
-      if (fin) {
-        if (a.bias) v += a.bias[row];
-        if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
-      }
-      ob[(long long)row * a.HoWo] = v;
-    }
-}
-
 // one launch for many weights: item i covers blocks [first_i, first_{i+1}) of 256 threads = 256 (z, m tile, k slice, k group, row) tuples
 struct PrepItem { const float* src; uint4* dst; int M, K, nz, pad; long long zw; long long first; };   // zw: first block of four rows (fp16 row pass); weights are dense
 __global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items, int n) {
@@ -593,55 +440,17 @@ __global__ void split16_prepare_batched_kernel(const PrepItem* __restrict__ item
   o[g * 128 + r] = h; o[(4 + g) * 128 + r] = l;
 }
 
-// weight pointer -> images the caller keeps current (prn_split_images_register): launches on such a weight skip the per-call split
-struct RegEntry { const void* images; int M, K, nz, kind; };
-std::map<const void*, RegEntry> g_registry;
-std::mutex g_registry_mu;
-const void* registered_images(const float* w, int M, int K, int nz, int knd) {
-  std::lock_guard<std::mutex> lock(g_registry_mu);
-  auto it = g_registry.find((const void*)w);
-  if (it == g_registry.end() || it->second.M != M || it->second.K != K || it->second.nz != nz || it->second.kind != knd) return nullptr;
-  return it->second.images;
-}
-
-// Launches with fewer 128 x 128 tiles than this keep the fp32 kernel.  300 is where the split kernel starts to win launch by launch; the
-// DEFAULT is 2500 because of what the board does, not the kernel: with the split kernel on every launch it wins (214 of 296 plain-GEMM
-// launches of a PlaneRecNet_101 training step) the firmware lowers the shader clock from 2.35 to 2.17-2.20 GHz for the WHOLE step (socket
-// power falls 1.2 -> 1.05-1.1 kW at the same time: a current / di-dt limit of the bf16 matrix pipe, not the 1.4 kW cap), and every other
-// kernel pays 7 %: 50.5 -> 51.5 ms per step on three boxes (tools/smi_ab.sh, profiles/r03_c_*).  Restricted to the big launches the clock
-// stays (2.33-2.34 GHz) and the step gains 0.3 %; at inference (no weight-gradient stream beside it, 0.85-1.05 kW) the low threshold is
-// the better one (high-resolution workload +4 %) -- planerecnet_amd.ops.split_gemm_policy() switches it with the model's train() / eval().
-int g_min_tiles = -1;
-int min_tiles() {
-  if (g_min_tiles < 0) { const char* e = getenv("PRN_SPLIT_MIN_TILES"); g_min_tiles = e ? atoi(e) : 2500; }
-  return g_min_tiles;
-}
-// PRN_SPLIT_KIND: "f16" (default) = fp16 pieces, two per operand, three products, operands scaled into fp16's range by exact powers of two;
-// "bf16" = bf16 pieces, three per operand, six products, no scaling needed (bf16 has fp32's exponent range).  Same error on the network's
-// tensors (both at the fp32 MFMA's level); the bf16 form keeps it for ANY operands, the fp16 form loses relative precision on elements more
-// than 2^17 below their row's / column's largest (max error 1e-5 instead of 1e-6 of sum|a||b| on log-normal operands spanning 12 decades).
-// Half the matrix-pipe work buys little per launch (the kernel is bound by its L2 stream, not by the pipe: 48 vs 49 us on 256->1024
-// @30x40) but the firmware takes less clock for it: the 960-pixel inference workload 236 (f16) / 228 (bf16) / 221 (fp32 only) img/s.
-int g_kind = -1;
-int kind() {
-  if (g_kind < 0) { const char* e = getenv("PRN_SPLIT_KIND"); g_kind = (e && !strcmp(e, "bf16")) ? 0 : 16; }
-  return g_kind;
-}
-int g_mode = -1;       // PRN_SPLIT_GEMM: 0 = off (fp32 MFMA everywhere), 1 = where the plan says so (default), 2 = wherever the kernel applies
-int mode() {
-  if (g_mode < 0) { const char* e = getenv("PRN_SPLIT_GEMM"); g_mode = e ? atoi(e) : 1; }
-  return g_mode;
-}
-
 }  // namespace
 
 // ---- internal interface (prn_common.h) ------------------------------------------------------------------------------------------------
-// Should y[nz][B][M][HW] = w[nz][M][K] * x[nz][B][K][HW] run on the split kernel, and with how many K splits?  0 = no.
+// Should y[nz][B][M][HW] = w[nz][M][K] * x[nz][B][K][HW] run on the split kernel under `o`, and with how many K splits?  0 = no.
 // Plan (tools/native/gemm_split_lab on the step's shapes): the kernel wins where at least ~300 of its 128 x 128 tiles exist and the last
 // m tile is more than half full; short of tiles, a K split of 2 .. 4 fills the GPU as long as every split keeps >= 8 slices.
-int prn_split_gemm_plan(int M, int K, int B, int HW, int nz) {
-  const int md = mode();
-  if (md == 0) return 0;
+// The threshold (split_min_tiles) is a BOARD-level trade the caller makes: broad use of the 16-bit pipe makes the firmware lower the
+// shader clock for everything else (bf16 pieces: 2.35 -> 2.17 GHz over a training step, fp16 pieces: -> 2.25 GHz).
+int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts* o) {
+  if (o == nullptr || o->split_mode == PRN_SPLIT_OFF) return 0;
+  if (M <= 0 || K <= 0 || B <= 0 || HW <= 0 || nz <= 0) return 0;
   if ((int64_t)K * HW >= (1LL << 29) || (int64_t)M * HW >= (1LL << 29)) return 0;
   const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32);
   const int64_t tiles = (int64_t)mtiles * cdiv(HW, 128) * B * nz;
@@ -652,21 +461,25 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz) {
     if (splits > 4) splits = 4;
     if (splits < 1) splits = 1;
   }
-  if (md == 2) return splits;
+  if (o->split_mode == PRN_SPLIT_ALWAYS) return splits;
   if (M % 128 != 0 && M % 128 <= 64) return 0;
-  static double min_flops = -1.;                                 // PRN_SPLIT_MIN_GFLOP (tuning)
-  if (min_flops < 0.) { const char* e = getenv("PRN_SPLIT_MIN_GFLOP"); min_flops = (e ? atof(e) : 4.0) * 1e9; }
-  if (2.0 * M * K * (double)HW * B * nz < min_flops) return 0;   // small launches are all launch latency: one kernel beats split + GEMM (+ sum)
-  if (tiles * splits < min_tiles()) return 0;
+  if (2.0 * M * K * (double)HW * B * nz < (double)o->split_min_gflop * 1e9) return 0;   // small launches are all launch latency: one kernel beats split + GEMM (+ sum)
+  if (tiles * splits < o->split_min_tiles) return 0;
   return splits;
+}
+extern "C" void prn_gemm_opts_default(prn_gemm_opts* o) {
+  if (!o) return;
+  o->split_mode = PRN_SPLIT_PLAN; o->split_kind = PRN_PIECES_F16; o->split_products = 3; o->split_min_tiles = 300; o->split_min_gflop = 4.0f;
+  o->wgrad_wgs = 0; o->wgrad_target = 0; o->reserved = 0;
 }
 extern "C" int64_t prn_split_images_bytes(int M, int K, int nz) {
   if (M <= 0 || K <= 0 || nz <= 0) return -1;
   return prn_split_gemm_image_bytes(M, K, nz);
 }
-extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, int64_t total_row_blocks, void* stream) {
+extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int64_t total_blocks, int64_t total_row_blocks, int kind, void* stream) {
   PRN_REQUIRE(items_dev && n_items > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "prn_split_prepare_batched: bad arguments");
-  if (kind() == 16) {
+  PRN_REQUIRE(kind == PRN_PIECES_F16 || kind == PRN_PIECES_BF16, "prn_split_prepare_batched: kind is PRN_PIECES_F16 or PRN_PIECES_BF16");
+  if (kind == PRN_PIECES_F16) {
     PRN_REQUIRE(total_row_blocks > 0 && total_row_blocks < (1LL << 31), "prn_split_prepare_batched: the fp16 piece format needs the row-block count");
     hipLaunchKernelGGL(split16_rowmax_batched_kernel, dim3((unsigned)total_row_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n_items);
     hipLaunchKernelGGL(split16_prepare_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n_items);
@@ -677,13 +490,12 @@ extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int
   PRN_CHECK_LAUNCH("prn_split_prepare_batched");
   return 0;
 }
-// cuts ONE dense weight [nz][M][K] into images of the current piece format (prn_split_images_bytes bytes)
-extern "C" int prn_split_prepare(const float* w, void* images, int M, int K, int nz, void* stream) {
-  PRN_REQUIRE(w && images && M > 0 && K > 0 && nz > 0 && (reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_prepare: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+// cuts w[nz][M][K] (z stride zw) into `images` in the given piece format
+int cut_weight(const float* w, void* images, int M, int K, int nz, long long zw, int kind, hipStream_t st, const char* who) {
   const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32);
-  const long long ptotal = (long long)nz * mtiles * kslices * 512, zw = (long long)M * K;
-  if (kind() == 16) {
+  const long long ptotal = (long long)nz * mtiles * kslices * 512;
+  if (kind == PRN_PIECES_F16) {
     int* ex = (int*)((char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
     const long long rows = (long long)nz * mtiles * 128;
     hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, zw, mtiles * 128, rows);
@@ -691,161 +503,62 @@ extern "C" int prn_split_prepare(const float* w, void* images, int M, int K, int
   } else {
     hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, zw, mtiles, kslices, ptotal);
   }
-  PRN_CHECK_LAUNCH("prn_split_prepare");
+  PRN_CHECK_LAUNCH(who);
   return 0;
 }
-extern "C" int prn_split_images_register(const float* w, const void* images, int M, int K, int nz) {
-  PRN_REQUIRE(w != nullptr, "prn_split_images_register: null weight");
-  std::lock_guard<std::mutex> lock(g_registry_mu);
-  if (images == nullptr) { g_registry.erase((const void*)w); return 0; }
-  PRN_REQUIRE(M > 0 && K > 0 && nz > 0 && (reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_images_register: bad arguments");
-  g_registry[(const void*)w] = RegEntry{images, M, K, nz, kind()};
-  return 0;
+}  // namespace
+// cuts ONE dense weight [nz][M][K] into images of the given piece format (prn_split_images_bytes bytes)
+extern "C" int prn_split_prepare(const float* w, void* images, int M, int K, int nz, int kind, void* stream) {
+  PRN_REQUIRE(w && images && M > 0 && K > 0 && nz > 0 && (reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_prepare: bad arguments");
+  PRN_REQUIRE(kind == PRN_PIECES_F16 || kind == PRN_PIECES_BF16, "prn_split_prepare: kind is PRN_PIECES_F16 or PRN_PIECES_BF16");
+  return cut_weight(w, images, M, K, nz, (long long)M * K, kind, (hipStream_t)stream, "prn_split_prepare");
 }
-extern "C" int prn_split_gemm_min_tiles(int n) {
-  const int old = min_tiles();
-  if (n >= 0) g_min_tiles = n;
-  return old;
-}
-extern "C" int prn_split_gemm_kind(int k) {
-  const int old = kind();
-  if (k == 0 || k == 16) g_kind = k;
-  return old;
-}
-extern "C" int prn_split_gemm_mode(int m) {
-  const int old = mode();
-  if (m >= 0) g_mode = m;
-  return old;
-}
-extern "C" int prn_gemm_pipe(int M, int K, int B, int HW, int nz) {
-  if (M <= 0 || K <= 0 || B <= 0 || HW <= 0 || nz <= 0) return 0;
-  return prn_split_gemm_plan(M, K, B, HW, nz);
+extern "C" int prn_gemm_pipe(int M, int K, int B, int HW, int nz, const prn_gemm_opts* opts) {
+  return prn_split_gemm_plan(M, K, B, HW, nz, opts);
 }
 // (the larger of the two kinds' images, plus the fp16 kind's row exponents behind them)
 int64_t prn_split_gemm_image_bytes(int M, int K, int nz) { return (int64_t)nz * cdiv(M, 128) * cdiv(K, 32) * IMG_U4 * 16 + (int64_t)nz * cdiv(M, 128) * 128 * 4; }
 int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits) { return splits > 1 ? (int64_t)splits * nz * B * M * HW * 4 : 0; }
 
-// images: prn_split_gemm_image_bytes; partial: prn_split_gemm_partial_bytes (splits > 1).  zw / zx / zy: element strides per z.
+// w_images: current images of w handed in by the caller (nullptr: cut w into images_ws first).  partial: prn_split_gemm_partial_bytes
+// (splits > 1).  zw / zx / zy: element strides per z.
 // phase: 0 = everything, 1 = the split + GEMM launches only, 2 = the K-split sum only (profiler brackets, like prn_conv2d_fwd_phase).
-int prn_split_gemm(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images, float* partial, int M, int K, int B, int HW,
-                   int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, hipStream_t st, int phase) {
-  PRN_REQUIRE(w && x && y && (splits == 1 || partial), "prn_split_gemm: null operand");
-  PRN_REQUIRE((reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_gemm: images must be 16-byte aligned");
+int prn_split_gemm(const float* w, const void* w_images, const float* x, const float* bias, const float* addend, float* y, void* images_ws, float* partial, int M,
+                   int K, int B, int HW, int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, const prn_gemm_opts* o, hipStream_t st, int phase) {
+  PRN_REQUIRE(o != nullptr && w && x && y && (splits == 1 || partial), "prn_split_gemm: null operand");
   const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32), ptiles = cdiv(HW, 128);
   PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)K * HW < (1LL << 29), "prn_split_gemm: operand larger than a buffer descriptor");
-  const long long ptotal = (long long)nz * mtiles * kslices * 512;
-  if (kind() == 16) {
-    if (phase != 2) {
-      const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz, 16) : nullptr;
-      if (reg) images = const_cast<void*>(reg);                    // cut by the caller since the weight last changed
-      PRN_REQUIRE(images != nullptr, "prn_split_gemm: no workspace for the weight images");
-      int* ex = (int*)((char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
-      if (!reg) {
-        const long long rows = (long long)nz * mtiles * 128;
-        hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, (long long)zw, mtiles * 128, rows);
-        hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, (long long)zw, mtiles, kslices, ptotal);
-        PRN_CHECK_LAUNCH("prn_split_gemm/prepare16");
-      }
+  const int kind = o->split_kind;
+  PRN_REQUIRE(kind == PRN_PIECES_F16 || kind == PRN_PIECES_BF16, "prn_split_gemm: unknown piece format %d", kind);
+  if (phase != 2) {
+    const void* images = w_images;
+    if (images == nullptr) {
+      PRN_REQUIRE(images_ws != nullptr, "prn_split_gemm: no workspace for the weight images");
+      if (int e = cut_weight(w, images_ws, M, K, nz, (long long)zw, kind, st, "prn_split_gemm/prepare")) return e;
+      images = images_ws;
+    }
+    PRN_REQUIRE((reinterpret_cast<uintptr_t>(images) & 15) == 0, "prn_split_gemm: images must be 16-byte aligned");
+    if (kind == PRN_PIECES_F16) {
       Split16Args a;
-      a.img = (const uint4*)images; a.ex = ex; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
+      a.img = (const uint4*)images; a.ex = (const int*)((const char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
+      a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
       a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
       a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
-      static int np = -1;
-      if (np < 0) { const char* e = getenv("PRN_SPLIT16_PRODUCTS"); np = e ? atoi(e) : 3; }
-      if (np >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);
+      if (o->split_products >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(split16_gemm_kernel<3>, dim3(a.total, splits), dim3(256), 0, st, a);
       PRN_CHECK_LAUNCH("prn_split_gemm/f16");
+    } else {
+      SplitArgs a;
+      a.img = (const uint4*)images; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
+      a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
+      a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
+      hipLaunchKernelGGL(split_gemm_kernel, dim3(a.total, splits), dim3(256), 0, st, a);
+      PRN_CHECK_LAUNCH("prn_split_gemm");
     }
-    if (splits > 1 && phase != 1) {
-      PRN_REQUIRE(nz == 1 || (zy == (int64_t)B * M * HW), "prn_split_gemm: K splits need a dense output");
-      return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)nz * B * M * HW, M, HW, splits, epi, st);
-    }
-    return 0;
-  }
-  if (phase != 2) {
-  if (const void* reg = (nz == 1 || zw == (int64_t)M * K) ? registered_images(w, M, K, nz, 0) : nullptr) {
-    images = const_cast<void*>(reg);                               // split by the caller since the weight last changed
-  } else {
-    hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, (long long)zw, mtiles, kslices, ptotal);
-    PRN_CHECK_LAUNCH("prn_split_gemm/prepare");
-  }
-  SplitArgs a;
-  a.img = (const uint4*)images; a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
-  a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
-  a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
-  hipLaunchKernelGGL(split_gemm_kernel, dim3(a.total, splits), dim3(256), 0, st, a);
-  PRN_CHECK_LAUNCH("prn_split_gemm");
   }
   if (splits > 1 && phase != 1) {
     PRN_REQUIRE(nz == 1 || (zy == (int64_t)B * M * HW), "prn_split_gemm: K splits need a dense output");
     return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)nz * B * M * HW, M, HW, splits, epi, st);
   }
-  return 0;
-}
-
-// Device scratch for callers whose entry point has no workspace argument (prn_gemm_batched): one grow-only buffer per stream, so that
-// launches queued on different streams never share images.  nullptr on allocation failure (the caller keeps the fp32 MFMA kernel).
-void* prn_split_scratch(hipStream_t st, int64_t bytes) {
-  struct Buf { void* p; int64_t cap; };
-  static std::map<hipStream_t, Buf> bufs;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  Buf& b = bufs[st];
-  if (b.cap >= bytes) return b.p;
-  if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
-  const int64_t cap = (bytes + (8 << 20) - 1) & ~(int64_t)((8 << 20) - 1);
-  if (hipMalloc(&b.p, cap) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
-  b.cap = cap;
-  return b.p;
-}
-
-// ---- DCNv2 forward on the split kernel (internal, prn_common.h): plan = number of K splits, 0 = keep the fp32 kernel ---------------------------------
-int prn_split_dcn_plan(int M, int K, int N) {
-  if (mode() == 0 || kind() != 16) return 0;
-  // OFF by default (PRN_SPLIT_DCN=1): the launch is bound by the sampler, not by the matrix pipe -- 131 against 141 us on 256 ch @30x40, and two
-  // row tiles sample every pixel twice -- and with it the R101 gradient test (direct-kernel build, K = 2) leaves its bound; kept as an experiment.
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("PRN_SPLIT_DCN"); on = e ? atoi(e) : 0; }
-  if (!on || (K & 31) != 0 || M < 96) return 0;
-  const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128);
-  const int kslices = K / 32;
-  int splits = 1;
-  if (tiles < 400) {
-    splits = (int)(512 / (tiles > 0 ? tiles : 1));
-    if (splits > kslices / 8) splits = kslices / 8;
-    if (splits > 8) splits = 8;
-    if (splits < 1) splits = 1;
-  }
-  return splits;
-}
-int64_t prn_split_dcn_ws_bytes(int M, int K, int B, int HoWo, int splits) {
-  return ((prn_split_gemm_image_bytes(M, K, 1) + 255) & ~255LL) + (splits > 1 ? (int64_t)splits * B * M * HoWo * 4 : 0);
-}
-// table: prn_dcnv2_table's output (nchunks 16-pixel chunks); ws: prn_split_dcn_ws_bytes
-int prn_split_dcn_fwd(const float* w, const float* x, const void* table, const float* bias, float* y, void* ws, int B, int C, int HW, int M, int HoWo, int nchunks,
-                      int epi, int splits, hipStream_t st, int phase) {
-  const int K = C * 9, N = B * HoWo;
-  PRN_REQUIRE(w && x && table && y && ws && (K & 31) == 0, "prn_split_dcn_fwd: bad arguments");
-  const int mtiles = cdiv(M, 128), kslices = K / 32, ntiles = cdiv(N, 128);
-  const int64_t ib = (prn_split_gemm_image_bytes(M, K, 1) + 255) & ~255LL;
-  float* partial = (float*)((char*)ws + ib);
-  if (phase != 2) {
-    const void* reg = registered_images(w, M, K, 1, 16);
-    void* images = reg ? const_cast<void*>(reg) : ws;
-    int* ex = (int*)((char*)images + (int64_t)mtiles * kslices * IMG16_U4 * 16);
-    if (!reg) {
-      const long long rows = (long long)mtiles * 128, ptotal = (long long)mtiles * kslices * 512;
-      hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, (long long)M * K, mtiles * 128, rows);
-      hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, (long long)M * K, mtiles, kslices, ptotal);
-      PRN_CHECK_LAUNCH("prn_split_dcn_fwd/prepare");
-    }
-    Dcn16Args a;
-    a.img = (const uint4*)images; a.ex = ex; a.x = x; a.tab = (const float4*)table; a.bias = bias; a.y = y; a.partial = partial;
-    a.M = M; a.K = K; a.HW = HW; a.HoWo = HoWo; a.N = N; a.nchunks = nchunks; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ntiles = ntiles;
-    a.total = mtiles * ntiles; a.splits = splits; a.xbytes = B * C * HW * 4; a.slice = (long long)B * M * HoWo;
-    hipLaunchKernelGGL(split16_dcn_kernel, dim3(a.total, splits), dim3(256), 0, st, a);
-    PRN_CHECK_LAUNCH("prn_split_dcn_fwd");
-  }
-  if (splits > 1 && phase != 1) return prn_launch_reduce_epilogue(partial, bias, nullptr, y, (int64_t)B * M * HoWo, M, HoWo, splits, epi, st);
   return 0;
 }

@@ -121,9 +121,9 @@ __global__ __launch_bounds__(256) void gt_quarter_masks_kernel(const unsigned ch
   out[i] = (unsigned char)((s + 2) >> 2);
 }
 
-// Philox4x32-10 (Salmon et al., SC'11): counter (i, 0, 0, 0), key (seed lo, seed hi) -> four 32-bit words
-__device__ __forceinline__ void philox(unsigned long long idx, unsigned long long seed, unsigned out[4]) {
-  unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = 0, c3 = 0, k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+// Philox4x32-10 (Salmon et al., SC'11): counter (i lo, i hi, call lo, call hi), key (seed lo, seed hi) -> four 32-bit words
+__device__ __forceinline__ void philox(unsigned long long idx, unsigned long long call, unsigned long long seed, unsigned out[4]) {
+  unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)call, c3 = (unsigned)(call >> 32), k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
   for (int round = 0; round < 10; ++round) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
@@ -140,15 +140,15 @@ __device__ __forceinline__ void philox(unsigned long long idx, unsigned long lon
 __global__ __launch_bounds__(256) void gt_sample_triplets_kernel(const unsigned char* __restrict__ masks, const int* __restrict__ img_first, int Ntot, int nseg,
                                                                  long long HW, const int* __restrict__ segstart, const int* __restrict__ trip_seg,
                                                                  const int* __restrict__ seg_region, const int* __restrict__ seg_img,
-                                                                 const int* __restrict__ ranks, unsigned long long seed, long long n_tot,
-                                                                 int* __restrict__ gid) {
+                                                                 const int* __restrict__ ranks, unsigned long long seed, unsigned long long call,
+                                                                 long long n_tot, int* __restrict__ gid) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_tot) return;
   const int g = trip_seg[t], r = seg_region[g];
   const int* st = segstart + (size_t)r * (nseg + 1);
   const int count = st[nseg];
   unsigned rnd[4];
-  if (!ranks) philox((unsigned long long)t, seed, rnd);
+  if (!ranks) philox((unsigned long long)t, call, seed, rnd);
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     int rank;
@@ -186,23 +186,24 @@ extern "C" int prn_gt_mask_stats(const unsigned char* masks, const int* img_firs
 }
 
 extern "C" int prn_gt_quarter_masks(const unsigned char* masks, unsigned char* out, int N, int H, int W, void* stream) {
-  PRN_REQUIRE(masks && out && N >= 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "prn_gt_quarter_masks: bad arguments (H, W multiples of 4)");
+  PRN_REQUIRE(N >= 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "prn_gt_quarter_masks: bad arguments (H, W multiples of 4)");
   const long long total = (long long)N * (H / 4) * (W / 4);
-  if (total == 0) return 0;
+  if (total == 0) return 0;                                    // (a batch without a single plane: nothing to do, the pointers may be NULL)
+  PRN_REQUIRE(masks && out, "prn_gt_quarter_masks: null tensor");
   hipLaunchKernelGGL(gt_quarter_masks_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, masks, out, total, H, W);
   PRN_CHECK_LAUNCH("prn_gt_quarter_masks");
   return 0;
 }
 
 extern "C" int prn_gt_sample_triplets(const unsigned char* masks, const int* img_first, int B, int Ntot, int H, int W, const int* segstart, const int* trip_seg,
-                                      const int* seg_region, const int* seg_img, const int* ranks, unsigned long long seed, int64_t n_tot, int* gid,
+                                      const int* seg_region, const int* seg_img, const int* ranks, unsigned long long seed, unsigned long long call, int64_t n_tot, int* gid,
                                       void* stream) {
   PRN_REQUIRE(masks && img_first && segstart && trip_seg && seg_region && seg_img && gid && B > 0 && n_tot >= 0, "prn_gt_sample_triplets: bad arguments");
   PRN_REQUIRE((int64_t)B * H * W < (1LL << 31), "prn_gt_sample_triplets: batch too large for 32-bit pixel ids");
   if (n_tot == 0) return 0;
   const int nseg = (int)(((int64_t)H * W) / SEG);
   hipLaunchKernelGGL(gt_sample_triplets_kernel, dim3(cdiv(n_tot, 256)), dim3(256), 0, (hipStream_t)stream, masks, img_first, Ntot, nseg, (long long)H * W, segstart,
-                     trip_seg, seg_region, seg_img, ranks, seed, (long long)n_tot, gid);
+                     trip_seg, seg_region, seg_img, ranks, seed, call, (long long)n_tot, gid);
   PRN_CHECK_LAUNCH("prn_gt_sample_triplets");
   return 0;
 }

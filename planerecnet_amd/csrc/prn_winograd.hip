@@ -409,8 +409,17 @@ int dy_impl(const float* dy, float* Y, const prn_ragged* rg, int B, int M, int H
   return 0;
 }
 
-int fwd_impl(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M,
-             int in_mode, int epilogue, void* stream) {
+int64_t fwd_ws(const prn_ragged* rg, int B, int C, int H, int W, int M, const prn_gemm_opts* opts) {
+  WSeg g;
+  const int64_t P = make_seg(g, rg, B, H, W, "prn_conv3x3_winograd_ws_bytes");
+  if (P < 0 || C <= 0 || M <= 0) return -1;
+  const int64_t P4 = pad4(P);
+  const int64_t gb = prn_gemm_batched_ws_bytes(M, C, (int)P4, 36, opts);
+  return gb < 0 ? -1 : ((4 * 36 * (int64_t)(C + M) * P4 + 255) & ~255LL) + gb;
+}
+
+int fwd_impl(const float* x, const float* U, const void* u_images, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B, int C,
+             int H, int W, int M, int in_mode, int epilogue, const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(ws && U, "prn_conv3x3_winograd: workspace and transformed weights required");
   WSeg g;
   const int64_t P = make_seg(g, rg, B, H, W, "prn_conv3x3_winograd");
@@ -419,22 +428,23 @@ int fwd_impl(const float* x, const float* U, const float* bias, const float* add
   float* V = (float*)ws;
   float* Yt = V + 36 * (int64_t)C * P4;
   if (int e = input_impl(x, V, rg, B, C, H, W, in_mode, stream)) return e;
-  if (int e = prn_gemm_batched(M, C, (int)P4, 36, U, V, Yt, stream)) return e;
+  char* gws = (char*)ws + ((4 * 36 * (int64_t)(C + M) * P4 + 255) & ~255LL);      // (only touched when the split kernel cuts U itself)
+  if (int e = prn_gemm_batched(M, C, (int)P4, 36, U, u_images, V, Yt, prn_gemm_batched_ws_bytes(M, C, (int)P4, 36, opts) > 0 ? gws : nullptr, opts, stream)) return e;
   return output_impl(Yt, bias, addend, y, rg, B, M, H, W, epilogue, stream);
 }
 
-int64_t wgrad_ws(const prn_ragged* rg, int B, int C, int H, int W, int M) {
+int64_t wgrad_ws(const prn_ragged* rg, int B, int C, int H, int W, int M, const prn_gemm_opts* opts) {
   WSeg g;
   const int64_t P = make_seg(g, rg, B, H, W, "prn_winograd_wgrad_ws_bytes");
   if (P < 0) return -1;
   const int64_t P4 = pad4(P);
-  const int splits = prn_gemm_batched_nt_splits(M, C, (int)P4, 36);
+  const int splits = prn_gemm_batched_nt_splits(M, C, (int)P4, 36, opts);
   return 4 * (36 * (int64_t)(C + M) * P4 + (int64_t)splits * 36 * M * C);
 }
 
 // phase: 0 = everything, 1 = transforms of x and dy, 2 = the 36 products, 3 = reduction + G^T . G (profilers bracket them separately)
-int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M, int in_mode, void* stream, int phase,
-               const float* V_in = nullptr) {
+int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int H, int W, int M, int in_mode, const prn_gemm_opts* opts,
+               void* stream, int phase, const float* V_in = nullptr) {
   PRN_REQUIRE(ws && (x || V_in) && dy && dw, "prn_conv3x3_winograd_wgrad: null tensor / workspace");
   WSeg g;
   const int64_t P = make_seg(g, rg, B, H, W, "prn_conv3x3_winograd_wgrad");
@@ -457,9 +467,9 @@ int wgrad_impl(const float* x, const float* dy, float* dw, void* ws, const prn_r
     }
   }
   if (phase == 0 || phase == 2)
-    if (int e = prn_gemm_batched_nt(M, C, (int)P4, 36, Yt, V, part, stream)) return e;
+    if (int e = prn_gemm_batched_nt(M, C, (int)P4, 36, Yt, V, part, opts, stream)) return e;
   if (phase == 0 || phase == 3)
-    return prn_winograd_dw(part, dw, M, C, prn_gemm_batched_nt_splits(M, C, (int)P4, 36), stream);
+    return prn_winograd_dw(part, dw, M, C, prn_gemm_batched_nt_splits(M, C, (int)P4, 36, opts), stream);
   return 0;
 }
 }  // namespace
@@ -480,32 +490,40 @@ extern "C" int prn_winograd_dw(const float* partials, float* dw, int M, int C, i
   return 0;
 }
 
-// x -> V -> (36 GEMMs) -> Y' -> y in one call.  ws: 36 * (C + M) * prn_winograd_tiles(B, H, W) floats.
-extern "C" int prn_conv3x3_winograd(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, int B, int C, int H, int W, int M,
-                                    int in_mode, int epilogue, void* stream) {
-  return fwd_impl(x, U, bias, addend, y, ws, nullptr, B, C, H, W, M, in_mode, epilogue, stream);
+// x -> V -> (36 GEMMs) -> Y' -> y in one call.  ws: prn_conv3x3_winograd_ws_bytes.
+extern "C" int64_t prn_conv3x3_winograd_ws_bytes(int B, int C, int H, int W, int M, const prn_gemm_opts* opts) { return fwd_ws(nullptr, B, C, H, W, M, opts); }
+extern "C" int64_t prn_conv3x3_winograd_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M, const prn_gemm_opts* opts) {
+  return rg ? fwd_ws(rg, B, C, 0, 0, M, opts) : -1;
+}
+extern "C" int prn_conv3x3_winograd(const float* x, const float* U, const void* u_images, const float* bias, const float* addend, float* y, void* ws, int B, int C,
+                                    int H, int W, int M, int in_mode, int epilogue, const prn_gemm_opts* opts, void* stream) {
+  return fwd_impl(x, U, u_images, bias, addend, y, ws, nullptr, B, C, H, W, M, in_mode, epilogue, opts, stream);
 }
 // The same over a ragged batch (prn_ragged: every segment convolved with the same weights; zero padding).
-extern "C" int prn_conv3x3_winograd_ragged(const float* x, const float* U, const float* bias, const float* addend, float* y, void* ws, const prn_ragged* rg, int B,
-                                           int C, int M, int epilogue, void* stream) {
+extern "C" int prn_conv3x3_winograd_ragged(const float* x, const float* U, const void* u_images, const float* bias, const float* addend, float* y, void* ws,
+                                           const prn_ragged* rg, int B, int C, int M, int epilogue, const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(rg, "prn_conv3x3_winograd_ragged: null segment table");
-  return fwd_impl(x, U, bias, addend, y, ws, rg, B, C, 0, 0, M, PRN_IN_ZERO, epilogue, stream);
+  return fwd_impl(x, U, u_images, bias, addend, y, ws, rg, B, C, 0, 0, M, PRN_IN_ZERO, epilogue, opts, stream);
 }
 
 /* ---- weight gradient: dw = G^T [ sum_tiles (A dy A^T) .* (B^T x B) ] G */
-extern "C" int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M) { return wgrad_ws(nullptr, B, C, H, W, M); }
-extern "C" int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M) { return rg ? wgrad_ws(rg, B, C, 0, 0, M) : -1; }
-extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, void* stream,
-                                          int phase) {
-  return wgrad_impl(x, dy, dw, ws, nullptr, B, C, H, W, M, in_mode, stream, phase);
+extern "C" int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M, const prn_gemm_opts* opts) { return wgrad_ws(nullptr, B, C, H, W, M, opts); }
+extern "C" int64_t prn_winograd_wgrad_ragged_ws_bytes(const prn_ragged* rg, int B, int C, int M, const prn_gemm_opts* opts) {
+  return rg ? wgrad_ws(rg, B, C, 0, 0, M, opts) : -1;
+}
+extern "C" int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode,
+                                          const prn_gemm_opts* opts, void* stream, int phase) {
+  return wgrad_impl(x, dy, dw, ws, nullptr, B, C, H, W, M, in_mode, opts, stream, phase);
 }
 // The same with V = B^T x B supplied by the caller (the first 36 * C * P floats of the forward call's workspace, kept alive):
 // the input transform is skipped.
-extern "C" int prn_conv3x3_winograd_wgrad_v(const float* V, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, void* stream) {
+extern "C" int prn_conv3x3_winograd_wgrad_v(const float* V, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, const prn_gemm_opts* opts,
+                                            void* stream) {
   PRN_REQUIRE(V, "prn_conv3x3_winograd_wgrad_v: null V");
-  return wgrad_impl(nullptr, dy, dw, ws, nullptr, B, C, H, W, M, PRN_IN_ZERO, stream, 0, V);
+  return wgrad_impl(nullptr, dy, dw, ws, nullptr, B, C, H, W, M, PRN_IN_ZERO, opts, stream, 0, V);
 }
-extern "C" int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M, void* stream) {
+extern "C" int prn_conv3x3_winograd_wgrad_ragged(const float* x, const float* dy, float* dw, void* ws, const prn_ragged* rg, int B, int C, int M,
+                                                 const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(rg, "prn_conv3x3_winograd_wgrad_ragged: null segment table");
-  return wgrad_impl(x, dy, dw, ws, rg, B, C, 0, 0, M, PRN_IN_ZERO, stream, 0);
+  return wgrad_impl(x, dy, dw, ws, rg, B, C, 0, 0, M, PRN_IN_ZERO, opts, stream, 0);
 }

@@ -84,8 +84,10 @@ class PlaneRecNetLoss(nn.Module):
         cell).  Shared by the host path (prepare_ground_truth) and the device path (targets.DeviceTargetBuilder, which gets the
         statistics from prn_gt_mask_stats)."""
         # numpy SCALARS of the reference's dtypes instead of 0-d tensors (float64 boxes, float32 centres; float32 op float64 -> float64,
-        # a python float next to a float32 stays float32 -- the promotion rules torch applies to the reference's 0-d tensors): the same
-        # IEEE operations in the same precisions, ~20x less host time per instance (the loop was 9 ms per batch of 8 on 0-d tensors)
+        # a python float next to a float32 tensor stays float32 -- the promotion rules torch applies to the reference's 0-d tensors): the same
+        # IEEE operations in the same precisions, ~20x less host time per instance (the loop was 9 ms per batch of 8 on 0-d tensors).
+        # The python-float operands (g, up_w, up_h) are cast to the OTHER operand's dtype explicitly, so the result does not depend on
+        # numpy's scalar promotion rules (NumPy 1.x would promote float32 // python float to float64; NEP 50 does not).
         fh, fw = int(mask_feat_size[0]), int(mask_feat_size[1])
         up_h, up_w = fh * 4, fw * 4
         bx = boxes.numpy() if torch.is_tensor(boxes) else np.asarray(boxes)
@@ -108,11 +110,12 @@ class PlaneRecNetLoss(nn.Module):
                 hw = 0.5 * (bx[i, 2] - bx[i, 0]) * sigma
                 hh = 0.5 * (bx[i, 3] - bx[i, 1]) * sigma
                 cx, cy = cxs[i], cys[i]
-                coord_w, coord_h = int((cx / up_w) // g), int((cy / up_h) // g)
-                top = max(max(0, int(((cy - hh) / up_h) // g)), coord_h - 1)
-                down = min(min(S - 1, int(((cy + hh) / up_h) // g)), coord_h + 1)
-                left = max(coord_w - 1, max(0, int(((cx - hw) / up_w) // g)))
-                right = min(min(S - 1, int(((cx + hw) / up_w) // g)), coord_w + 1)
+                f32, f64 = np.float32, np.float64
+                coord_w, coord_h = int((cx / f32(up_w)) // f32(g)), int((cy / f32(up_h)) // f32(g))     # float32 centre: all float32
+                top = max(max(0, int(((cy - hh) / f64(up_h)) // f64(g))), coord_h - 1)                    # float32 - float64 half extent: float64
+                down = min(min(S - 1, int(((cy + hh) / f64(up_h)) // f64(g))), coord_h + 1)
+                left = max(coord_w - 1, max(0, int(((cx - hw) / f64(up_w)) // f64(g))))
+                right = min(min(S - 1, int(((cx + hw) / f64(up_w)) // f64(g))), coord_w + 1)
                 cate[top:down + 1, left:right + 1] = lab[i]
                 for r in range(top, down + 1):
                     for c in range(left, right + 1):

@@ -15,7 +15,7 @@ import weakref
 import torch
 
 from . import _lib, profiling
-from ._lib import ConvDesc, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
+from ._lib import ConvDesc, GemmOpts, IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1, EPI_NONE, EPI_RELU, EPI_SIGMOID, lib, check
 
 
 _SIDE = {}
@@ -37,20 +37,70 @@ WGRAD_ASYNC = bool(int(os.environ.get("PRN_WGRAD_ASYNC", "0")))
 
 # Workgroups a deferred weight-gradient launch is planned for (see plan_wgrad in csrc/prn_conv.hip): the side stream shares the CUs
 # with the main chain, and a launch that fills every CU's register file stalls the main chain's small kernels.  0: the library's
-# stand-alone plan.  The library reads PRN_WGRAD_WGS per call; the cached workspace sizes depend on it and are dropped on a change.
+# stand-alone plan.  It travels to the library in every call's prn_gemm_opts (wgrad_wgs); cached workspace sizes are keyed by the options.
 WGRAD_WGS_ASYNC = os.environ.get("PRN_WGRAD_WGS_ASYNC", "512")
 
 
-_WGS = [os.environ.get("PRN_WGRAD_WGS")]        # the setting the library currently sees; part of every cached workspace-size key
+# ------------------------------------------------------------------------------------------ execution options (prn_gemm_opts)
+# The library keeps NO state between calls (include/prn.h): which matrix pipe a plain GEMM takes, the piece format, the thresholds and the
+# weight-gradient launch size are this host layer's policy and go into every call -- inside the descriptors or as the `opts` argument.
+# PRN_SPLIT_GEMM: 0 = fp32 MFMA everywhere, 1 = where the plan says so (default), 2 = wherever the split kernel applies.
+# PRN_SPLIT_KIND: f16 (default: two fp16 pieces, three products, power-of-two scaling) / bf16 (three pieces, six products).
+_POLICY = {"split_mode": int(os.environ.get("PRN_SPLIT_GEMM", "1")),
+           "kind": _lib.PIECES_BF16 if os.environ.get("PRN_SPLIT_KIND", "f16") == "bf16" else _lib.PIECES_F16,
+           "products": int(os.environ.get("PRN_SPLIT16_PRODUCTS", "3")),
+           "min_gflop": float(os.environ.get("PRN_SPLIT_MIN_GFLOP", "4.0")),
+           "min_tiles": 300,
+           "wgrad_wgs": int(os.environ.get("PRN_WGRAD_WGS", "0") or 0),
+           "wgrad_target": int(os.environ.get("PRN_WGRAD_TARGET", "0") or 0)}
+_OPTS = {}          # policy tuple -> (GemmOpts, byref)
+_WGS = [None]       # (kept for cache keys: the current options' key)
+
+
+def _opts_entry():
+    key = (_POLICY["split_mode"], _POLICY["kind"], _POLICY["products"], _POLICY["min_tiles"], _POLICY["min_gflop"], _POLICY["wgrad_wgs"], _POLICY["wgrad_target"])
+    e = _OPTS.get(key)
+    if e is None:
+        o = GemmOpts(*key[:4], key[4], key[5], key[6], 0)
+        e = _OPTS[key] = (o, ctypes.byref(o), key)
+    _WGS[0] = key
+    return e
+
+
+def opts_ref():
+    """byref(prn_gemm_opts) of the current policy: the `opts` argument of the entry points that take one."""
+    return _opts_entry()[1]
+
+
+def opts_key():
+    return _opts_entry()[2]
+
+
+def set_split_gemm(mode=None, kind=None, products=None, min_gflop=None, min_tiles=None):
+    """Change this process's split-GEMM policy (tests, tools, bench.py's fp32-only leg); returns the previous values as a dict that can be
+    passed back as keyword arguments.  kind: 'f16' / 'bf16' or the PRN_PIECES_* value."""
+    old = {"mode": _POLICY["split_mode"], "kind": _POLICY["kind"], "products": _POLICY["products"], "min_gflop": _POLICY["min_gflop"],
+           "min_tiles": _POLICY["min_tiles"]}
+    if mode is not None:
+        _POLICY["split_mode"] = int(mode)
+    if kind is not None:
+        _POLICY["kind"] = {"f16": _lib.PIECES_F16, "bf16": _lib.PIECES_BF16}.get(kind, kind)
+    if products is not None:
+        _POLICY["products"] = int(products)
+    if min_gflop is not None:
+        _POLICY["min_gflop"] = float(min_gflop)
+    if min_tiles is not None:
+        _POLICY["min_tiles"] = int(min_tiles)
+        _SPLIT_POLICY.pop("current", None)
+    return old
+
+
+def split_mode():
+    return _POLICY["split_mode"]
 
 
 def _set_wgs(want):
-    if _WGS[0] != want:
-        _WGS[0] = want
-        if want is None:
-            os.environ.pop("PRN_WGRAD_WGS", None)
-        else:
-            os.environ["PRN_WGRAD_WGS"] = want
+    _POLICY["wgrad_wgs"] = int(want) if want else 0
 
 
 def set_wgrad_async(on):
@@ -279,16 +329,17 @@ _DESC = {}        # (shape key) -> (ConvDesc, byref, fwd workspace bytes, wgrad 
 
 
 def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, ystride=0, yH=0, yW=0):
-    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW, _WGS[0])
+    oe = _opts_entry()
+    key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW, oe[2])
     e = _DESC.get(key)
     if e is None:
-        d = ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW)
+        d = ConvDesc(B, C, H, W, M, K, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW, 0, oe[0])
         ref = ctypes.byref(d)
         fb = lib.prn_conv2d_fwd_ws_bytes(ref)
         wb = lib.prn_conv2d_wgrad_ws_bytes(ref) if (mode != IN_DILATED and K != 4 and ystride <= 1) else 0
         if fb < 0 or wb < 0:
             raise RuntimeError(lib.prn_last_error().decode())
-        d.kind = lib.prn_conv2d_kernel_kind(ref)             # 2 / 3: plain GEMM on the bf16-split kernel
+        d.kind = lib.prn_conv2d_kernel_kind(ref)             # 2 / 3: plain GEMM on the split kernel
         e = _DESC[key] = (d, ref, fb, wb)
     return e
 
@@ -317,7 +368,7 @@ def _counters(dev):
 
 def split_products():
     """Piece products the split GEMM kernel issues per fp32 multiply-add (csrc/prn_gemm_split.hip): 3 with the fp16 pieces, 6 with the bf16 ones."""
-    return 3.0 if lib.prn_split_gemm_kind(-1) == 16 else 6.0
+    return float(max(_POLICY["products"], 3)) if _POLICY["kind"] == _lib.PIECES_F16 else 6.0
 
 
 def _gemm_family(M, K, B, HW, nz, flops):
@@ -363,10 +414,7 @@ def split_gemm_policy(which):
     _SPLIT_POLICY["mode"] = which                                # (autograd functions run with grad mode off: this, not torch.is_grad_enabled(), tells training from inference)
     if _SPLIT_POLICY.get("current") != n:
         _SPLIT_POLICY["current"] = n
-        lib.prn_split_gemm_min_tiles(n)
-        _DESC.clear()
-        _PIPE.clear()
-        _DCN.clear()
+        _POLICY["min_tiles"] = n                                 # (descriptor / plan caches are keyed by the options: nothing to drop)
 
 
 def autotune_split_policy(run_step, which, alternatives=None, steps=10, skip=3, rounds=2, margin=0.015, reduce_max=None):
@@ -380,7 +428,7 @@ def autotune_split_policy(run_step, which, alternatives=None, steps=10, skip=3, 
     import time
     base = _SPLIT_POLICY[which]
     alts = [a for a in (alternatives if alternatives is not None else ((300,) if which == "train" else (10 ** 9,))) if a != base]
-    if lib.prn_split_gemm_mode(-1) != 1 or "PRN_SPLIT_MIN_TILES" in os.environ or not alts:
+    if _POLICY["split_mode"] != 1 or "PRN_SPLIT_MIN_TILES" in os.environ or not alts:
         return {"tuned": False, "min_tiles": base}
     times = {n: [] for n in [base] + alts}
     for _ in range(rounds):
@@ -407,10 +455,11 @@ def autotune_split_policy(run_step, which, alternatives=None, steps=10, skip=3, 
 
 
 def gemm_pipe(M, K, B, HW, nz):
-    key = (M, K, B, HW, nz)
+    oe = _opts_entry()
+    key = (M, K, B, HW, nz, oe[2])
     v = _PIPE.get(key)
     if v is None:
-        v = _PIPE[key] = lib.prn_gemm_pipe(int(M), int(K), int(B), int(HW), int(nz))
+        v = _PIPE[key] = lib.prn_gemm_pipe(int(M), int(K), int(B), int(HW), int(nz), oe[1])
     return v
 
 
@@ -428,7 +477,6 @@ def _split_drop(ptr, stamp=True):
     if stamp:
         _STAMP.pop(ptr, None)
     if _SPLIT_IMG.pop(ptr, None) is not None:
-        lib.prn_split_images_register(ctypes.c_void_p(ptr), None, 0, 0, 0)
         _SPLIT_ITEMS[0] = None
 
 
@@ -436,7 +484,9 @@ def _split_state(e):
     """Current content stamp of an entry's operand, or None when its owner is gone."""
     if e.owner is not None:
         o = e.owner()
-        return None if o is None else o._version
+        if o is None or o.data_ptr() != e.ptr:                   # owner gone, or its storage moved (p.data = ..., module.to()): the address may be reused
+            return None
+        return o._version
     return _STAMP.get(e.ptr)
 
 
@@ -453,25 +503,26 @@ def _prep_items(entries, dev):
 
 
 def split_images(t, M, K, nz, cols=None):
-    """Call in front of a launch that takes the split kernel with weight operand t [nz, M, K] (dense): makes sure the library holds
-    current images of t when t persists (a parameter / a view of one / a stamped derived buffer); otherwise the launch cuts t itself.
+    """Call in front of a launch that takes the split kernel with weight operand t [nz, M, K] (dense): returns the device pointer of CURRENT
+    images of t (cut now if needed) when t persists (a parameter / a view of one / a stamped derived buffer) -- the `*_images` argument of
+    the launch -- or None: the launch then cuts t itself, into its workspace.
     cols = (B, HW) of the activation side: small launches keep cutting per launch (SPLIT_CACHE_MIN_TILES)."""
     training = _SPLIT_POLICY.get("mode", "eval") == "train"
     if SPLIT_CACHE in ("0", False) or (SPLIT_CACHE == "eval" and training):
-        return
+        return None
     floor = SPLIT_CACHE_MIN_TILES if (SPLIT_CACHE == "eval" or (SPLIT_CACHE == "auto" and not training)) else 0
     if cols is not None and ((M + 127) // 128) * ((cols[1] + 127) // 128) * cols[0] * nz < floor:
         if t.data_ptr() in _SPLIT_IMG:
             _split_drop(t.data_ptr(), stamp=False)               # (the same weight seen earlier with a larger batch)
-        return
-    kind = lib.prn_split_gemm_kind(-1)
+        return None
+    kind = _POLICY["kind"]
     ptr = t.data_ptr()
     e = _SPLIT_IMG.get(ptr)
     if e is not None:
         cur = _split_state(e)
         if cur is not None and cur == e.stamp and e.dims == (M, K, nz, kind):
             SPLIT_STATS["hits"] += 1
-            return                                              # registered and current
+            return _p(e.images)                                 # current
         if cur is None or e.dims != (M, K, nz, kind):           # owner gone (address reused), another view of the storage, other piece format
             _split_drop(ptr, stamp=False)
             e = None
@@ -479,9 +530,9 @@ def split_images(t, M, K, nz, cols=None):
         owner = t if isinstance(t, torch.nn.Parameter) else (t._base if isinstance(t._base, torch.nn.Parameter) else None)
         if owner is None and ptr not in _STAMP:
             SPLIT_STATS["uncached"] += 1
-            return                                              # a temporary: the launch cuts it
+            return None                                         # a temporary: the launch cuts it
         if owner is not None and owner.data_ptr() != ptr:
-            return                                              # a view that does not start at the parameter's first element
+            return None                                         # a view that does not start at the parameter's first element
         e = _SplitEntry()
         e.owner = weakref.ref(owner) if owner is not None else None
         e.tensor = None if owner is not None else t              # derived buffers are kept alive by the entry (no address reuse)
@@ -492,12 +543,12 @@ def split_images(t, M, K, nz, cols=None):
         _SPLIT_ITEMS[0] = None
         if owner is not None:
             weakref.finalize(owner, lambda p=ptr, r=e: _split_drop(p) if _SPLIT_IMG.get(p) is r else None)
-        check(lib.prn_split_images_register(ctypes.c_void_p(ptr), _p(e.images), M, K, nz), "prn_split_images_register")
-    check(lib.prn_split_prepare(ctypes.c_void_p(ptr), _p(e.images), M, K, nz, _stream()), "prn_split_prepare")
+    check(lib.prn_split_prepare(ctypes.c_void_p(ptr), _p(e.images), M, K, nz, kind, _stream()), "prn_split_prepare")
     e.stamp = _split_state(e)
     SPLIT_STATS["cuts"] += 1
     if os.environ.get("PRN_SPLIT_DEBUG"):
         SPLIT_STATS.setdefault("who", {}).setdefault((M, K, nz, "param" if e.owner is not None else "derived"), []).append(SPLIT_STATS["refreshes"])
+    return _p(e.images)
 
 
 def split_refresh_all():
@@ -512,7 +563,7 @@ def split_refresh_all():
         _split_drop(p)
     if not _SPLIT_IMG:
         return
-    kind = lib.prn_split_gemm_kind(-1)
+    kind = _POLICY["kind"]
     for e in [e for e in _SPLIT_IMG.values() if e.dims[3] != kind]:          # images of the other piece format: start over at their next launch
         _split_drop(e.ptr, stamp=False)
     entries = list(_SPLIT_IMG.values())
@@ -521,7 +572,7 @@ def split_refresh_all():
     if _SPLIT_ITEMS[0] is None or _SPLIT_ITEMS[1] != [id(e) for e in entries]:
         items, blocks, rblocks = _prep_items(entries, entries[0].images.device)
         _SPLIT_ITEMS[0], _SPLIT_ITEMS[1], _SPLIT_ITEMS[2] = items, [id(e) for e in entries], (blocks, rblocks)
-    check(lib.prn_split_prepare_batched(_p(_SPLIT_ITEMS[0]), len(entries), _SPLIT_ITEMS[2][0], _SPLIT_ITEMS[2][1], _stream()), "prn_split_prepare_batched")
+    check(lib.prn_split_prepare_batched(_p(_SPLIT_ITEMS[0]), len(entries), _SPLIT_ITEMS[2][0], _SPLIT_ITEMS[2][1], kind, _stream()), "prn_split_prepare_batched")
     for e in entries:
         e.stamp = _split_state(e)
     SPLIT_STATS["refreshes"] += 1
@@ -534,9 +585,9 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     if scatter2 is None:
         y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
         d_, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
-        if d_.kind >= 2:
-            split_images(w2d, M, C, 1, (B, Ho * Wo))
+        wimg = split_images(w2d, M, C, 1, (B, Ho * Wo)) if d_.kind >= 2 else None
     else:
+        wimg = None
         y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
         _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
@@ -552,12 +603,12 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         with profiling.span("conv3x3_direct" if direct else ("split_gemm_kernel" if split else "conv_igemm_kernel"), "hbm" if direct else "mfma",
                             nb_ if direct else (split_products() * fl if split else fl), ref=None if direct else fl, nbytes=nb_,
                             tag=None if direct else ("conv", C, H, W, M, K, stride, mode, dil, B)):
-            check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 1), "prn_conv2d_fwd")
+            check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), wimg, _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 1), "prn_conv2d_fwd")
         if nbytes and kind != 2:
             with profiling.span("reduce_epilogue_kernel", "hbm", float(nbytes) + 4.0 * y.numel()):
-                check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 2), "prn_conv2d_fwd")
+                check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), wimg, _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 2), "prn_conv2d_fwd")
     else:
-        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 0), "prn_conv2d_fwd")
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), wimg, _p(bias), _p(addend), _p(y), _p(ws), _p(cnt), _stream(), 0), "prn_conv2d_fwd")
     return y
 
 
@@ -779,6 +830,7 @@ class WinogradWeights:
             _wino_store(w, U, Ut)
 
 
+_WINO_WG_WS = {}
 WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
 
 
@@ -791,43 +843,48 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         H, W = H + 2, W + 4
     P = lib.prn_winograd_tiles(B, H, W)
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
-    ws = torch.empty(36 * (C + M) * P, device=x.device, dtype=torch.float32)
-    if gemm_pipe(M, C, 1, P, 36) >= 1:
-        split_images(U, M, C, 36, (1, P))
+    uimg = split_images(U, M, C, 36, (1, P)) if gemm_pipe(M, C, 1, P, 36) >= 1 else None
+    oref = opts_ref()
+    wkey = ("wino-fwd", B, C, H, W, M, opts_key())
+    nb_ws = _WINO_WG_WS.get(wkey)
+    if nb_ws is None:
+        nb_ws = _WINO_WG_WS[wkey] = lib.prn_conv3x3_winograd_ws_bytes(B, C, H, W, M, oref)
+        if nb_ws < 0:
+            raise RuntimeError(lib.prn_last_error().decode())
+    ws = torch.empty(nb_ws // 4, device=x.device, dtype=torch.float32)
     if profiling._enabled:
-        V, Yt = ws[:36 * C * P], ws[36 * C * P:]
+        V, Yt = ws[:36 * C * P], ws[36 * C * P:36 * (C + M) * P]
+        gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
             check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
         fam, ex, _ = _gemm_family(M, C, 1, P, 36, 2.0 * 36 * M * C * P)
         with profiling.span(fam, "mfma", ex, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P),
                             tag=("wino-products", C, H, W, M, 3, 1, mode, 1, B)):
-            check(lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()), "prn_gemm_batched")
+            check(lib.prn_gemm_batched(M, C, P, 36, _p(U), uimg, _p(V), _p(Yt), _p(gws) if gws.numel() else None, oref, _stream()), "prn_gemm_batched")
         with profiling.span("winograd_output_kernel", "hbm", 4.0 * Yt.numel() + 4.0 * y.numel() * (2 if addend is not None else 1), 0.0):
             check(lib.prn_winograd_output(_p(Yt), _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
     else:
-        check(lib.prn_conv3x3_winograd(_p(x), _p(U), _p(bias), _p(addend), _p(y), _p(ws), B, C, H, W, M, mode, epi, _stream()), "prn_conv3x3_winograd")
+        check(lib.prn_conv3x3_winograd(_p(x), _p(U), uimg, _p(bias), _p(addend), _p(y), _p(ws), B, C, H, W, M, mode, epi, oref, _stream()), "prn_conv3x3_winograd")
     if keep is not None and mode == IN_ZERO and 4 * 36 * C * P <= WINOGRAD_KEEP_V:
         keep.append(ws)
     return y
-
-
-_WINO_WG_WS = {}
 
 
 def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
     """Weight gradient [M,C,3,3] of a 3x3 / stride 1 / pad 1 convolution on the Winograd path.  V: the forward call's kept
     workspace (see conv3x3_winograd_raw) -- the input transform is then not recomputed."""
     B, C, H, W = x.shape
-    key = (B, C, H, W, M, _WGS[0])
+    oref = opts_ref()
+    key = (B, C, H, W, M, opts_key())
     nbytes = _WINO_WG_WS.get(key)
     if nbytes is None:
-        nbytes = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M)
+        nbytes = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M, oref)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
     if V is not None and not profiling._enabled:
-        check(lib.prn_conv3x3_winograd_wgrad_v(_p(V), _p(dy), _p(dw), _p(ws), B, C, H, W, M, _stream()), "prn_conv3x3_winograd_wgrad_v")
+        check(lib.prn_conv3x3_winograd_wgrad_v(_p(V), _p(dy), _p(dw), _p(ws), B, C, H, W, M, oref, _stream()), "prn_conv3x3_winograd_wgrad_v")
         return dw
-    args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, mode, _stream())
+    args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, mode, oref, _stream())
     if profiling._enabled:
         P = lib.prn_winograd_tiles(B, H, W)
         with profiling.span("winograd_wgrad_transforms", "hbm", 4.0 * (x.numel() + dy.numel()) + 4.0 * 36 * (C + M) * P, 0.0):
@@ -1052,11 +1109,12 @@ _DCN = {}          # geometry key -> (DcnDesc, byref, table bytes, fwd ws bytes,
 
 
 def _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset, epi=EPI_NONE):
-    key = (B, C, H, W, M, stride, pad, raw, float(max_offset), epi, _WGS[0])
+    oe = _opts_entry()
+    key = (B, C, H, W, M, stride, pad, raw, float(max_offset), epi, oe[2])
     e = _DCN.get(key)
     if e is None:
         Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
-        d = _lib.DcnDesc(B, C, H, W, M, stride, pad, Ho, Wo, int(raw), float(max_offset), epi)
+        d = _lib.DcnDesc(B, C, H, W, M, stride, pad, Ho, Wo, int(raw), float(max_offset), epi, oe[0])
         ref = ctypes.byref(d)
         sizes = [lib.prn_dcnv2_table_bytes(ref), lib.prn_dcnv2_fwd_ws_bytes(ref), lib.prn_dcnv2_bwd_weight_ws_bytes(ref), lib.prn_dcnv2_bwd_ws_bytes(ref)]
         if min(sizes) < 0:
@@ -1121,8 +1179,8 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
     d, ref, _, _, _, db = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset)
     wt = flip_transpose(w.view(M, C * 9, 1, 1))                   # [9C, M, 1, 1]
     ws = _f32(db, x.device)
-    if gemm_pipe(9 * C, M, B, d.Ho * d.Wo, 1) >= 1:
-        split_images(wt, 9 * C, M, 1, (B, d.Ho * d.Wo))          # the column-gradient GEMM's weight operand
+    # the column-gradient GEMM's weight operand: current images, or None (the launch cuts wt itself)
+    wimg = split_images(wt, 9 * C, M, 1, (B, d.Ho * d.Wo)) if gemm_pipe(9 * C, M, B, d.Ho * d.Wo, 1) >= 1 else None
     dx = torch.empty_like(x) if need_x else None
     ncols = 4.0 * B * C * 9 * d.Ho * d.Wo
     if profiling._enabled:
@@ -1130,14 +1188,14 @@ def dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, raw, max_offset, nee
         fam, ex, fl = _gemm_family(9 * C, M, B, d.Ho * d.Wo, 1, 2.0 * M * C * 9 * B * d.Ho * d.Wo)
         with profiling.span(fam, "mfma", ex, fl, nbytes=4.0 * (dy.numel() + wt.numel()) + ncols,
                             tag=("dcn-colgrad", M, d.Ho, d.Wo, 9 * C, 1, 1, 0, 1, B)):
-            check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 1), "prn_dcnv2_bwd_input")
+            check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), wimg, _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 1), "prn_dcnv2_bwd_input")
         with profiling.span("reduce_epilogue_kernel", "hbm", 0.0):      # (no-op without a K split: an empty bracket, ~0 us)
-            check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 2), "prn_dcnv2_bwd_input")
+            check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), wimg, _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 2), "prn_dcnv2_bwd_input")
         if need_x:
             with profiling.span("dcnv2_bwd_input", "hbm", ncols + 4.0 * x.numel() + 8.0 * offset.numel()):
-                check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 3), "prn_dcnv2_bwd_input")
+                check(lib.prn_dcnv2_bwd_input_phase(ref, _p(dy), _p(wt), wimg, _p(offset), _p(mask), _p(dx), _p(ws), _stream(), 3), "prn_dcnv2_bwd_input")
     else:
-        check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), _p(offset), _p(mask), _p(dx), _p(ws), _stream()), "prn_dcnv2_bwd_input")
+        check(lib.prn_dcnv2_bwd_input(ref, _p(dy), _p(wt), wimg, _p(offset), _p(mask), _p(dx), _p(ws), _stream()), "prn_dcnv2_bwd_input")
     d_off = d_msk = None
     if need_om:
         d_off = torch.empty_like(offset)
@@ -1290,14 +1348,15 @@ class _PlanePrior(torch.autograd.Function):
         seg, kernels, w1, b1 = _c(seg), _c(kernels), _c(w1), _c(b1)
         B, E, h, w = seg.shape
         NK, F = kernels.shape[1], w1.shape[0]
-        nb = lib.prn_plane_prior_ws_bytes(B, E, h, w, NK, F)
+        oref = opts_ref()              # (the block's split-kernel launches cut their weights per call: nothing cached, nothing stale)
+        nb = lib.prn_plane_prior_ws_bytes(B, E, h, w, NK, F, oref)
         if nb < 0:
             raise RuntimeError(lib.prn_last_error().decode())
         ws = _f32(nb, seg.device)
         pooled = torch.empty(B, NK, h // 4, w // 4, device=seg.device, dtype=torch.float32)
         out = torch.empty(B, F, h // 4, w // 4, device=seg.device, dtype=torch.float32)
         if profiling._enabled:
-            args = (_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream())
+            args = (_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, oref, _stream())
             npx = (h // 2) * (w // 2)
             g1 = _gemm_family(NK, E, 1, npx, B, 2.0 * NK * E * B * npx)
             g2 = _gemm_family(F, NK, B, npx // 4, 1, 2.0 * F * NK * B * npx / 4)
@@ -1309,7 +1368,7 @@ class _PlanePrior(torch.autograd.Function):
                 with profiling.span(fam, bound, work, rf, nbytes=nb_, tag=tag):
                     check(lib.prn_plane_prior_fwd_phase(*args, ph), "prn_plane_prior_fwd")
         else:
-            check(lib.prn_plane_prior_fwd(_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, _stream()),
+            check(lib.prn_plane_prior_fwd(_p(seg), _p(kernels), _p(w1), _p(b1), _p(pooled), _p(out), _p(ws), B, E, h, w, NK, F, oref, _stream()),
                   "prn_plane_prior_fwd")
         ctx.save_for_backward(pooled, w1)
         ctx.dims = (B, h, w, NK, F, b1 is not None)
@@ -1324,10 +1383,11 @@ class _PlanePrior(torch.autograd.Function):
 
         def wgrad():
             dw = torch.empty(F, NK, 1, 1, device=d_out.device, dtype=torch.float32)
-            ws = _f32(lib.prn_plane_prior_wgrad_ws_bytes(B, h, w, NK, F), d_out.device)
+            oref = opts_ref()
+            ws = _f32(lib.prn_plane_prior_wgrad_ws_bytes(B, h, w, NK, F, oref), d_out.device)
             with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * F * NK * B * (h // 4) * (w // 4), nbytes=4.0 * (pooled.numel() + d_out.numel() + dw.numel()),
                                 tag=("wgrad", NK, h // 4, w // 4, F, 1, 1, 0, 1, B)):      # (GEMM + split sum in one bracket)
-                check(lib.prn_plane_prior_wgrad(_p(pooled), _p(d_out), _p(dw), _p(ws), B, h, w, NK, F, _stream()), "prn_plane_prior_wgrad")
+                check(lib.prn_plane_prior_wgrad(_p(pooled), _p(d_out), _p(dw), _p(ws), B, h, w, NK, F, oref, _stream()), "prn_plane_prior_wgrad")
             return dw
         dw = None
         if _defer(ctx.needs_input_grad[2], w1):
@@ -1352,7 +1412,8 @@ def fpn_level(x, w_lat, b_lat, prev, w_out, b_out, relu):
     B, C, H, W = x.shape
     F = w_lat.shape[0]
     U = winograd_weights(w_out)[0] if winograd_ok(B, F, H, W, F, 3, 1, 1, IN_ZERO, EPI_RELU if relu else EPI_NONE) else None
-    nb = lib.prn_fpn_level_ws_bytes(B, C, H, W, F, int(relu), int(prev is not None), int(U is not None))
+    oref = opts_ref()                  # (split-kernel launches inside the block cut w_lat / U per call: no kept images to go stale)
+    nb = lib.prn_fpn_level_ws_bytes(B, C, H, W, F, int(relu), int(prev is not None), int(U is not None), oref)
     if nb < 0:
         raise RuntimeError(lib.prn_last_error().decode())
     ws = _f32(nb, x.device) if nb else None
@@ -1360,7 +1421,7 @@ def fpn_level(x, w_lat, b_lat, prev, w_out, b_out, relu):
     p_out = torch.empty(B, F, H, W, device=x.device, dtype=torch.float32)
     Hp, Wp = (prev.shape[2], prev.shape[3]) if prev is not None else (0, 0)
     check(lib.prn_fpn_level_fwd(_p(x), _p(w_lat), _p(b_lat), _p(prev), Hp, Wp, _p(w_out), _p(U), _p(b_out), _p(lateral), _p(p_out), _p(ws), B, C, H, W, F,
-                                int(relu), _stream()), "prn_fpn_level_fwd")
+                                int(relu), oref, _stream()), "prn_fpn_level_fwd")
     return lateral, p_out
 
 
@@ -1589,11 +1650,12 @@ _RDESC = {}
 
 
 def _rdesc(rs, C, M, K, epi=EPI_NONE):
-    key = (rs.key, C, M, K, epi, _WGS[0])
+    oe = _opts_entry()
+    key = (rs.key, C, M, K, epi, oe[2])
     e = _RDESC.get(key)
     if e is None:
         h, w = rs.sizes[0]
-        d = ConvDesc(rs.B, C, h, w, M, K, K, 1, (K - 1) // 2, h, w, IN_ZERO, 1, epi, 0, 0, 0)
+        d = ConvDesc(rs.B, C, h, w, M, K, K, 1, (K - 1) // 2, h, w, IN_ZERO, 1, epi, 0, 0, 0, 0, oe[0])
         ref = ctypes.byref(d)
         wb = lib.prn_conv2d_wgrad_ragged_ws_bytes(ref, rs.ref)
         if wb < 0:
@@ -1604,9 +1666,17 @@ def _rdesc(rs, C, M, K, epi=EPI_NONE):
 
 def _ragged_winograd_raw(xp, U, bias, addend, rs, C, M, P, epi=EPI_NONE):
     y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
-    ws = torch.empty(36 * (C + M) * P, device=xp.device, dtype=torch.float32)
+    oref = opts_ref()
+    key = ("wino-fwd-ragged", rs.key, C, M, opts_key())
+    nb = _WINO_WG_WS.get(key)
+    if nb is None:
+        nb = _WINO_WG_WS[key] = lib.prn_conv3x3_winograd_ragged_ws_bytes(rs.ref, rs.B, C, M, oref)
+        if nb < 0:
+            raise RuntimeError(lib.prn_last_error().decode())
+    ws = torch.empty(nb // 4, device=xp.device, dtype=torch.float32)
+    uimg = split_images(U, M, C, 36, (1, P)) if gemm_pipe(M, C, 1, P, 36) >= 1 else None
     with profiling.span("conv3x3_winograd_ragged", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * rs.pixels):   # (three launches in one bracket)
-        check(lib.prn_conv3x3_winograd_ragged(_p(xp), _p(U), _p(bias), _p(addend), _p(y), _p(ws), rs.ref, rs.B, C, M, epi, _stream()),
+        check(lib.prn_conv3x3_winograd_ragged(_p(xp), _p(U), uimg, _p(bias), _p(addend), _p(y), _p(ws), rs.ref, rs.B, C, M, epi, oref, _stream()),
               "prn_conv3x3_winograd_ragged")
     return y
 
@@ -1645,14 +1715,15 @@ class _RaggedConv(torch.autograd.Function):
             dx = _ragged_winograd_raw(dy, winograd_weights(w)[1], None, None, rs, M, C, P) if P else _ragged_conv_raw(dy, flip_transpose(w), None, None, rs, M, C, K)
         def wgrad():
             if P and WINOGRAD_WGRAD:
-                key = (rs.key, C, M, _WGS[0])
+                oref = opts_ref()
+                key = (rs.key, C, M, opts_key())
                 nb = _WINO_WG_WS.get(key)
                 if nb is None:
-                    nb = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ragged_ws_bytes(rs.ref, rs.B, C, M)
+                    nb = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ragged_ws_bytes(rs.ref, rs.B, C, M, oref)
                 ws = torch.empty(nb // 4, device=xp.device, dtype=torch.float32)
                 dwo = torch.empty_like(w)
                 with profiling.span("conv3x3_winograd_wgrad_ragged", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * rs.pixels):
-                    check(lib.prn_conv3x3_winograd_wgrad_ragged(_p(xp), _p(dy), _p(dwo), _p(ws), rs.ref, rs.B, C, M, _stream()), "prn_conv3x3_winograd_wgrad_ragged")
+                    check(lib.prn_conv3x3_winograd_wgrad_ragged(_p(xp), _p(dy), _p(dwo), _p(ws), rs.ref, rs.B, C, M, oref, _stream()), "prn_conv3x3_winograd_wgrad_ragged")
                 return dwo
             _, ref, nbytes = _rdesc(rs, C, M, K)
             ws = torch.empty(max(nbytes // 4, 1), device=xp.device, dtype=torch.float32)

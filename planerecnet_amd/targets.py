@@ -76,12 +76,14 @@ _TORCH_DT = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, n
 class DeviceTargetBuilder:
     """Drop-in for losses.TargetPrefetcher (submit / get / pending / discard / close); no worker processes."""
 
-    def __init__(self, criterion, sampler=None, seed=0, depth=3):
+    def __init__(self, criterion, sampler=None, seed=0, depth=3, first_call=0):
+        """seed: the Philox KEY of the device sampler -- (run seed << 32) | rank, so that ranks and runs draw different streams;
+        first_call: the batch COUNTER the stream starts at -- the global iteration a resumed run continues from."""
         self.criterion = criterion
         self.sampler = sampler or os.environ.get("PRN_TARGET_SAMPLER", "philox")
         if self.sampler not in ("philox", "numpy"):
             raise ValueError("sampler must be 'philox' or 'numpy'")
-        self.seed, self.calls = int(seed), 0
+        self.seed, self.calls = int(seed), int(first_call)
         self.queue = collections.deque()
         self._stage = []                                   # rotating page-locked staging buffers for the packed masks
         self._depth = depth
@@ -150,7 +152,8 @@ class DeviceTargetBuilder:
             totals = torch.empty(R * 3, dtype=torch.int64, device=dev)
             check(lib.prn_gt_mask_stats(_p(masks), _p(first_d), B, Ntot, H, W, _p(segcnt), _p(segstart), _p(totals), _stream()), "prn_gt_mask_stats")
             small = torch.empty(Ntot, H // 4, W // 4, dtype=torch.uint8, device=dev)
-            check(lib.prn_gt_quarter_masks(_p(masks), _p(small), Ntot, H, W, _stream()), "prn_gt_quarter_masks")
+            if Ntot:                                           # (a batch without a single plane: an empty tensor has no address to pass)
+                check(lib.prn_gt_quarter_masks(_p(masks), _p(small), Ntot, H, W, _stream()), "prn_gt_quarter_masks")
             self._totals_i = (self._totals_i + 1) % len(self._totals)
             if self._totals[self._totals_i].numel() < R * 3:
                 self._totals[self._totals_i] = torch.empty(R * 3 * 2, dtype=torch.int64).pin_memory()
@@ -264,7 +267,7 @@ class DeviceTargetBuilder:
         gid = torch.empty(3, n_tot, dtype=torch.int32, device=device)
         if n_tot:
             check(lib.prn_gt_sample_triplets(_p(job["masks"]), _p(job["first_d"]), B, Ntot, H, W, _p(job["segstart"]), _p(seg), _p(d["seg_region"]), _p(d["seg_img32"]),
-                                             _p(d["ranks"]), ctypes.c_uint64((self.seed << 20) ^ self.calls), n_tot, _p(gid), _stream()), "prn_gt_sample_triplets")
+                                             _p(d["ranks"]), ctypes.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), ctypes.c_uint64(self.calls), n_tot, _p(gid), _stream()), "prn_gt_sample_triplets")
         return {"B": B, "n_seg": n_seg, "n_tot": n_tot, "npts": B * H * W, "N": d["N"], "fx": d["fx"], "fy": d["fy"], "gid": gid, "seg": seg,
                 "seg_start": d["seg_start"], "seg_img": d["seg_img"], "seg_is_plane": d["seg_is_plane"], "seg_normal": d["seg_normal"]}
 

@@ -15,3 +15,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# The arithmetic the plain GEMMs run in (csrc/prn_gemm_split.hip, include/prn.h: prn_gemm_opts):
+#   default   what bench.py times: launches of >= 300 tiles and >= 4 GFLOP on the 16-bit matrix pipe as fp16-piece products -- at the
+#             B = 1 / 2 of the parity tests only the 120x160-map products qualify
+#   all-f16 / all-bf16   PRN_SPLIT_ALWAYS: EVERY launch the split kernel can take runs on it (stage-3 / stage-4 1x1 layers, every Winograd
+#             product, the DCN column gradients, the plane prior) -- so that B = 2 covers what B = 8 times, in both piece formats
+#   fp32      fp32 MFMA everywhere (PRN_SPLIT_GEMM=0)
+# The model-level parity tests run under all four with the SAME bounds and print their error percentiles per arithmetic.
+GEMM_ARITHMETICS = {"default": {}, "all-f16": {"mode": 2, "kind": "f16"}, "all-bf16": {"mode": 2, "kind": "bf16"}, "fp32": {"mode": 0}}
+
+
+@pytest.fixture(params=list(GEMM_ARITHMETICS))
+def gemm_arith(request):
+    from planerecnet_amd import ops
+    old = ops.set_split_gemm(**GEMM_ARITHMETICS[request.param])
+    ops.SPLIT_STATS.update({"hits": 0, "cuts": 0, "uncached": 0})
+    yield request.param
+    ops.set_split_gemm(**old)

@@ -37,35 +37,92 @@ def test_python_binding_covers_every_symbol():
 def test_argument_validation_without_gpu():
     """Descriptor validation happens on the host before any launch: must fail cleanly (rc != 0 + message)."""
     from planerecnet_amd import _lib
-    d = _lib.ConvDesc(1, 4, 8, 8, 4, 5, 5, 1, 2, 8, 8, 0, 1, 0)       # 5x5 kernels are not part of the path
+    d = _lib.ConvDesc(1, 4, 8, 8, 4, 5, 5, 1, 2, 8, 8, 0, 1, 0)       # 5x5 kernels are not part of the path (options: all zero)
     rc = _lib.lib.prn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
     assert rc != 0 and b"unsupported" in _lib.lib.prn_last_error()
 
 
+def _opts(mode=1, kind=16, products=3, min_tiles=300, min_gflop=4.0, wgs=0, target=0):
+    from planerecnet_amd import _lib
+    o = _lib.GemmOpts(mode, kind, products, min_tiles, min_gflop, wgs, target, 0)
+    return o, ctypes.byref(o)
+
+
 def test_split_gemm_plan_is_host_logic():
-    """prn_gemm_pipe / the mode, kind and threshold switches of the 16-bit-pipe GEMM (csrc/prn_gemm_split.hip) decide on the host: checked here
-    without a GPU.  Mode 0 keeps every launch on the fp32 MFMA kernel; mode 1 takes launches of at least min_tiles 128x128 tiles and 4 GFLOP whose
-    last row tile is more than half full, K-splitting short-of-tiles launches; workspace sizes do not depend on the piece format."""
+    """prn_gemm_pipe decides on the host from the CALL's prn_gemm_opts (mode, piece format, thresholds): checked here without a GPU.
+    Mode 0 (and a NULL / all-zero opts) keeps every launch on the fp32 MFMA kernel; mode 1 takes launches of at least min_tiles 128x128 tiles
+    and min_gflop GFLOP whose last row tile is more than half full, K-splitting short-of-tiles launches; image sizes cover both piece formats."""
     from planerecnet_amd import _lib
     lib = _lib.lib
-    old_mode, old_tiles, old_kind = lib.prn_split_gemm_mode(1), lib.prn_split_gemm_min_tiles(300), lib.prn_split_gemm_kind(16)
-    try:
-        assert lib.prn_gemm_pipe(1024, 256, 8, 1200, 1) == 1          # stage-3 expand: 640 tiles
-        assert lib.prn_gemm_pipe(256, 1024, 8, 1200, 1) == 4          # stage-3 reduce: 160 tiles -> 4 K splits of 8 slices
-        assert lib.prn_gemm_pipe(64, 256, 8, 19200, 1) == 0           # half-empty row tile
-        assert lib.prn_gemm_pipe(256, 256, 1, 1200, 1) == 0           # batch-1 launch below the FLOP floor
-        assert lib.prn_gemm_pipe(256, 256, 1, 9600, 36) == 1          # Winograd products, 36 batched GEMMs
-        assert lib.prn_gemm_pipe(0, 256, 8, 1200, 1) == 0
-        lib.prn_split_gemm_min_tiles(2500)
-        assert lib.prn_gemm_pipe(1024, 256, 8, 1200, 1) == 0 and lib.prn_gemm_pipe(256, 256, 1, 9600, 36) == 1
-        lib.prn_split_gemm_mode(0)
-        assert lib.prn_gemm_pipe(256, 256, 1, 9600, 36) == 0
-        lib.prn_split_gemm_mode(2)
-        assert lib.prn_gemm_pipe(64, 256, 8, 19200, 1) >= 1
-        nb = lib.prn_split_images_bytes(1000, 70, 3)
-        assert nb == 3 * 8 * 3 * 1536 * 16 + 3 * 8 * 128 * 4           # bf16-sized images of 8 row tiles x 3 slices + the fp16 format's row exponents
-        lib.prn_split_gemm_kind(0)
-        assert lib.prn_split_images_bytes(1000, 70, 3) == nb and lib.prn_split_gemm_kind(-1) == 0
-        assert lib.prn_split_images_bytes(0, 70, 3) == -1
-    finally:
-        lib.prn_split_gemm_mode(old_mode); lib.prn_split_gemm_min_tiles(old_tiles); lib.prn_split_gemm_kind(old_kind)
+    _, o = _opts()
+    assert lib.prn_gemm_pipe(1024, 256, 8, 1200, 1, o) == 1          # stage-3 expand: 640 tiles
+    assert lib.prn_gemm_pipe(256, 1024, 8, 1200, 1, o) == 4          # stage-3 reduce: 160 tiles -> 4 K splits of 8 slices
+    assert lib.prn_gemm_pipe(64, 256, 8, 19200, 1, o) == 0           # half-empty row tile
+    assert lib.prn_gemm_pipe(256, 256, 1, 1200, 1, o) == 0           # batch-1 launch below the FLOP floor
+    assert lib.prn_gemm_pipe(256, 256, 1, 9600, 36, o) == 1          # Winograd products, 36 batched GEMMs
+    assert lib.prn_gemm_pipe(0, 256, 8, 1200, 1, o) == 0
+    _, o2500 = _opts(min_tiles=2500)
+    assert lib.prn_gemm_pipe(1024, 256, 8, 1200, 1, o2500) == 0 and lib.prn_gemm_pipe(256, 256, 1, 9600, 36, o2500) == 1
+    _, off = _opts(mode=0)
+    assert lib.prn_gemm_pipe(256, 256, 1, 9600, 36, off) == 0
+    assert lib.prn_gemm_pipe(256, 256, 1, 9600, 36, None) == 0       # no options: fp32 MFMA
+    _, always = _opts(mode=2)
+    assert lib.prn_gemm_pipe(64, 256, 8, 19200, 1, always) >= 1
+    nb = lib.prn_split_images_bytes(1000, 70, 3)
+    assert nb == 3 * 8 * 3 * 1536 * 16 + 3 * 8 * 128 * 4           # bf16-sized images of 8 row tiles x 3 slices + the fp16 format's row exponents
+    assert lib.prn_split_images_bytes(0, 70, 3) == -1
+    # the one call that made an answer depend on a process-wide switch is gone: the same query under two option values, interleaved
+    assert [lib.prn_gemm_pipe(1024, 256, 8, 1200, 1, q) for q in (o, off, o2500, o)] == [1, 0, 0, 1]
+    d = _lib.GemmOpts()
+    lib.prn_gemm_opts_default(ctypes.byref(d))
+    assert d.key() == (1, 16, 3, 300, 4.0, 0, 0)
+
+
+def test_workspace_sizes_follow_the_descriptors_options():
+    """prn_conv2d_fwd_ws_bytes / _kernel_kind / the weight-gradient plan read the options INSIDE the descriptor; two threads asking with
+    different options at the same time get their own answers (no process-wide mode)."""
+    import threading
+    from planerecnet_amd import _lib
+    lib = _lib.lib
+
+    def desc(o):
+        return _lib.ConvDesc(8, 256, 30, 40, 1024, 1, 1, 1, 0, 30, 40, 0, 1, 0, 0, 0, 0, 0, o)
+    on, _ = _opts()
+    off, _ = _opts(mode=0)
+    wgs, _ = _opts(mode=0, wgs=128)
+    d_on, d_off, d_wgs = desc(on), desc(off), desc(wgs)
+    assert lib.prn_conv2d_kernel_kind(ctypes.byref(d_on)) == 2 and lib.prn_conv2d_kernel_kind(ctypes.byref(d_off)) == 0
+    assert lib.prn_conv2d_fwd_ws_bytes(ctypes.byref(d_on)) >= lib.prn_split_images_bytes(1024, 256, 1)
+    assert lib.prn_conv2d_fwd_ws_bytes(ctypes.byref(d_off)) == 0
+    full, part = lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d_off)), lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d_wgs))
+    assert full > part > 0                                          # fewer workgroups per launch -> fewer pixel splits -> smaller workspace
+    out = {}
+
+    def worker(name, d, want):
+        ok = True
+        for _ in range(2000):
+            ok = ok and lib.prn_conv2d_kernel_kind(ctypes.byref(d)) == want
+        out[name] = ok
+    ts = [threading.Thread(target=worker, args=("on", d_on, 2)), threading.Thread(target=worker, args=("off", d_off, 0))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert out == {"on": True, "off": True}
+
+
+def test_library_allocates_nothing_and_keeps_no_registry():
+    """caller-owned buffers, no global mutable state.  Source-level check of csrc/: no device allocation / free / blocking
+    synchronisation, no process-wide containers or locks, no writes to the environment."""
+    csrc = os.path.join(ROOT, "planerecnet_amd", "csrc")
+    banned = ("hipMalloc", "hipFree", "hipHostMalloc", "hipStreamSynchronize", "hipDeviceSynchronize", "hipEventSynchronize", "std::map", "std::unordered_map",
+              "std::mutex", "setenv", "putenv")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        txt = open(os.path.join(csrc, f)).read()
+        txt = re.sub(r"//[^\n]*", "", txt)
+        for b in banned:
+            if b in txt:
+                hits.append((f, b))
+    assert hits == [], hits
+    syms = declared_symbols()
+    for gone in ("prn_split_gemm_mode", "prn_split_gemm_kind", "prn_split_gemm_min_tiles", "prn_split_images_register"):
+        assert gone not in syms

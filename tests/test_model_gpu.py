@@ -39,7 +39,7 @@ def setup():
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_forward_matches_oracle(setup, mode):
+def test_forward_matches_oracle(setup, mode, gemm_arith):
     from oracle import model_ref, synth
     net, sd, arch = setup
     net.load_state_dict(sd)
@@ -193,7 +193,7 @@ def test_inference_matches_oracle(setup):
     net.load_state_dict(sd)
 
 
-def test_full_size_inference_matches_oracle(setup):
+def test_full_size_inference_matches_oracle(setup, gemm_arith):
     """The inference workloads bench.py times (c2 / c5) at their real frame size: PlaneRecNet_50, B = 2, 480x640, with the category
     bias conditioned so that every image keeps >= 5 detections through matrix NMS -- the post-process is checked where it is timed, on
     non-empty candidate sets.  Detections are matched by mask IoU (near-equal scores may swap places between two fp32
@@ -423,7 +423,7 @@ def test_gt_assignment_bit_exact_vs_golden(setup, golden_dir):
 
 
 @pytest.mark.parametrize("wgrad_async", [False, True])
-def test_e2e_train_step_matches_oracle(setup, golden_dir, wgrad_async):
+def test_e2e_train_step_matches_oracle(setup, golden_dir, wgrad_async, gemm_arith):
     """R50, 480x640, B=1: forward + joint loss + backward. Losses vs oracle and vs the reference's golden values;
     parameter gradients vs oracle autograd.  Run with the weight gradients in line and deferred to the side stream
     (ops.set_wgrad_async, the mode train.py / bench.py use)."""

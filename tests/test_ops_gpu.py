@@ -214,10 +214,10 @@ def test_conv_split_sum_inside_the_gemm_is_bit_identical(shape, monkeypatch):
     for rep in range(30):
         x = x0 * (1.0 + rep)                                # different partials every round
         ws.fill_(float("nan"))
-        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w), _p(bias), _p(add), _p(y_two), _p(ws), None, _stream(), 0), "two-kernel")
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w), None, _p(bias), _p(add), _p(y_two), _p(ws), None, _stream(), 0), "two-kernel")
         ws.fill_(float("nan"))
         y_one.fill_(float("nan"))
-        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w), _p(bias), _p(add), _p(y_one), _p(ws), _p(cnt), _stream(), 0), "folded")
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w), None, _p(bias), _p(add), _p(y_one), _p(ws), _p(cnt), _stream(), 0), "folded")
         assert torch.equal(y_one, y_two), (rep, float((y_one - y_two).abs().max()))
         assert int(cnt.abs().sum()) == 0
     ref_y = F.conv2d(F.pad(x.double().cpu(), (pad,) * 4, mode="reflect") if mode == ops.IN_REFLECT else x.double().cpu(),
@@ -868,13 +868,11 @@ def test_fpn_level_block_equals_operator_sequence(B, C, H, W, with_prev):
 
 @pytest.fixture
 def split_everywhere():
-    """PRN_SPLIT_GEMM=2 for one test: every plain GEMM the split kernel can take runs on it (workspace sizes are re-queried)."""
+    """PRN_SPLIT_GEMM=2 for one test: every plain GEMM the split kernel can take runs on it (plans and workspace sizes are keyed by the options)."""
     from planerecnet_amd import ops
-    old = ops.lib.prn_split_gemm_mode(2)
-    ops._DESC.clear(); ops._PIPE.clear()
+    old = ops.set_split_gemm(mode=2)
     yield ops
-    ops.lib.prn_split_gemm_mode(old)
-    ops._DESC.clear(); ops._PIPE.clear()
+    ops.set_split_gemm(**old)
 
 
 def _gemm_errors(y, w, x, bias, add, epi):
@@ -896,9 +894,9 @@ def _gemm_errors(y, w, x, bias, add, epi):
 def split_kind(request):
     """Both piece formats of csrc/prn_gemm_split.hip: two fp16 pieces / three products (default) and three bf16 pieces / six products."""
     from planerecnet_amd import ops
-    old = ops.lib.prn_split_gemm_kind(16 if request.param == "f16" else 0)
+    old = ops.set_split_gemm(kind=request.param)
     yield request.param
-    ops.lib.prn_split_gemm_kind(old)
+    ops.set_split_gemm(**old)
 
 
 @pytest.mark.parametrize("M,K,B,HW,bias,add,epi", [
@@ -922,13 +920,12 @@ def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywher
     w = ((torch.rand(M, K, generator=g) * 2 - 1) * K ** -0.5).cuda()
     bv = torch.randn(M, generator=g).cuda() if bias else None
     av = torch.randn(B, M, HW, generator=g).cuda() if add else None
-    assert lib.prn_gemm_pipe(M, K, B, HW, 1) >= 1
+    assert ops.gemm_pipe(M, K, B, HW, 1) >= 1
     out = {}
     for mode in (2, 0):
-        lib.prn_split_gemm_mode(mode)
-        ops._DESC.clear(); ops._PIPE.clear()
+        ops.set_split_gemm(mode=mode)
         _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, epi)
-        assert lib.prn_conv2d_kernel_kind(ref) == (0 if mode == 0 else (3 if lib.prn_gemm_pipe(M, K, B, HW, 1) > 1 else 2))
+        assert lib.prn_conv2d_kernel_kind(ref) == (0 if mode == 0 else (3 if ops.gemm_pipe(M, K, B, HW, 1) > 1 else 2))
         ws = torch.full((max(nbytes, 16) // 4,), float("nan"), device="cuda")
         y = torch.full((B, M, HW), float("nan"), device="cuda")
         check(lib.prn_conv2d_fwd(ref, _p(x), _p(w), _p(bv), _p(av), _p(y), _p(ws), _stream()), "conv")
@@ -945,14 +942,17 @@ def test_split_gemm_batched_and_special_values(split_everywhere, split_kind):
     ops = split_everywhere
     lib, _p, _stream, check = ops.lib, ops._p, ops._stream, ops.check
     M, C, P, nb = 256, 96, 640, 5
-    assert lib.prn_gemm_pipe(M, C, 1, P, nb) == 1
+    assert ops.gemm_pipe(M, C, 1, P, nb) == 1
     g = torch.Generator().manual_seed(3)
     U = torch.randn(nb, M, C, generator=g)
     V = torch.randn(nb, C, P, generator=g)
     U[0, :, :8] = 0.0; U[1, :, 8:16] = 2.0 ** -20; U[2, 3] = 1.0; V[0, :4] = 0.0; V[3] *= 1e18; U[3] *= 1e-18; V[4, :, ::7] = -4096.0
     V[2, 5] = 1e-38                                                            # below bf16's / fp32's normal range after the second slice
     Y = torch.empty(nb, M, P, device="cuda")
-    check(lib.prn_gemm_batched(M, C, P, nb, _p(U.cuda()), _p(V.cuda()), _p(Y), _stream()), "batched")
+    nws = lib.prn_gemm_batched_ws_bytes(M, C, P, nb, ops.opts_ref())
+    assert nws == lib.prn_split_images_bytes(M, C, nb)
+    ws = torch.empty(nws // 4, device="cuda")
+    check(lib.prn_gemm_batched(M, C, P, nb, _p(U.cuda()), None, _p(V.cuda()), _p(Y), _p(ws), ops.opts_ref(), _stream()), "batched")
     torch.cuda.synchronize()
     ref = torch.bmm(U.double(), V.double())
     mag = torch.bmm(U.double().abs(), V.double().abs())
@@ -973,8 +973,7 @@ def test_split_gemm_on_operands_spanning_twelve_decades(split_everywhere, split_
     w = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 3) * torch.exp(torch.randn(M, 1, generator=g) * 6)).cuda()
     out = {}
     for mode in (2, 0):
-        lib.prn_split_gemm_mode(mode)
-        ops._DESC.clear(); ops._PIPE.clear()
+        ops.set_split_gemm(mode=mode)
         _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
         ws = torch.empty(max(nbytes, 16) // 4, device="cuda")
         y = torch.empty(B, M, HW, device="cuda")
@@ -1029,3 +1028,90 @@ def test_split_gemm_weight_images_follow_the_weight(split_everywhere, split_kind
     import gc
     gc.collect()
     assert ptr not in ops._SPLIT_IMG
+
+
+def test_split_gemm_never_reads_a_stale_image_after_an_optimizer_step(split_everywhere, monkeypatch):
+    """The C side keeps no table of images (include/prn.h): a launch reads the images its caller passes -- ops.split_images validates them
+    against the parameter's version counter AND storage address -- or cuts the weight itself.  Sequence the advisor flagged in round 3:
+    train-mode launches keep images of an FPN lateral weight, optimizer.step() changes it, then the INFERENCE block (ops.fpn_level -> C)
+    runs on a split-planned shape: it must see the new weight.  Same after the parameter's storage is replaced (p.data = ...)."""
+    ops = split_everywhere
+    monkeypatch.setattr(ops, "SPLIT_CACHE", "1")
+    monkeypatch.setattr(ops, "SPLIT_CACHE_MIN_TILES", 0)
+    monkeypatch.setitem(ops._SPLIT_POLICY, "mode", "train")
+    B, C, H, W, Fc = 2, 256, 24, 32, 256
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    wl = torch.nn.Parameter((torch.randn(Fc, C, 1, 1, generator=g) * C ** -0.5).cuda())
+    bl = torch.randn(Fc, generator=g).cuda()
+    wo = torch.nn.Parameter((torch.randn(Fc, Fc, 3, 3, generator=g) * (9 * Fc) ** -0.5).cuda())
+    bo = torch.randn(Fc, generator=g).cuda()
+
+    def ref():
+        lat = F.conv2d(x.double().cpu(), wl.detach().double().cpu(), bl.double().cpu())
+        return lat, F.relu(F.conv2d(lat, wo.detach().double().cpu(), bo.double().cpu(), padding=1))
+    with torch.no_grad():
+        y = ops.conv_fwd_raw(x, wl.view(Fc, C), bl, None, Fc, 1, 1, 0, H, W)          # a training-mode launch: images of wl are cut and kept
+        assert wl.data_ptr() in ops._SPLIT_IMG
+        close(y, ref()[0], "lateral, training launch")
+        wl.add_(torch.randn(wl.shape, generator=g).cuda() * 0.05)                    # optimizer.step()
+        wo.mul_(1.5)
+        monkeypatch.setitem(ops._SPLIT_POLICY, "mode", "eval")
+        lat, p = ops.fpn_level(x, wl, bl, None, wo, bo, True)
+        close(lat, ref()[0], "fpn lateral after the update")
+        close(p, ref()[1], "fpn output after the update")
+        monkeypatch.setitem(ops._SPLIT_POLICY, "mode", "train")
+        old_ptr = wl.data_ptr()
+        wl.data = (torch.randn(wl.shape, generator=g) * C ** -0.5).cuda()            # storage replaced, version counter unchanged
+        y = ops.conv_fwd_raw(x, wl.view(Fc, C), bl, None, Fc, 1, 1, 0, H, W)
+        close(y, ref()[0], "lateral after the storage moved")
+        if old_ptr != wl.data_ptr():
+            e = ops._SPLIT_IMG.get(old_ptr)
+            assert e is None or ops._split_state(e) is None
+
+
+def test_two_threads_with_different_options_do_not_interfere():
+    """No process-wide mode in the library: thread A runs 1x1 convolutions with the split kernel on every launch, thread B with fp32 MFMAs
+    only, concurrently on two streams through the raw C ABI; each must reproduce its own single-threaded result bit for bit."""
+    import ctypes, threading
+    from planerecnet_amd import ops, _lib
+    lib, _p, check = ops.lib, ops._p, ops.check
+    M, K, B, HW = 256, 128, 2, 1280
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, K, HW, generator=g).cuda()
+    w = (torch.randn(M, K, generator=g) * K ** -0.5).cuda()
+
+    def make(mode):
+        o = _lib.GemmOpts(mode, 16, 3, 300, 4.0, 0, 0, 0)
+        d = _lib.ConvDesc(B, K, 1, HW, M, 1, 1, 1, 0, 1, HW, 0, 1, 0, 0, 0, 0, 0, o)
+        nb = lib.prn_conv2d_fwd_ws_bytes(ctypes.byref(d))
+        return d, torch.empty(max(nb, 16) // 4, device="cuda")
+
+    def run(d, ws, st, y):
+        check(lib.prn_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), None, None, _p(y), _p(ws), ctypes.c_void_p(st.cuda_stream)), "conv")
+    torch.cuda.synchronize()
+    want = {}
+    for mode in (2, 0):
+        d, ws = make(mode)
+        y = torch.empty(B, M, HW, device="cuda")
+        run(d, ws, torch.cuda.current_stream(), y)
+        torch.cuda.synchronize()
+        want[mode] = y.clone()
+    assert not torch.equal(want[2], want[0])                     # (different summation orders: the two kernels are distinguishable)
+    bad = []
+
+    def worker(mode):
+        d, ws = make(mode)
+        st = torch.cuda.Stream()
+        y = torch.empty(B, M, HW, device="cuda")
+        for _ in range(50):
+            y.fill_(float("nan"))
+            st.wait_stream(torch.cuda.current_stream())
+            run(d, ws, st, y)
+            st.synchronize()
+            if not torch.equal(y, want[mode]):
+                bad.append(mode)
+    ts = [threading.Thread(target=worker, args=(m,)) for m in (2, 0)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert bad == []

@@ -83,7 +83,7 @@ def oracle64(net101, golden_dir):
 
 
 @pytest.mark.parametrize("winograd", [False, True])
-def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, oracle64, winograd):
+def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, oracle64, winograd, gemm_arith):
     from oracle import loss_ref, model_ref, synth
     from planerecnet_amd import ops
     from planerecnet_amd.losses import PlaneRecNetLoss
@@ -162,7 +162,10 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
                 f.write("%-64s err %.2e spread %.2e ratio %.2f\n" % (n, l2, sp, r))
     ratios = np.array([r for r, _, _, _ in worst])
     pct = np.round(np.percentile(ratios, [50, 90, 99, 100]), 3)
-    print("error / bound percentiles (50, 90, 99, max): %s" % pct)
+    print("[gemm arithmetic %s, winograd %s] error / bound percentiles (50, 90, 99, max): %s" % (gemm_arith, winograd, pct))
+    if os.environ.get("PRN_TEST_PCT_LOG"):
+        with open(os.environ["PRN_TEST_PCT_LOG"], "a") as f:
+            f.write("r101_train_step gemm=%s winograd=%s  error/bound percentiles 50/90/99/max = %s  worst: %s\n" % (gemm_arith, winograd, pct.tolist(), [(round(r, 2), n) for r, n, _, _ in worst[:3]]))
     assert not bad, "parameter gradients outside the calibrated bound (error / bound percentiles 50 / 90 / 99 / max: %s): %s" % (pct, bad[:10])
     # the DCN blocks the interval rule places in the 23-block stage are all among the checked parameters
     for b in range(3, 23, 3):

@@ -202,3 +202,38 @@ def test_loss_on_device_targets(crit):
         if k != "pln":
             assert ph[k] == ref[k], k                                       # only the plane term depends on the draws
     assert abs(ph["pln"] - ref["pln"]) <= 0.05 * abs(ref["pln"]) + 1e-3, (ph["pln"], ref["pln"])
+
+
+def test_batch_without_a_single_plane_and_resumed_sampler_stream(crit):
+    """(1) A batch in which NO image has a plane (a real loader can produce one; the synthetic set never does): the device path must build
+    targets -- no positive cell, only the non-planar regions sampled -- instead of failing on the empty mask tensor.  (2) The device sampler's
+    stream is a function of (key, batch counter): a builder started at first_call = k reproduces the k-th batch of one started at 0 (a resumed
+    run continues its stream), and two keys (ranks / run seeds) never share a batch."""
+    from planerecnet_amd.targets import DeviceTargetBuilder
+    H, W = 480, 640
+    empty = [{"masks": torch.zeros(0, H, W, dtype=torch.uint8), "boxes": torch.zeros(0, 4, dtype=torch.float64), "classes": torch.zeros(0, dtype=torch.int64),
+              "plane_paras": torch.zeros(0, 6, dtype=torch.float64), "k_matrix": torch.tensor([[577.0, 0, W / 2], [0, 577.0, H / 2], [0, 0, 1]], dtype=torch.float64)}
+             for _ in range(2)]
+    gtd = (0.5 + 4.0 * torch.rand(2, 1, H, W, generator=torch.Generator().manual_seed(3))).cuda()
+    tb = DeviceTargetBuilder(crit, sampler="philox", seed=1)
+    tb.submit(empty, (H, W))
+    t = tb.get(gtd, torch.device("cuda"))
+    torch.cuda.synchronize()
+    assert t.vnl.n_seg == 2 and t.vnl.n_tot == 2 * int(H * W * 0.3) and not bool(t.vnl.seg_is_plane.any())
+
+    inst = _irregular_batch(3)
+    gtd3 = (0.5 + 4.0 * torch.rand(3, 1, H, W, generator=torch.Generator().manual_seed(2))).cuda()
+
+    def batches(seed, first, n):
+        tb = DeviceTargetBuilder(crit, sampler="philox", seed=seed, first_call=first)
+        out = []
+        for _ in range(n):
+            tb.submit(inst, (H, W))
+            out.append(tb.get(gtd3, torch.device("cuda")).vnl.gid.clone())
+        torch.cuda.synchronize()
+        return out
+    a = batches((7 << 32) | 0, 0, 3)
+    assert torch.equal(batches((7 << 32) | 0, 2, 1)[0], a[2])             # resumed at iteration 2
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[1], a[2])
+    b = batches((7 << 32) | 1, 0, 2)                                       # the next rank
+    assert all(not torch.equal(x, y) for x in a for y in b)

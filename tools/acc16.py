@@ -7,8 +7,8 @@ def errs(y, w, x):
     ref = torch.einsum("mk,bkp->bmp", wd, xd); mag = torch.einsum("mk,bkp->bmp", wd.abs(), xd.abs())
     e = (y.double().cpu() - ref) / (mag + 1e-300)
     return float(e.abs().max()), float(e.pow(2).mean().sqrt()), float(e.mean())
-lib.prn_split_gemm_mode(2)
-print("piece format:", "fp16 x 2, three products" if lib.prn_split_gemm_kind(-1) == 16 else "bf16 x 3, six products")
+ops.set_split_gemm(mode=2)
+print("piece format:", "fp16 x 2, %d products" % ops.split_products() if ops._POLICY["kind"] == 16 else "bf16 x 3, six products")
 for (M, K, B, HW, dist) in [(1024,256,2,1200,"uniform"),(256,1024,2,1200,"uniform"),(200,72,3,1205,"uniform"),(512,2048,8,300,"uniform"),(1024,256,2,1200,"normal"),(1024,256,2,1200,"wide"),(256,256,2,4800,"relu")]:
     g = torch.Generator().manual_seed(M+K)
     if dist == "uniform":
@@ -23,7 +23,7 @@ for (M, K, B, HW, dist) in [(1024,256,2,1200,"uniform"),(256,1024,2,1200,"unifor
     x, w = x.cuda(), w.cuda()
     out = {}
     for mode in (2, 0):
-        lib.prn_split_gemm_mode(mode); ops._DESC.clear(); ops._PIPE.clear()
+        ops.set_split_gemm(mode=mode)
         _, ref, nb, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
         ws = torch.empty(max(nb,16)//4, device="cuda"); y = torch.full((B,M,HW), float("nan"), device="cuda")
         check(lib.prn_conv2d_fwd(ref, _p(x), _p(w), None, None, _p(y), _p(ws), _s()), "conv"); torch.cuda.synchronize()

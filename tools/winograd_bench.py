@@ -40,9 +40,10 @@ def main():
         P = lib.prn_winograd_tiles(B, H, W)
         ws = torch.empty(36 * (C + M) * P, device=dev)
         V, Yt = ws[:36 * C * P], ws[36 * C * P:]
+        gws = torch.empty(max(lib.prn_gemm_batched_ws_bytes(M, C, P, 36, ops.opts_ref()), 16) // 4, device=dev)
         y = torch.empty(B, M, H, W, device=dev)
         ti = timeit(lambda: lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, 0, _stream()))
-        tg = timeit(lambda: lib.prn_gemm_batched(M, C, P, 36, _p(U), _p(V), _p(Yt), _stream()))
+        tg = timeit(lambda: lib.prn_gemm_batched(M, C, P, 36, _p(U), None, _p(V), _p(Yt), _p(gws), ops.opts_ref(), _stream()))
         to = timeit(lambda: lib.prn_winograd_output(_p(Yt), None, None, _p(y), B, M, H, W, 0, _stream()))
         gfl = 2.0 * 36 * M * C * P
         print(f"{name:34s} {fl / 1e9:7.2f} | {td * 1e6:9.1f} {fl / td / 1e12:6.1f} | {tw * 1e6:8.1f} {fl / tw / 1e12:6.1f} {td / tw:5.2f} | "
@@ -63,15 +64,15 @@ def wgrad_main():
         td = timeit(lambda: ops.conv_wgrad_raw(x, dy, M, 3, 1, 1, 0))
         tw = timeit(lambda: ops.conv3x3_winograd_wgrad_raw(x, dy, M))
         P = lib.prn_winograd_tiles(B, H, W)
-        ws = torch.empty(lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M) // 4, device=dev)
+        ws = torch.empty(lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M, ops.opts_ref()) // 4, device=dev)
         dw = torch.empty(M, C, 3, 3, device=dev)
-        args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, 0, _stream())
+        args = (_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, M, 0, ops.opts_ref(), _stream())
         t1 = timeit(lambda: lib.prn_conv3x3_winograd_wgrad(*args, 1))
         t2 = timeit(lambda: lib.prn_conv3x3_winograd_wgrad(*args, 2))
         t3 = timeit(lambda: lib.prn_conv3x3_winograd_wgrad(*args, 3))
         gfl = 2.0 * 36 * M * C * P
         print(f"{name:34s} {fl / 1e9:7.2f} | {td * 1e6:9.1f} {fl / td / 1e12:6.1f} | {tw * 1e6:8.1f} {fl / tw / 1e12:6.1f} {td / tw:5.2f} | "
-              f"{t1 * 1e6:8.1f} {t2 * 1e6:8.1f} {gfl / t2 / 1e12:6.1f} {t3 * 1e6:7.1f} {lib.prn_gemm_batched_nt_splits(M, C, P, 36)}", flush=True)
+              f"{t1 * 1e6:8.1f} {t2 * 1e6:8.1f} {gfl / t2 / 1e12:6.1f} {t3 * 1e6:7.1f} {lib.prn_gemm_batched_nt_splits(M, C, P, 36, ops.opts_ref())}", flush=True)
 
 
 if __name__ == "__main__":

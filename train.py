@@ -79,6 +79,7 @@ parser.add_argument("--hw-queues", dest="hw_queues", default=None, type=int,
                     help="(extension) GPU_MAX_HW_QUEUES for this run (default 3; applied before the HIP runtime starts).")
 parser.add_argument("--target_prep", default="device", choices=("device", "workers"),
                     help="(extension) where the GT-only part of the loss is prepared: HIP kernels a batch ahead, or host worker processes.")
+parser.add_argument("--seed", default=0, type=int, help="Run seed of the device triplet sampler (Philox key; the rank is mixed in).")
 parser.add_argument("--triplet_sampler", default="philox", choices=("philox", "numpy"),
                     help="(extension, --target_prep device) virtual-normal triplet ranks: drawn on the device, or from numpy's global stream like the reference.")
 parser.add_argument("--synthetic_val_size", default=8, type=int, help="(extension) frames in the synthetic validation set.")
@@ -240,7 +241,8 @@ def main():
     save_path = lambda epoch, it: SavePath(cfg.name, epoch, it).get_path(root=args.save_folder)
     if args.target_prep == "device":
         from planerecnet_amd.targets import DeviceTargetBuilder
-        prefetch = DeviceTargetBuilder(criterion, sampler=args.triplet_sampler, seed=rank)
+        # Philox key = (run seed, rank); counter = (triplet, global iteration): ranks and runs draw different streams, a resumed run continues its own
+        prefetch = DeviceTargetBuilder(criterion, sampler=args.triplet_sampler, seed=(int(args.seed) << 32) | rank, first_call=iteration)
     else:
         prefetch = TargetPrefetcher(criterion)
     stager = FrameStager(dev)
