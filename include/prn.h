@@ -57,11 +57,15 @@ enum { PRN_EPI_NONE = 0, PRN_EPI_RELU = 1, PRN_EPI_SIGMOID = 2 };
  *   split_kind      PRN_PIECES_F16: two fp16 pieces per operand element after an exact power-of-two scaling per weight row / activation
  *                   column, split_products = 3 (l*h, h*l, h*h) or 4 (+ l*l) v_mfma_f32_32x32x16_f16 per multiply-add.  PRN_PIECES_BF16:
  *                   three exact bf16 pieces, six v_mfma_f32_32x32x16_bf16, no scaling.  Both accumulate in fp32.
+ *   wgrad_split     PRN_SPLIT_OFF / _PLAN / _ALWAYS for the WEIGHT-GRADIENT GEMMs of the same layers (dW = dy * x^T of stride-1 1x1 convolutions,
+ *                   grouped or not, and the 36 products of the Winograd weight gradient; csrc/prn_wgrad16.hip): both operands are
+ *                   activations and are cut into two fp16 pieces INSIDE the launch, each row scaled by an exact power of two that follows
+ *                   the row's running maximum; three (split_products = 4: four) fp16 MFMA products per multiply-add, fp32 accumulate.
  *   wgrad_wgs       weight-gradient launches are planned for this many workgroups instead of a full residency round (0): a weight
  *                   gradient that shares the GPU with the main chain should not fill every CU's registers.  wgrad_target: workgroups a
  *                   many-tile launch splits up to (0 = 2048).
  * An all-zero value means "fp32 MFMA kernels, full-round weight gradients"; prn_gemm_opts_default() fills the shipping defaults
- * (PRN_SPLIT_PLAN, fp16 pieces, three products, 300 tiles, 4 GFLOP).  A NULL `opts` argument means the all-zero value. */
+ * (PRN_SPLIT_PLAN for both, fp16 pieces, three products, 300 tiles, 4 GFLOP).  A NULL `opts` argument means the all-zero value. */
 enum { PRN_SPLIT_OFF = 0, PRN_SPLIT_PLAN = 1, PRN_SPLIT_ALWAYS = 2 };
 enum { PRN_PIECES_BF16 = 0, PRN_PIECES_F16 = 16 };
 typedef struct prn_gemm_opts {
@@ -72,7 +76,7 @@ typedef struct prn_gemm_opts {
   float split_min_gflop;    /* PRN_SPLIT_PLAN */
   int32_t wgrad_wgs;
   int32_t wgrad_target;
-  int32_t reserved;
+  int32_t wgrad_split;      /* PRN_SPLIT_* */
 } prn_gemm_opts;
 void prn_gemm_opts_default(prn_gemm_opts* o);
 

@@ -16,10 +16,10 @@ class GemmOpts(ctypes.Structure):
     """mirror of prn_gemm_opts: per-call execution options (which matrix pipe, piece format, thresholds, weight-gradient launch size).
     The library keeps no such state; this value travels inside every descriptor / as an argument."""
     _fields_ = [("split_mode", ctypes.c_int32), ("split_kind", ctypes.c_int32), ("split_products", ctypes.c_int32), ("split_min_tiles", ctypes.c_int32),
-                ("split_min_gflop", ctypes.c_float), ("wgrad_wgs", ctypes.c_int32), ("wgrad_target", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("split_min_gflop", ctypes.c_float), ("wgrad_wgs", ctypes.c_int32), ("wgrad_target", ctypes.c_int32), ("wgrad_split", ctypes.c_int32)]
 
     def key(self):
-        return (self.split_mode, self.split_kind, self.split_products, self.split_min_tiles, self.split_min_gflop, self.wgrad_wgs, self.wgrad_target)
+        return (self.split_mode, self.split_kind, self.split_products, self.split_min_tiles, self.split_min_gflop, self.wgrad_wgs, self.wgrad_target, self.wgrad_split)
 
 
 SPLIT_OFF, SPLIT_PLAN, SPLIT_ALWAYS = 0, 1, 2

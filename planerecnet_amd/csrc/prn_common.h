@@ -71,6 +71,12 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
 static inline prn_gemm_opts prn_opts_or_zero(const prn_gemm_opts* o) {
   prn_gemm_opts z;
   if (o) return *o;
-  z.split_mode = 0; z.split_kind = 0; z.split_products = 0; z.split_min_tiles = 0; z.split_min_gflop = 0.f; z.wgrad_wgs = 0; z.wgrad_target = 0; z.reserved = 0;
+  z.split_mode = 0; z.split_kind = 0; z.split_products = 0; z.split_min_tiles = 0; z.split_min_gflop = 0.f; z.wgrad_wgs = 0; z.wgrad_target = 0; z.wgrad_split = 0;
   return z;
 }
+
+// Weight gradient of a plain GEMM layer on the 16-bit pipe (prn_wgrad16.hip): dW[z][m][c] = sum_n dy[z][m][n] x[z][c][n], n = (image, pixel).
+// plan: pixel splits (0: keep the fp32 kernel); launch: out = dw (splits == 1) or partials [splits][nz][M][C].
+int prn_wgrad16_plan(int M, int C, int64_t N, int HW, int nz, const prn_gemm_opts* opts);
+int prn_wgrad16_launch(const float* dy, const float* x, const float* const* gdy, const float* const* gx, int ngroup, float* out, int M, int C, int B, int HW, int nz,
+                       int64_t zdy, int64_t zx, int splits, const prn_gemm_opts* opts, hipStream_t st);

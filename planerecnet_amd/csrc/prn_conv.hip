@@ -516,6 +516,7 @@ struct WgArgs {
   int K, N, HoWo, HW, tilesM, tilesJ, splits, chunks;
   int xbytes, dybytes;       // dybytes: one phase of dy
   int xz;                    // element stride of x per blockIdx.z (prn_gemm_batched_nt; 0 for a convolution)
+  int nzg;                   // grid depth: phases / batched products / layers of a group (the third grid dimension, folded into the 1-D grid)
   int ngroup;                // > 0: blockIdx.z = layer of a group of same-shape layers (prn_conv2d_wgrad_grouped): x / dy from the tables below
   const float* gx[PRN_WGRAD_GROUP_MAX];
   const float* gdy[PRN_WGRAD_GROUP_MAX];
@@ -539,15 +540,21 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   __shared__ float Bs[2][BJ * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WJ, wj = wave % WJ;
-  const int m0 = (blockIdx.x % a.tilesM) * BM, j0 = (blockIdx.x / a.tilesM) * BJ;
-  const int split = blockIdx.y;
+  // 1-D grid renumbered XCD-aware: the output tiles of one (pixel split, z) stream the same dy / x pixels and sit on one XCD's L2
+  // (see prn_wgrad16.hip; as a (tile, split, z) grid the tiles of a split were dealt out round-robin over the eight L2s)
+  const int ntile_ = a.tilesM * a.tilesJ;
+  const int lid_ = prn_xcd_remap(blockIdx.x, ntile_ * a.splits * a.nzg);
+  const int tile_ = lid_ % ntile_, rest_ = lid_ / ntile_;
+  const int m0 = (tile_ % a.tilesM) * BM, j0 = (tile_ / a.tilesM) * BJ;
+  const int split = rest_ % a.splits;
+  const int bz = rest_ / a.splits;               // phase / batch index / layer of the group (was bz)
   const int cbeg = (int)((int64_t)split * a.chunks / a.splits), cend = (int)((int64_t)(split + 1) * a.chunks / a.splits);
 
-  // PRN_IN_UP2_PHASE: blockIdx.z = phase; dy is phase-major [4][B][M][H][W] (prn_space_to_depth2), out is [4][M][4C]
-  const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(blockIdx.z & 1) : 0;
+  // PRN_IN_UP2_PHASE: bz = phase; dy is phase-major [4][B][M][H][W] (prn_space_to_depth2), out is [4][M][4C]
+  const int py = (MODE == PRN_IN_UP2_PHASE) ? (int)(bz >> 1) : 0, px = (MODE == PRN_IN_UP2_PHASE) ? (int)(bz & 1) : 0;
   const int pad_y = (MODE == PRN_IN_UP2_PHASE) ? 1 - py : a.pad, pad_x = (MODE == PRN_IN_UP2_PHASE) ? 1 - px : a.pad;
-  const float* dyz = a.ngroup > 0 ? kernarg_ptr<WgArgs>(offsetof(WgArgs, gdy), blockIdx.z) : a.dy + (size_t)blockIdx.z * (a.dybytes / 4);
-  const float* xz_ = a.ngroup > 0 ? kernarg_ptr<WgArgs>(offsetof(WgArgs, gx), blockIdx.z) : a.x + (size_t)blockIdx.z * a.xz;
+  const float* dyz = a.ngroup > 0 ? kernarg_ptr<WgArgs>(offsetof(WgArgs, gdy), bz) : a.dy + (size_t)bz * (a.dybytes / 4);
+  const float* xz_ = a.ngroup > 0 ? kernarg_ptr<WgArgs>(offsetof(WgArgs, gx), bz) : a.x + (size_t)bz * a.xz;
   int H_ = a.H, W_ = a.W, HW_ = a.HW, Ho_ = a.Ho, Wo_ = a.Wo, HoWo_ = a.HoWo, N_ = a.N;     // current segment's geometry (ragged) / the tensor's
   __amdgpu_buffer_rsrc_t xr = make_rsrc(xz_, a.xbytes), dyr = make_rsrc(dyz, a.dybytes);
   const int arow = tid >> 2, anq = (tid & 3) * 4;
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   };
   if (n4) run(std::true_type{}); else run(std::false_type{});
 
-  float* out = a.out + ((size_t)split * gridDim.z + blockIdx.z) * a.M * a.K;
+  float* out = a.out + ((size_t)split * a.nzg + bz) * a.M * a.K;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int jj = j0 + wj * TJ * 32 + j * 32 + (lane & 31);
@@ -1217,7 +1224,8 @@ WgPlan plan_wgrad(const prn_gemm_opts& o, int M, int K, int64_t N, int phases = 
 
 template <int KS, int MODE>
 int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st, int phases = 1) {
-  dim3 grid(p.tilesM * p.tilesJ, p.splits, phases), block(256);
+  a.nzg = phases;
+  dim3 grid((unsigned)(p.tilesM * p.tilesJ * p.splits * phases)), block(256);
   if constexpr ((KS == 1 || KS == 3) && MODE == PRN_IN_ZERO) {
     if (a.seg.nseg > 0) {                                  // plan_wgrad(..., ragged) only hands out these two tiles
       if (p.wm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, MODE, 1, 1, 1, true>), grid, block, 0, st, a);
@@ -1293,6 +1301,11 @@ int tail_of(const prn_conv_desc* d, const Geo& g, const FwdPlan& p, int* pieces)
 int split_plan_of(const prn_conv_desc* d) {
   if (!(d->KH == 1 && d->in_mode == PRN_IN_ZERO && d->stride == 1 && d->pad == 0 && d->ystride <= 1 && d->Ho == d->H && d->Wo == d->W)) return 0;
   return prn_split_gemm_plan(d->M, d->C, d->B, d->H * d->W, 1, &d->opts);
+}
+// Dense stride-1 1x1 weight gradients may run on the 16-bit pipe (prn_wgrad16.hip): pixel splits, 0 = no.  G: layers in the launch.
+int wgrad16_plan_of(const prn_conv_desc* d, int G) {
+  if (!(d->KH == 1 && d->in_mode == PRN_IN_ZERO && d->stride == 1 && d->pad == 0 && d->ystride <= 1 && d->Ho == d->H && d->Wo == d->W)) return 0;
+  return prn_wgrad16_plan(d->M, d->C, (int64_t)d->B * d->H * d->W, d->H * d->W, G, &d->opts);
 }
 int64_t split_ws_bytes(const prn_conv_desc* d, int splits) {
   return ((prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->H * d->W, 1, splits);
@@ -1496,6 +1509,7 @@ extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_wgrad_ws_bytes")) return -1;
   const int K = d->C * d->KH * d->KW;
   if (direct_small_m(d)) return (int64_t)direct_wgrad_splits(d) * d->M * K * 4;
+  if (const int s16 = wgrad16_plan_of(d, 1)) return s16 > 1 ? (int64_t)s16 * d->M * K * 4 : 0;
   const Geo g = geo_of(d);
   WgPlan p = plan_wgrad(d->opts, d->M, K, (int64_t)d->B * g.gH * g.gW, g.phases);
   return p.splits > 1 ? (int64_t)p.splits * g.phases * d->M * K * 4 : 0;
@@ -1516,6 +1530,7 @@ extern "C" int64_t prn_conv2d_wgrad_grouped_ws_bytes(const prn_conv_desc* d, int
   if (check_desc(d, "prn_conv2d_wgrad_grouped_ws_bytes")) return -1;
   if (G < 1 || G > PRN_WGRAD_GROUP_MAX || geo_of(d).phases != 1 || direct_small_m(d)) { prn_set_error("prn_conv2d_wgrad_grouped_ws_bytes: unsupported group"); return -1; }
   const int K = d->C * d->KH * d->KW;
+  if (const int s16 = wgrad16_plan_of(d, G)) return s16 > 1 ? (int64_t)s16 * G * d->M * K * 4 : 0;
   const WgPlan p = plan_wgrad(d->opts, d->M, K, (int64_t)d->B * d->Ho * d->Wo, G);
   return p.splits > 1 ? (int64_t)p.splits * G * d->M * K * 4 : 0;
 }
@@ -1527,6 +1542,16 @@ extern "C" int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const flo
   const Geo g = geo_of(d);
   PRN_REQUIRE(g.phases == 1 && !direct_small_m(d) && d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->KH != 2 && d->ystride <= 1,
               "prn_conv2d_wgrad_grouped: dense 1x1 / 3x3 / 7x7 weight gradients only");
+  if (const int s16 = wgrad16_plan_of(d, G)) {               // both operands cut into fp16 pieces in the launch (prn_wgrad16.hip)
+    bool al = true;
+    for (int i = 0; i < G; ++i) al = al && x[i] && dy[i] && (reinterpret_cast<uintptr_t>(x[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0;
+    if (al) {
+      PRN_REQUIRE(s16 == 1 || ws != nullptr, "prn_conv2d_wgrad_grouped: workspace required (%d splits)", s16);
+      if (int e = prn_wgrad16_launch(nullptr, nullptr, dy, x, G, s16 > 1 ? (float*)ws : dw, d->M, d->C, d->B, d->H * d->W, G, 0, 0, s16, &d->opts, (hipStream_t)stream)) return e;
+      if (s16 > 1) return prn_launch_reduce_splits((const float*)ws, dw, (int64_t)G * d->M * d->C, s16, (hipStream_t)stream);
+      return 0;
+    }
+  }
   WgArgs a;
   a.x = x[0]; a.dy = dy[0];
   a.B = d->B; a.C = d->C; a.H = d->H; a.W = d->W; a.M = d->M; a.stride = d->stride; a.pad = d->pad;
@@ -1602,6 +1627,15 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
       PRN_CHECK_LAUNCH("prn_conv2d_wgrad/direct reduce");
     }
     return 0;
+  }
+  if (rg == nullptr && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    if (const int s16 = wgrad16_plan_of(d, 1)) {             // both operands cut into fp16 pieces in the launch (prn_wgrad16.hip)
+      PRN_REQUIRE(s16 == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", s16);
+      if (phase != 2)
+        if (int e = prn_wgrad16_launch(dy, x, nullptr, nullptr, 0, s16 > 1 ? (float*)ws : dw, d->M, d->C, d->B, d->H * d->W, 1, 0, 0, s16, &d->opts, (hipStream_t)stream)) return e;
+      if (phase != 1 && s16 > 1) return prn_launch_reduce_splits((const float*)ws, dw, (int64_t)d->M * d->C, s16, (hipStream_t)stream);
+      return 0;
+    }
   }
   WgArgs a;
   a.x = x; a.dy = dy;
@@ -1711,11 +1745,15 @@ WgPlan plan_batched_nt(const prn_gemm_opts* opts, int M, int C, int P, int nb) {
 }
 }  // namespace
 extern "C" int prn_gemm_batched_nt_splits(int M, int C, int P, int nb, const prn_gemm_opts* opts) {
+  if (const int s16 = prn_wgrad16_plan(M, C, P, P, nb, opts)) return s16;
   return plan_batched_nt(opts, M, C, P, nb).splits;
 }
 extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(A && Bm && ws && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched_nt: bad arguments");
   PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched_nt: operand larger than a buffer descriptor");
+  if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) == 0)
+    if (const int s16 = prn_wgrad16_plan(M, C, P, P, nb, opts))     // (partials [splits][nb][M][C], the layout of the fp32 kernel)
+      return prn_wgrad16_launch(A, Bm, nullptr, nullptr, 0, ws, M, C, 1, P, nb, (int64_t)M * P, (int64_t)C * P, s16, opts, (hipStream_t)stream);
   WgArgs a;
   a.x = Bm; a.dy = A; a.out = ws;
   a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
   float rn[16];
   bf16x8_t bp[2][3];
+  const unsigned sflip16 = (px & 1) ? 0x80008000u : 0u, sflip32 = (px & 1) ? 0x80000000u : 0u;      // see split16_gemm_kernel: odd pixels enter negated
 #define SPLIT_DMA(ks_, st_) do { \
     _Pragma("unroll") for (int i = 0; i < 6; ++i) \
       lds_dma16(lds0 + (unsigned)(st_) * (IMG_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG_U4 + (i * 4 + wave) * 64) * 16); \
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       uint4 h, m, l; \
       split2(rn[s2 * 8 + 0], rn[s2 * 8 + 1], h.x, m.x, l.x); split2(rn[s2 * 8 + 2], rn[s2 * 8 + 3], h.y, m.y, l.y); \
       split2(rn[s2 * 8 + 4], rn[s2 * 8 + 5], h.z, m.z, l.z); split2(rn[s2 * 8 + 6], rn[s2 * 8 + 7], h.w, m.w, l.w); \
+      h.x ^= sflip16; h.y ^= sflip16; h.z ^= sflip16; h.w ^= sflip16; m.x ^= sflip16; m.y ^= sflip16; m.z ^= sflip16; m.w ^= sflip16; \
+      l.x ^= sflip16; l.y ^= sflip16; l.z ^= sflip16; l.w ^= sflip16; \
       bp[s2][0] = __builtin_bit_cast(bf16x8_t, h); bp[s2][1] = __builtin_bit_cast(bf16x8_t, m); bp[s2][2] = __builtin_bit_cast(bf16x8_t, l); \
     } } while (0)
   // products smallest first: l*h, h*l, m*m, m*h, h*m, h*h
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = mt * BM + i * 32 + gs * 4 + (e >> 2) * 8 + (e & 3);
-        if (cok && row < M) pb[(long long)row * HW + px] = acc[i][e];
+        if (cok && row < M) pb[(long long)row * HW + px] = __uint_as_float(__float_as_uint(acc[i][e]) ^ sflip32);
       }
     return;
   }
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = rbase + (e >> 2) * 8 + (e & 3);
-      float v = acc[i][e] + bv[e] + av[e];
+      float v = __uint_as_float(__float_as_uint(acc[i][e]) ^ sflip32) + bv[e] + av[e];
       if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
       else if (a.epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
       if (cok && row < M) yb[(long long)row * HW + px] = v;
@@ -269,6 +272,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float rn[16];
   f16x8_t bp[2][2];
   int erun = -1000, de = 0;        // running exponent of this column's largest element; pending rescale of the accumulators
+  // The 16-bit pipe's accumulate step truncates toward -infinity: every output carries an error of about -1e-9 of sum|w||x| whatever its sign --
+  // 1/20 of the rounding noise per element, but COHERENT, so it adds up linearly in every later sum over pixels (BatchNorm / GroupNorm
+  // statistics and their backward sums, weight gradients) where rounding noise adds up as a square root.  Odd pixels therefore enter with
+  // their sign flipped (the pieces' sign bits; the epilogue flips the result back): the truncation error then alternates in sign from one
+  // pixel to the next and cancels in spatial sums.  Costs 16 v_xor per slice.
+  const unsigned sflip16 = (px & 1) ? 0x80008000u : 0u, sflip32 = (px & 1) ? 0x80000000u : 0u;
 #define S16_DMA(ks_, st_) do { \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) \
       lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       uint4 h, l; \
       split2_f16(ldexpf(rn[s2 * 8 + 0], sh), ldexpf(rn[s2 * 8 + 1], sh), h.x, l.x); split2_f16(ldexpf(rn[s2 * 8 + 2], sh), ldexpf(rn[s2 * 8 + 3], sh), h.y, l.y); \
       split2_f16(ldexpf(rn[s2 * 8 + 4], sh), ldexpf(rn[s2 * 8 + 5], sh), h.z, l.z); split2_f16(ldexpf(rn[s2 * 8 + 6], sh), ldexpf(rn[s2 * 8 + 7], sh), h.w, l.w); \
+      h.x ^= sflip16; h.y ^= sflip16; h.z ^= sflip16; h.w ^= sflip16; l.x ^= sflip16; l.y ^= sflip16; l.z ^= sflip16; l.w ^= sflip16; \
       bp[s2][0] = __builtin_bit_cast(f16x8_t, h); bp[s2][1] = __builtin_bit_cast(f16x8_t, l); \
     } } while (0)
 #define S16_STEP(s2_) do { \
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int rl = i * 32 + gs * 4 + (e >> 2) * 8 + (e & 3), row = mt * BM + rl;
-        if (cok && row < M) pb[(long long)row * HW + px] = ldexpf(acc[i][e], erun + exm[rl] - 28);
+        if (cok && row < M) pb[(long long)row * HW + px] = __uint_as_float(__float_as_uint(ldexpf(acc[i][e], erun + exm[rl] - 28)) ^ sflip32);
       }
     return;
   }
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = rbase + (e >> 2) * 8 + (e & 3);
-      float v = ldexpf(acc[i][e], erun + ev[e] - 28) + bv[e] + av[e];
+      float v = __uint_as_float(__float_as_uint(ldexpf(acc[i][e], erun + ev[e] - 28)) ^ sflip32) + bv[e] + av[e];
       if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
       else if (a.epi == PRN_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
       if (cok && row < M) yb[(long long)row * HW + px] = v;
@@ -470,7 +480,7 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
 extern "C" void prn_gemm_opts_default(prn_gemm_opts* o) {
   if (!o) return;
   o->split_mode = PRN_SPLIT_PLAN; o->split_kind = PRN_PIECES_F16; o->split_products = 3; o->split_min_tiles = 300; o->split_min_gflop = 4.0f;
-  o->wgrad_wgs = 0; o->wgrad_target = 0; o->reserved = 0;
+  o->wgrad_wgs = 0; o->wgrad_target = 0; o->wgrad_split = PRN_SPLIT_PLAN;
 }
 extern "C" int64_t prn_split_images_bytes(int M, int K, int nz) {
   if (M <= 0 || K <= 0 || nz <= 0) return -1;

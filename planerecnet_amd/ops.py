@@ -52,16 +52,19 @@ _POLICY = {"split_mode": int(os.environ.get("PRN_SPLIT_GEMM", "1")),
            "min_gflop": float(os.environ.get("PRN_SPLIT_MIN_GFLOP", "4.0")),
            "min_tiles": 300,
            "wgrad_wgs": int(os.environ.get("PRN_WGRAD_WGS", "0") or 0),
-           "wgrad_target": int(os.environ.get("PRN_WGRAD_TARGET", "0") or 0)}
+           "wgrad_target": int(os.environ.get("PRN_WGRAD_TARGET", "0") or 0),
+           # PRN_WGRAD_SPLIT: the weight gradients of the plain-GEMM layers on the 16-bit pipe (csrc/prn_wgrad16.hip): 0 = fp32 MFMA, 1 = by plan, 2 = wherever it applies
+           "wgrad_split": int(os.environ.get("PRN_WGRAD_SPLIT", "1"))}
 _OPTS = {}          # policy tuple -> (GemmOpts, byref)
 _WGS = [None]       # (kept for cache keys: the current options' key)
 
 
 def _opts_entry():
-    key = (_POLICY["split_mode"], _POLICY["kind"], _POLICY["products"], _POLICY["min_tiles"], _POLICY["min_gflop"], _POLICY["wgrad_wgs"], _POLICY["wgrad_target"])
+    key = (_POLICY["split_mode"], _POLICY["kind"], _POLICY["products"], _POLICY["min_tiles"], _POLICY["min_gflop"], _POLICY["wgrad_wgs"], _POLICY["wgrad_target"],
+           _POLICY["wgrad_split"] if _POLICY["kind"] == _lib.PIECES_F16 else 0)          # (the weight-gradient kernel exists for the fp16 pieces only)
     e = _OPTS.get(key)
     if e is None:
-        o = GemmOpts(*key[:4], key[4], key[5], key[6], 0)
+        o = GemmOpts(*key[:4], key[4], key[5], key[6], key[7])
         e = _OPTS[key] = (o, ctypes.byref(o), key)
     _WGS[0] = key
     return e
@@ -76,22 +79,28 @@ def opts_key():
     return _opts_entry()[2]
 
 
-def set_split_gemm(mode=None, kind=None, products=None, min_gflop=None, min_tiles=None):
+def set_split_gemm(mode=None, kind=None, products=None, min_gflop=None, min_tiles=None, wgrad=None):
     """Change this process's split-GEMM policy (tests, tools, bench.py's fp32-only leg); returns the previous values as a dict that can be
     passed back as keyword arguments.  kind: 'f16' / 'bf16' or the PRN_PIECES_* value."""
     old = {"mode": _POLICY["split_mode"], "kind": _POLICY["kind"], "products": _POLICY["products"], "min_gflop": _POLICY["min_gflop"],
-           "min_tiles": _POLICY["min_tiles"]}
+           "min_tiles": (_SPLIT_POLICY["train"], _SPLIT_POLICY["eval"]), "wgrad": _POLICY["wgrad_split"]}
     if mode is not None:
         _POLICY["split_mode"] = int(mode)
+        if wgrad is None:
+            wgrad = int(mode)                                    # (one switch for tests / tools unless told otherwise)
+    if wgrad is not None:
+        _POLICY["wgrad_split"] = int(wgrad)
     if kind is not None:
         _POLICY["kind"] = {"f16": _lib.PIECES_F16, "bf16": _lib.PIECES_BF16}.get(kind, kind)
     if products is not None:
         _POLICY["products"] = int(products)
     if min_gflop is not None:
         _POLICY["min_gflop"] = float(min_gflop)
-    if min_tiles is not None:
-        _POLICY["min_tiles"] = int(min_tiles)
-        _SPLIT_POLICY.pop("current", None)
+    if min_tiles is not None:                                    # an int (both phases) or (train, eval): the thresholds split_gemm_policy switches between
+        tr, ev = (min_tiles if isinstance(min_tiles, (tuple, list)) else (min_tiles, min_tiles))
+        _SPLIT_POLICY["train"], _SPLIT_POLICY["eval"] = int(tr), int(ev)
+        _POLICY["min_tiles"] = _SPLIT_POLICY[_SPLIT_POLICY.get("mode", "eval")]
+        _SPLIT_POLICY["current"] = _POLICY["min_tiles"]
     return old
 
 
@@ -397,7 +406,8 @@ SPLIT_CACHE = os.environ.get("PRN_SPLIT_CACHE", "auto")
 # PlaneRecNet_101 B = 4 at 736x960: 246 against 253)
 SPLIT_CACHE_MIN_TILES = int(os.environ.get("PRN_SPLIT_CACHE_MIN_TILES", "2500"))
 _SPLIT_IMG = {}    # operand data_ptr -> _SplitEntry
-_STAMP = {}        # data_ptr of a derived persistent operand (flipped weight view, Winograd U / Ut) -> generation of its contents
+_STAMP = {}        # data_ptr of a derived persistent operand (flipped weight view, Winograd U / Ut) -> (generation of its contents, weakref to the stamped tensor)
+_STAMP_GEN = [0]   # generations are unique across operands: an address re-stamped by another tensor never repeats a stamp
 _SPLIT_ITEMS = [None, None, 0]     # [item table on the device, the entry set it was built for, total blocks]
 _PIPE = {}
 SPLIT_STATS = {"hits": 0, "cuts": 0, "uncached": 0, "refreshes": 0}     # launches on current images / single re-cuts / temporaries / batched refreshes
@@ -470,7 +480,20 @@ class _SplitEntry:
 def _stamp(t):
     """A derived persistent operand (one the caches below keep and rewrite in place) got new contents."""
     p = t.data_ptr()
-    _STAMP[p] = _STAMP.get(p, 0) + 1
+    _STAMP_GEN[0] += 1
+    _STAMP[p] = (_STAMP_GEN[0], weakref.ref(t))
+
+
+def _stamp_of(ptr):
+    """Generation of the live stamped operand at this address, or None: a stamp whose tensor died says nothing about whatever tensor the
+    allocator put there next (a temporary must not inherit it and get its images cached)."""
+    s = _STAMP.get(ptr)
+    if s is None:
+        return None
+    if s[1]() is None:
+        _STAMP.pop(ptr, None)
+        return None
+    return s[0]
 
 
 def _split_drop(ptr, stamp=True):
@@ -487,7 +510,7 @@ def _split_state(e):
         if o is None or o.data_ptr() != e.ptr:                   # owner gone, or its storage moved (p.data = ..., module.to()): the address may be reused
             return None
         return o._version
-    return _STAMP.get(e.ptr)
+    return _stamp_of(e.ptr)
 
 
 def _prep_items(entries, dev):
@@ -528,7 +551,7 @@ def split_images(t, M, K, nz, cols=None):
             e = None
     if e is None:
         owner = t if isinstance(t, torch.nn.Parameter) else (t._base if isinstance(t._base, torch.nn.Parameter) else None)
-        if owner is None and ptr not in _STAMP:
+        if owner is None and _stamp_of(ptr) is None:
             SPLIT_STATS["uncached"] += 1
             return None                                         # a temporary: the launch cuts it
         if owner is not None and owner.data_ptr() != ptr:
@@ -831,6 +854,8 @@ class WinogradWeights:
 
 
 _WINO_WG_WS = {}
+# the 36 transform-domain products of a layer take the split kernel only from this many 128 x 128 output tiles (0: whenever the plan says so)
+WINOGRAD_SPLIT_MIN_TILES = int(os.environ.get("PRN_SPLIT_WINO_MIN_TILES", "0"))
 WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
 
 
@@ -843,9 +868,10 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         H, W = H + 2, W + 4
     P = lib.prn_winograd_tiles(B, H, W)
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
-    uimg = split_images(U, M, C, 36, (1, P)) if gemm_pipe(M, C, 1, P, 36) >= 1 else None
-    oref = opts_ref()
-    wkey = ("wino-fwd", B, C, H, W, M, opts_key())
+    split_ok = gemm_pipe(M, C, 1, P, 36) >= 1 and ((M + 127) // 128) * ((P + 127) // 128) * 36 >= WINOGRAD_SPLIT_MIN_TILES
+    uimg = split_images(U, M, C, 36, (1, P)) if split_ok else None
+    oref = opts_ref() if split_ok else None
+    wkey = ("wino-fwd", B, C, H, W, M, opts_key() if split_ok else None)
     nb_ws = _WINO_WG_WS.get(wkey)
     if nb_ws is None:
         nb_ws = _WINO_WG_WS[wkey] = lib.prn_conv3x3_winograd_ws_bytes(B, C, H, W, M, oref)
@@ -857,7 +883,7 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
         with profiling.span("winograd_input_kernel", "hbm", 4.0 * x.numel() + 4.0 * V.numel(), 0.0):
             check(lib.prn_winograd_input(_p(x), _p(V), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        fam, ex, _ = _gemm_family(M, C, 1, P, 36, 2.0 * 36 * M * C * P)
+        fam, ex, _ = _gemm_family(M, C, 1, P, 36, 2.0 * 36 * M * C * P) if split_ok else ("conv_igemm_kernel", 2.0 * 36 * M * C * P, None)
         with profiling.span(fam, "mfma", ex, 2.0 * 9 * M * C * B * H * W, nbytes=4.0 * 36 * (C * P + M * C + M * P),
                             tag=("wino-products", C, H, W, M, 3, 1, mode, 1, B)):
             check(lib.prn_gemm_batched(M, C, P, 36, _p(U), uimg, _p(V), _p(Yt), _p(gws) if gws.numel() else None, oref, _stream()), "prn_gemm_batched")
@@ -1666,15 +1692,18 @@ def _rdesc(rs, C, M, K, epi=EPI_NONE):
 
 def _ragged_winograd_raw(xp, U, bias, addend, rs, C, M, P, epi=EPI_NONE):
     y = torch.empty(rs.pixels * M, device=xp.device, dtype=torch.float32)
-    oref = opts_ref()
-    key = ("wino-fwd-ragged", rs.key, C, M, opts_key())
+    # The instance head's towers keep the fp32 MFMA kernel for their 36 products (opts = NULL): five of their parameters are near-cancelling sums
+    # behind a GroupNorm backward (condition ~400, tests/test_r101_train_gpu.py) and F(4x4,3x3)'s output transform amplifies product error by its
+    # coefficients (up to 8); with the fp16-piece products there, three more tower parameters left the R101 gradient bound (3.5x).
+    oref = None
+    key = ("wino-fwd-ragged", rs.key, C, M, None)
     nb = _WINO_WG_WS.get(key)
     if nb is None:
         nb = _WINO_WG_WS[key] = lib.prn_conv3x3_winograd_ragged_ws_bytes(rs.ref, rs.B, C, M, oref)
         if nb < 0:
             raise RuntimeError(lib.prn_last_error().decode())
     ws = torch.empty(nb // 4, device=xp.device, dtype=torch.float32)
-    uimg = split_images(U, M, C, 36, (1, P)) if gemm_pipe(M, C, 1, P, 36) >= 1 else None
+    uimg = None
     with profiling.span("conv3x3_winograd_ragged", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * rs.pixels):   # (three launches in one bracket)
         check(lib.prn_conv3x3_winograd_ragged(_p(xp), _p(U), uimg, _p(bias), _p(addend), _p(y), _p(ws), rs.ref, rs.B, C, M, epi, oref, _stream()),
               "prn_conv3x3_winograd_ragged")

@@ -159,7 +159,7 @@ class DeviceTargetBuilder:
                 self._totals[self._totals_i] = torch.empty(R * 3 * 2, dtype=torch.int64).pin_memory()
             totals_h = self._totals[self._totals_i][:R * 3]
             totals_h.copy_(totals, non_blocking=True)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(blocking=True)          # (a waiting host thread sleeps instead of spinning: the wait is not host WORK)
             done.record()
         small_meta = [{k: (g[k].cpu() if torch.is_tensor(g[k]) else g[k]) for k in ("boxes", "classes", "plane_paras", "k_matrix")} for g in gt_instances]
         self.queue.append({"hw": (H, W), "feat": mask_feat_size, "B": B, "N_per": N_per, "Ntot": Ntot, "img_first": img_first, "first_d": first_d,

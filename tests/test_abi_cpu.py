@@ -42,9 +42,9 @@ def test_argument_validation_without_gpu():
     assert rc != 0 and b"unsupported" in _lib.lib.prn_last_error()
 
 
-def _opts(mode=1, kind=16, products=3, min_tiles=300, min_gflop=4.0, wgs=0, target=0):
+def _opts(mode=1, kind=16, products=3, min_tiles=300, min_gflop=4.0, wgs=0, target=0, wgrad=0):
     from planerecnet_amd import _lib
-    o = _lib.GemmOpts(mode, kind, products, min_tiles, min_gflop, wgs, target, 0)
+    o = _lib.GemmOpts(mode, kind, products, min_tiles, min_gflop, wgs, target, wgrad)
     return o, ctypes.byref(o)
 
 
@@ -75,7 +75,7 @@ def test_split_gemm_plan_is_host_logic():
     assert [lib.prn_gemm_pipe(1024, 256, 8, 1200, 1, q) for q in (o, off, o2500, o)] == [1, 0, 0, 1]
     d = _lib.GemmOpts()
     lib.prn_gemm_opts_default(ctypes.byref(d))
-    assert d.key() == (1, 16, 3, 300, 4.0, 0, 0)
+    assert d.key() == (1, 16, 3, 300, 4.0, 0, 0, 1)
 
 
 def test_workspace_sizes_follow_the_descriptors_options():
@@ -126,3 +126,26 @@ def test_library_allocates_nothing_and_keeps_no_registry():
     syms = declared_symbols()
     for gone in ("prn_split_gemm_mode", "prn_split_gemm_kind", "prn_split_gemm_min_tiles", "prn_split_images_register"):
         assert gone not in syms
+
+
+def test_wgrad16_plan_is_host_logic():
+    """Which weight gradients take the fp16-piece kernel (csrc/prn_wgrad16.hip) is decided on the host from the descriptor's options: dense
+    stride-1 1x1 layers whose dW tiles are mostly full and that carry >= 1 GFLOP; the workspace then holds the pixel-split partial sums."""
+    from planerecnet_amd import _lib
+    lib = _lib.lib
+
+    def desc(o, M=1024, C=256, k=1, stride=1, H=30, W=40):
+        Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        return _lib.ConvDesc(8, C, H, W, M, k, k, stride, k // 2, Ho, Wo, 0, 1, 0, 0, 0, 0, 0, o)
+    on, _ = _opts(mode=0, wgrad=1)
+    off, _ = _opts(mode=0, wgrad=0)
+    d_on, d_off = desc(on), desc(off)
+    b_on, b_off = lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d_on)), lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d_off))
+    assert b_on > 0 and b_on % (1024 * 256 * 4) == 0 and b_off > 0
+    d3 = desc(on, k=3)                                              # 3x3: the fp32 implicit GEMM whatever the option says
+    assert lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(d3)) == lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(desc(off, k=3)))
+    small = desc(on, M=64, C=64)                                    # half-empty tiles: fp32
+    assert lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(small)) == lib.prn_conv2d_wgrad_ws_bytes(ctypes.byref(desc(off, M=64, C=64)))
+    _, o_on = _opts(mode=0, wgrad=1)
+    _, o_off = _opts(mode=0, wgrad=0)
+    assert lib.prn_gemm_batched_nt_splits(256, 256, 9600, 36, o_on) >= 1 and lib.prn_gemm_batched_nt_splits(256, 256, 9600, 36, o_off) >= 1

@@ -1115,3 +1115,103 @@ def test_two_threads_with_different_options_do_not_interfere():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert bad == []
+
+
+def _wgrad_errors(dw, dy, x):
+    """(max, rms, mean) of (dw - fp64 reference) / sum_n |dy||x| per element; dy [B,M,HW], x [B,C,HW]."""
+    dyd, xd = dy.double().cpu(), x.double().cpu()
+    ref = torch.einsum("bmp,bcp->mc", dyd, xd)
+    mag = torch.einsum("bmp,bcp->mc", dyd.abs(), xd.abs())
+    e = (dw.double().cpu().reshape(ref.shape) - ref) / (mag + 1e-300)
+    return float(e.abs().max()), float(e.pow(2).mean().sqrt()), float(e.mean())
+
+
+@pytest.mark.parametrize("M,C,B,H,W", [
+    (1024, 256, 2, 30, 40),      # stage-3 expand
+    (256, 1024, 2, 30, 40),      # stage-3 reduce
+    (200, 136, 3, 15, 20),       # tails in both tile dimensions; 300 pixels per image: chunks straddle images
+    (128, 128, 1, 8, 8),         # one tile, four chunks
+    (2048, 512, 8, 15, 20),      # stage 4
+    (256, 256, 1, 120, 160),     # FPN-sized map: many chunks per workgroup
+])
+def test_wgrad16_is_an_fp32_weight_gradient(M, C, B, H, W):
+    """csrc/prn_wgrad16.hip (both operands cut into two fp16 pieces inside the launch, per-row power-of-two scaling that follows the running
+    maximum, three fp16 MFMA products, fp32 accumulate) against fp64, next to the fp32 MFMA kernel on the same operands: error at fp32
+    rounding level -- max <= 2x the fp32 kernel's (or 4e-7 of sum|dy||x|), rms <= 1.5x (or 2.5e-8)."""
+    from planerecnet_amd import ops
+    g = torch.Generator().manual_seed(M + C + H)
+    x = torch.relu(torch.randn(B, C, H, W, generator=g)).cuda()                 # post-ReLU activations
+    dy = (torch.randn(B, M, H, W, generator=g) * torch.exp(torch.randn(1, M, 1, 1, generator=g))).cuda()      # per-channel gradient scales
+    out = {}
+    old = ops.set_split_gemm(wgrad=2)
+    try:
+        for mode in (2, 0):
+            ops.set_split_gemm(wgrad=mode)
+            dw = ops.conv_wgrad_raw(x, dy, M, 1, 1, 0, ops.IN_ZERO)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(dw).all())
+            out[mode] = _wgrad_errors(dw, dy.flatten(2), x.flatten(2))
+    finally:
+        ops.set_split_gemm(**old)
+    (smax, srms, smean), (fmax, frms, fmean) = out[2], out[0]
+    print("wgrad16 %s: max %.2e rms %.2e mean %+.1e | fp32 max %.2e rms %.2e mean %+.1e" % ((M, C, B, H, W), smax, srms, smean, fmax, frms, fmean))
+    assert smax <= max(2.0 * fmax, 4e-7) and srms <= max(1.5 * frms, 2.5e-8), out
+
+
+def test_wgrad16_rows_that_grow_vanish_and_overflow_fp16():
+    """The per-row running scale: rows whose magnitude jumps by 2^20 halfway through the pixels (accumulators rescaled), all-zero rows, rows of
+    1e-20 / 1e+15 magnitudes (far outside fp16's range before scaling), a row that is zero except for its last pixel, negative rows."""
+    from planerecnet_amd import ops
+    M, C, B, H, W = 256, 128, 2, 20, 24
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, C, H, W, generator=g)
+    dy = torch.randn(B, M, H, W, generator=g)
+    dy[:, 3] = 0.0
+    dy[:, 5] *= 1e-20; dy[:, 6] *= 1e15; x[:, 7] *= 1e-15; x[:, 8] *= 1e10      # (products stay inside fp32's NORMAL range: 1e-35 .. 1e25)
+    dy[1, 9] *= 2.0 ** 20; x[1, 10, 10:] *= 2.0 ** 24                            # maxima that rise late
+    dy[:, 11] = 0.0; dy[1, 11, -1, -1] = -3.0
+    x[:, 12] = -x[:, 12].abs()
+    dy[0, 13] *= 2.0 ** 20                                                      # and one that falls: early pixels dominate, late ones lose relative precision only
+    x, dy = x.cuda(), dy.cuda()
+    old = ops.set_split_gemm(wgrad=2)
+    try:
+        dw = ops.conv_wgrad_raw(x, dy, M, 1, 1, 0, ops.IN_ZERO)
+    finally:
+        ops.set_split_gemm(**old)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dw).all())
+    smax, srms, _ = _wgrad_errors(dw, dy.flatten(2), x.flatten(2))
+    assert smax <= 1e-6 and srms <= 3e-8, (smax, srms)
+    assert float(dw[3].abs().max()) == 0.0
+
+
+def test_wgrad16_grouped_and_batched_products():
+    """The same kernel behind prn_conv2d_wgrad_grouped (blockIdx.z = layer, pointer tables) and prn_gemm_batched_nt (the 36 products of the
+    Winograd weight gradient: partial sums in the fp32 kernel's layout)."""
+    from planerecnet_amd import ops
+    lib, _p, _stream, check = ops.lib, ops._p, ops._stream, ops.check
+    g = torch.Generator().manual_seed(9)
+    M, C, B, H, W, G = 256, 256, 2, 30, 40, 3
+    xs = [torch.randn(B, C, H, W, generator=g).cuda() for _ in range(G)]
+    dys = [torch.randn(B, M, H, W, generator=g).cuda() for _ in range(G)]
+    old = ops.set_split_gemm(wgrad=2)
+    try:
+        dw = ops.conv_wgrad_grouped_raw(xs, dys, M, 1, 1, 0, ops.IN_ZERO)
+        torch.cuda.synchronize()
+        for i in range(G):
+            smax, srms, _ = _wgrad_errors(dw[i], dys[i].flatten(2), xs[i].flatten(2))
+            assert smax <= 4e-7 and srms <= 2.5e-8, (i, smax, srms)
+        nb, P = 5, 644
+        A = torch.randn(nb, M, P, generator=g).cuda()
+        Bm = torch.randn(nb, 136, P, generator=g).cuda()
+        oref = ops.opts_ref()
+        S = lib.prn_gemm_batched_nt_splits(M, 136, P, nb, oref)
+        part = torch.full((S, nb, M, 136), float("nan"), device="cuda")
+        check(lib.prn_gemm_batched_nt(M, 136, P, nb, _p(A), _p(Bm), _p(part), oref, _stream()), "batched nt")
+        torch.cuda.synchronize()
+        got = part.sum(0)
+        for zi in range(nb):
+            smax, srms, _ = _wgrad_errors(got[zi], A[zi][None], Bm[zi][None])
+            assert smax <= 4e-7 and srms <= 2.5e-8, (zi, smax, srms)
+    finally:
+        ops.set_split_gemm(**old)
