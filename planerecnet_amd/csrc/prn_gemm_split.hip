@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
   float rn[16];
   bf16x8_t bp[2][3];
-  const unsigned sflip16 = (px & 1) ? 0x80008000u : 0u, sflip32 = (px & 1) ? 0x80000000u : 0u;      // see split16_gemm_kernel: odd pixels enter negated
+  const unsigned podd = (unsigned)__builtin_popcount((unsigned)px) & 1u;                            // see split16_gemm_kernel: Thue-Morse pixels enter negated
+  const unsigned sflip16 = podd ? 0x80008000u : 0u, sflip32 = podd ? 0x80000000u : 0u;
 #define SPLIT_DMA(ks_, st_) do { \
     _Pragma("unroll") for (int i = 0; i < 6; ++i) \
       lds_dma16(lds0 + (unsigned)(st_) * (IMG_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG_U4 + (i * 4 + wave) * 64) * 16); \
@@ -276,8 +277,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // 1/20 of the rounding noise per element, but COHERENT, so it adds up linearly in every later sum over pixels (BatchNorm / GroupNorm
   // statistics and their backward sums, weight gradients) where rounding noise adds up as a square root.  Odd pixels therefore enter with
   // their sign flipped (the pieces' sign bits; the epilogue flips the result back): the truncation error then alternates in sign from one
-  // pixel to the next and cancels in spatial sums.  Costs 16 v_xor per slice.
-  const unsigned sflip16 = (px & 1) ? 0x80008000u : 0u, sflip32 = (px & 1) ? 0x80000000u : 0u;
+  // pixel to the next and cancels in spatial sums.  Costs 16 v_xor per slice.  Which pixels: those whose index has an odd number of set bits
+  // (the Thue-Morse sequence), not simply the odd ones -- a plain alternation along x survives every stride-2 subsampling (downsample
+  // convolutions, resize x0.5) as a constant sign; t(2n) = t(n) makes the subsampled pattern the same balanced sequence again.
+  const unsigned podd = (unsigned)__builtin_popcount((unsigned)px) & 1u;
+  const unsigned sflip16 = podd ? 0x80008000u : 0u, sflip32 = podd ? 0x80000000u : 0u;
 #define S16_DMA(ks_, st_) do { \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) \
       lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \

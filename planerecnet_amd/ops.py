@@ -59,8 +59,8 @@ _OPTS = {}          # policy tuple -> (GemmOpts, byref)
 _WGS = [None]       # (kept for cache keys: the current options' key)
 
 
-def _opts_entry():
-    key = (_POLICY["split_mode"], _POLICY["kind"], _POLICY["products"], _POLICY["min_tiles"], _POLICY["min_gflop"], _POLICY["wgrad_wgs"], _POLICY["wgrad_target"],
+def _opts_entry(no_split=False):
+    key = (0 if no_split else _POLICY["split_mode"], _POLICY["kind"], _POLICY["products"], _POLICY["min_tiles"], _POLICY["min_gflop"], _POLICY["wgrad_wgs"], _POLICY["wgrad_target"],
            _POLICY["wgrad_split"] if _POLICY["kind"] == _lib.PIECES_F16 else 0)          # (the weight-gradient kernel exists for the fp16 pieces only)
     e = _OPTS.get(key)
     if e is None:
@@ -338,7 +338,7 @@ _DESC = {}        # (shape key) -> (ConvDesc, byref, fwd workspace bytes, wgrad 
 
 
 def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, ystride=0, yH=0, yW=0):
-    oe = _opts_entry()
+    oe = _opts_entry("conv1x1" in SPLIT_SKIP)
     key = (B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, ystride, yH, yW, oe[2])
     e = _DESC.get(key)
     if e is None:
@@ -856,6 +856,7 @@ class WinogradWeights:
 _WINO_WG_WS = {}
 # the 36 transform-domain products of a layer take the split kernel only from this many 128 x 128 output tiles (0: whenever the plan says so)
 WINOGRAD_SPLIT_MIN_TILES = int(os.environ.get("PRN_SPLIT_WINO_MIN_TILES", "0"))
+SPLIT_SKIP = set(filter(None, os.environ.get("PRN_SPLIT_SKIP", "").split(",")))      # bisecting aid: launch families kept on the fp32 kernel: conv1x1, colgrad, prior, wino
 WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
 
 
@@ -868,7 +869,7 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         H, W = H + 2, W + 4
     P = lib.prn_winograd_tiles(B, H, W)
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
-    split_ok = gemm_pipe(M, C, 1, P, 36) >= 1 and ((M + 127) // 128) * ((P + 127) // 128) * 36 >= WINOGRAD_SPLIT_MIN_TILES
+    split_ok = "wino" not in SPLIT_SKIP and gemm_pipe(M, C, 1, P, 36) >= 1 and ((M + 127) // 128) * ((P + 127) // 128) * 36 >= WINOGRAD_SPLIT_MIN_TILES
     uimg = split_images(U, M, C, 36, (1, P)) if split_ok else None
     oref = opts_ref() if split_ok else None
     wkey = ("wino-fwd", B, C, H, W, M, opts_key() if split_ok else None)
@@ -1135,7 +1136,7 @@ _DCN = {}          # geometry key -> (DcnDesc, byref, table bytes, fwd ws bytes,
 
 
 def _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset, epi=EPI_NONE):
-    oe = _opts_entry()
+    oe = _opts_entry("colgrad" in SPLIT_SKIP)
     key = (B, C, H, W, M, stride, pad, raw, float(max_offset), epi, oe[2])
     e = _DCN.get(key)
     if e is None:
@@ -1374,7 +1375,7 @@ class _PlanePrior(torch.autograd.Function):
         seg, kernels, w1, b1 = _c(seg), _c(kernels), _c(w1), _c(b1)
         B, E, h, w = seg.shape
         NK, F = kernels.shape[1], w1.shape[0]
-        oref = opts_ref()              # (the block's split-kernel launches cut their weights per call: nothing cached, nothing stale)
+        oref = _opts_entry("prior" in SPLIT_SKIP)[1]              # (the block's split-kernel launches cut their weights per call: nothing cached, nothing stale)
         nb = lib.prn_plane_prior_ws_bytes(B, E, h, w, NK, F, oref)
         if nb < 0:
             raise RuntimeError(lib.prn_last_error().decode())

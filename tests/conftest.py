@@ -33,7 +33,10 @@ GEMM_ARITHMETICS = {"default": {}, "b8-plan": {"mode": 1, "kind": "f16", "min_ti
 @pytest.fixture(params=list(GEMM_ARITHMETICS))
 def gemm_arith(request):
     from planerecnet_amd import ops
-    old = ops.set_split_gemm(**GEMM_ARITHMETICS[request.param])
+    kw = dict(GEMM_ARITHMETICS[request.param])
+    if os.environ.get("PRN_TEST_WGRAD") is not None and kw.get("mode", 1) != 0:      # (bisecting aid: the weight-gradient kernel on / off under any arithmetic)
+        kw["wgrad"] = int(os.environ["PRN_TEST_WGRAD"])
+    old = ops.set_split_gemm(**kw)
     ops.SPLIT_STATS.update({"hits": 0, "cuts": 0, "uncached": 0})
     yield request.param
     ops.set_split_gemm(**old)
