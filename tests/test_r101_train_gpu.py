@@ -86,9 +86,10 @@ def oracle64(net101, golden_dir):
 # this parametrisation (profiles/r04_*_pct*.txt): with the pipe's truncation bias uncorrected the instance head's ill-conditioned tower
 # parameters reached 7.9x their bound (both piece formats); flipping the sign of every second pixel brought the fp16 form to 0.91 with the direct
 # kernels but left 3.5x with Winograd and 1.4x under the B = 8 plan; the Thue-Morse pixel pattern (csrc/prn_gemm_split.hip) brings the B = 8
-# plan to 0.90 and PRN_SPLIT_ALWAYS + Winograd to 0.86.  The all-* combinations are REPORTED (percentile log), not gated; what gates is every
-# arithmetic the product can be configured to time: default, the B = 8 plan, fp32 only.
-_REPORT_ONLY = {("all-f16", False), ("all-f16", True), ("all-bf16", False), ("all-bf16", True)}
+# plan to 0.90 and PRN_SPLIT_ALWAYS to 0.99 (direct) / 0.86 (Winograd), all gating now.  The bf16-piece form (not the default; its truncating cut
+# adds a second, sign-symmetric bias the pixel pattern cannot cancel) still reaches 4.2x / 1.3x under PRN_SPLIT_ALWAYS: REPORTED (percentile
+# log, xfail non-strict), not gated.
+_REPORT_ONLY = {("all-bf16", False), ("all-bf16", True)}
 
 
 @pytest.mark.parametrize("winograd", [False, True])
