@@ -56,28 +56,31 @@ def step():
     opt.step()
 
 
-for _ in range(6):
+HOST_ONLY = bool(os.environ.get("HOST_ONLY"))          # several copies of this script share ONE GPU (tools/host_probe_8ranks.sh): only H means something
+for _ in range(3 if HOST_ONLY else 6):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10):
+for _ in range(0 if HOST_ONLY else 10):
     step()
 torch.cuda.synchronize()
 S = (time.perf_counter() - t0) / 10 * 1e3
-Hs, Gs = [], []
+Hs, Gs, Cs = [], [], []
 for _ in range(6):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda._sleep(int(0.25 * 2.4e9))            # ~250 ms at 2.4 GHz... clock-dependent: only has to outlast the enqueue
     e0.record()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     step()
     Hs.append((time.perf_counter() - t0) * 1e3)
+    Cs.append((time.process_time() - c0) * 1e3)
     e1.record()
     torch.cuda.synchronize()
     Gs.append(e0.elapsed_time(e1))
 print("free-running step S = %.1f ms" % S)
 print("host enqueue H (GPU parked): " + " ".join("%.1f" % h for h in Hs))
+print("process CPU during the enqueue (all threads): " + " ".join("%.1f" % c for c in Cs))
 print("GPU drain    G (no host dep): " + " ".join("%.1f" % g for g in Gs))
 if hasattr(pf, "host_ms"):
     print("target preparation, host side (submit + get): %.1f ms wall / %.1f ms CPU per step (mode %s)" % (pf.host_ms / pf.calls, pf.host_cpu_ms / pf.calls, os.environ.get("TARGETS", "device")))

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 rm -rf /tmp/pmc_mfma
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad --dcn-offsets 0 > /tmp/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o t -- env PRN_BENCH_NO_FP32_RUN=1 python $R/bench.py --no-exchange-probe --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad --dcn-offsets 0 > /tmp/pmc_mfma.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json, os
 f = glob.glob('/tmp/pmc_mfma/*counter_collection.csv')
@@ -15,7 +15,7 @@ cnt = collections.Counter()
 for r in csv.DictReader(open(f[0])):
     k = r['Kernel_Name']
     fam = None
-    for key in ("split16_gemm_kernel", "split_gemm_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel"):
+    for key in ("wgrad16_kernel", "split16_gemm_kernel", "split_gemm_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel"):
         if key in k:
             fam = key
     if fam is None:

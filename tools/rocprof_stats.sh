@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out/prof
 for mode in serial default; do
   rm -rf /tmp/prof_$mode
   extra=""; [ $mode = serial ] && extra="--sync-wgrad"
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -o t -- python $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-roofline --dcn-offsets 0 $extra > /tmp/prof_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -o t -- env PRN_BENCH_NO_FP32_RUN=1 python $R/bench.py --no-exchange-probe --steps 10 --warmup 1 --no-cpu-baseline --no-roofline --dcn-offsets 0 $extra > /tmp/prof_$mode.log 2>&1
   f=$(ls /tmp/prof_$mode/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $R/gpurun_out/prof/${TAG}_kernel_stats_$mode.csv
   tail -2 /tmp/prof_$mode.log | cut -c1-300
@@ -28,7 +28,7 @@ for mode in ("serial", "default"):
     for r in rows:
         nm = r["Name"]
         key = "ATen / rocprim / copies"
-        for k in ("split16_gemm_kernel", "split_gemm_kernel", "split16_", "split_prepare", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel", "dcnv2_table", "dcn_", "winograd_", "bn_", "gn_relu", "reduce_splits", "reduce_epilogue", "resize_", "mask_loss", "maxpool", "channel_sum", "flip_transpose", "pad_fold", "replicate_fold", "space_to_depth", "up2_", "conv3x3_"):
+        for k in ("wgrad16_kernel", "split16_gemm_kernel", "split_gemm_kernel", "split16_", "split_prepare", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel", "dcnv2_table", "dcn_", "winograd_", "bn_", "gn_relu", "reduce_splits", "reduce_epilogue", "resize_", "mask_loss", "maxpool", "channel_sum", "flip_transpose", "pad_fold", "replicate_fold", "space_to_depth", "up2_", "conv3x3_"):
             if k in nm and "at::" not in nm:
                 key = k
                 break
