@@ -112,7 +112,11 @@ int prn_conv2d_kernel_kind(const prn_conv_desc* d);
  *                    v_mfma_f32_32x32x16_f16.  Error against fp64 at the fp32 MFMA kernel's level on this network's tensors; on operands
  *                    spanning > 2^17 inside one row / column the smallest elements lose relative precision (tests/test_ops_gpu.py).
  *   PRN_PIECES_BF16: the three 8-bit slices of the 24-bit significand (exact), six of the nine products as v_mfma_f32_32x32x16_bf16;
- *                    the dropped three are <= 2^-23 of the product.
+ *                    the dropped three are <= 2^-23 of the product.  (Pieces cut by truncation: a small sign-symmetric bias the pixel sign
+ *                    pattern below cannot cancel; under PRN_SPLIT_ALWAYS the R101 gradient test reports 4x its bound for it -- not the default.)
+ * Both forms flip the sign of the activation pieces of the pixels whose index has odd bit parity (Thue-Morse) and flip the result back: the
+ * 16-bit pipe's accumulate step truncates toward -infinity (-1e-9 of sum|a||b| on every output, coherent), and the pattern makes that error
+ * cancel in every later sum over pixels, also after stride-2 subsampling.
  * This is NOT the reference's fp32 FMA chain bit for bit (neither is any other summation order); bench.py reports it in `dtype`. */
 int prn_gemm_pipe(int M, int K, int B, int HW, int nz, const prn_gemm_opts* opts);
 /* The weight side of the split kernel ("images": [z][m tile of 128][k slice of 32][piece][k group][row][8 x 16 bit], zero padded; the fp16
