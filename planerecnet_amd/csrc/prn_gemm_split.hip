@@ -323,13 +323,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  // Schedule (round 4): the activation loads of slice ks + 2 are issued at the END of iteration ks, right after the registers they land in
+  // were cut into the pieces of slice ks + 1 -- so they have a whole iteration (barrier, weight DMA, 24 MFMAs, the cut) to arrive, at no
+  // register cost.  Before, they were issued at the top of iteration ks + 1 and needed at its end: only the MFMA phase covered their latency.
   S16_DMA(ks0, 0);
   S16_LOADB(ks0);
   S16_PIECES();
   de = 0;                                                        // nothing accumulated yet
+  S16_LOADB(ks0 + 1);                                            // (slices past K read zeros through the descriptor's range check)
   for (int ks = ks0; ks < ks1; ++ks) {
     const int st = (ks - ks0) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // this slice's weight DMA is older than the 16 activation loads that stay in flight
     __syncthreads();
     if (__builtin_amdgcn_ballot_w64(de != 0) != 0ull) {          // a column's maximum grew: bring its partial sums to the new scale (exact)
 #pragma unroll
@@ -338,14 +342,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int e = 0; e < 16; ++e) acc[i][e] = ldexpf(acc[i][e], de);
     }
     const bool more = ks + 1 < ks1;
-    const int kn = more ? ks + 1 : ks;
     if (more) S16_DMA(ks + 1, st ^ 1);
-    S16_LOADB(kn);
     __builtin_amdgcn_sched_barrier(0);
     S16_STEP(0);
     __builtin_amdgcn_sched_barrier(0);
     S16_STEP(1);
-    if (more) S16_PIECES(); else de = 0;                        // (the last slice was loaded twice: its pieces are not needed again)
+    if (more) S16_PIECES(); else de = 0;                        // slice ks + 1 (of THIS K split only: the running scale must not see the next split's data)
+    __builtin_amdgcn_sched_barrier(0);
+    S16_LOADB(ks + 2);
   }
 #undef S16_DMA
 #undef S16_LOADB
