@@ -481,7 +481,7 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
     if (splits < 1) splits = 1;
   }
   if (o->split_mode == PRN_SPLIT_ALWAYS) return splits;
-  if (M % 128 != 0 && M % 128 <= 64) return 0;
+  if ((int64_t)mtiles * 128 * 4 > (int64_t)M * 5) return 0;      // more than a fifth of the row tiles' rows would be padding (M = 64, 160, 192: yes; 3728: no)
   if (2.0 * M * K * (double)HW * B * nz < (double)o->split_min_gflop * 1e9) return 0;   // small launches are all launch latency: one kernel beats split + GEMM (+ sum)
   if (tiles * splits < o->split_min_tiles) return 0;
   return splits;

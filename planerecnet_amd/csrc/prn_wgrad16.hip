@@ -256,7 +256,7 @@ int prn_wgrad16_plan(int M, int C, int64_t N, int HW, int nz, const prn_gemm_opt
   const int chunks = cdiv(N, 16);
   if (o->wgrad_split != PRN_SPLIT_ALWAYS) {
     // where it pays (tools/wgrad16_bench.py): both tile dimensions mostly full and enough work to amortise the partial-sum round trip
-    if (M < 96 || C < 96 || (M % 128 != 0 && M % 128 < 64) || (C % 128 != 0 && C % 128 < 64)) return 0;
+    if ((int64_t)cdiv(M, 128) * 128 * 4 > (int64_t)M * 5 || (int64_t)cdiv(C, 128) * 128 * 4 > (int64_t)C * 5) return 0;      // > 1/5 of a tile dimension padding
     if (2.0 * M * C * (double)N * nz < 0.25e9 * (double)o->split_min_gflop) return 0;      // (1 GFLOP at the default floor of 4)
   }
   const int target = o->wgrad_wgs > 0 ? o->wgrad_wgs : 768;            // three workgroups per CU (168 VGPRs): one full residency round
