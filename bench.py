@@ -72,9 +72,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 256 * 4 * 1024 * 2.4e9 / 1e12
 
 
+PIPE16 = ("split_gemm_kernel", "wgrad16_kernel")      # profiler families whose launches issue 16-bit piece products (work credited = products x 2*M*N*K)
+
+
 def mfma_peak(kernel):
     """Peak of the matrix pipe a kernel family issues on: the split GEMM runs bf16 piece products, everything else fp32 MFMA."""
-    return PEAK_BF16_MFMA_TFLOPS if kernel == "split_gemm_kernel" else PEAK_FP32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if kernel in PIPE16 else PEAK_FP32_MFMA_TFLOPS
 PEAK_HBM_GBS = 8000.0
 
 
@@ -124,6 +127,8 @@ def pmc_traffic(kernel):
     fam = fams.get(kernel)
     if fam is None and kernel == "split_gemm_kernel":           # (the profiler family of both piece formats; the fp16 one's kernel is split16_gemm_kernel)
         fam = fams.get("split16_gemm_kernel")
+    if fam is not None and "hbm_bytes_per_launch" not in fam:
+        fam = None
     return None if fam is None else {"bytes_per_launch": fam["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
 
 
@@ -537,12 +542,17 @@ def main():
         # ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMMs a launch evaluates) over the launch time, against the dense matrix peak of the dtype the
         # path computes in (fp32: 157.3 TFLOP/s).  For the fp32 MFMA kernels that is also what they execute; the split kernel executes three
         # (fp16 pieces) or six (bf16 pieces) products per multiply-add on the 16-bit pipe -- its pipe-side view is in `split_gemm` below.
-        dom_alg = dom["achieved"] / (ops.split_products() if dom["kernel"] == "split_gemm_kernel" else 1.0)
+        dom_alg = dom["achieved"] / (ops.split_products() if dom["kernel"] in PIPE16 else 1.0)
         roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom_alg, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom_alg / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"],
                 "avg_launch_us": 1e3 * dom["time_ms"] / dom["launches"],
-                "flops_per_launch": dom["work"] / dom["launches"] / (ops.split_products() if dom["kernel"] == "split_gemm_kernel" else 1.0),
+                "flops_per_launch": dom["work"] / dom["launches"] / (ops.split_products() if dom["kernel"] in PIPE16 else 1.0),
                 "hbm_families_above_copy_rate": over}
+        if dom["kernel"] in PIPE16:         # the dominant family issues 16-bit piece products: `frac` above is ALGORITHMIC fp32 FLOPs over the fp32 MFMA peak;
+            roof["executed_on"] = "fp16 matrix pipe (%g piece products per multiply-add)" % ops.split_products()      # this is the same launches against the pipe they run on
+            roof["executed_achieved"] = dom["achieved"]
+            roof["executed_peak"] = PEAK_BF16_MFMA_TFLOPS
+            roof["executed_frac"] = dom["achieved"] / PEAK_BF16_MFMA_TFLOPS
         # `achieved` above credits every launch with the FLOPs it EXECUTES (an MFMA utilisation) -- that is the headline
         # figure.  Footnote: the Winograd launches execute a quarter of the multiply-adds of the convolution they evaluate, so the
         # same step is also summarised as FLOPs of the REFERENCE convolutions over the time of every kernel of the convolution
@@ -550,11 +560,9 @@ def main():
         # The plain-GEMM launches that run on the bf16 matrix pipe by exact operand splitting (csrc/prn_gemm_split.hip): `achieved` /
         # `frac` price the six bf16 piece products each fp32 multiply-add costs against the bf16 peak; `fp32_equivalent` is the fp32
         # GEMM rate the launches deliver (2*M*N*K over their time), next to the fp32 MFMA peak it would otherwise be bounded by.
-        sp = [f for f in fams if f["kernel"] == "split_gemm_kernel"]
-        if sp:
-            f = sp[0]
+        for f in [f for f in fams if f["kernel"] in PIPE16]:
             eq = f["work"] / ops.split_products() / (f["time_ms"] * 1e-3) / 1e12     # 2*M*N*K of the GEMMs the launches evaluate
-            roof["split_gemm"] = {"launches": f["launches"], "time_ms": f["time_ms"], "achieved": f["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            roof["split_gemm" if f["kernel"] == "split_gemm_kernel" else "wgrad16"] = {"launches": f["launches"], "time_ms": f["time_ms"], "achieved": f["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": f["achieved"] / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent": eq, "fp32_equivalent_over_fp32_mfma_peak": eq / PEAK_FP32_MFMA_TFLOPS,
                                   "pieces": ("2 x fp16 per fp32 operand (scaled by exact powers of two per weight row / activation column), 3 of 4 products, fp32 accumulate"
                                              if ops.split_products() <= 4.0 else "3 x bf16 per fp32 operand (exact), 6 of 9 products, fp32 accumulate")}
@@ -563,13 +571,13 @@ def main():
         # launches that moved to it were conv_igemm's most efficient ones, so that family's own `frac` falls when they leave).
         gm = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "split_gemm_kernel")]
         if len(gm) == 2:
-            fl = sum(f["work"] / (ops.split_products() if f["kernel"] == "split_gemm_kernel" else 1.0) for f in gm)
+            fl = sum(f["work"] / (ops.split_products() if f["kernel"] in PIPE16 else 1.0) for f in gm)
             ms = sum(f["time_ms"] for f in gm)
             roof["gemm_launches_fp32_equivalent"] = {"kernels": [f["kernel"] for f in gm], "launches": sum(f["launches"] for f in gm), "time_ms": ms,
                                                      "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
                                                      "frac": fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         conv = [f for f in fams if f["kernel"] in ("conv_igemm_kernel", "split_gemm_kernel", "reduce_epilogue_kernel", "winograd_input_kernel", "winograd_output_kernel",
-                                                    "conv3x3_winograd_ragged", "conv_wgrad_kernel", "reduce_splits_kernel", "winograd_wgrad_transforms",
+                                                    "conv3x3_winograd_ragged", "conv_wgrad_kernel", "wgrad16_kernel", "reduce_splits_kernel", "winograd_wgrad_transforms",
                                                     "winograd_dw_kernel", "conv3x3_winograd_wgrad_ragged", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel")]
         ref_flops = sum(f["ref_work"] for f in conv if f["bound"] == "mfma")
         conv_ms = sum(f["time_ms"] for f in conv)
@@ -585,8 +593,8 @@ def main():
         # north star: ">= 60 % of the relevant roofline on the DCNv2 + conv kernels" -- one line per kernel group, all as ALGORITHMIC fp32 FLOPs
         # over launch time against the fp32 MFMA peak (the dominant-kernel object above is one of these rows, whichever is largest by time)
         def _alg(f):
-            return f["achieved"] / (ops.split_products() if f["kernel"] == "split_gemm_kernel" else 1.0)
-        groups = {"forward_and_input_gradient_gemms": ("conv_igemm_kernel", "split_gemm_kernel"), "weight_gradient_gemms": ("conv_wgrad_kernel",),
+            return f["achieved"] / (ops.split_products() if f["kernel"] in PIPE16 else 1.0)
+        groups = {"forward_and_input_gradient_gemms": ("conv_igemm_kernel", "split_gemm_kernel"), "weight_gradient_gemms": ("conv_wgrad_kernel", "wgrad16_kernel"),
                   "dcnv2_forward": ("dcnv2_fwd_kernel",), "dcnv2_weight_gradient": ("dcnv2_wgrad_kernel",)}
         view = {}
         for name, ks in groups.items():

@@ -222,6 +222,7 @@ int prn_winograd_output(const float* Y, const float* bias, const float* addend, 
 int64_t prn_winograd_wgrad_ws_bytes(int B, int C, int H, int W, int M, const prn_gemm_opts* opts);
 int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream);
 int prn_gemm_batched_nt_splits(int M, int C, int P, int nb, const prn_gemm_opts* opts);
+int prn_gemm_batched_nt_kind(int M, int C, int P, int nb, const prn_gemm_opts* opts);   /* 0: fp32 MFMA kernel, 2: fp16-piece kernel */
 int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, const prn_gemm_opts* opts, void* stream);
 int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream);
 int prn_conv3x3_winograd_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int C, int H, int W, int M, int in_mode, const prn_gemm_opts* opts,
@@ -245,6 +246,9 @@ int prn_conv3x3_winograd(const float* x, const float* U, const void* u_images, c
 /* dw[m, c*KH*KW + r*KW + s] = sum_{b,oh,ow} dy[b,m,oh,ow] * gather(x)[b,c,oh*stride-pad+r,ow*stride-pad+s]
  * `ws` is a caller-owned workspace of prn_conv2d_wgrad_ws_bytes(d) bytes (deterministic split reduction). */
 int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d);
+/* 0: the descriptor's weight gradient runs on the fp32 MFMA kernel, 1: on the direct HBM-bound kernel (one- / two-channel 3x3 layers), 2: on the
+ * fp16-piece kernel (csrc/prn_wgrad16.hip; d->opts.wgrad_split) -- G = layers per launch (prn_conv2d_wgrad_grouped), 1 otherwise. */
+int prn_conv2d_wgrad_kernel_kind(const prn_conv_desc* d, int G);
 int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream);
 /* The same for G layers of one shape in ONE launch (blockIdx.z = layer; x[g], dy[g]: HOST arrays of G device pointers;
  * dw: [G, M, C*KH*KW], caller-owned like the workspace of prn_conv2d_wgrad_grouped_ws_bytes(d, G) bytes).  The 1x1 layers of a

@@ -82,6 +82,8 @@ SIGNATURES = {
     "prn_winograd_wgrad_ws_bytes": (c_i64, [c_int] * 5 + [_OP]),
     "prn_winograd_dy": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_gemm_batched_nt_splits": (c_int, [c_int] * 4 + [_OP]),
+    "prn_gemm_batched_nt_kind": (c_int, [c_int] * 4 + [_OP]),
+    "prn_conv2d_wgrad_kernel_kind": (c_int, [_DP, c_int]),
     "prn_gemm_batched_nt": (c_int, [c_int, c_int, c_int, c_int, P, P, P, _OP, P]),
     "prn_winograd_dw": (c_int, [P, P, c_int, c_int, c_int, P]),
     "prn_conv3x3_winograd_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, _OP, P, c_int]),

@@ -1515,6 +1515,13 @@ extern "C" int64_t prn_conv2d_wgrad_ws_bytes(const prn_conv_desc* d) {
   return p.splits > 1 ? (int64_t)p.splits * g.phases * d->M * K * 4 : 0;
 }
 
+// which kernel a descriptor's weight gradient runs on: 0 = fp32 MFMA (conv_wgrad_kernel), 1 = the direct HBM-bound kernel, 2 = the fp16-piece
+// kernel of prn_wgrad16.hip (G = layers per launch, 1 for prn_conv2d_wgrad) -- for profilers that attribute launches to a roofline
+extern "C" int prn_conv2d_wgrad_kernel_kind(const prn_conv_desc* d, int G) {
+  if (check_desc(d, "prn_conv2d_wgrad_kernel_kind")) return -1;
+  if (direct_small_m(d)) return 1;
+  return wgrad16_plan_of(d, G < 1 ? 1 : G) ? 2 : 0;
+}
 extern "C" int prn_conv2d_wgrad(const prn_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, void* stream) {
   return prn_conv2d_wgrad_phase(d, x, dy, dw, ws, stream, 0);
 }
@@ -1744,6 +1751,9 @@ WgPlan plan_batched_nt(const prn_gemm_opts* opts, int M, int C, int P, int nb) {
   return p;
 }
 }  // namespace
+extern "C" int prn_gemm_batched_nt_kind(int M, int C, int P, int nb, const prn_gemm_opts* opts) {      // 0: fp32 MFMA, 2: fp16-piece kernel
+  return prn_wgrad16_plan(M, C, P, P, nb, opts) ? 2 : 0;
+}
 extern "C" int prn_gemm_batched_nt_splits(int M, int C, int P, int nb, const prn_gemm_opts* opts) {
   if (const int s16 = prn_wgrad16_plan(M, C, P, P, nb, opts)) return s16;
   return plan_batched_nt(opts, M, C, P, nb).splits;

@@ -646,9 +646,11 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     _, ref, _, nbytes = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     if profiling._enabled:
-        direct = M <= 2 and lib.prn_conv2d_kernel_kind(ref) == 1       # (the one- / two-channel 3x3 layers: direct HBM-bound kernel)
-        with profiling.span("conv3x3_direct" if direct else "conv_wgrad_kernel", "hbm" if direct else "mfma",
-                            4.0 * (x.numel() + dy.numel()) if direct else 2.0 * M * C * K * K * B * Ho * Wo,
+        wkind = lib.prn_conv2d_wgrad_kernel_kind(ref, 1)               # 1: the one- / two-channel 3x3 layers (direct HBM-bound kernel); 2: fp16-piece kernel
+        direct = wkind == 1
+        fl_w = 2.0 * M * C * K * K * B * Ho * Wo
+        with profiling.span("conv3x3_direct" if direct else ("wgrad16_kernel" if wkind == 2 else "conv_wgrad_kernel"), "hbm" if direct else "mfma",
+                            4.0 * (x.numel() + dy.numel()) if direct else (split_products() * fl_w if wkind == 2 else fl_w), ref=None if direct else fl_w,
                             nbytes=4.0 * (x.numel() + dy.numel() + dw.numel()),
                             tag=None if direct else ("wgrad", C, H, W, M, K, stride, mode, 1, B)):
             check(lib.prn_conv2d_wgrad_phase(ref, _p(x), _p(dy), _p(dw), _p(ws), _stream(), 1), "prn_conv2d_wgrad")
@@ -916,7 +918,9 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
         P = lib.prn_winograd_tiles(B, H, W)
         with profiling.span("winograd_wgrad_transforms", "hbm", 4.0 * (x.numel() + dy.numel()) + 4.0 * 36 * (C + M) * P, 0.0):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 1), "prn_conv3x3_winograd_wgrad")
-        with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W, tag=("wino-wgrad-products", C, H, W, M, 3, 1, mode, 1, B)):
+        w16 = lib.prn_gemm_batched_nt_kind(M, C, P, 36, oref) == 2
+        with profiling.span("wgrad16_kernel" if w16 else "conv_wgrad_kernel", "mfma", (split_products() if w16 else 1.0) * 2.0 * 36 * M * C * P, 2.0 * 9 * M * C * B * H * W,
+                            tag=("wino-wgrad-products", C, H, W, M, 3, 1, mode, 1, B)):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 2), "prn_conv3x3_winograd_wgrad")
         with profiling.span("winograd_dw_kernel", "hbm", float(nbytes) - 4.0 * 36 * (C + M) * P + 4.0 * dw.numel(), 0.0):
             check(lib.prn_conv3x3_winograd_wgrad(*args, 3), "prn_conv3x3_winograd_wgrad")
