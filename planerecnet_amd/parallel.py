@@ -38,6 +38,8 @@ class GradAllReduce:
             return
         dev = self.params[0].device
         self.on_gpu = dev.type == "cuda"
+        # RCCL averages inside the collective (ncclAvg): no separate division pass over the 229 MB of gradients.  gloo (the CPU tests) has no AVG.
+        self.avg_in_collective = self.on_gpu and dist.get_backend(process_group) == "nccl" and not _os.environ.get("PRN_EXCHANGE_NO_AVG")
         self.main = torch.cuda.current_stream(dev) if self.on_gpu else None      # the stream forward / backward are issued on
         # The exchange shares the weight-gradient side stream (ops.set_wgrad_async): most of a bucket is produced there, the
         # side stream is never on the critical path, and every extra HIP stream is one more customer for the four hardware
@@ -130,9 +132,12 @@ class GradAllReduce:
             ctx = contextlib.nullcontext()
         with ctx:
             torch._foreach_copy_(self.windows[bi], [p.grad for p in bucket])
-            if self.world > 1:
-                flat.div_(self.world)
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.avg_in_collective:
+                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            else:
+                if self.world > 1:
+                    flat.div_(self.world)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((bi, work))
 
     def finish(self):

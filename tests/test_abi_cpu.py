@@ -149,3 +149,22 @@ def test_wgrad16_plan_is_host_logic():
     _, o_on = _opts(mode=0, wgrad=1)
     _, o_off = _opts(mode=0, wgrad=0)
     assert lib.prn_gemm_batched_nt_splits(256, 256, 9600, 36, o_on) >= 1 and lib.prn_gemm_batched_nt_splits(256, 256, 9600, 36, o_off) >= 1
+
+
+def test_one_default_plan_in_one_place():
+    """The shipping defaults of the per-call options exist once: prn_gemm_opts_default() in the library; the Python layer's policy (what
+    ops.py puts into every descriptor when no environment variable overrides it) must be that value, field by field."""
+    import subprocess
+    import sys
+    code = ("import ctypes, os\n"
+            "for k in list(os.environ):\n"
+            "    if k.startswith('PRN_SPLIT') or k.startswith('PRN_WGRAD'): del os.environ[k]\n"
+            "from planerecnet_amd import _lib, ops\n"
+            "d = _lib.GemmOpts(); _lib.lib.prn_gemm_opts_default(ctypes.byref(d))\n"
+            "ops.split_gemm_policy('train'); a = ops.opts_key(); ops.split_gemm_policy('eval'); b = ops.opts_key()\n"
+            "assert a == d.key() and b == d.key(), (a, b, d.key())\n"
+            "assert _lib.lib.prn_conv2d_wgrad_kernel_kind(ctypes.byref(_lib.ConvDesc(8, 256, 30, 40, 1024, 1, 1, 1, 0, 30, 40, 0, 1, 0, 0, 0, 0, 0, d)), 1) == 2\n"
+            "assert _lib.lib.prn_gemm_batched_nt_kind(256, 256, 9600, 36, ctypes.byref(d)) == 2 and _lib.lib.prn_gemm_batched_nt_kind(256, 256, 9600, 36, None) == 0\n"
+            "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
