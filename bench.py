@@ -22,8 +22,9 @@ Extra objects:
                   GEMMs, conv_wgrad_kernel; `roofline.kernel` names it, `conv_kernel_groups` has every group).  Every launch of
                   one extra, untimed step is bracketed by HIP events on the launch stream; achieved = sum of ALGORITHMIC fp32
                   FLOPs (2*M*N*K of the GEMMs the launches evaluate) / sum of event durations.  peak = 157.3 TFLOP/s (fp32 MFMA,
-                  MI355X_MICROARCH.md); launches on the 16-bit pipe (split kernels) are priced against their own peak in
-                  `roofline.split_gemm`.  `traffic` puts
+                  MI355X_MICROARCH.md); launches on the 16-bit pipe (split_gemm_kernel: forward / input-gradient plain GEMMs; wgrad16_kernel: their
+                  weight gradients) are ALSO priced against the pipe they run on, in `roofline.split_gemm` / `roofline.wgrad16` (and
+                  `executed_*` in the top-level object when such a family is the dominant one).  `traffic` puts
                   the PMC bytes per launch (profiles/*pmc_traffic.json) next to the algorithmic bytes per launch logged live
                   (4 B x operand + result elements of every launch).  `kernels` lists the other families the same way.
   cpu_baseline -- the oracle (CPU restatement proven equal to the reference) timed on the host cores on a bounded sample:
