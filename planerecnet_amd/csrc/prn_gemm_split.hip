@@ -17,6 +17,7 @@
 // operand with 16 dword buffer loads per slice (rows beyond K read 0: the row is part of the VGPR offset, which the descriptor's range check sees), splits it in registers (5.5 VALU
 // per element, under the MFMAs of the slice before) and feeds the pieces straight to the matrix pipe.  One barrier per slice.
 #include "prn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -249,6 +250,7 @@ __global__ void split16_prepare_kernel(const float* __restrict__ w, uint4* __res
 struct Split16Args {
   const uint4* img; const int* ex; const float* x; const float* bias; const float* addend; float* y; float* partial;
   int M, K, B, HW, epi, mtiles, kslices, ptiles, total, splits;
+  int wide;                       // epilogue through the LDS transpose (float4 stores): HW % 4 == 0 and 16-byte aligned output / addend / partial planes
   long long zx, zy, slice;
 };
 
@@ -357,8 +359,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef S16_STEP
   const bool cok = px < HW;
   const int* exm = a.ex + (long long)z * a.mtiles * 128 + mt * 128;
+  float* yb = a.y + (long long)z * a.zy + (long long)b * M * HW;
+  const float* ab = a.addend ? a.addend + (long long)z * a.zy + (long long)b * M * HW : nullptr;
+  float* pb = a.splits > 1 ? a.partial + (long long)sp * a.slice + ((long long)z * a.B + b) * (long long)M * HW : nullptr;
+  if (a.wide) {
+    // Epilogue through an LDS transpose (the weight images are dead by now): an accumulator block holds 16 rows of ONE pixel per lane, i.e. 16
+    // dword stores per block and lane; transposed, a lane owns four consecutive pixels of one row -- 4 dwordx4 stores, bias / addend as float4s.
+    // (Host side: HW % 4 == 0 and 16-byte aligned y / addend / partial planes.)
+    __syncthreads();                                               // every wave has read its last weight fragments
+    float* cw = reinterpret_cast<float*>(lds) + wave * (32 * 36);  // 32 rows x 36 floats per wave
+    const int crow = lane >> 3, ccol = (lane & 7) * 4;
+    const int px4 = pt * 128 + wave * 32 + ccol;
+    const bool pok = px4 < HW;
+    const bool fin = a.splits == 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ro = (e >> 2) * 8 + (e & 3) + gs * 4;
+        cw[ro * 36 + r] = __uint_as_float(__float_as_uint(ldexpf(acc[i][e], erun + exm[i * 32 + ro] - 28)) ^ sflip32);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = crow + 8 * q, row = mt * BM + i * 32 + rl;
+        float4 v = *reinterpret_cast<const float4*>(&cw[rl * 36 + ccol]);
+        if (!pok || row >= M) continue;
+        const long long idx = (long long)row * HW + px4;
+        if (fin) {
+          if (a.bias) { const float bm = a.bias[row]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+          if (ab) { const float4 t4 = *reinterpret_cast<const float4*>(ab + idx); v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w; }
+          if (a.epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (a.epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w)); }
+          *reinterpret_cast<float4*>(yb + idx) = v;
+        } else {
+          *reinterpret_cast<float4*>(pb + idx) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                             // the pad is rewritten by the next block
+    }
+    return;
+  }
   if (a.splits > 1) {
-    float* pb = a.partial + (long long)sp * a.slice + ((long long)z * a.B + b) * (long long)M * HW;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -368,8 +410,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     return;
   }
-  float* yb = a.y + (long long)z * a.zy + (long long)b * M * HW;
-  const float* ab = a.addend ? a.addend + (long long)z * a.zy + (long long)b * M * HW : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rl0 = i * 32 + gs * 4, rbase = mt * BM + rl0;
@@ -563,6 +603,12 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
       a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
       a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
       a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
+      {
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        static int wide_on = -1;                                 // PRN_SPLIT_WIDE_STORE=0: the per-element epilogue (A/B)
+        if (wide_on < 0) { const char* e = getenv("PRN_SPLIT_WIDE_STORE"); wide_on = e ? atoi(e) : 1; }
+        a.wide = wide_on && (HW & 3) == 0 && ((int64_t)M * HW & 3) == 0 && (zy & 3) == 0 && al16(y) && al16(addend) && al16(partial);
+      }
       if (o->split_products >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(split16_gemm_kernel<3>, dim3(a.total, splits), dim3(256), 0, st, a);
       PRN_CHECK_LAUNCH("prn_split_gemm/f16");
