@@ -536,8 +536,11 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   constexpr int WJ = 4 / WM;                     // WM = 1: 32 x 128 tile for <= 32 output channels (see conv_igemm_kernel)
   constexpr int BM = 32 * WM * TM, BJ = 32 * WJ * TJ, LD = 17, KK = KS * KS;
   constexpr int NBJ = BJ / 16;
-  __shared__ float As[2][BM * LD];
-  __shared__ float Bs[2][BJ * LD];
+  // one LDS allocation: the operand double buffers during the reduction, then (epilogue) one 32 x 36 transpose pad per wave
+  constexpr int AS_ = 2 * BM * LD, BS_ = 2 * BJ * LD, CS_ = 4 * 32 * 36;
+  __shared__ __attribute__((aligned(16))) float smem_[(AS_ + BS_) > CS_ ? (AS_ + BS_) : CS_];
+  float (*As)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem_);
+  float (*Bs)[BJ * LD] = reinterpret_cast<float (*)[BJ * LD]>(smem_ + AS_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WJ, wj = wave % WJ;
   // 1-D grid renumbered XCD-aware: the output tiles of one (pixel split, z) stream the same dy / x pixels and sit on one XCD's L2
@@ -695,6 +698,31 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
   if (n4) run(std::true_type{}); else run(std::false_type{});
 
   float* out = a.out + ((size_t)split * a.nzg + bz) * a.M * a.K;
+  if ((a.K & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) && (((size_t)a.M * a.K) & 3) == 0) {
+    // epilogue through an LDS transpose (the operand buffers are dead): dwordx4 stores of four consecutive dW columns per lane instead of
+    // 16 dword stores per accumulator block (as in conv_igemm_kernel / split16_gemm_kernel)
+    __syncthreads();
+    float* cw = smem_ + wave * (32 * 36);
+    const int crow = lane >> 3, ccol = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int jj4 = j0 + wj * TJ * 32 + j * 32 + ccol;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + wm * TM * 32 + i * 32 + crow + 8 * q;
+          const float4 v = *reinterpret_cast<const float4*>(&cw[(crow + 8 * q) * 36 + ccol]);
+          if (m < a.M && jj4 < a.K) *reinterpret_cast<float4*>(out + (size_t)m * a.K + jj4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int jj = j0 + wj * TJ * 32 + j * 32 + (lane & 31);

@@ -45,6 +45,7 @@ struct Wg16Args {
   long long zdy, zx;               // element strides per blockIdx.z (batched products); 0 for a convolution
   long long zout;                  // M * C
   int nz;
+  int wide;                        // epilogue through the LDS transpose: C % 4 == 0 and a 16-byte aligned output
   int ngroup;                      // > 0: blockIdx.z = layer of a group of same-shape layers, operands from the tables below
   const float* gx[PRN_WGRAD_GROUP_MAX];
   const float* gdy[PRN_WGRAD_GROUP_MAX];
@@ -228,6 +229,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   scratch[wave][lane] = prevA;
   __builtin_amdgcn_wave_barrier();
   float* ob = a.out + ((long long)sp * a.nz + z) * a.zout;       // partial [split][z][M][C]
+  if (a.wide) {
+    // through an LDS transpose (the piece buffers are dead): a lane then owns four consecutive columns of one row -- dwordx4 stores instead
+    // of 64 dword stores per lane (the same epilogue that took 2.6 % off the training step in split16_gemm_kernel)
+    __syncthreads();
+    float* cw = reinterpret_cast<float*>(pieces) + wave * (32 * 36);
+    const int crow = lane >> 3, ccol = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int eb = __shfl(prevB, j * 32 + r, 64);
+      const int col4 = tc * 128 + wn * 64 + j * 32 + ccol;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ro = (e >> 2) * 8 + g * 4 + (e & 3);
+          const int ea = scratch[wave][i * 32 + ro];
+          cw[ro * 36 + r] = (ea <= -200 || eb <= -200) ? 0.f : __builtin_amdgcn_ldexpf(acc[i][j][e], ea + eb - 22);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rl = crow + 8 * q, row = tm * 128 + wm * 64 + i * 32 + rl;
+          const float4 v = *reinterpret_cast<const float4*>(&cw[rl * 36 + ccol]);
+          if (row < a.M && col4 < a.C) *reinterpret_cast<float4*>(ob + (long long)row * a.C + col4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = tc * 128 + wn * 64 + j * 32 + r;
@@ -283,6 +314,7 @@ int prn_wgrad16_launch(const float* dy, const float* x, const float* const* gdy,
       PRN_REQUIRE(a.gx[i] && a.gdy[i] && (reinterpret_cast<uintptr_t>(a.gx[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.gdy[i]) & 15) == 0, "prn_wgrad16: null / unaligned tensor in the group");
     }
   }
+  a.wide = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   const dim3 grid((unsigned)(a.tilesM * a.tilesC * splits * a.nz)), block(256);
   if (o && o->split_products >= 4) hipLaunchKernelGGL(wgrad16_kernel<4>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(wgrad16_kernel<3>, grid, block, 0, st, a);
