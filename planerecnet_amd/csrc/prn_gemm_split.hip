@@ -368,6 +368,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // (Host side: HW % 4 == 0 and 16-byte aligned y / addend / partial planes.)
     __syncthreads();                                               // every wave has read its last weight fragments
     float* cw = reinterpret_cast<float*>(lds) + wave * (32 * 36);  // 32 rows x 36 floats per wave
+    int* exl = reinterpret_cast<int*>(lds) + 4 * (32 * 36);        // the tile's 128 row exponents: one global load per row instead of one per accumulator element
+    if (t < 128) exl[t] = exm[t];
+    __syncthreads();
     const int crow = lane >> 3, ccol = (lane & 7) * 4;
     const int px4 = pt * 128 + wave * 32 + ccol;
     const bool pok = px4 < HW;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int ro = (e >> 2) * 8 + (e & 3) + gs * 4;
-        cw[ro * 36 + r] = __uint_as_float(__float_as_uint(ldexpf(acc[i][e], erun + exm[i * 32 + ro] - 28)) ^ sflip32);
+        cw[ro * 36 + r] = __uint_as_float(__float_as_uint(ldexpf(acc[i][e], erun + exl[i * 32 + ro] - 28)) ^ sflip32);
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
