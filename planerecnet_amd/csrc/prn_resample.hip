@@ -174,6 +174,43 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
   dx[i] = acc;
 }
 
+// The same for four consecutive input pixels per thread (W % 4 == 0, 16-byte aligned dx): the four pixels (h, w0 .. w0 + 3), w0 even, lie in the
+// window columns wo = w0/2 .. w0/2 + 2 of one or two window rows -- at most six (arg, dy) pairs for one dwordx4 store.  The scalar form
+// moved 157 MB of dx with one dword store per thread (217 us at the stem, 0.7 TB/s).
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const unsigned char* __restrict__ arg, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int64_t total4, int H, int W, int Ho, int Wo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int W4 = W >> 2;
+  const int w0 = (int)(i % W4) * 4, h = (int)((i / W4) % H);
+  const int64_t bc = i / ((int64_t)W4 * H);
+  const int64_t ob = bc * (int64_t)Ho * Wo;
+  const int wb = w0 >> 1;                                   // window columns wb, wb + 1, wb + 2
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  for (int r = (h + 1) & 1; r < 3; r += 2) {
+    const int ho = (h + 1 - r) >> 1;
+    if (ho < 0 || ho >= Ho) continue;
+    const int64_t rowo = ob + (int64_t)ho * Wo;
+    int a[3]; float g[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bool ok = wb + q < Wo;
+      a[q] = ok ? (int)arg[rowo + wb + q] : 255;
+      g[q] = ok ? dy[rowo + wb + q] : 0.f;
+    }
+    const int base = r * 3;
+    // input column w: even w = 2 wo -> position s = 1 of window wo;  odd w = 2 wo + 1 -> s = 2 of window wo and s = 0 of window wo + 1
+    // (same order of additions as the scalar kernel -- s = 0 before s = 2 --: bit-identical results)
+    if (a[0] == base + 1) o0 += g[0];                       // w0     : s = 1 of window wb
+    if (a[1] == base + 0) o1 += g[1];                       // w0 + 1 : s = 0 of window wb + 1
+    if (a[0] == base + 2) o1 += g[0];                       //          s = 2 of window wb
+    if (a[1] == base + 1) o2 += g[1];                       // w0 + 2 : s = 1 of window wb + 1
+    if (a[2] == base + 0) o3 += g[2];                       // w0 + 3 : s = 0 of window wb + 2
+    if (a[1] == base + 2) o3 += g[1];                       //          s = 2 of window wb + 1
+  }
+  *reinterpret_cast<float4*>(dx + i * 4) = make_float4(o0, o1, o2, o3);
+}
+
 }  // namespace
 
 extern "C" int prn_resize_bilinear_fwd(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, void* stream) {
@@ -226,7 +263,10 @@ extern "C" int prn_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, 
 extern "C" int prn_maxpool3s2_bwd(const unsigned char* arg, const float* dy, float* dx, int BC, int H, int W, int Ho, int Wo, void* stream) {
   PRN_REQUIRE(arg && dy && dx && BC > 0, "prn_maxpool3s2_bwd: bad arguments");
   const int64_t n = (int64_t)BC * H * W;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, arg, dy, dx, n, H, W, Ho, Wo);
+  if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0)
+    hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, arg, dy, dx, n / 4, H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, arg, dy, dx, n, H, W, Ho, Wo);
   PRN_CHECK_LAUNCH("prn_maxpool3s2_bwd");
   return 0;
 }

@@ -665,7 +665,7 @@ def test_resize_matches_scale_factor_semantics():
         close(yd, yr, f"resize x{sf}", rtol=1e-5)
 
 
-@pytest.mark.parametrize("H,W", [(24, 32), (15, 21)])
+@pytest.mark.parametrize("H,W", [(24, 32), (15, 21), (17, 20), (9, 4)])
 def test_maxpool_fwd_bwd(H, W):
     from planerecnet_amd import ops
     x = rnd(2, 6, H, W, seed=1).requires_grad_(True)
