@@ -43,7 +43,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
 __global__ void split_prepare_kernel(const float* __restrict__ w, uint4* __restrict__ img, int M, int K, long long zw, int mtiles, int kslices, long long total) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per (z, m tile, k slice, k group, row)
   if (i >= total) return;
-  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int g = i % 4; const int r = (i / 4) % 128; const long long t = i / 512;      // k group fastest: four lanes read 128 contiguous bytes of one weight row
   const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   float v[8];
@@ -234,7 +234,7 @@ __global__ void split16_prepare_kernel(const float* __restrict__ w, uint4* __res
                                        long long total) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per (z, m tile, k slice, k group, row)
   if (i >= total) return;
-  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int g = i % 4; const int r = (i / 4) % 128; const long long t = i / 512;      // k group fastest: four lanes read 128 contiguous bytes of one weight row
   const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   const int sh = 14 - ex[z * (mtiles * 128) + m];
@@ -444,7 +444,7 @@ __global__ void split_prepare_batched_kernel(const PrepItem* __restrict__ items,
   const long long total = (long long)it.nz * mtiles * kslices * 512;
   const long long i = (blk - it.first) * 256 + threadIdx.x;
   if (i >= total) return;
-  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int g = i % 4; const int r = (i / 4) % 128; const long long t = i / 512;      // k group fastest: four lanes read 128 contiguous bytes of one weight row
   const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   float v[8];
@@ -489,7 +489,7 @@ __global__ void split16_prepare_batched_kernel(const PrepItem* __restrict__ item
   const long long i = ((long long)blockIdx.x - it.first) * 256 + threadIdx.x;
   if (i >= total) return;
   const int* ex = (const int*)((const char*)it.dst + (long long)it.nz * mtiles * kslices * IMG16_U4 * 16);
-  const int r = i % 128; const int g = (i / 128) % 4; const long long t = i / 512;
+  const int g = i % 4; const int r = (i / 4) % 128; const long long t = i / 512;      // k group fastest: four lanes read 128 contiguous bytes of one weight row
   const int ks = t % kslices; const long long zm = t / kslices; const int mt = zm % mtiles; const long long z = zm / mtiles;
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   const int sh = 14 - ex[z * (mtiles * 128) + m];
