@@ -507,7 +507,7 @@ __global__ void split16_prepare_batched_kernel(const PrepItem* __restrict__ item
 // ---- internal interface (prn_common.h) ------------------------------------------------------------------------------------------------
 // Should y[nz][B][M][HW] = w[nz][M][K] * x[nz][B][K][HW] run on the split kernel under `o`, and with how many K splits?  0 = no.
 // Plan (tools/native/gemm_split_lab on the step's shapes): the kernel wins where at least ~300 of its 128 x 128 tiles exist and the last
-// m tile is more than half full; short of tiles, a K split of 2 .. 4 fills the GPU as long as every split keeps >= 8 slices.
+// m tile is more than half full; short of tiles, a K split of 2 .. 3 fills the GPU as long as every split keeps >= 8 slices.
 // The threshold (split_min_tiles) is a BOARD-level trade the caller makes: broad use of the 16-bit pipe makes the firmware lower the
 // shader clock for everything else (bf16 pieces: 2.35 -> 2.17 GHz over a training step, fp16 pieces: -> 2.25 GHz).
 int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts* o) {
@@ -520,7 +520,9 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
   if (tiles < 300) {
     splits = (int)(640 / (tiles > 0 ? tiles : 1));
     if (splits > kslices / 8) splits = kslices / 8;
-    if (splits > 4) splits = 4;
+    static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 3 -- training step 44.75 (4) / 44.54 (3) / 45.4 (2) ms, three alternations
+    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 3; }
+    if (splits > smax) splits = smax;
     if (splits < 1) splits = 1;
   }
   if (o->split_mode == PRN_SPLIT_ALWAYS) return splits;
