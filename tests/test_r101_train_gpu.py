@@ -220,8 +220,9 @@ def test_r101_b8_losses_equal_oracle(net101):
     assert not missing, missing[:5]
 
 
-@pytest.mark.skipif(not os.environ.get("PRN_TEST_B8"), reason="~6 minutes of fp64 oracle on the host: PRN_TEST_B8=1 (log kept under profiles/)")
-def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
+@pytest.mark.skipif(not os.environ.get("PRN_TEST_B8"), reason="minutes of fp64 oracle on the host: PRN_TEST_B8=1 (log kept under profiles/)")
+@pytest.mark.parametrize("arith", ["default", "fp32"])
+def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir, arith):
     """The benchmark's own configuration, directly: PlaneRecNet_101, B = 8, 480x640, DEFAULT options (the launch plan bench.py times: every plain
     GEMM of >= 300 tiles / 4 GFLOP and its weight gradient on the fp16 pipe, Winograd, ragged instance head, deferred and grouped weight
     gradients) against the fp64 oracle run on the same batch: every parameter gradient within the shipping build's bound (2.5 x the
@@ -235,6 +236,7 @@ def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
     net.train()
     x, inst, gtd = synth.make_batch(8, 480, 640, seed=21)
     crit = PlaneRecNetLoss().cuda()
+    old = ops.set_split_gemm(mode=0) if arith == "fp32" else None
     ops.set_wgrad_async(True)
     try:
         np.random.seed(5)
@@ -245,6 +247,8 @@ def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
         ops.wgrad_join()
     finally:
         ops.set_wgrad_async(False)
+        if old is not None:
+            ops.set_split_gemm(**old)
     torch.cuda.synchronize()
     names = [str(n) for n in fx["grad_names"]]
     zero = set(str(n) for n in fx["grad_structurally_zero"])
@@ -270,7 +274,7 @@ def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
             bad.append((n, l2, bound))
     worst.sort(reverse=True)
     pct = np.round(np.percentile(np.array([r for r, _, _ in worst]), [50, 90, 99, 100]), 3)
-    msg = "r101 B=8 default plan vs fp64 oracle: error / bound percentiles 50/90/99/max = %s  worst: %s" % (pct.tolist(), [(round(r, 2), n) for r, n, _ in worst[:5]])
+    msg = "r101 B=8 %s plan vs fp64 oracle: error / bound percentiles 50/90/99/max = %s  worst: %s" % (arith, pct.tolist(), [(round(float(r), 2), n, "%.2e" % l) for r, n, l in worst[:6]])
     print(msg)
     if os.environ.get("PRN_TEST_PCT_LOG"):
         with open(os.environ["PRN_TEST_PCT_LOG"], "a") as f:
