@@ -24,6 +24,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BK = 32;
 constexpr int IMG_U4 = 1536;      // uint4 per image: 3 pieces x 4 k-groups x 128 rows x 16 B = 24 KB
@@ -207,11 +208,15 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int IMG16_U4 = 1024;    // uint4 per fp16 image: 2 pieces x 4 k-groups x 128 rows x 16 B = 16 KB
 
 __device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
   f16x2_t hv, lv;
-  hv[0] = h0; hv[1] = h1; lv[0] = (_Float16)r0; lv[1] = (_Float16)r1;
-  h = __builtin_bit_cast(unsigned, hv); l = __builtin_bit_cast(unsigned, lv);
+  hv[0] = (_Float16)x0; hv[1] = (_Float16)x1;                    // one v_cvt_pk_f16_f32 (round to nearest even)
+  h = __builtin_bit_cast(unsigned, hv);
+  // residual x - float(h), exact: v_fma_mix_f32 reads the f16 half as its fp32 value (one instruction instead of convert back + subtract)
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+  lv[0] = (_Float16)r0; lv[1] = (_Float16)r1;
+  l = __builtin_bit_cast(unsigned, lv);
 }
 
 // ex[z * Mpad + m] = frexp exponent of max_k |w[z][m][k]| (0 for an all-zero or padding row): one wave per row
@@ -247,10 +252,39 @@ __global__ void split16_prepare_kernel(const float* __restrict__ w, uint4* __res
   o[g * 128 + r] = h; o[(4 + g) * 128 + r] = l;
 }
 
+#ifdef PRN_S16_TIMING
+// Profiling aid (side build only: tools/split16_phase_timing.py compiles this file with -DPRN_S16_TIMING into its own library): per workgroup,
+// the 100 MHz wall clock at kernel entry / loop entry / loop exit / kernel exit and the hardware id (XCC, SE, CU) it ran on.
+__device__ long long prn_s16_dbg[8192 * 6];
+#define S16_T(slot_) do { if (t == 0 && blockIdx.x + gridDim.x * blockIdx.y < 8192) prn_s16_dbg[(blockIdx.x + gridDim.x * blockIdx.y) * 6 + (slot_)] = (long long)wall_clock64(); } while (0)
+__device__ long long prn_s16_it[64 * 4 * 4];      // workgroup 0 (and the one in the middle of the grid), wave 0: per iteration, the clock after the barrier / after the
+                                                  // MFMA issue / when the next slice's activations are in registers / at the end of the iteration
+#define S16_IT(slot_) do { if (t == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0 && ks - ks0 < 64) { \
+    if ((slot_) == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    prn_s16_it[((blockIdx.x ? 1 : 0) * 64 + (ks - ks0)) * 4 + (slot_)] = (long long)wall_clock64(); } } while (0)
+extern "C" int prn_debug_s16_iter(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(prn_s16_it), sizeof(long long) * (size_t)n); }
+extern "C" int prn_debug_s16_timing(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(prn_s16_dbg), sizeof(long long) * (size_t)n); }
+#else
+#define S16_T(slot_) do { } while (0)
+#define S16_IT(slot_) do { } while (0)
+#endif
+
+// Store policy of the epilogue (experiment, PRN_SPLIT_STORE_POLICY): 0 plain (write-back in L2: the dirty lines are flushed when the kernel ends),
+// 1 sc1 (agent scope: written through), 2 nt, 3 sc0 sc1 (system scope), 4 sc1 nt
+__device__ __forceinline__ void store4_policy(float* p, float4 v, int pol) {
+  const f32x4_t q = {v.x, v.y, v.z, v.w};
+  if (pol == 0) *reinterpret_cast<float4*>(p) = v;
+  else if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(q) : "memory");
+  else if (pol == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(q) : "memory");
+}
+
 struct Split16Args {
   const uint4* img; const int* ex; const float* x; const float* bias; const float* addend; float* y; float* partial;
   int M, K, B, HW, epi, mtiles, kslices, ptiles, total, splits;
   int wide;                       // epilogue through the LDS transpose (float4 stores): HW % 4 == 0 and 16-byte aligned output / addend / partial planes
+  int store_policy;
   long long zx, zy, slice;
 };
 
@@ -265,11 +299,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int ks0 = (int)((long long)a.kslices * sp / a.splits), ks1 = (int)((long long)a.kslices * (sp + 1) / a.splits);
   const int HW = a.HW, M = a.M;
   const int r = lane & 31, gs = lane >> 5;
+  S16_T(0);
+#ifdef PRN_S16_TIMING
+  if (t == 0 && blockIdx.x + gridDim.x * blockIdx.y < 8192) {
+    unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    prn_s16_dbg[(blockIdx.x + gridDim.x * blockIdx.y) * 6 + 4] = ((long long)(xcc & 15) << 32) | hw;
+  }
+#endif
   const int px = pt * 128 + wave * 32 + r;
   const int pxc = px < HW ? px : HW - 1;
   const float* xb = a.x + (long long)z * a.zx + (long long)b * a.K * HW;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.K * HW * 4, 0x00020000);
   const int xoff = (pxc + gs * 8 * HW) * 4;
+  int choff[16];                                                   // scalar byte offsets of a lane's 16 channels within a slice, clamped to the buffer: the range check
+#pragma unroll                                                     // subtracts the scalar offset from the size, which must not wrap (K < 32)
+  for (int j = 0; j < 16; ++j) choff[j] = __builtin_amdgcn_readfirstlane(min(((j >> 3) * 16 + (j & 7)) * HW * 4, a.K * HW * 4));
   const uint4* ag = a.img + ((long long)(z * a.mtiles + mt) * a.kslices) * IMG16_U4;
   const i32x4_t adesc = make_desc(ag, (unsigned)a.kslices * IMG16_U4 * 16u);
   const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
@@ -290,9 +334,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \
   } while (0)
 #define S16_LOADB(ks_) do { \
+    const int vo = xoff + (ks_) * (BK * 4) * HW;                   /* one vector add per slice; the 16 channel offsets are scalars */ \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) \
-        rn[s2 * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff + ((ks_) * BK + s2 * 16 + j) * HW * 4, 0, 0)); \
+        rn[s2 * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, choff[s2 * 8 + j], 0)); \
   } while (0)
 #define S16_PIECES() do { \
     float mx = 0.f; \
@@ -301,12 +346,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int en = max(erun, mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : -200); \
     de = erun - en; erun = en; \
     const int sh = 14 - en; \
-    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) { \
-      uint4 h, l; \
-      split2_f16(ldexpf(rn[s2 * 8 + 0], sh), ldexpf(rn[s2 * 8 + 1], sh), h.x, l.x); split2_f16(ldexpf(rn[s2 * 8 + 2], sh), ldexpf(rn[s2 * 8 + 3], sh), h.y, l.y); \
-      split2_f16(ldexpf(rn[s2 * 8 + 4], sh), ldexpf(rn[s2 * 8 + 5], sh), h.z, l.z); split2_f16(ldexpf(rn[s2 * 8 + 6], sh), ldexpf(rn[s2 * 8 + 7], sh), h.w, l.w); \
-      h.x ^= sflip16; h.y ^= sflip16; h.z ^= sflip16; h.w ^= sflip16; l.x ^= sflip16; l.y ^= sflip16; l.z ^= sflip16; l.w ^= sflip16; \
-      bp[s2][0] = __builtin_bit_cast(f16x8_t, h); bp[s2][1] = __builtin_bit_cast(f16x8_t, l); \
+    if (__builtin_amdgcn_ballot_w64(sh > 127 && mx > 0.f) == 0ull) { \
+      /* scale and sign in one packed multiply by +-2^sh (exact; a column of zeros so far may carry any scale) */ \
+      f32x2_t sc; sc[0] = __uint_as_float(((unsigned)(min(sh, 127) + 127) << 23) | sflip32); sc[1] = sc[0]; \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) { \
+        uint4 h, l; f32x2_t v; \
+        v[0] = rn[s2 * 8 + 0]; v[1] = rn[s2 * 8 + 1]; v = v * sc; split2_f16(v[0], v[1], h.x, l.x); \
+        v[0] = rn[s2 * 8 + 2]; v[1] = rn[s2 * 8 + 3]; v = v * sc; split2_f16(v[0], v[1], h.y, l.y); \
+        v[0] = rn[s2 * 8 + 4]; v[1] = rn[s2 * 8 + 5]; v = v * sc; split2_f16(v[0], v[1], h.z, l.z); \
+        v[0] = rn[s2 * 8 + 6]; v[1] = rn[s2 * 8 + 7]; v = v * sc; split2_f16(v[0], v[1], h.w, l.w); \
+        bp[s2][0] = __builtin_bit_cast(f16x8_t, h); bp[s2][1] = __builtin_bit_cast(f16x8_t, l); \
+      } \
+    } else {                                                      /* activations below 2^-113: 2^sh is not a float */ \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) { \
+        uint4 h, l; \
+        split2_f16(ldexpf(rn[s2 * 8 + 0], sh), ldexpf(rn[s2 * 8 + 1], sh), h.x, l.x); split2_f16(ldexpf(rn[s2 * 8 + 2], sh), ldexpf(rn[s2 * 8 + 3], sh), h.y, l.y); \
+        split2_f16(ldexpf(rn[s2 * 8 + 4], sh), ldexpf(rn[s2 * 8 + 5], sh), h.z, l.z); split2_f16(ldexpf(rn[s2 * 8 + 6], sh), ldexpf(rn[s2 * 8 + 7], sh), h.w, l.w); \
+        h.x ^= sflip16; h.y ^= sflip16; h.z ^= sflip16; h.w ^= sflip16; l.x ^= sflip16; l.y ^= sflip16; l.z ^= sflip16; l.w ^= sflip16; \
+        bp[s2][0] = __builtin_bit_cast(f16x8_t, h); bp[s2][1] = __builtin_bit_cast(f16x8_t, l); \
+      } \
     } } while (0)
 #define S16_STEP(s2_) do { \
     const int kg = 2 * (s2_) + gs; \
@@ -333,6 +391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   S16_PIECES();
   de = 0;                                                        // nothing accumulated yet
   S16_LOADB(ks0 + 1);                                            // (slices past K read zeros through the descriptor's range check)
+  S16_T(1);
   for (int ks = ks0; ks < ks1; ++ks) {
     const int st = (ks - ks0) & 1;
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // this slice's weight DMA is older than the 16 activation loads that stay in flight
@@ -344,19 +403,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int e = 0; e < 16; ++e) acc[i][e] = ldexpf(acc[i][e], de);
     }
     const bool more = ks + 1 < ks1;
+    S16_IT(0);
     if (more) S16_DMA(ks + 1, st ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     S16_STEP(0);
     __builtin_amdgcn_sched_barrier(0);
     S16_STEP(1);
+    S16_IT(1);
+    S16_IT(2);
     if (more) S16_PIECES(); else de = 0;                        // slice ks + 1 (of THIS K split only: the running scale must not see the next split's data)
     __builtin_amdgcn_sched_barrier(0);
     S16_LOADB(ks + 2);
+    S16_IT(3);
   }
 #undef S16_DMA
 #undef S16_LOADB
 #undef S16_PIECES
 #undef S16_STEP
+  S16_T(2);
   const bool cok = px < HW;
   const int* exm = a.ex + (long long)z * a.mtiles * 128 + mt * 128;
   float* yb = a.y + (long long)z * a.zy + (long long)b * M * HW;
@@ -394,13 +458,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           if (ab) { const float4 t4 = *reinterpret_cast<const float4*>(ab + idx); v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w; }
           if (a.epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           else if (a.epi == PRN_EPI_SIGMOID) { v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w)); }
-          *reinterpret_cast<float4*>(yb + idx) = v;
+          store4_policy(yb + idx, v, a.store_policy);
         } else {
-          *reinterpret_cast<float4*>(pb + idx) = v;
+          store4_policy(pb + idx, v, a.store_policy);
         }
       }
       __builtin_amdgcn_wave_barrier();                             // the pad is rewritten by the next block
     }
+#ifdef PRN_S16_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    S16_T(3);
     return;
   }
   if (a.splits > 1) {
@@ -613,6 +681,9 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
         static int wide_on = -1;                                 // PRN_SPLIT_WIDE_STORE=0: the per-element epilogue (A/B)
         if (wide_on < 0) { const char* e = getenv("PRN_SPLIT_WIDE_STORE"); wide_on = e ? atoi(e) : 1; }
         a.wide = wide_on && (HW & 3) == 0 && ((int64_t)M * HW & 3) == 0 && (zy & 3) == 0 && al16(y) && al16(addend) && al16(partial);
+        static int policy = -1;
+        if (policy < 0) { const char* e = getenv("PRN_SPLIT_STORE_POLICY"); policy = e ? atoi(e) : 0; }
+        a.store_policy = policy;
       }
       if (o->split_products >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(split16_gemm_kernel<3>, dim3(a.total, splits), dim3(256), 0, st, a);

@@ -220,63 +220,75 @@ def test_r101_b8_losses_equal_oracle(net101):
     assert not missing, missing[:5]
 
 
-@pytest.mark.skipif(not os.environ.get("PRN_TEST_B8"), reason="minutes of fp64 oracle on the host: PRN_TEST_B8=1 (log kept under profiles/)")
-@pytest.mark.parametrize("arith", ["default", "fp32"])
-def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir, arith):
+@pytest.mark.skipif(not os.environ.get("PRN_TEST_B8"), reason="minutes of fp64 + fp32 oracle on the host: PRN_TEST_B8=1 (log kept under profiles/)")
+def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
     """The benchmark's own configuration, directly: PlaneRecNet_101, B = 8, 480x640, DEFAULT options (the launch plan bench.py times: every plain
     GEMM of >= 300 tiles / 4 GFLOP and its weight gradient on the fp16 pipe, Winograd, ragged instance head, deferred and grouped weight
-    gradients) against the fp64 oracle run on the same batch: every parameter gradient within the shipping build's bound (2.5 x the
-    reference's own fp32-vs-fp64 spread of the B = 2 fixture + 1e-3).  The `b8-plan` parametrisation above is the fast proxy of this."""
+    gradients) against the fp64 oracle on the same batch.  The yardstick is measured on THIS batch: the oracle run in fp32 (the reference's
+    arithmetic) against the oracle in fp64; every parameter gradient of the product has to be within 2.5 x max(that spread, the B = 2 fixture's
+    spread) + 1e-3 -- the shipping bound -- under the default plan AND with the 16-bit pipe off, and the default plan may not be further from
+    fp64 than the fp32-only build by more than a quarter of the bound.  The `b8-plan` parametrisation above is the fast proxy of this test."""
     from oracle import loss_ref, model_ref, synth
     from planerecnet_amd import ops
     from planerecnet_amd.losses import PlaneRecNetLoss
     net, sd = net101
     fx = np.load(os.path.join(golden_dir, "e2e_r101_480x640.npz"))
-    net.load_state_dict(sd)
-    net.train()
     x, inst, gtd = synth.make_batch(8, 480, 640, seed=21)
     crit = PlaneRecNetLoss().cuda()
-    old = ops.set_split_gemm(mode=0) if arith == "fp32" else None
-    ops.set_wgrad_async(True)
-    try:
-        np.random.seed(5)
-        out = net(x.cuda())
-        losses = crit(net, *out, [{k: v.cuda() for k, v in g.items()} for g in inst], gtd.cuda())
-        net.zero_grad(set_to_none=True)
-        sum(losses.values()).sum().backward()
-        ops.wgrad_join()
-    finally:
-        ops.set_wgrad_async(False)
-        if old is not None:
-            ops.set_split_gemm(**old)
-    torch.cuda.synchronize()
     names = [str(n) for n in fx["grad_names"]]
     zero = set(str(n) for n in fx["grad_structurally_zero"])
-    spread = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
-    sdg = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
-               (v.double().clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
-    np.random.seed(5)
-    oo = model_ref.forward(sdg, x.double(), model_ref.ARCH[CN], training=True)
-    ol = loss_ref.joint_loss(*oo, inst, gtd)
-    for k in ol:
-        assert abs(float(losses[k]) - float(ol[k])) <= 1e-3 * abs(float(ol[k])) + 1e-4, (k, float(losses[k]), float(ol[k]))
-    g64 = dict(zip(names, torch.autograd.grad(sum(ol.values()).sum(), [sdg[n] for n in names])))
-    params = dict(net.named_parameters())
-    worst, bad = [], []
-    for n in names:
-        if n in zero:
-            continue
-        got = params[n].grad.detach().double().cpu()
-        l2 = ((got - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()
-        bound = WINOGRAD_SENSITIVE.get(n, GRAD_K_WINOGRAD * spread[n] + GRAD_FLOOR_WINOGRAD)
-        worst.append((l2 / bound, n, l2))
-        if l2 > bound:
-            bad.append((n, l2, bound))
-    worst.sort(reverse=True)
-    pct = np.round(np.percentile(np.array([r for r, _, _ in worst]), [50, 90, 99, 100]), 3)
-    msg = "r101 B=8 %s plan vs fp64 oracle: error / bound percentiles 50/90/99/max = %s  worst: %s" % (arith, pct.tolist(), [(round(float(r), 2), n, "%.2e" % l) for r, n, l in worst[:6]])
-    print(msg)
+    fix_spread = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
+
+    def product(arith):
+        net.load_state_dict(sd)
+        net.train()
+        old = ops.set_split_gemm(mode=0) if arith == "fp32" else None
+        ops.set_wgrad_async(True)
+        try:
+            np.random.seed(5)
+            out = net(x.cuda())
+            losses = crit(net, *out, [{k: v.cuda() for k, v in g.items()} for g in inst], gtd.cuda())
+            net.zero_grad(set_to_none=True)
+            sum(losses.values()).sum().backward()
+            ops.wgrad_join()
+        finally:
+            ops.set_wgrad_async(False)
+            if old is not None:
+                ops.set_split_gemm(**old)
+        torch.cuda.synchronize()
+        params = dict(net.named_parameters())
+        return {k: float(v) for k, v in losses.items()}, {n: params[n].grad.detach().double().cpu() for n in names if n not in zero}
+
+    def oracle(dt):
+        sdg = {k: (v.to(dt).clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
+                   (v.to(dt).clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
+        np.random.seed(5)
+        oo = model_ref.forward(sdg, x.to(dt), model_ref.ARCH[CN], training=True)
+        ol = loss_ref.joint_loss(*oo, inst, gtd)
+        g = torch.autograd.grad(sum(ol.values()).sum(), [sdg[n] for n in names])
+        return {k: float(v) for k, v in ol.items()}, {n: t.double() for n, t in zip(names, g)}
+
+    l64, g64 = oracle(torch.float64)
+    _, g32 = oracle(torch.float32)
+    rel = lambda a, n: ((a - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()      # noqa: E731
+    bound = {n: WINOGRAD_SENSITIVE.get(n, GRAD_K_WINOGRAD * max(fix_spread[n], rel(g32[n], n)) + GRAD_FLOOR_WINOGRAD) for n in names if n not in zero}
+    err, msgs, bad = {}, [], []
+    for arith in ("default", "fp32"):
+        losses, g = product(arith)
+        for k in l64:
+            assert abs(losses[k] - l64[k]) <= 1e-3 * abs(l64[k]) + 1e-4, (arith, k, losses[k], l64[k])
+        err[arith] = {n: rel(g[n], n) for n in bound}
+        ratios = sorted(((err[arith][n] / bound[n], n) for n in bound), reverse=True)
+        pct = np.round(np.percentile(np.array([r for r, _ in ratios]), [50, 90, 99, 100]), 3)
+        msgs.append("r101 B=8 %s vs fp64 oracle: error / bound percentiles 50/90/99/max = %s  worst: %s" % (arith, pct.tolist(), [(round(float(r), 2), n) for r, n in ratios[:4]]))
+        bad += [(arith, n, err[arith][n], bound[n]) for n in bound if err[arith][n] > bound[n]]
+    s32 = np.array([rel(g32[n], n) for n in bound])
+    msgs.append("oracle fp32 vs fp64 on this batch (the yardstick): spread percentiles 50/90/99/max = %s" % np.array2string(np.percentile(s32, [50, 90, 99, 100]), precision=5))
+    d = np.array([(err["default"][n] - err["fp32"][n]) / bound[n] for n in bound])
+    msgs.append("default minus fp32-only error, in units of the bound: percentiles 1/50/99/max = %s" % np.round(np.percentile(d, [1, 50, 99, 100]), 3).tolist())
+    print("\n".join(msgs))
     if os.environ.get("PRN_TEST_PCT_LOG"):
         with open(os.environ["PRN_TEST_PCT_LOG"], "a") as f:
-            f.write(msg + "\n")
-    assert not bad, (pct, bad[:10])
+            f.write("\n".join(msgs) + "\n")
+    assert not bad, bad[:10]
+    assert d.max() <= 0.25, ("the 16-bit plan is further from fp64 than the fp32-only build", d.max())
