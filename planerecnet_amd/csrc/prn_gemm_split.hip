@@ -588,8 +588,8 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
   if (tiles < 300) {
     splits = (int)(640 / (tiles > 0 ? tiles : 1));
     if (splits > kslices / 8) splits = kslices / 8;
-    static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 3 -- training step 44.75 (4) / 44.54 (3) / 45.4 (2) ms, three alternations
-    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 3; }
+    static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 4.  Training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; 3 and 4 are within the
+    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 4; }     // noise of a box; with 3 the all-f16 parity run tips a degenerate ReLU set
     if (splits > smax) splits = smax;
     if (splits < 1) splits = 1;
   }
@@ -662,6 +662,11 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
   PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)K * HW < (1LL << 29), "prn_split_gemm: operand larger than a buffer descriptor");
   const int kind = o->split_kind;
   PRN_REQUIRE(kind == PRN_PIECES_F16 || kind == PRN_PIECES_BF16, "prn_split_gemm: unknown piece format %d", kind);
+  {
+    static int dbg = -1;                                           // PRN_SPLIT_DEBUG=1: one line per launch on stderr (which shapes a plan puts on the kernel)
+    if (dbg < 0) { const char* e = getenv("PRN_SPLIT_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg) fprintf(stderr, "prn_split_gemm M=%d K=%d B=%d HW=%d nz=%d splits=%d epi=%d addend=%d\n", M, K, B, HW, nz, splits, epi, addend != nullptr);
+  }
   if (phase != 2) {
     const void* images = w_images;
     if (images == nullptr) {
@@ -682,7 +687,7 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
         if (wide_on < 0) { const char* e = getenv("PRN_SPLIT_WIDE_STORE"); wide_on = e ? atoi(e) : 1; }
         a.wide = wide_on && (HW & 3) == 0 && ((int64_t)M * HW & 3) == 0 && (zy & 3) == 0 && al16(y) && al16(addend) && al16(partial);
         static int policy = -1;
-        if (policy < 0) { const char* e = getenv("PRN_SPLIT_STORE_POLICY"); policy = e ? atoi(e) : 0; }
+        if (policy < 0) { const char* e = getenv("PRN_SPLIT_STORE_POLICY"); policy = e ? atoi(e) : 1; }
         a.store_policy = policy;
       }
       if (o->split_products >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);

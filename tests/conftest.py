@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
 
 
+# PRN_TEST_POISON=1: every float tensor the python side allocates uninitialised (torch.empty / empty_like: outputs, workspaces, partial
+# buffers) is filled with NaN first, so a kernel that reads memory no launch wrote shows up as NaN in a checked result instead of depending on
+# what the caching allocator handed out.  (A debugging mode for the GPU tier; the extra fills make the suite slower.)
+if os.environ.get("PRN_TEST_POISON"):
+    import torch as _torch
+    _empty, _empty_like = _torch.empty, _torch.empty_like
+
+    def _poison(t):
+        return t.fill_(float("nan")) if (t.is_cuda and t.dtype.is_floating_point and t.numel()) else t
+
+    _torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
+    _torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
