@@ -392,8 +392,8 @@ def _gemm_family(M, K, B, HW, nz, flops):
 # ------------------------------------------------------------------------------------------ split-GEMM weight images
 # The split GEMM kernel (csrc/prn_gemm_split.hip, both piece formats) reads its weight operand as pre-cut "images".  Left alone the library cuts the
 # weight inside every launch (one more small kernel in front of each GEMM); for operands that persist -- parameters, the per-step flipped
-# dgrad layouts, the Winograd transform-domain weights -- this cache keeps the images, registers them with the library
-# (prn_split_images_register) and re-cuts ALL of them with one launch per training step (split_refresh_all, called by the model next to
+# dgrad layouts, the Winograd transform-domain weights -- this cache keeps the images (the caller's memory: their pointer travels
+# with each call, include/prn.h `w_images`; the library holds no table) and re-cuts ALL of them with one launch per training step (split_refresh_all, called by the model next to
 # FlippedWeights / WinogradWeights); at inference they are cut once.  Every launch site checks its operand's entry against the version
 # counter of the parameter (or the generation stamp of the derived buffer) first, so a stale image is never read.
 # "auto" (default): while training every operand's images are kept and re-cut by ONE batched pass per step (two launches) -- the launches then
