@@ -1,10 +1,24 @@
 """Where a split16 GEMM launch spends its time: per workgroup, the 100 MHz wall clock at kernel entry / loop entry / loop exit / kernel exit and
 the compute unit it ran on (csrc/prn_gemm_split.hip built with -DPRN_S16_TIMING into planerecnet_amd/build/libprn_s16timing.so -- a side build,
-not the product library).  Run on the GPU box:
+not the product library).  Build the side library here or on the GPU box (after the product build, whose objects it links), then run on the GPU box:
+    python tools/split16_phase_timing.py --build
     PRN_LIB=planerecnet_amd/build/libprn_s16timing.so python tools/split16_phase_timing.py"""
 import ctypes
+import glob
 import os
+import subprocess
 import sys
+
+if "--build" in sys.argv:
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planerecnet_amd")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    obj = os.path.join(pkg, "build", "prn_gemm_split_timing.o")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-DPRN_S16_TIMING", "-c",
+                           os.path.join(pkg, "csrc", "prn_gemm_split.hip"), "-o", obj])
+    others = [o for o in glob.glob(os.path.join(pkg, "build", "prn_*.o")) if not o.endswith(("prn_gemm_split.o", "_timing.o", "_old.o"))]
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(pkg, "build", "libprn_s16timing.so")] + others + [obj])
+    print("built", os.path.join(pkg, "build", "libprn_s16timing.so"))
+    sys.exit(0)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
