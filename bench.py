@@ -539,6 +539,8 @@ def main():
                                           "ratio": None if pm is None else pm["bytes_per_launch"] / alg_f, "source": None if pm is None else pm["source"]}
         if traffic is not None:
             traffic["by_family"] = by_family
+            traffic["note"] = ("counter bytes come from a step run with --sync-wgrad (one kernel at a time): weight gradients are then launched one layer at a "
+                               "time with ~48 pixel splits each, not eight layers per launch as in the timed step -- their ratio is an upper bound (DESIGN.md 10.5b)")
         # HBM-bound families are credited with the bytes their kernels EXECUTE (per variant), so none can exceed what the memory
         # system delivers; a figure above the measured copy rate means the accounting of that family is wrong
         over = [f["kernel"] for f in fams if f["bound"] == "hbm" and f["achieved"] > 6300.0 and f["time_ms"] > 0.02]
