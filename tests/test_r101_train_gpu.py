@@ -34,6 +34,9 @@ CN = "PlaneRecNet_101_config"
 SEED_W, SEED_X, SEED_NP = 3, 12, 13          # as in tests/golden/make_golden_r101.py
 GRAD_K, GRAD_FLOOR = 2.0, 5e-4               # direct kernels: the HIP gradient within 2 x the reference's own fp32-vs-fp64 spread (measured max: 0.83 of it)
 GRAD_K_WINOGRAD, GRAD_FLOOR_WINOGRAD = 2.5, 1e-3   # default build (measured: 99th percentile 0.65 of the K = 2 bound, one DCN modulator bias at 1.14): F(4x4,3x3)'s ~1e-5 forward error (direct: ~1e-7) through gradients of condition ~100
+# (Where that error sits, PRN_TEST_CHANNEL_SHARE=<file>, profiles/r04_e_winograd_allowance_tensors_error_by_channel.txt: tower.3.weight has 92 % and
+# tower.4.bias 100 % of their squared error in ONE output channel (114), tower.0 / tower.1 spread theirs over a few (76, 50, 202): single
+# low-variance GroupNorm channels whose normalisation amplifies the ~1e-5 forward error of F(4x4,3x3), the same with the 16-bit pipe on or off.)
 WINOGRAD_SENSITIVE = {"inst_head.kernel_tower.0.weight": 2e-2, "inst_head.kernel_tower.1.weight": 2e-2, "inst_head.kernel_tower.1.bias": 2e-2,
                       "inst_head.kernel_tower.3.weight": 2e-2, "inst_head.kernel_tower.4.bias": 2e-2}
 
@@ -162,6 +165,27 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
         bound = (GRAD_K_WINOGRAD * spread[n] + GRAD_FLOOR_WINOGRAD) if (winograd or gemm_arith in ("b8-plan", "all-f16", "all-bf16")) else (GRAD_K * spread[n] + GRAD_FLOOR)
         if winograd and n in WINOGRAD_SENSITIVE:
             bound = WINOGRAD_SENSITIVE[n]
+            if os.environ.get("PRN_TEST_CHANNEL_SHARE"):          # where the error of an allowance-list tensor sits (diagnostic)
+                d = (got.double().cpu() - g64[n].double().cpu())
+                e2 = d.pow(2)
+                tot = e2.sum().item()
+                by_out = e2.reshape(e2.shape[0], -1).sum(1)
+                msg = "%s: rel err %.2e; share of squared error in the top output channel %d: %.3f" % (n, l2, int(by_out.argmax()), by_out.max().item() / tot)
+                if d.dim() == 4:
+                    by_in = e2.sum((0, 2, 3))
+                    msg += "; top input channel %d: %.3f" % (int(by_in.argmax()), by_in.max().item() / tot)
+                    keep = torch.ones(d.shape[0], dtype=torch.bool); keep[202] = False
+                    msg += "; rel err without output channel 202: %.2e" % ((d[keep].norm() / g64[n].double().cpu()[keep].norm()).item())
+                    keep_i = torch.ones(d.shape[1], dtype=torch.bool)
+                    if d.shape[1] > 202:
+                        keep_i[202] = False
+                        msg += ", without input channel 202: %.2e" % ((d[:, keep_i].norm() / g64[n].double().cpu()[:, keep_i].norm()).item())
+                else:
+                    keep = torch.ones(d.shape[0], dtype=torch.bool); keep[202] = False
+                    msg += "; rel err without channel 202: %.2e" % ((d[keep].norm() / g64[n].double().cpu()[keep].norm()).item())
+                msg += "  (standard bound %.2e)" % (GRAD_K_WINOGRAD * spread[n] + GRAD_FLOOR_WINOGRAD)
+                with open(os.environ["PRN_TEST_CHANNEL_SHARE"], "a") as f:
+                    f.write("[%s] %s\n" % (gemm_arith, msg))
         worst.append((l2 / bound, n, l2, spread[n]))
         if l2 > bound:
             bad.append((n, l2, bound))
