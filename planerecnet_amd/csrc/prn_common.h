@@ -35,6 +35,23 @@ __device__ __forceinline__ int prn_xcd_remap(int bid, int nblocks) {
   return (bid & 7) * per + (bid >> 3);
 }
 
+// PRN_EPT elements per thread, a whole grid apart (every load instruction stays as coalesced as with one), all loads issued before the first store.
+// Pays where an element needs MANY loads (the x2 resize adjoint: sixteen, 72 -> 40 us); measured useless for the one-load-per-element folds, which are
+// bound by bytes per memory instruction, not by loads in flight (they got the four-pixels-per-thread form instead).
+// four consecutive floats at a 4-byte aligned address: ONE global_load_dwordx4 (gfx950 global memory takes unaligned vector accesses)
+struct __attribute__((packed, aligned(4))) prn_f4u { float v[4]; };
+constexpr int PRN_EPT = 4;
+__host__ __device__ inline unsigned prn_ept_blocks(int64_t n) { return (unsigned)((((n + PRN_EPT - 1) / PRN_EPT) + 255) / 256); }
+#define PRN_EPT_BEGIN(total_) \
+  const int64_t T_ = (int64_t)gridDim.x * 256, i0_ = (int64_t)blockIdx.x * 256 + threadIdx.x; \
+  float v_[PRN_EPT]; \
+  _Pragma("unroll") for (int k_ = 0; k_ < PRN_EPT; ++k_) { \
+    const int64_t i = (i0_ + k_ * T_ < (total_)) ? i0_ + k_ * T_ : (total_) - 1;          /* past the end: recompute the last element, never stored */
+#define PRN_EPT_END(total_, out_) \
+  } \
+  _Pragma("unroll") for (int k_ = 0; k_ < PRN_EPT; ++k_) if (i0_ + k_ * T_ < (total_)) (out_)[i0_ + k_ * T_] = v_[k_];
+
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

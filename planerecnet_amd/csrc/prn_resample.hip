@@ -107,22 +107,37 @@ __device__ __forceinline__ float up2_weight(int o, int i, int in) {         // w
 }
 
 __global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ addend, float* __restrict__ dx, int64_t total, int H, int W) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int w = i % W, h = (i / W) % H;
-  const int64_t bc = i / ((int64_t)W * H);
-  const int Ho = 2 * H, Wo = 2 * W;
-  const float* p = dy + bc * (int64_t)Ho * Wo;
-  const int olo = max(2 * h - 1, 0), ohi = min(2 * h + 2, Ho - 1), wlo = max(2 * w - 1, 0), whi = min(2 * w + 2, Wo - 1);
-  float acc = 0.f;
-  for (int oh = olo; oh <= ohi; ++oh) {
-    const float wh = up2_weight(oh, h, H);
-    if (wh == 0.f) continue;
-    float row = 0.f;
-    for (int ow = wlo; ow <= whi; ++ow) row += up2_weight(ow, w, W) * p[(int64_t)oh * Wo + ow];
-    acc += wh * row;
-  }
-  dx[i] = addend ? acc + addend[i] : acc;
+  PRN_EPT_BEGIN(total)
+    const int w = i % W, h = (i / W) % H;
+    const int64_t bc = i / ((int64_t)W * H);
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float* p = dy + bc * (int64_t)Ho * Wo;
+    // Straight-line 4 x 4 footprint (rows 2h-1 .. 2h+2, columns 2w-1 .. 2w+2): sixteen loads in flight per element.  A position outside the
+    // map gets weight 0 and a clamped address -- it adds +-0 to a partial sum that is never -0, i.e. nothing: the same value, summed in the same
+    // order, as the loop over the clipped ranges it replaces (for finite gradients; a non-finite one stays non-finite).
+    float wr[4], wc[4]; int orow[4], ocol[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oh = 2 * h - 1 + a, ow = 2 * w - 1 + a;
+      wr[a] = (oh >= 0 && oh <= Ho - 1) ? up2_weight(oh, h, H) : 0.f;
+      wc[a] = (ow >= 0 && ow <= Wo - 1) ? up2_weight(ow, w, W) : 0.f;
+      orow[a] = min(max(oh, 0), Ho - 1); ocol[a] = min(max(ow, 0), Wo - 1);
+    }
+    float t[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) t[a][b] = p[(int64_t)orow[a] * Wo + ocol[b]];
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row += wc[b] * t[a][b];
+      acc += wr[a] * row;
+    }
+    v_[k_] = addend ? acc + addend[i] : acc;
+  PRN_EPT_END(total, dx)
 }
 
 // arg (optional): position r*3+s of the maximum inside the window (first maximum in scan order, ATen's
@@ -243,7 +258,7 @@ extern "C" int prn_resize_bilinear_bwd_add(const float* dy, const float* addend,
     return 0;
   }
   if (Ho == 2 * H && Wo == 2 * W) {
-    hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n, H, W);
+    hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(prn_ept_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n, H, W);
     PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd/up2");
     return 0;
   }

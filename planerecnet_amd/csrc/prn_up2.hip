@@ -97,6 +97,38 @@ __global__ __launch_bounds__(256) void replicate_fold_kernel(const float* __rest
   dx[i] = acc;
 }
 
+// The same for W % 4 == 0, four consecutive pixels per thread: an interior quad (no border row, neither border column) is ONE 16-byte load at
+// p[h+1][w+1 ..] (4-byte aligned: W + 2 columns) and one aligned 16-byte store; each value is 0 + p as in the loop above.  Quads that touch the
+// border run the loop per pixel.  (One pixel per thread moved 4 bytes per memory instruction and lane: 2.1 TB/s on the 8x64x240x320 gradient.)
+__global__ __launch_bounds__(256) void replicate_fold4_kernel(const float* __restrict__ dp, float* __restrict__ dx, int64_t BC, int H, int W) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int W4 = W >> 2;
+  if (i >= BC * H * W4) return;
+  const int w = (int)(i % W4) * 4, h = (i / W4) % H;
+  const int64_t bc = i / ((int64_t)H * W4);
+  const int Wp = W + 2;
+  const float* p = dp + bc * (int64_t)(H + 2) * Wp;
+  float4 o;
+  if (h != 0 && h != H - 1 && w != 0 && w != W - 4) {
+    const prn_f4u q = *reinterpret_cast<const prn_f4u*>(p + (int64_t)(h + 1) * Wp + (w + 1));
+    o = make_float4(0.f + q.v[0], 0.f + q.v[1], 0.f + q.v[2], 0.f + q.v[3]);
+  } else {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int wk = w + k;
+      const int r0 = h == 0 ? 0 : h + 1, r1 = h == H - 1 ? H + 1 : h + 1;
+      const int c0 = wk == 0 ? 0 : wk + 1, c1 = wk == W - 1 ? W + 1 : wk + 1;
+      float acc = 0.f;
+      for (int r = r0; r <= r1; ++r)
+        for (int c = c0; c <= c1; ++c) acc += p[(int64_t)r * Wp + c];
+      t[k] = acc;
+    }
+    o = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  *reinterpret_cast<float4*>(dx + (bc * H + h) * (int64_t)W + w) = o;
+}
+
 }  // namespace
 
 extern "C" int prn_up2_phase_weights(const float* w, float* wp, int M, int C, void* stream) {
@@ -132,7 +164,10 @@ extern "C" int prn_space_to_depth2(const float* in, float* out, int B, int C, in
 extern "C" int prn_replicate_fold(const float* dp, float* dx, int B, int C, int H, int W, void* stream) {
   PRN_REQUIRE(dp && dx && B > 0 && C > 0 && H > 1 && W > 1, "prn_replicate_fold: bad arguments");
   const int64_t n = (int64_t)B * C * H * W;
-  hipLaunchKernelGGL(replicate_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, (int64_t)B * C, H, W);
+  if ((W & 3) == 0 && W >= 8 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0)
+    hipLaunchKernelGGL(replicate_fold4_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, (int64_t)B * C, H, W);
+  else
+    hipLaunchKernelGGL(replicate_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, (int64_t)B * C, H, W);
   PRN_CHECK_LAUNCH("prn_replicate_fold");
   return 0;
 }
