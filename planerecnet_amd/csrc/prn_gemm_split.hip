@@ -544,7 +544,12 @@ __global__ __launch_bounds__(256) void split16_rowmax_batched_kernel(const PrepI
   float mx = 0.f;
   if (m < it.M) {
     const float* wr = it.src + z * (long long)it.M * it.K + (long long)m * it.K;
-    for (int k = lane; k < it.K; k += 64) mx = fmaxf(mx, fabsf(wr[k]));
+    if ((it.K & 3) == 0 && (reinterpret_cast<uintptr_t>(it.src) & 15) == 0) {       // rows are 16-byte aligned: 16 bytes per lane and load (a 256-deep row is one instruction)
+      const float4* w4 = reinterpret_cast<const float4*>(wr);
+      for (int k = lane; k < (it.K >> 2); k += 64) { const float4 q = w4[k]; mx = fmaxf(fmaxf(mx, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w))); }
+    } else {
+      for (int k = lane; k < it.K; k += 64) mx = fmaxf(mx, fabsf(wr[k]));
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -562,8 +567,15 @@ __global__ void split16_prepare_batched_kernel(const PrepItem* __restrict__ item
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   const int sh = 14 - ex[z * (mtiles * 128) + m];
   float v[8];
+  const float* wr = it.src + z * (long long)it.M * it.K + (long long)m * it.K + k0;
+  if (m < it.M && k0 + 8 <= it.K && (it.K & 3) == 0 && (reinterpret_cast<uintptr_t>(it.src) & 15) == 0) {     // the 32 bytes of this thread as two 16-byte loads
+    const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
+    v[0] = ldexpf(a.x, sh); v[1] = ldexpf(a.y, sh); v[2] = ldexpf(a.z, sh); v[3] = ldexpf(a.w, sh);
+    v[4] = ldexpf(b.x, sh); v[5] = ldexpf(b.y, sh); v[6] = ldexpf(b.z, sh); v[7] = ldexpf(b.w, sh);
+  } else {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (m < it.M && k0 + j < it.K) ? ldexpf(it.src[z * (long long)it.M * it.K + (long long)m * it.K + k0 + j], sh) : 0.f;
+    for (int j = 0; j < 8; ++j) v[j] = (m < it.M && k0 + j < it.K) ? ldexpf(wr[j], sh) : 0.f;
+  }
   uint4 h, l;
   split2_f16(v[0], v[1], h.x, l.x); split2_f16(v[2], v[3], h.y, l.y); split2_f16(v[4], v[5], h.z, l.z); split2_f16(v[6], v[7], h.w, l.w);
   uint4* o = it.dst + t * IMG16_U4;
