@@ -35,6 +35,18 @@ __device__ __forceinline__ int prn_xcd_remap(int bid, int nblocks) {
   return (bid & 7) * per + (bid >> 3);
 }
 
+// i -> (x = i % W, y = (i / W) % H, z = i / (W * H)) for the one-element-per-thread kernels.  With i as int64_t the three 64-bit divisions were
+// most of such a kernel's instructions (the generic resize adjoint: ~350 VALU instructions per pixel); every tensor of this network indexes in
+// 32 bits, where a division is a float reciprocal and a correction.
+__device__ __forceinline__ void prn_idx3(int64_t i, int W, int H, int& x, int& y, int64_t& z) {
+  if (i < (1LL << 31)) {
+    const unsigned u = (unsigned)i, q = u / (unsigned)W, q2 = q / (unsigned)H;
+    x = (int)(u - q * (unsigned)W); y = (int)(q - q2 * (unsigned)H); z = q2;
+  } else {
+    x = (int)(i % W); y = (int)((i / W) % H); z = i / ((int64_t)W * H);
+  }
+}
+
 // PRN_EPT elements per thread, a whole grid apart (every load instruction stays as coalesced as with one), all loads issued before the first store.
 // Pays where an element needs MANY loads (the x2 resize adjoint: sixteen, 72 -> 40 us); measured useless for the one-load-per-element folds, which are
 // bound by bytes per memory instruction, not by loads in flight (they got the four-pixels-per-thread form instead).

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
                                                          int H, int W, int Ho, int Wo, float sh, float sw) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int w = i % W, h = (i / W) % H;
-  const int64_t bc = i / ((int64_t)W * H);
+  int w, h; int64_t bc;
+  prn_idx3(i, W, H, w, h, bc);
   int hlo, hhi, wlo, whi;
   cand_range(h, Ho, sh, hlo, hhi);
   cand_range(w, Wo, sw, wlo, whi);

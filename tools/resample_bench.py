@@ -39,7 +39,7 @@ def main():
         dp = torch.randn(B, C, H + 2, W + 2, device=dev)
         dx = torch.empty(B, C, H, W, device=dev)
         row("replicate_fold %dx%dx%dx%d" % (B, C, H, W), timeit(lambda: lib.prn_replicate_fold(_p(dp), _p(dx), B, C, H, W, _s())), 4.0 * (dp.numel() + dx.numel()))
-    for (BC, H, W, Ho, Wo) in [(8 * 128, 60, 80, 120, 160), (8 * 256, 30, 40, 120, 160), (8 * 128, 30, 40, 60, 80), (8 * 256, 15, 20, 40, 40)]:
+    for (BC, H, W, Ho, Wo) in [(8 * 128, 60, 80, 120, 160), (8 * 256, 30, 40, 120, 160), (8 * 128, 30, 40, 60, 80), (8 * 256, 15, 20, 40, 40), (8 * 256, 60, 80, 40, 40), (8 * 256, 60, 80, 36, 36), (8 * 256, 30, 40, 24, 24)]:
         x = torch.randn(BC, H, W, device=dev)
         y = torch.empty(BC, Ho, Wo, device=dev)
         add = torch.randn(BC, Ho, Wo, device=dev)
