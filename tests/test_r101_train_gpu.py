@@ -250,7 +250,8 @@ def test_r101_b8_losses_equal_oracle(net101):
     assert not missing, missing[:5]
 
 
-@pytest.mark.skipif(bool(os.environ.get("PRN_TEST_SKIP_B8")), reason="three minutes of fp64 + fp32 oracle on the host: skipped on request (PRN_TEST_SKIP_B8=1)")
+@pytest.mark.skipif(not os.environ.get("PRN_TEST_B8"), reason="3-4 minutes of fp64 + fp32 oracle on the host (it would double the GPU suite): PRN_TEST_B8=1; logs of its runs are kept "
+                                                                "under profiles/ (r04_e_r101_b8_gradients_vs_fp64.txt, r04_f / r04_g_pytest_gpu.txt ran it as part of the suite)")
 def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
     """The benchmark's own configuration, directly: PlaneRecNet_101, B = 8, 480x640, DEFAULT options (the launch plan bench.py times: every plain
     GEMM of >= 300 tiles / 4 GFLOP and its weight gradient on the fp16 pipe, Winograd, ragged instance head, deferred and grouped weight
