@@ -495,7 +495,9 @@ def main():
         detections = sum(0 if r["pred_scores"] is None else len(r["pred_scores"]) for r in last)
 
     roof, kernels = None, None
-    if rank == 0 and not args.no_roofline:
+    # (EVERY rank runs this leg: its steps contain the gradient exchange and `timed` ends in a barrier and a reduction -- rank 0 alone would issue
+    # collectives nobody answers.  Only rank 0's brackets are reported.)
+    if not args.no_roofline:
         if graphed:
             raise SystemExit("bench.py: the roofline leg needs eagerly issued launches; combine --graph with --no-roofline")
         branch_streams, ops.BRANCH_STREAMS = ops.BRANCH_STREAMS, False      # one stream: an event pair then times one launch, not its neighbours
@@ -638,7 +640,7 @@ def main():
     # inference workloads: the timed post-process at the init state sees (almost) no candidates.  Shift the category bias until every image
     # keeps >= 5 detections and time the same batch again (the product's own forward picks the shift: no oracle on this path).
     cond_run = None
-    if not train and rank == 0 and not os.environ.get("PRN_BENCH_NO_CONDITIONED_RUN"):
+    if not train and not os.environ.get("PRN_BENCH_NO_CONDITIONED_RUN"):       # (every rank: `timed` synchronises the ranks; all ranks hold the same batch and weights)
         bias = net.inst_head.cate_pred.bias
         b0 = bias.detach().clone()
         for shift in (0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0):

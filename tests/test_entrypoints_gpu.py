@@ -59,10 +59,13 @@ def _two_rank_env():
 
 def test_bench_self_launches_two_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it (the driver's SCALE command): bench.py re-executes itself under
-    torch.distributed.run, one process per rank, and rank 0 prints the one JSON line with the whole-job throughput."""
+    torch.distributed.run, one process per rank, and rank 0 prints the one JSON line with the whole-job throughput.  With EVERY leg of the
+    default command on (roofline brackets, fp32-only re-run, DCN-offset re-run): until the end of round 4 the roofline leg ran on rank 0 only,
+    and its steps' collectives and `timed`'s barrier had no partner -- `bench.py --gpus N` hung for N > 1 unless --no-roofline was passed,
+    which is what this test used to pass."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config",
-                        "PlaneRecNet_50_config", "--batch", "2", "--no-cpu-baseline", "--no-roofline"], cwd=str(tmp_path), capture_output=True,
+                        "PlaneRecNet_50_config", "--batch", "2"], cwd=str(tmp_path), capture_output=True,
                        text=True, timeout=900, env=_two_rank_env())
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -70,6 +73,17 @@ def test_bench_self_launches_two_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
     assert line["losses_finite"] and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["roofline"] is not None and line["fp32_only_run"] is not None and line["cpu_baseline"] is None       # (the CPU baseline is an N = 1 leg)
+
+
+def test_bench_inference_two_ranks(tmp_path):
+    """An inference workload under two ranks: the conditioned re-run (rank 0 only until round 4) synchronises the ranks as well."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "3", "--warmup", "2"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900, env=_two_rank_env())
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"] is not None
 
 
 @pytest.mark.parametrize("workload,batch,hw", [("c1", 1, "480x640"), ("c2", 8, "480x640"), ("c5", 4, "736x960")])
