@@ -512,7 +512,7 @@ def main():
         step()
         torch.cuda.synchronize()
         fams = profiling.summary()
-        if os.environ.get("PRN_BENCH_SHAPES"):                  # per-shape table of the MFMA launches of the bracketed step
+        if os.environ.get("PRN_BENCH_SHAPES") and rank == 0:    # per-shape table of the MFMA launches of the bracketed step
             with open(os.environ["PRN_BENCH_SHAPES"], "w") as fh:
                 fh.write("%-22s %-44s %6s %9s %8s %7s\n" % ("family", "(kind, C, H, W, M, K, stride, mode, dil, B)", "calls", "ms/step", "us/call", "TF/s"))
                 for fam, tag, n, ms, work in profiling.by_shape():
