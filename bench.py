@@ -640,7 +640,7 @@ def main():
     # inference workloads: the timed post-process at the init state sees (almost) no candidates.  Shift the category bias until every image
     # keeps >= 5 detections and time the same batch again (the product's own forward picks the shift: no oracle on this path).
     cond_run = None
-    if not train and not os.environ.get("PRN_BENCH_NO_CONDITIONED_RUN"):       # (every rank: `timed` synchronises the ranks; all ranks hold the same batch and weights)
+    if not train and not os.environ.get("PRN_BENCH_NO_CONDITIONED_RUN"):       # (every rank: `timed` synchronises the ranks; the shift is agreed by a MIN over ranks)
         bias = net.inst_head.cate_pred.bias
         b0 = bias.detach().clone()
         for shift in (0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0):
@@ -648,7 +648,10 @@ def main():
                 bias.copy_(b0 + shift)
             res = step()                                         # (in-place copy_: version counters move, cached derived weights follow)
             counts = [0 if r["pred_scores"] is None else len(r["pred_scores"]) for r in res]
-            if min(counts) >= 5:
+            least = torch.tensor([min(counts)], device=dev, dtype=torch.int64)
+            if world > 1:                                        # every rank draws its own batch (seed 1000 + rank): the decision to stop at this
+                dist.all_reduce(least, op=dist.ReduceOp.MIN)     # shift -- and to enter `timed`, which ends in collectives -- is taken by ALL ranks together
+            if int(least) >= 5:
                 n2 = max(args.steps // 2, 5)
                 el2, res = timed(2, n2)
                 cond_run = {"cate_bias_shift": shift, "detections_per_image": [0 if r["pred_scores"] is None else len(r["pred_scores"]) for r in res],

@@ -1611,14 +1611,15 @@ extern "C" int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const flo
   PRN_REQUIRE(g.phases == 1 && !direct_small_m(d) && d->in_mode != PRN_IN_DILATED && d->KH != 4 && d->KH != 2 && d->ystride <= 1,
               "prn_conv2d_wgrad_grouped: dense 1x1 / 3x3 / 7x7 weight gradients only");
   if (const int s16 = wgrad16_plan_of(d, G)) {               // both operands cut into fp16 pieces in the launch (prn_wgrad16.hip)
-    bool al = true;
-    for (int i = 0; i < G; ++i) al = al && x[i] && dy[i] && (reinterpret_cast<uintptr_t>(x[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0;
-    if (al) {
-      PRN_REQUIRE(s16 == 1 || ws != nullptr, "prn_conv2d_wgrad_grouped: workspace required (%d splits)", s16);
-      if (int e = prn_wgrad16_launch(nullptr, nullptr, dy, x, G, s16 > 1 ? (float*)ws : dw, d->M, d->C, d->B, d->H * d->W, G, 0, 0, s16, &d->opts, (hipStream_t)stream)) return e;
-      if (s16 > 1) return prn_launch_reduce_splits((const float*)ws, dw, (int64_t)G * d->M * d->C, s16, (hipStream_t)stream);
-      return 0;
-    }
+    // The plan (kernel, pixel splits, workspace size: prn_conv2d_wgrad_grouped_ws_bytes) is a function of the descriptor alone, never of
+    // the pointers: an operand the planned kernel cannot take is an error, not a silent switch to a kernel with another split count.
+    for (int i = 0; i < G; ++i)
+      PRN_REQUIRE(x[i] && dy[i] && ((reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(dy[i])) & 15) == 0,
+                  "prn_conv2d_wgrad_grouped: x / dy of layer %d must be non-null and 16-byte aligned (the descriptor plans the 16-bit-pipe kernel; opts.wgrad_split = PRN_SPLIT_OFF selects the fp32 kernel)", i);
+    PRN_REQUIRE(s16 == 1 || ws != nullptr, "prn_conv2d_wgrad_grouped: workspace required (%d splits)", s16);
+    if (int e = prn_wgrad16_launch(nullptr, nullptr, dy, x, G, s16 > 1 ? (float*)ws : dw, d->M, d->C, d->B, d->H * d->W, G, 0, 0, s16, &d->opts, (hipStream_t)stream)) return e;
+    if (s16 > 1) return prn_launch_reduce_splits((const float*)ws, dw, (int64_t)G * d->M * d->C, s16, (hipStream_t)stream);
+    return 0;
   }
   WgArgs a;
   a.x = x[0]; a.dy = dy[0];
@@ -1696,8 +1697,11 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
     }
     return 0;
   }
-  if (rg == nullptr && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+  if (rg == nullptr) {
     if (const int s16 = wgrad16_plan_of(d, 1)) {             // both operands cut into fp16 pieces in the launch (prn_wgrad16.hip)
+      // (plan = f(descriptor) only, as prn_conv2d_wgrad_ws_bytes sized the workspace: a misaligned operand is an error, not a fallback)
+      PRN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
+                  "prn_conv2d_wgrad: x and dy must be 16-byte aligned (the descriptor plans the 16-bit-pipe kernel; opts.wgrad_split = PRN_SPLIT_OFF selects the fp32 kernel)");
       PRN_REQUIRE(s16 == 1 || ws != nullptr, "prn_conv2d_wgrad: workspace required (%d splits)", s16);
       if (phase != 2)
         if (int e = prn_wgrad16_launch(dy, x, nullptr, nullptr, 0, s16 > 1 ? (float*)ws : dw, d->M, d->C, d->B, d->H * d->W, 1, 0, 0, s16, &d->opts, (hipStream_t)stream)) return e;
@@ -1822,9 +1826,12 @@ extern "C" int prn_gemm_batched_nt_splits(int M, int C, int P, int nb, const prn
 extern "C" int prn_gemm_batched_nt(int M, int C, int P, int nb, const float* A, const float* Bm, float* ws, const prn_gemm_opts* opts, void* stream) {
   PRN_REQUIRE(A && Bm && ws && M > 0 && C > 0 && P > 0 && nb > 0 && nb < 65536, "prn_gemm_batched_nt: bad arguments");
   PRN_REQUIRE((int64_t)C * P < (1LL << 29) && (int64_t)M * P < (1LL << 29), "prn_gemm_batched_nt: operand larger than a buffer descriptor");
-  if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) == 0)
-    if (const int s16 = prn_wgrad16_plan(M, C, P, P, nb, opts))     // (partials [splits][nb][M][C], the layout of the fp32 kernel)
-      return prn_wgrad16_launch(A, Bm, nullptr, nullptr, 0, ws, M, C, 1, P, nb, (int64_t)M * P, (int64_t)C * P, s16, opts, (hipStream_t)stream);
+  if (const int s16 = prn_wgrad16_plan(M, C, P, P, nb, opts)) {   // (partials [splits][nb][M][C], the layout of the fp32 kernel)
+    // prn_gemm_batched_nt_splits told the caller s16 partial slabs: the plan does not depend on the pointers, a misaligned operand is an error
+    PRN_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) == 0,
+                "prn_gemm_batched_nt: A and B must be 16-byte aligned (the options plan the 16-bit-pipe kernel; opts->wgrad_split = PRN_SPLIT_OFF selects the fp32 kernel)");
+    return prn_wgrad16_launch(A, Bm, nullptr, nullptr, 0, ws, M, C, 1, P, nb, (int64_t)M * P, (int64_t)C * P, s16, opts, (hipStream_t)stream);
+  }
   WgArgs a;
   a.x = Bm; a.dy = A; a.out = ws;
   a.B = 1; a.C = C; a.H = 1; a.W = P; a.M = M; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = P;

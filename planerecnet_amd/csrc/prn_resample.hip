@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __rest
     const float* p = dy + bc * (int64_t)Ho * Wo;
     // Straight-line 4 x 4 footprint (rows 2h-1 .. 2h+2, columns 2w-1 .. 2w+2): sixteen loads in flight per element.  A position outside the
     // map gets weight 0 and a clamped address -- it adds +-0 to a partial sum that is never -0, i.e. nothing: the same value, summed in the same
-    // order, as the loop over the clipped ranges it replaces (for finite gradients; a non-finite one stays non-finite).
+    // order, as the loop over the clipped ranges it replaces.
     float wr[4], wc[4]; int orow[4], ocol[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -157,6 +157,12 @@ __global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __rest
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) t[a][b] = p[(int64_t)orow[a] * Wo + ocol[b]];
+    // taps with weight 0 (outside the map, or an in-range position the interpolation does not use) contribute NOTHING, as in the clipped loop
+    // and in ATen's backward: selected, not multiplied, so that an inf / NaN gradient next to the border does not leak into dx through 0 * inf
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) t[a][b] = (wr[a] != 0.f && wc[b] != 0.f) ? t[a][b] : 0.f;
     float acc = 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {

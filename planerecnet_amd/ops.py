@@ -50,7 +50,8 @@ _POLICY = {"split_mode": int(os.environ.get("PRN_SPLIT_GEMM", "1")),
            "kind": _lib.PIECES_BF16 if os.environ.get("PRN_SPLIT_KIND", "f16") == "bf16" else _lib.PIECES_F16,
            "products": int(os.environ.get("PRN_SPLIT16_PRODUCTS", "3")),
            "min_gflop": float(os.environ.get("PRN_SPLIT_MIN_GFLOP", "4.0")),
-           "min_tiles": 300,
+           # (the eval entry of the train / eval thresholds below: what applies until a model's train() / eval() calls split_gemm_policy)
+           "min_tiles": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_EVAL", "300"))),
            "wgrad_wgs": int(os.environ.get("PRN_WGRAD_WGS", "0") or 0),
            "wgrad_target": int(os.environ.get("PRN_WGRAD_TARGET", "0") or 0),
            # PRN_WGRAD_SPLIT: the weight gradients of the plain-GEMM layers on the 16-bit pipe (csrc/prn_wgrad16.hip): 0 = fp32 MFMA, 1 = by plan, 2 = wherever it applies
@@ -415,6 +416,7 @@ SPLIT_STATS = {"hits": 0, "cuts": 0, "uncached": 0, "refreshes": 0}     # launch
 
 _SPLIT_POLICY = {"train": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_TRAIN", "300"))),
                  "eval": int(os.environ.get("PRN_SPLIT_MIN_TILES", os.environ.get("PRN_SPLIT_MIN_TILES_EVAL", "300")))}
+_SPLIT_POLICY["current"] = _POLICY["min_tiles"]                  # (== the eval entry: direct ops calls from tools / tests honour the env threshold too)
 
 
 def split_gemm_policy(which):

@@ -152,6 +152,28 @@ def test_wgrad16_plan_is_host_logic():
     assert lib.prn_gemm_batched_nt_splits(256, 256, 9600, 36, o_on) >= 1 and lib.prn_gemm_batched_nt_splits(256, 256, 9600, 36, o_off) >= 1
 
 
+def test_wgrad16_plan_does_not_depend_on_pointer_alignment():
+    """The workspace of a weight gradient is sized from the descriptor (prn_conv2d_wgrad_ws_bytes, prn_gemm_batched_nt_splits).  An operand
+    the planned 16-bit-pipe kernel cannot take (not 16-byte aligned: a C caller's offset sub-tensor) must be REFUSED on the host -- it used to
+    fall back to the fp32 kernel, whose own split count then wrote past a workspace sized for the other plan (advisor, round 4)."""
+    from planerecnet_amd import _lib
+    lib = _lib.lib
+    on, o_on = _opts(mode=0, wgrad=1)
+    d = _lib.ConvDesc(8, 256, 30, 40, 1024, 1, 1, 1, 0, 30, 40, 0, 1, 0, 0, 0, 0, 0, on)
+    assert lib.prn_conv2d_wgrad_kernel_kind(ctypes.byref(d), 1) == 2
+    fake, odd = ctypes.c_void_p(0x10000), ctypes.c_void_p(0x10004)
+    for x, dy in ((odd, fake), (fake, odd)):
+        rc = lib.prn_conv2d_wgrad(ctypes.byref(d), x, dy, fake, fake, None)
+        assert rc != 0 and b"16-byte aligned" in lib.prn_last_error()
+    arr = (ctypes.c_void_p * 2)(0x10000, 0x10004)
+    ok = (ctypes.c_void_p * 2)(0x10000, 0x20000)
+    rc = lib.prn_conv2d_wgrad_grouped(ctypes.byref(d), 2, arr, ok, fake, fake, None)
+    assert rc != 0 and b"16-byte aligned" in lib.prn_last_error()
+    assert lib.prn_gemm_batched_nt_kind(256, 256, 9600, 36, o_on) == 2
+    rc = lib.prn_gemm_batched_nt(256, 256, 9600, 36, odd, fake, fake, o_on, None)
+    assert rc != 0 and b"16-byte aligned" in lib.prn_last_error()
+
+
 def test_one_default_plan_in_one_place():
     """The shipping defaults of the per-call options exist once: prn_gemm_opts_default() in the library; the Python layer's policy (what
     ops.py puts into every descriptor when no environment variable overrides it) must be that value, field by field."""

@@ -636,6 +636,26 @@ def test_resize_bilinear_fwd_bwd(H, W, Ho, Wo):
     close(gd, gr, "resize bwd", rtol=1e-5)
 
 
+def test_resize_up2_adjoint_keeps_a_non_finite_gradient_where_aten_keeps_it():
+    """x2 upsample backward: an inf in dy reaches exactly the input pixels whose interpolation used that output (ATen's rule).  Taps of the
+    straight-line 4 x 4 footprint that lie outside the map or carry weight 0 are selected away, never multiplied (0 * inf = NaN): advisor, round 4."""
+    from planerecnet_amd import ops
+    H, W = 6, 8
+    x = rnd(1, 3, H, W, seed=3).requires_grad_(True)
+    go = rnd(1, 3, 2 * H, 2 * W, seed=4)
+    for (oh, ow) in ((0, 0), (0, 5), (2 * H - 1, 2 * W - 1), (5, 0), (6, 7)):
+        g = go.clone()
+        g[0, 1, oh, ow] = float("inf")
+        (gr,) = torch.autograd.grad(F.interpolate(x, size=(2 * H, 2 * W), mode="bilinear", align_corners=False), [x], g)
+        xd = x.detach().float().to(dev()).requires_grad_(True)
+        (gd,) = torch.autograd.grad(ops.resize_bilinear(xd, (2 * H, 2 * W)), [xd], g.float().to(dev()))
+        gd = gd.cpu()
+        assert torch.equal(torch.isfinite(gd), torch.isfinite(gr)), (oh, ow)
+        assert not torch.isnan(gd).any(), (oh, ow)
+        fin = torch.isfinite(gr)
+        assert (gd[fin].double() - gr[fin]).abs().max().item() <= 1e-5 * gr[fin].abs().max().item()
+
+
 @pytest.mark.parametrize("H,W,Ho,Wo", [(15, 20, 30, 40), (30, 40, 15, 20), (7, 9, 16, 11)])
 def test_resize_bilinear_with_addend_fwd_bwd(H, W, Ho, Wo):
     """resize(x) + addend from one launch (the level sum of SOLOv2MaskHead): value, and both gradients (d addend = dy as is)."""
