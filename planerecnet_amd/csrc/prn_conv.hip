@@ -56,6 +56,7 @@ struct ConvArgs {
   int ystride, yW, yHW;     // output map: GEMM pixel (oh, ow) is stored at (oh*ystride + phase_y, ow*ystride + phase_x) of a yHW plane
   int zx, zw, zy;           // VEC instances: element strides of x / w / y per blockIdx.z (prn_gemm_batched; 0 for a plain conv)
   int wide_store;           // epilogue through the LDS transpose (float4 stores): output / addend / workspace 16-byte aligned
+  int ilv;                  // K loop with the staging work issued inside the MFMA loop (see conv_igemm_kernel)
   int tail_first, tail_splits;   // tail split (see plan_tail): blocks >= tail_first are K-split pieces of the last tiles; 0 splits = off
   float* ws;
   unsigned* cnt;                 // per-tile arrival counters (zero between launches) when the K-split sum is folded into this kernel, else null
@@ -372,7 +373,109 @@ __global__ __launch_bounds__(64 * WM * WN, (TM * TN == 4 ? 4 : 1)) void conv_ige
       }
     };
     const int KTall = (a.K + BK - 1) / BK;
-    const int kt0 = (int)((int64_t)ksplit * KTall / nsplit), KT = (int)((int64_t)(ksplit + 1) * KTall / nsplit);
+    const int kt0 = __builtin_amdgcn_readfirstlane((int)((int64_t)ksplit * KTall / nsplit)), KT = __builtin_amdgcn_readfirstlane((int)((int64_t)(ksplit + 1) * KTall / nsplit));
+    if (a.ilv && KT - kt0 >= 2) {
+      // Interleaved schedule (round 5).  In the loop below a wave issues its loads, runs its MFMAs, THEN stores to LDS and waits at the barrier:
+      // only the other resident waves can hide the last two phases, and with 2-4 of them per SIMD that leaves the matrix pipe ~50 % busy.
+      // Here the staging work of a wave is issued in the shadow of its own MFMAs (a v_mfma_f32_32x32x2_f32 holds the pipe for 64 cycles, a k
+      // step has TM * TN of them): the operand pieces of a slice (A float4 groups, B float4 groups / gathered elements) are spread over the k
+      // steps; in its step a piece is stored from registers to the LDS buffer of slice kt + 1 and immediately RE-LOADED for slice kt + 2 into
+      // the same registers, so every load has a whole iteration to land and no register is added.  MFMA operands are read one k step ahead.
+      constexpr int G = BK / 2, NBP = (VEC || V3) ? NBV : NB, NP = NA + NBP;
+      unsigned rc[V3 ? NBV : 1];
+      auto load_a_piece = [&](int i, int k0) {
+        const int k = k0 + akq;
+        if (K4) {
+          const float4 v = bload4(wr, abase[i] | (k < a.K ? 0u : OOB), k0 * 4);
+          ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ra[i][j] = bload(wr, (k + j < a.K) ? abase[i] + 4u * j : OOB, k0 * 4);
+        }
+      };
+      auto store_a_piece = [&](int i, int buf) {
+        if (AALL || arow < BM) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) As[buf][(arow + AROWS * i) * LDA + akq + j] = ra[i][j];
+        }
+      };
+      auto load_b_piece = [&](int i, int k0) {
+        if (VEC) {
+          const int kr = k0 + i * VROWS;
+          rv[i] = bload4(xr, (kr + vrow0 < a.K) ? vbase : OOB, kr * HW_ * 4);
+        } else if (V3) {
+          const int kr = k0 + vrow0 + i * VROWS;
+          const int c = kr / 9, rs = kr - c * 9;
+          const unsigned e = taps[rs * VG + vg];
+          rc[V3 ? i : 0] = e & 3u;
+          rv[i] = bload4(xr, (kr < a.K) ? (e & ~3u) + (unsigned)(c * HW_ * 4) : OOB, 0);
+        } else {
+          const int kr = k0 + krow0 + i * KSTEP;
+          const int c = kr / KK, rs = kr - c * KK;
+          const unsigned off = (KS == 1) ? off1 : taps[rs * BN + nl];
+          if (BN >= 64) rb[i] = bload(xr, (kr < a.K) ? off : OOB, c * HW_ * 4);
+          else rb[i] = bload(xr, (kr < a.K) ? off + (unsigned)(c * HW_ * 4) : OOB, 0);
+        }
+      };
+      auto store_b_piece = [&](int i, int buf) {
+        if (VEC) {
+          *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = rv[i];
+        } else if (V3) {
+          const unsigned code = rc[V3 ? i : 0];
+          float4 v = rv[i];
+          if (code == 1u) v = make_float4(0.f, v.x, v.y, v.z);
+          else if (code == 2u) v = make_float4(v.y, v.z, v.w, 0.f);
+          *reinterpret_cast<float4*>(&Bs[buf][(vrow0 + i * VROWS) * BN + vg * 4]) = v;
+        } else {
+          Bs[buf][(krow0 + i * KSTEP) * BN + nl] = rb[i];
+        }
+      };
+      // slice kt0 -> LDS, slice kt0 + 1 -> registers
+#pragma unroll
+      for (int i = 0; i < NA; ++i) load_a_piece(i, kt0 * BK);
+#pragma unroll
+      for (int i = 0; i < NBP; ++i) load_b_piece(i, kt0 * BK);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) store_a_piece(i, kt0 & 1);
+#pragma unroll
+      for (int i = 0; i < NBP; ++i) store_b_piece(i, kt0 & 1);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) load_a_piece(i, (kt0 + 1) * BK);
+#pragma unroll
+      for (int i = 0; i < NBP; ++i) load_b_piece(i, (kt0 + 1) * BK);
+      __syncthreads();
+      for (int kt = kt0; kt + 1 < KT; ++kt) {
+        const int buf = kt & 1, nbuf = buf ^ 1, k2 = (kt + 2) * BK;
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[0][i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[0][j] = Bs[buf][(lane >> 5) * BN + wn * TN * 32 + j * 32 + (lane & 31)];
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+          if (kk + 1 < G) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[(kk + 1) & 1][i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + (kk + 1) * 2 + (lane >> 5)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[(kk + 1) & 1][j] = Bs[buf][((kk + 1) * 2 + (lane >> 5)) * BN + wn * TN * 32 + j * 32 + (lane & 31)];
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if ((p * G) / NP == kk) {
+              if (p < NA) { store_a_piece(p < NA ? p : 0, nbuf); load_a_piece(p < NA ? p : 0, k2); }
+              else { store_b_piece(p >= NA ? p - NA : 0, nbuf); load_b_piece(p >= NA ? p - NA : 0, k2); }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+      }
+      mma_tile((KT - 1) & 1);
+      return;
+    }
     load_tile(kt0 * BK);
     store_tile(kt0 & 1);
     __syncthreads();
@@ -1177,6 +1280,11 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
   a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
   a.splits = p.splits;
   a.wide_store = wide_store_ok(a, p);
+  {
+    static int ilv = -1;                                   // PRN_CONV_ILV=0: the phase-separated K loop (A/B runs)
+    if (ilv < 0) { const char* e = getenv("PRN_CONV_ILV"); ilv = e ? atoi(e) : 1; }
+    a.ilv = ilv;
+  }
   a.tail_first = a.nblocks; a.tail_splits = 0;
   int gx = a.nblocks;
   if (tail_pieces > 1 && phases == 1 && a.seg.nseg == 0 && a.ystride == 1) {

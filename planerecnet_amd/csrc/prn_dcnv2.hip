@@ -406,6 +406,449 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ windowed forward (round 5)
+// The gathers above fetch every operand element from L2 (two 8-byte loads for ONE sampled value, 16 KB of gathered bytes per 8-deep K slice
+// of a 256 x 64 tile) one slice ahead of the MFMA loop: the launch is bound by that round trip, not by the matrix pipe (the same operand on
+// the 16-bit pipe ran no faster: DESIGN 9.6).  Here the pixel tile is a PATCH (PH x PW output pixels of one image, PH * PW = 64) and the
+// input WINDOW the patch's 9 x 64 sampling points fall into -- (PH - 1) * stride + 3 rows plus the offsets' spread -- is staged in LDS per
+// channel: a K slice is TWO channels x 9 taps = 18 rows, its windows are fetched once (coalesced row segments, ~0.1-0.4 KB per channel
+// instead of 4.6 KB of gathers), two slices ahead, and the bilinear gather is two ds_read2_b32 per element.  A thread samples the same
+// (tap, pixel) pairs in every slice, so its table entries (LDS offset of the 2 x 2 footprint, four weights) live in registers for the
+// whole K loop.  The window is zero-padded where it leaves the image, which IS torchvision's rule (corners outside contribute nothing; a
+// point at or beyond -1 / H / W has all its weight on zero rows) -- no validity select in the loop.
+//   table2 : one workgroup per patch: sampling geometry of its 9 x 64 points, bounding box of the live ones (LDS min / max) -> window
+//            origin and extent; entries {LDS offset | corner validity, global byte offset of the top-left corner} + 4 weights.
+//   fallback: a patch whose window exceeds WROWS x WPITCH (offsets are clamped at +-max(h, w) / 4, so it can) samples from global memory
+//            with four guarded dword loads per element -- same weights, same summation order, bit-identical to the window path.
+constexpr int WPITCH = 40;                   // floats per window row in LDS: == 8 (mod 32), the 4 x 8 lanes of a half-wave hit 32 banks
+constexpr int WROWS = 32;
+constexpr int WCH = WPITCH * WROWS;          // floats per channel window
+constexpr int W2_BK = 18;                    // two channels x nine taps
+constexpr int TILE2_F4 = 2 + 2 * 9 * 64;     // float4 per patch in the table: header (8 ints), meta[9][64], weights[9][64]
+
+struct Tab2Args {
+  const float* off; const float* msk; float4* tab;
+  int B, C, H, W, Ho, Wo, stride, pad, raw;
+  int64_t off_bs, msk_bs;
+  float maxoff;
+  int PH, PW, tilesY, tilesX;
+};
+
+__global__ __launch_bounds__(256) void dcnv2_table2_kernel(Tab2Args a) {
+  __shared__ int wbb[4][4];
+  const int tid = threadIdx.x, tile = blockIdx.x;
+  const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, b = tile / (a.tilesX * a.tilesY);
+  int bb[4] = {0x7fffffff, -0x7fffffff, 0x7fffffff, -0x7fffffff};      // this thread's y0 min, y0 + 1 max, x0 min, x0 + 1 max
+  const int plane = a.Ho * a.Wo;
+  int y0v[3], x0v[3]; bool live[3]; float4 wv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = tid + 256 * i;
+    live[i] = false; y0v[i] = 0; x0v[i] = 0; wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e >= 576) continue;
+    const int t = e >> 6, p = e & 63;
+    const int py = p / a.PW, px = p - py * a.PW;
+    const int ho = ty * a.PH + py, wo = tx * a.PW + px;
+    if (py >= a.PH || ho >= a.Ho || wo >= a.Wo) continue;
+    const int pix = ho * a.Wo + wo;
+    const float* ob = a.off + (size_t)b * a.off_bs;
+    float dy = ob[(size_t)(2 * t) * plane + pix], dx = ob[(size_t)(2 * t + 1) * plane + pix];
+    float mod = 1.f;
+    if (a.raw) {                                           // models/dcn.py:53-57: clamp(+-max_offset), 2 * sigmoid
+      dy = fminf(fmaxf(dy, -a.maxoff), a.maxoff);
+      dx = fminf(fmaxf(dx, -a.maxoff), a.maxoff);
+      mod = 2.f / (1.f + expf(-ob[(size_t)(18 + t) * plane + pix]));
+    } else if (a.msk) {
+      mod = a.msk[(size_t)b * a.msk_bs + (size_t)t * plane + pix];
+    }
+    const int ki = t / 3, kj = t - ki * 3;
+    const float y = (float)(ho * a.stride - a.pad + ki) + dy, x = (float)(wo * a.stride - a.pad + kj) + dx;
+    const bool inside = (y > -1.f) && (y < (float)a.H) && (x > -1.f) && (x < (float)a.W);
+    if (!inside) continue;
+    const float fy = floorf(y), fx = floorf(x);
+    const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+    y0v[i] = (int)fy; x0v[i] = (int)fx; live[i] = true;
+    wv[i] = make_float4(mod * hy * hx, mod * hy * lx, mod * ly * hx, mod * ly * lx);
+    bb[0] = min(bb[0], y0v[i]); bb[1] = max(bb[1], y0v[i] + 1);
+    bb[2] = min(bb[2], x0v[i]); bb[3] = max(bb[3], x0v[i] + 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {                       // wave reduction, then the four waves through LDS (atomics on four LDS words: 31 us)
+    bb[0] = min(bb[0], __shfl_xor(bb[0], o, 64)); bb[1] = max(bb[1], __shfl_xor(bb[1], o, 64));
+    bb[2] = min(bb[2], __shfl_xor(bb[2], o, 64)); bb[3] = max(bb[3], __shfl_xor(bb[3], o, 64));
+  }
+  if ((tid & 63) == 0) { wbb[tid >> 6][0] = bb[0]; wbb[tid >> 6][1] = bb[1]; wbb[tid >> 6][2] = bb[2]; wbb[tid >> 6][3] = bb[3]; }
+  __syncthreads();
+  bb[0] = min(min(wbb[0][0], wbb[1][0]), min(wbb[2][0], wbb[3][0])); bb[1] = max(max(wbb[0][1], wbb[1][1]), max(wbb[2][1], wbb[3][1]));
+  bb[2] = min(min(wbb[0][2], wbb[1][2]), min(wbb[2][2], wbb[3][2])); bb[3] = max(max(wbb[0][3], wbb[1][3]), max(wbb[2][3], wbb[3][3]));
+  const bool any = bb[1] >= bb[0];
+  const int wy0 = any ? bb[0] : 0, wx0 = any ? bb[2] : 0, wh = any ? bb[1] - bb[0] + 1 : 0, ww = any ? bb[3] - bb[2] + 1 : 0;
+  const int fallback = (wh > WROWS || ww > WPITCH) ? 1 : 0;
+  float4* tp = a.tab + (size_t)tile * TILE2_F4;
+  if (tid == 0) {
+    tp[0] = make_float4(__int_as_float(wy0), __int_as_float(wx0), __int_as_float(wh), __int_as_float(ww));
+    tp[1] = make_float4(__int_as_float(fallback), 0.f, 0.f, 0.f);
+  }
+  const unsigned base = (unsigned)b * (unsigned)a.C * (unsigned)(a.H * a.W);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = tid + 256 * i;
+    if (e >= 576) continue;
+    unsigned meta = 0u, goff = 0u;
+    if (live[i]) {
+      const int y0 = y0v[i], x0 = x0v[i];
+      const unsigned v00 = (y0 >= 0 && x0 >= 0) ? 1u : 0u, v01 = (y0 >= 0 && x0 + 1 <= a.W - 1) ? 2u : 0u;
+      const unsigned v10 = (y0 + 1 <= a.H - 1 && x0 >= 0) ? 4u : 0u, v11 = (y0 + 1 <= a.H - 1 && x0 + 1 <= a.W - 1) ? 8u : 0u;
+      const unsigned loff = fallback ? 0u : (unsigned)((y0 - wy0) * WPITCH + (x0 - wx0));
+      meta = loff | ((v00 | v01 | v10 | v11) << 16);
+      goff = (base + (unsigned)(y0 * a.W + x0)) * 4u;      // (wraps for y0 / x0 = -1: used only through the validity bits)
+    }
+    tp[2 + e] = make_float4(__uint_as_float(meta), __uint_as_float(goff), 0.f, 0.f);
+    tp[2 + 576 + e] = wv[i];
+  }
+}
+
+struct Fwd2Args {
+  const float* x; const float* w; const float* bias; const float4* tab; float* y; float* ws;
+  int B, C, H, W, M, K, Ho, Wo;
+  int PH, PW, tilesY, tilesX, tilesM, ptiles, nblocks, splits, epi;
+  int xbytes, wbytes;
+};
+
+// Tile (64 * TM) output channels x one 64-pixel patch, 256 threads = 2 x 2 waves (wave tile 32 * TM x 32), K slices of 18 (two channels).
+// Per iteration s: [global loads: weights of slice s + 1, windows of slice s + 2] -> [sample slice s + 1 from its windows (in LDS since the
+// previous iteration) into Bs] -> [MFMA loop on slice s] -> [weights, windows -> LDS] -> ONE barrier.  The loop body is straight-line code:
+// whatever a thread has no work for (weight pieces beyond the tile, window elements beyond the window, sampling rows 18 / 19 of waves 2 / 3)
+// is a load at the out-of-range offset and a store to a dummy LDS word, never a branch (hipcc's waitcnt pass gives up across uniform branches).
+// NWL: window elements per thread and channel (1: windows up to 256 elements, 2: 512, 5: WROWS x WPITCH); 0: the global-memory fallback.
+#ifdef PRN_DCN2_TIMING
+// Profiling aid (side build only, tools/dcn2_phase_timing.py): wave 0 of every workgroup sums the shader clocks it spends in the five phases of
+// an iteration (load issue, sampling, MFMA loop, LDS stores, barrier) + iterations + entry / exit wall clock.
+__device__ long long prn_dcn2_dbg[4096 * 10];
+#define D2_STAMP(v_) const long long v_ = (long long)__builtin_readcyclecounter()
+#else
+#define D2_STAMP(v_) do { } while (0)
+#endif
+
+template <int TM> struct Fwd2Lds {
+  static constexpr int BM = 64 * TM, LDA = W2_BK + 1;
+  static constexpr int ABUF = BM * LDA + 2;             // + a dummy pair
+  static constexpr int BBUF = (W2_BK + 2) * 64;         // + two dummy rows
+  static constexpr int WBUF = 2 * WCH + 1;              // two channels + a dummy word
+};
+
+template <int TM, int NWL>
+__device__ __forceinline__ void dcnv2_fwd2_body(const Fwd2Args& a, float* As, float* Bs, float* Win, int wy0, int wx0, int wh, int ww, int ptile, int mt) {
+  using L = Fwd2Lds<TM>;
+  constexpr int BM = L::BM, LDA = L::LDA;
+  constexpr bool FALLBACK = NWL == 0;
+  constexpr int NW = FALLBACK ? 1 : NWL;
+  constexpr int NAL = (BM * 9 + 255) / 256;            // 8-byte weight pieces per thread per slice (a row's slice is 9 pieces)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = mt * BM;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.xbytes), wr = make_rsrc(a.w, a.wbytes);
+  const int tpp = a.tilesY * a.tilesX, b = ptile / tpp;
+  const int HW = a.H * a.W;
+
+  // table entries of this thread's sampling rows r = wave + 4 * i (tap r % 9, channel r / 9 of the slice), pixel = lane; rows 18 / 19: weight 0
+  const float4* tp = a.tab + (size_t)ptile * TILE2_F4;
+  int soff[5]; unsigned goff[5], vbits[5]; float4 sw[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = wave + 4 * i, t = r % 9, cl = r / 9;
+    const bool ok = r < W2_BK;
+    const float4 mq = tp[2 + (ok ? t : 0) * 64 + lane];
+    sw[i] = tp[2 + 576 + (ok ? t : 0) * 64 + lane];
+    if (!ok) sw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned meta = __float_as_uint(mq.x);
+    soff[i] = ok ? (int)(meta & 0xffffu) + cl * WCH : 0;
+    vbits[i] = ok ? meta >> 16 : 0u;
+    goff[i] = __float_as_uint(mq.y);
+  }
+  // weight pieces: e = tid + 256 * i -> (row e / 9, piece e % 9)
+  unsigned aoff[NAL]; int alds[NAL];
+#pragma unroll
+  for (int i = 0; i < NAL; ++i) {
+    const int e = tid + 256 * i, row = e / 9, pc = e - row * 9;
+    aoff[i] = (row < BM && m0 + row < a.M) ? (unsigned)((m0 + row) * a.K + pc * 2) * 4u : OOB;
+    alds[i] = row < BM ? row * LDA + pc * 2 : BM * LDA;
+  }
+  // window elements: e = tid + 256 * i -> (row e / ww, column e % ww); outside the image: zero (buffer range check)
+  unsigned woff[NW]; int wlds[2][NW];
+  if (!FALLBACK) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tid + 256 * i;
+      const int r = ww > 0 ? e / ww : 0, j = e - r * ww;
+      const int gy = wy0 + r, gx = wx0 + j;
+      const bool in = e < wh * ww;
+      woff[i] = (in && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((unsigned)b * (unsigned)a.C * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOB;
+      wlds[0][i] = in ? r * WPITCH + j : 2 * WCH;
+      wlds[1][i] = in ? WCH + r * WPITCH + j : 2 * WCH;
+    }
+  }
+
+  float2 ra[NAL];
+  float rw[2][NW];
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int S = a.K / W2_BK;                               // slices (C is even: checked on the host)
+  const int s0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * S / a.splits)), s1 = __builtin_amdgcn_readfirstlane((int)((blockIdx.y + 1) * S / a.splits));
+
+  auto load_a = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < NAL; ++i) ra[i] = bload2(wr, aoff[i], s * (W2_BK * 4));
+  };
+  auto store_a = [&](int buf) {
+    float* A = As + buf * L::ABUF;
+#pragma unroll
+    for (int i = 0; i < NAL; ++i) { A[alds[i]] = ra[i].x; A[alds[i] + 1] = ra[i].y; }
+  };
+  auto load_w = [&](int s) {                               // windows of slice s (channels 2s, 2s + 1); past the end: nothing is fetched
+    if (FALLBACK) return;
+    const unsigned dead = s < s1 ? 0u : OOB;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+      for (int i = 0; i < NW; ++i) rw[cl][i] = bload(xr, woff[i] | dead, (2 * s + cl) * HW * 4);
+  };
+  auto store_w = [&](int buf) {
+    if (FALLBACK) return;
+    float* Wb = Win + buf * L::WBUF;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+      for (int i = 0; i < NW; ++i) Wb[wlds[cl][i]] = rw[cl][i];
+  };
+  auto sample = [&](int s, int buf) {                      // slice s -> Bs[buf] (rows wave + 4 i, pixel = lane)
+    float* Bq = Bs + buf * L::BBUF;
+    if (!FALLBACK) {
+      const float* Wb = Win + (s & 1) * L::WBUF;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const float* q = Wb + soff[i];
+        Bq[(wave + 4 * i) * 64 + lane] = (sw[i].x * q[0] + sw[i].y * q[1]) + (sw[i].z * q[WPITCH] + sw[i].w * q[WPITCH + 1]);
+      }
+    } else {
+      float g[5][4];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int r = wave + 4 * i;
+        const int so = __builtin_amdgcn_readfirstlane((2 * s + (r >= 9 ? 1 : 0)) * HW * 4);
+        g[i][0] = bload(xr, (vbits[i] & 1u) ? goff[i] : OOB, so);
+        g[i][1] = bload(xr, (vbits[i] & 2u) ? goff[i] + 4u : OOB, so);
+        g[i][2] = bload(xr, (vbits[i] & 4u) ? goff[i] + (unsigned)a.W * 4u : OOB, so);
+        g[i][3] = bload(xr, (vbits[i] & 8u) ? goff[i] + (unsigned)a.W * 4u + 4u : OOB, so);
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        Bq[(wave + 4 * i) * 64 + lane] = (sw[i].x * g[i][0] + sw[i].y * g[i][1]) + (sw[i].z * g[i][2] + sw[i].w * g[i][3]);
+    }
+  };
+  auto mma = [&](int buf) {
+    const float* A = As + buf * L::ABUF;
+    const float* Bq = Bs + buf * L::BBUF;
+#pragma unroll
+    for (int kk = 0; kk < W2_BK / 2; ++kk) {
+      float av[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = A[(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + kk * 2 + (lane >> 5)];
+      const float bv = Bq[(kk * 2 + (lane >> 5)) * 64 + wn * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+    }
+  };
+
+#ifdef PRN_DCN2_TIMING
+  long long ph[5] = {0, 0, 0, 0, 0};
+  const long long wall0 = (long long)wall_clock64();
+#endif
+  if (FALLBACK) {
+    if (s0 < s1) {
+      load_a(s0);
+      store_a(s0 & 1);
+      __syncthreads();
+      sample(s0, s0 & 1);
+      __syncthreads();
+      for (int s = s0; s + 1 < s1; ++s) {
+        load_a(s + 1);
+        sample(s + 1, (s + 1) & 1);
+        mma(s & 1);
+        store_a((s + 1) & 1);
+        __syncthreads();
+      }
+      mma((s1 - 1) & 1);
+    }
+  } else if (s0 < s1) {
+    // Windowed path.  A wave's staging work is issued INSIDE its own MFMA loop, one piece per k step (a v_mfma_f32_32x32x2_f32 holds the
+    // matrix pipe for 64 cycles, TM of them per k step: ~60 issue slots in their shadow) -- measured before: load issue 820 + sampling 1020 +
+    // LDS stores 390 + barrier 330 cycles per iteration NEXT TO 2620 of MFMA loop, the co-resident workgroup hiding only part of it.
+    // State at the top of iteration s: As[s & 1], Bs[s & 1] hold slice s; Win[(s + 1) & 1] the windows of slice s + 1; registers ra the
+    // weights of slice s + 1, rw the windows of slice s + 2 (both loaded a whole iteration ago).  Group kk of the iteration:
+    //   operands of k step kk + 1 -> registers; TM MFMAs of k step kk; weight piece kk: registers -> As[(s + 1) & 1], then its load for
+    //   slice s + 2 into the same registers; even kk: one sampled element of slice s + 1 -> Bs[(s + 1) & 1]; kk = 1: windows -> Win[s & 1];
+    //   kk = 3: window loads of slice s + 3.
+    load_a(s0);
+    load_w(s0);
+    store_a(s0 & 1);
+    store_w(s0 & 1);
+    load_w(s0 + 1);
+    store_w((s0 + 1) & 1);
+    __syncthreads();
+    sample(s0, s0 & 1);
+    load_a(s0 + 1);
+    load_w(s0 + 2);
+    __syncthreads();
+    for (int s = s0; s + 1 < s1; ++s) {
+      D2_STAMP(c0);
+      const float* A = As + (s & 1) * L::ABUF;
+      const float* Bq = Bs + (s & 1) * L::BBUF;
+      float* An = As + ((s + 1) & 1) * L::ABUF;
+      float* Bn = Bs + ((s + 1) & 1) * L::BBUF;
+      const float* Wb = Win + ((s + 1) & 1) * L::WBUF;
+      float* Wn = Win + (s & 1) * L::WBUF;
+      const unsigned wdead = s + 3 < s1 ? 0u : OOB;
+      float av[2][TM], bv[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[0][i] = A[(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + (lane >> 5)];
+      bv[0] = Bq[(lane >> 5) * 64 + wn * 32 + (lane & 31)];
+#pragma unroll
+      for (int kk = 0; kk < W2_BK / 2; ++kk) {
+        if (kk + 1 < W2_BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[(kk + 1) & 1][i] = A[(wm * TM * 32 + i * 32 + (lane & 31)) * LDA + (kk + 1) * 2 + (lane >> 5)];
+          bv[(kk + 1) & 1] = Bq[((kk + 1) * 2 + (lane >> 5)) * 64 + wn * 32 + (lane & 31)];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1], acc[i], 0, 0, 0);
+        // weight pieces i with i % 9 == kk (NAL <= 9: one piece per group; TM < 4 leaves some groups without)
+#pragma unroll
+        for (int i = 0; i < NAL; ++i)
+          if (i == kk) {
+            An[alds[i]] = ra[i].x; An[alds[i] + 1] = ra[i].y;
+            ra[i] = bload2(wr, aoff[i], (s + 2) * (W2_BK * 4));
+          }
+        if ((kk & 1) == 0) {                                 // sampled element kk / 2 of slice s + 1
+          const int e = kk >> 1;
+          const float* q = Wb + soff[e];
+          Bn[(wave + 4 * e) * 64 + lane] = (sw[e].x * q[0] + sw[e].y * q[1]) + (sw[e].z * q[WPITCH] + sw[e].w * q[WPITCH + 1]);
+        }
+        if (kk == 1) {
+#pragma unroll
+          for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) Wn[wlds[cl][i]] = rw[cl][i];
+        }
+        if (kk == 3) {
+#pragma unroll
+          for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) rw[cl][i] = bload(xr, woff[i] | wdead, (2 * (s + 3) + cl) * HW * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      D2_STAMP(c4);
+      __syncthreads();
+#ifdef PRN_DCN2_TIMING
+      D2_STAMP(c5);
+      ph[2] += c4 - c0; ph[4] += c5 - c4;
+#endif
+    }
+    mma((s1 - 1) & 1);
+  }
+#ifdef PRN_DCN2_TIMING
+  {
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (tid == 0 && wg < 4096) {
+      long long* o = prn_dcn2_dbg + wg * 10;
+      for (int i = 0; i < 5; ++i) o[i] = ph[i];
+      o[5] = s1 - s0 - 1; o[6] = wall0; o[7] = (long long)wall_clock64(); o[8] = NWL; o[9] = wh * 1000 + ww;
+    }
+  }
+#endif
+
+  // epilogue (C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+  const int p = wn * 32 + (lane & 31);
+  if (a.splits > 1) {                                      // partials [split][patch][M][64]
+    float* outp = a.ws + ((size_t)blockIdx.y * a.ptiles + ptile) * (size_t)a.M * 64 + p;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m < a.M) outp[(size_t)m * 64] = acc[i][r];
+      }
+    }
+  } else {
+    const int trem = ptile - b * tpp, ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
+    const int py = p / a.PW, px = p - py * a.PW;
+    const int ho = ty * a.PH + py, wo = tx * a.PW + px;
+    if (py < a.PH && ho < a.Ho && wo < a.Wo) {
+      float* outp = a.y + (size_t)b * a.M * a.Ho * a.Wo + (size_t)ho * a.Wo + wo;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m >= a.M) continue;
+          float v = acc[i][r];
+          if (a.bias) v += a.bias[m];
+          if (a.epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+          outp[(size_t)m * a.Ho * a.Wo] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TM>
+__global__ __launch_bounds__(256, (TM == 4 ? 2 : 3)) void dcnv2_fwd2_kernel(Fwd2Args a) {
+  using L = Fwd2Lds<TM>;
+  __shared__ float As[2 * L::ABUF];
+  __shared__ float Bs[2 * L::BBUF];
+  __shared__ float Win[2 * L::WBUF];
+  const int id = prn_xcd_remap(blockIdx.x, a.nblocks);
+  const int mt = id % a.tilesM, ptile = id / a.tilesM;
+  const float4* tp = a.tab + (size_t)ptile * TILE2_F4;
+  const float4 h0 = tp[0], h1 = tp[1];
+  const int wy0 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.x)), wx0 = __builtin_amdgcn_readfirstlane(__float_as_int(h0.y));
+  const int wh = __builtin_amdgcn_readfirstlane(__float_as_int(h0.z)), ww = __builtin_amdgcn_readfirstlane(__float_as_int(h0.w));
+  const int fallback = __builtin_amdgcn_readfirstlane(__float_as_int(h1.x));
+  // zero windows once: what a slice's loads do not cover (dead entries point at offset 0) must read as finite zeros in every slice
+  for (int i = threadIdx.x; i < 2 * L::WBUF; i += 256) Win[i] = 0.f;
+  __syncthreads();
+  if (fallback) dcnv2_fwd2_body<TM, 0>(a, As, Bs, Win, wy0, wx0, wh, ww, ptile, mt);
+  else if (wh * ww <= 256) dcnv2_fwd2_body<TM, 1>(a, As, Bs, Win, wy0, wx0, wh, ww, ptile, mt);
+  else if (wh * ww <= 512) dcnv2_fwd2_body<TM, 2>(a, As, Bs, Win, wy0, wx0, wh, ww, ptile, mt);
+  else dcnv2_fwd2_body<TM, 5>(a, As, Bs, Win, wy0, wx0, wh, ww, ptile, mt);
+}
+
+// y = epi(bias + sum over splits of the patch-major partials [split][patch][M][64])
+__global__ __launch_bounds__(256) void dcnv2_patch_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ y, int B, int M,
+                                                                 int Ho, int Wo, int PH, int PW, int tilesY, int tilesX, int splits, int epi) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * M * Ho * Wo;
+  if (i >= total) return;
+  int wo, ho; int64_t bm;
+  prn_idx3(i, Wo, Ho, wo, ho, bm);
+  const int m = (int)(bm % M), b = (int)(bm / M);
+  const int ty = ho / PH, py = ho - ty * PH, tx = wo / PW, px = wo - tx * PW;
+  const int64_t ptiles = (int64_t)B * tilesY * tilesX, ptile = ((int64_t)b * tilesY + ty) * tilesX + tx;
+  const float* q = ws + (ptile * M + m) * 64 + py * PW + px;
+  float v = 0.f;
+  for (int s = 0; s < splits; ++s) v += q[(size_t)s * ptiles * M * 64];
+  if (bias) v += bias[m];
+  if (epi == PRN_EPI_RELU) v = fmaxf(v, 0.f);
+  y[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int check_dcn(const prn_dcn_desc* d, const char* who) {
   PRN_REQUIRE(d != nullptr, "%s: null descriptor", who);
@@ -451,6 +894,48 @@ FPlan plan_dcn_fwd(int M, int N, int K) {
   return p;
 }
 
+// windowed forward: patch shape (fewest patches; the window of a patch must leave room for the offsets inside WROWS x WPITCH), tile height, K splits
+struct F2Plan { int on, tm, tilesM, splits, PH, PW, tilesY, tilesX, ptiles; };
+int dcn_v2_enabled() {
+  static int v = -1;                                     // PRN_DCN_V2=0: the gather kernels (A/B runs)
+  if (v < 0) { const char* e = getenv("PRN_DCN_V2"); v = e ? atoi(e) : 1; }
+  return v;
+}
+F2Plan plan_dcn_fwd2(const prn_dcn_desc* d) {
+  F2Plan p;
+  p.on = dcn_v2_enabled() && (d->C % 2 == 0);            // (a K slice is two whole channels; an odd channel count keeps the gather kernel)
+  const int cand[4][2] = {{8, 8}, {4, 16}, {16, 4}, {6, 10}};
+  int best = -1;
+  p.PH = 8; p.PW = 8;
+  for (int q = 0; q < 4; ++q) {
+    const int ph = cand[q][0], pw = cand[q][1];
+    if ((ph - 1) * d->stride + 3 + 4 > WROWS || (pw - 1) * d->stride + 3 + 4 > WPITCH) continue;      // room for +-2 pixels of offset
+    const int n = cdiv(d->Ho, ph) * cdiv(d->Wo, pw);
+    if (best < 0 || n < best) { best = n; p.PH = ph; p.PW = pw; }
+  }
+  p.tilesY = cdiv(d->Ho, p.PH); p.tilesX = cdiv(d->Wo, p.PW); p.ptiles = d->B * p.tilesY * p.tilesX;
+  p.tm = d->M > 128 ? 4 : (d->M > 64 ? 2 : 1);
+  p.tilesM = cdiv(d->M, 64 * p.tm);
+  static int forced[2] = {-1, 0};                        // PRN_DCN_FWD2="tm,splits" (tuning sweeps)
+  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_FWD2")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  if (forced[0] > 0) { p.tm = forced[0]; p.tilesM = cdiv(d->M, 64 * p.tm); }
+  const int S = d->C / 2, res = p.tm == 4 ? 2 : 3;
+  const int64_t tiles = (int64_t)p.ptiles * p.tilesM;
+  double bs = -1.0;
+  p.splits = 1;
+  for (int s = 1; s <= 8; ++s) {
+    if (s > 1 && S / s < 8) break;
+    const double waves = (double)(tiles * s) / (256.0 * res);
+    double eff = waves / (double)((int64_t)(waves + 0.999999));
+    if (waves < 1.0) eff = waves;
+    const double score = eff * (1.0 - 0.03 * (s - 1));
+    if (score > bs + 1e-9) { bs = score; p.splits = s; }
+  }
+  if (forced[0] > 0 && forced[1] > 0) p.splits = forced[1] < S ? forced[1] : S;
+  return p;
+}
+inline int64_t table1_bytes(const prn_dcn_desc* d) { return ((int64_t)npad(d) * 9 * 32 + 255) & ~255LL; }
+
 struct WPlan { int tm, tilesM, tilesJ, splits, chunks; };
 WPlan plan_dcn_wgrad(const prn_gemm_opts& o, int M, int K, int N) {
   static int forced[2] = {-1, 0};                        // PRN_DCN_WGRAD="tm,splits"
@@ -478,7 +963,8 @@ WPlan plan_dcn_wgrad(const prn_gemm_opts& o, int M, int K, int N) {
 
 extern "C" int64_t prn_dcnv2_table_bytes(const prn_dcn_desc* d) {
   if (check_dcn(d, "prn_dcnv2_table_bytes")) return -1;
-  return (int64_t)npad(d) * 9 * 32;
+  const F2Plan p2 = plan_dcn_fwd2(d);                      // [ per-pixel gather table (weight gradient) | per-patch window table (forward) ]
+  return table1_bytes(d) + (p2.on ? (int64_t)p2.ptiles * TILE2_F4 * 16 : 0);
 }
 
 extern "C" int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const float* mask, void* table, void* stream) {
@@ -493,11 +979,23 @@ extern "C" int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const
   a.N = d->B * d->Ho * d->Wo; a.Npad = npad(d);
   hipLaunchKernelGGL(dcnv2_table_kernel, dim3(cdiv((int64_t)a.Npad * 9, 256)), dim3(256), 0, (hipStream_t)stream, a);
   PRN_CHECK_LAUNCH("prn_dcnv2_table");
+  const F2Plan p2 = plan_dcn_fwd2(d);
+  if (p2.on) {
+    Tab2Args t;
+    t.off = offset; t.msk = a.msk; t.tab = (float4*)((char*)table + table1_bytes(d));
+    t.B = d->B; t.C = d->C; t.H = d->H; t.W = d->W; t.Ho = d->Ho; t.Wo = d->Wo; t.stride = d->stride; t.pad = d->pad; t.raw = d->raw;
+    t.off_bs = a.off_bs; t.msk_bs = a.msk_bs; t.maxoff = d->max_offset;
+    t.PH = p2.PH; t.PW = p2.PW; t.tilesY = p2.tilesY; t.tilesX = p2.tilesX;
+    hipLaunchKernelGGL(dcnv2_table2_kernel, dim3(p2.ptiles), dim3(256), 0, (hipStream_t)stream, t);
+    PRN_CHECK_LAUNCH("prn_dcnv2_table/windows");
+  }
   return 0;
 }
 
 extern "C" int64_t prn_dcnv2_fwd_ws_bytes(const prn_dcn_desc* d) {
   if (check_dcn(d, "prn_dcnv2_fwd_ws_bytes")) return -1;
+  const F2Plan p2 = plan_dcn_fwd2(d);
+  if (p2.on) return p2.splits > 1 ? (int64_t)p2.splits * p2.ptiles * 64 * d->M * 4 : 0;
   const FPlan p = plan_dcn_fwd(d->M, d->B * d->Ho * d->Wo, d->C * 9);
   return p.splits > 1 ? (int64_t)p.splits * d->B * d->M * d->Ho * d->Wo * 4 : 0;
 }
@@ -511,6 +1009,32 @@ extern "C" int prn_dcnv2_fwd_phase(const prn_dcn_desc* d, const float* x, const 
   a.B = d->B; a.C = d->C; a.HW = d->H * d->W; a.M = d->M; a.K = d->C * 9; a.HoWo = d->Ho * d->Wo; a.N = d->B * a.HoWo;
   a.epi = d->epilogue;
   a.xbytes = d->B * d->C * a.HW * 4; a.wbytes = d->M * a.K * 4;
+  const F2Plan p2 = plan_dcn_fwd2(d);
+  if (p2.on) {
+    Fwd2Args f;
+    f.x = x; f.w = w; f.bias = bias; f.tab = (const float4*)((const char*)table + table1_bytes(d)); f.y = y; f.ws = (float*)ws;
+    f.B = d->B; f.C = d->C; f.H = d->H; f.W = d->W; f.M = d->M; f.K = d->C * 9; f.Ho = d->Ho; f.Wo = d->Wo;
+    f.PH = p2.PH; f.PW = p2.PW; f.tilesY = p2.tilesY; f.tilesX = p2.tilesX; f.tilesM = p2.tilesM; f.ptiles = p2.ptiles;
+    f.nblocks = p2.ptiles * p2.tilesM; f.splits = p2.splits; f.epi = d->epilogue;
+    f.xbytes = a.xbytes; f.wbytes = a.wbytes;
+    PRN_REQUIRE(p2.splits == 1 || ws != nullptr, "prn_dcnv2_fwd: workspace required (%d K splits, see prn_dcnv2_fwd_ws_bytes)", p2.splits);
+    PRN_REQUIRE((reinterpret_cast<uintptr_t>(w) & 7) == 0, "prn_dcnv2_fwd: w must be 8-byte aligned");
+    hipStream_t st2 = (hipStream_t)stream;
+    if (phase != 2) {
+      const dim3 grid(f.nblocks, p2.splits), block(256);
+      if (p2.tm == 4) hipLaunchKernelGGL((dcnv2_fwd2_kernel<4>), grid, block, 0, st2, f);
+      else if (p2.tm == 2) hipLaunchKernelGGL((dcnv2_fwd2_kernel<2>), grid, block, 0, st2, f);
+      else hipLaunchKernelGGL((dcnv2_fwd2_kernel<1>), grid, block, 0, st2, f);
+      PRN_CHECK_LAUNCH("prn_dcnv2_fwd/windowed");
+    }
+    if (phase != 1 && p2.splits > 1) {
+      const int64_t total = (int64_t)d->B * d->M * d->Ho * d->Wo;
+      hipLaunchKernelGGL(dcnv2_patch_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st2, (const float*)ws, bias, y, d->B, d->M, d->Ho, d->Wo, p2.PH, p2.PW,
+                         p2.tilesY, p2.tilesX, p2.splits, d->epilogue);
+      PRN_CHECK_LAUNCH("prn_dcnv2_fwd/patch reduce");
+    }
+    return 0;
+  }
   const FPlan p = plan_dcn_fwd(a.M, a.N, a.K);
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_dcnv2_fwd: workspace required (%d K splits, see prn_dcnv2_fwd_ws_bytes)", p.splits);
   a.tilesM = cdiv(a.M, 64 * p.tm); a.nblocks = a.tilesM * cdiv(a.N, 64); a.splits = p.splits;
@@ -572,3 +1096,9 @@ extern "C" int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x,
 extern "C" int prn_dcnv2_bwd_weight(const prn_dcn_desc* d, const float* x, const void* table, const float* dy, float* dw, void* ws, void* stream) {
   return prn_dcnv2_bwd_weight_phase(d, x, table, dy, dw, ws, stream, 0);
 }
+
+#ifdef PRN_DCN2_TIMING
+extern "C" int prn_debug_dcn2_timing(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(prn_dcn2_dbg), sizeof(long long) * (size_t)(n < 4096 * 10 ? n : 4096 * 10)) == hipSuccess ? 0 : 1;
+}
+#endif
