@@ -621,6 +621,7 @@ struct WgArgs {
   int xz;                    // element stride of x per blockIdx.z (prn_gemm_batched_nt; 0 for a convolution)
   int nzg;                   // grid depth: phases / batched products / layers of a group (the third grid dimension, folded into the 1-D grid)
   int ngroup;                // > 0: blockIdx.z = layer of a group of same-shape layers (prn_conv2d_wgrad_grouped): x / dy from the tables below
+  int ilv;                   // interleaved reduction loop (conv_igemm_kernel has the description)
   const float* gx[PRN_WGRAD_GROUP_MAX];
   const float* gdy[PRN_WGRAD_GROUP_MAX];
   Seg seg;
@@ -785,6 +786,69 @@ __global__ __launch_bounds__(256, (RAG && TM * TJ == 4) ? 3 : 1) void conv_wgrad
       }
     };
     if (cbeg >= cend) return;
+    if (N4 && !RAG && a.ilv && cend - cbeg >= 2) {
+      // Interleaved schedule (see conv_igemm_kernel): a piece of the next chunk's operands (a dY float4 group, a gathered im2col element) is
+      // stored to LDS and re-loaded for the chunk after it in the shadow of each k step's MFMAs; operands are read one k step ahead.
+      constexpr int NP = TM + NBJ;
+      load_chunk(cbeg);
+      store_chunk(0);
+      load_chunk(cbeg + 1);
+      __syncthreads();
+      for (int ch = cbeg; ch + 1 < cend; ++ch) {
+        const int buf = (ch - cbeg) & 1, nbuf = buf ^ 1;
+        // cursors stand at chunk ch + 2
+        const bool aok = (ch + 2) * 16 + anq < N_;
+        const unsigned abase2 = (unsigned)((a_b * a.M + m0 + arow) * HoWo_ + a_p) * 4u;
+        const bool bok = (ch + 2) * 16 + nl < N_;
+        const int ih0 = g_oh * a.stride - pad_y, iw0 = g_ow * a.stride - pad_x;
+        const int pix0 = g_b * a.C * HW_;
+        float av[2][TM], bv[2][TJ];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[0][i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bv[0][j] = Bs[buf][(wj * TJ * 32 + j * 32 + (lane & 31)) * LD + (lane >> 5)];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          if (kk + 1 < 8) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[(kk + 1) & 1][i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + (kk + 1) * 2 + (lane >> 5)];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bv[(kk + 1) & 1][j] = Bs[buf][(wj * TJ * 32 + j * 32 + (lane & 31)) * LD + (kk + 1) * 2 + (lane >> 5)];
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if ((p * 8) / NP == kk) {
+              if (p < TM) {
+                const int i = p < TM ? p : 0;
+                if (BM >= 64 || arow < BM) {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) As[nbuf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
+                }
+                const float4 v = bload4(dyr, (aok && mok[i]) ? abase2 : OOB, i * 64 * HoWo_ * 4);
+                ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+              } else {
+                const int i = p >= TM ? p - TM : 0;
+                Bs[nbuf][(jrow + 16 * i) * LD + nl] = rb[i];
+                const int off = tap_offset<MODE>(ih0 + jr[i], iw0 + js[i], bok && jok[i], H_, W_);
+                rb[i] = bload(xr, off >= 0 ? (unsigned)(pix0 + jcoff[i] + off) * 4u : OOB, 0);
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        a_p += 16;
+        while (a_p >= HoWo_) { a_p -= HoWo_; ++a_b; }
+        g_ow += 16;
+        while (g_ow >= Wo_) { g_ow -= Wo_; ++g_oh; }
+        while (g_oh >= Ho_) { g_oh -= Ho_; ++g_b; }
+        __syncthreads();
+      }
+      mma_chunk((cend - 1 - cbeg) & 1);
+      return;
+    }
     load_chunk(cbeg);
     store_chunk(0);
     __syncthreads();
@@ -1263,6 +1327,12 @@ bool wide_store_ok(const ConvArgs& a, const FwdPlan& p) {
 // in isolation (62 -> 57 us on 1x1 1024->256 @30x40, 118 -> 108 us on 2304->256), but the training step does not move
 // (54.8-54.9 ms either way, four alternating runs): inside a step the 7 us sum kernels already ran in the shadow of the
 // weight-gradient stream, and the fold lengthens conv_igemm_kernel itself (roofline.frac 0.54 -> 0.53).
+int conv_ilv() {
+  static int ilv = -1;                                     // PRN_CONV_ILV=0: the phase-separated K loops (A/B runs)
+  if (ilv < 0) { const char* e = getenv("PRN_CONV_ILV"); ilv = e ? atoi(e) : 3; }
+  return ilv;
+}
+
 bool fused_reduce_ok(const ConvArgs& a, const FwdPlan& p, int phases, int tail_pieces, const unsigned* counters) {
   if (counters == nullptr) return false;
   const char* e = getenv("PRN_CONV_FUSED_REDUCE");
@@ -1280,11 +1350,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
   a.nblocks = a.tilesM * cdiv(a.N, 32 * p.wn * p.tn);
   a.splits = p.splits;
   a.wide_store = wide_store_ok(a, p);
-  {
-    static int ilv = -1;                                   // PRN_CONV_ILV=0: the phase-separated K loop (A/B runs)
-    if (ilv < 0) { const char* e = getenv("PRN_CONV_ILV"); ilv = e ? atoi(e) : 1; }
-    a.ilv = ilv;
-  }
+  a.ilv = conv_ilv() & 1;                                  // PRN_CONV_ILV: bit 0 = forward / input-gradient kernel, bit 1 = weight-gradient kernel
   a.tail_first = a.nblocks; a.tail_splits = 0;
   int gx = a.nblocks;
   if (tail_pieces > 1 && phases == 1 && a.seg.nseg == 0 && a.ystride == 1) {
@@ -1394,6 +1460,7 @@ WgPlan plan_wgrad(const prn_gemm_opts& o, int M, int K, int64_t N, int phases = 
 template <int KS, int MODE>
 int launch_wgrad(WgArgs a, const WgPlan& p, hipStream_t st, int phases = 1) {
   a.nzg = phases;
+  a.ilv = conv_ilv() & 2 ? 1 : 0;
   dim3 grid((unsigned)(p.tilesM * p.tilesJ * p.splits * phases)), block(256);
   if constexpr ((KS == 1 || KS == 3) && MODE == PRN_IN_ZERO) {
     if (a.seg.nseg > 0) {                                  // plan_wgrad(..., ragged) only hands out these two tiles
