@@ -601,7 +601,7 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
     splits = (int)(640 / (tiles > 0 ? tiles : 1));
     if (splits > kslices / 8) splits = kslices / 8;
     static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 4.  Training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; 3 and 4 are within the
-    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 4; }     // noise of a box; with 3 the all-f16 parity run tips a degenerate ReLU set
+    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 4; }     // noise of a box -- a performance choice only (the fixture's ReLU-boundary channel that 3 splits once tipped is bounded separately by the parity test since round 5)
     if (splits > smax) splits = smax;
     if (splits < 1) splits = 1;
   }

@@ -99,6 +99,14 @@ def oracle64(net101, golden_dir):
 # (the 1x1 layers of stage 3 in 3 instead of 4 K splits, or the bf16 cut) moves the set across together.  The fp64 oracle and the reference's
 # fp32 run sit on one side; an arithmetic is judged by whether it stays there, which the shipped plan, its B = 8 proxy and all-f16 do.
 _REPORT_ONLY = {("all-bf16", False), ("all-bf16", True)}
+# Round 5: that event is a property of the FIXTURE, not of an arithmetic, and it must not gate one -- the windowed DCNv2 forward (another K-split
+# count and slice order, i.e. another rounding of the same sums) tipped it in the default / direct-kernel run, as the K-split cap had before
+# (advisor, round 4: "make the parity check robust to this degenerate channel instead of tuning the plan to it").  The three gradient tensors
+# that own channel 202 of inst_head.kernel_tower.0 (its 3x3 weight rows and its GroupNorm scale / shift) are therefore checked in two parts: every
+# OTHER channel under the calibrated bound of the parameter, like all 450 remaining tensors; channel 202 itself under the size of the event
+# (measured 3.3e-3 .. 4.8e-3 of the tensor's norm when the set crosses, ~1e-5 when it does not).  Whether it crossed is printed.
+RELU_BOUNDARY_CHANNEL = {"inst_head.kernel_tower.0.weight": 202, "inst_head.kernel_tower.1.weight": 202, "inst_head.kernel_tower.1.bias": 202}
+RELU_BOUNDARY_EVENT = 1.5e-2
 
 
 @pytest.mark.parametrize("winograd", [False, True])
@@ -160,6 +168,14 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
             assert got.norm().item() <= 1e-4 * g64[wn].norm().item() + 1e-6, (n, got.norm().item())
             continue
         l2 = ((got - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()
+        l2_event = None
+        if n in RELU_BOUNDARY_CHANNEL:                              # (see RELU_BOUNDARY_CHANNEL: the rest of the tensor gates as usual)
+            ch = RELU_BOUNDARY_CHANNEL[n]
+            d = got - g64[n]
+            l2_event = (d[ch].norm() / (g64[n].norm() + 1e-30)).item()
+            d = d.clone()
+            d[ch] = 0
+            l2 = (d.norm() / (g64[n].norm() + 1e-30)).item()
         # K = 2 is what the fp32-MFMA direct-kernel build achieves (and the default plan at this batch, where few launches leave it); every
         # configuration that runs the B = 8 plan's launches on the 16-bit pipe is held to the shipping build's bound (K = 2.5, floor 1e-3)
         bound = (GRAD_K_WINOGRAD * spread[n] + GRAD_FLOOR_WINOGRAD) if (winograd or gemm_arith in ("b8-plan", "all-f16", "all-bf16")) else (GRAD_K * spread[n] + GRAD_FLOOR)
@@ -189,9 +205,18 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
         worst.append((l2 / bound, n, l2, spread[n]))
         if l2 > bound:
             bad.append((n, l2, bound))
+        if l2_event is not None:
+            print("ReLU-boundary channel %d of %s: error %.2e of the tensor's norm (%s; the other channels: %.2e, bound %.2e)"
+                  % (RELU_BOUNDARY_CHANNEL[n], n, l2_event, "the near-zero set CROSSED" if l2_event > bound else "same side as the oracle", l2, bound))
+            if l2_event > RELU_BOUNDARY_EVENT:
+                bad.append((n + " (ReLU-boundary channel)", l2_event, RELU_BOUNDARY_EVENT))
         # and against the REFERENCE's own fp32 gradient at the fixture's 64 sample positions (rel-L2 over the samples)
         ref = refdig[n][4:]
         smp = digest_samples(got, 64)[4:]
+        if n in RELU_BOUNDARY_CHANNEL:                              # samples inside the boundary channel are not part of this comparison
+            idx = torch.randint(0, got.numel(), (64,), generator=torch.Generator().manual_seed(123))
+            keep = ((idx // (got.numel() // got.shape[0])) != RELU_BOUNDARY_CHANNEL[n]).numpy()
+            ref, smp = ref[keep], smp[keep]
         d2 = float(np.linalg.norm(smp - ref) / (np.linalg.norm(ref) + 1e-30))
         worst_ref.append((d2 / bound, n, d2))
         if d2 > 2.0 * bound:
