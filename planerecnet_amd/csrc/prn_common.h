@@ -96,6 +96,9 @@ int64_t prn_split_gemm_partial_bytes(int M, int B, int HW, int nz, int splits);
 // w_images: the caller's current images of w, or NULL: w is cut into `images_ws` (prn_split_gemm_image_bytes) by this call.
 int prn_split_gemm(const float* w, const void* w_images, const float* x, const float* bias, const float* addend, float* y, void* images_ws, float* partial, int M,
                    int K, int B, int HW, int nz, int64_t zw, int64_t zx, int64_t zy, int epi, int splits, const prn_gemm_opts* opts, hipStream_t st, int phase);
+// the same kernel with a zero-padded KH x KW gather as activation operand (tap-major weight images cut per call; fp16 pieces, C % 32 == 0)
+int prn_split_conv_taps(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images_ws, float* partial, int M, int C, int B, int XH,
+                        int XW, int Ho, int Wo, int KH, int KW, int stride, int pad, int epi, int splits, const prn_gemm_opts* o, hipStream_t st, int phase);
 // weight-gradient plan knobs of a call (NULL opts: zeros)
 static inline prn_gemm_opts prn_opts_or_zero(const prn_gemm_opts* o) {
   prn_gemm_opts z;

@@ -1543,6 +1543,17 @@ int wgrad16_plan_of(const prn_conv_desc* d, int G) {
   if (!(d->KH == 1 && d->in_mode == PRN_IN_ZERO && d->stride == 1 && d->pad == 0 && d->ystride <= 1 && d->Ho == d->H && d->Wo == d->W)) return 0;
   return prn_wgrad16_plan(d->M, d->C, (int64_t)d->B * d->H * d->W, d->H * d->W, G, &d->opts);
 }
+// 4x4 / stride-2 zero-padded convolutions (the input gradient of the sub-pixel upsample-convolutions) on the 16-bit pipe by tap gather
+// (prn_split_conv_taps): K splits, 0 = keep the fp32 implicit GEMM
+int taps_plan_of(const prn_conv_desc* d) {
+  static int on = -1;                                      // PRN_SPLIT_TAPS=0: off (A/B)
+  if (on < 0) { const char* e = getenv("PRN_SPLIT_TAPS"); on = e ? atoi(e) : 1; }
+  if (!on || !(d->KH == 4 && d->in_mode == PRN_IN_ZERO && d->stride == 2 && d->ystride <= 1 && (d->C & 31) == 0 && d->opts.split_kind == PRN_PIECES_F16)) return 0;
+  return prn_split_gemm_plan(d->M, d->C * 16, d->B, d->Ho * d->Wo, 1, &d->opts);
+}
+int64_t taps_ws_bytes(const prn_conv_desc* d, int splits) {
+  return ((prn_split_gemm_image_bytes(d->M, d->C * 16, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->Ho * d->Wo, 1, splits);
+}
 int64_t split_ws_bytes(const prn_conv_desc* d, int splits) {
   return ((prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->H * d->W, 1, splits);
 }
@@ -1566,6 +1577,7 @@ extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_fwd_ws_bytes")) return -1;
   if (direct_small_m(d) || direct_one_c(d)) return 0;
   if (const int ss = split_plan_of(d)) return split_ws_bytes(d, ss);
+  if (const int st = taps_plan_of(d)) return taps_ws_bytes(d, st);
   const Geo g = geo_of(d);
   const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
                              wide_ks(d->KH, d->in_mode));
@@ -1618,7 +1630,8 @@ int conv_wgrad_impl(const prn_conv_desc* d, const prn_ragged* rg, const float* x
 extern "C" int prn_conv2d_kernel_kind(const prn_conv_desc* d) {
   if (check_desc(d, "prn_conv2d_kernel_kind")) return -1;
   if (direct_small_m(d) || direct_one_c(d)) return 1;
-  const int ss = split_plan_of(d);
+  int ss = split_plan_of(d);
+  if (ss == 0) ss = taps_plan_of(d);
   return ss == 0 ? 0 : (ss == 1 ? 2 : 3);
 }
 
@@ -1670,6 +1683,11 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
       const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL;
       return prn_split_gemm(w, w_images, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H * d->W, 1, 0, 0, 0, d->epilogue, ss, &d->opts,
                             (hipStream_t)stream, phase);
+    }
+    if (const int st = taps_plan_of(d)) {
+      const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C * 16, 1) + 255) & ~255LL;
+      return prn_split_conv_taps(w, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H, d->W, d->Ho, d->Wo, 4, 4, d->stride, d->pad, d->epilogue,
+                                 st, &d->opts, (hipStream_t)stream, phase);
     }
   }
   ConvArgs a;

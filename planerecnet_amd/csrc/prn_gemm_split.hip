@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256) void split16_rowmax_kernel(const float* __rest
   if (lane == 0) ex[row] = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) : 0;
 }
 
+// taps > 1: the images' K axis is TAP-major (k' = t * C + c for the weight w[m][c][t], C = K / taps) -- the order in which the tap-gather kernel walks
+// a KH x KW convolution's operand: a 32-deep slice then lies inside one tap and is loaded like a 1x1 layer's, at that tap's pixel shift
 __global__ void split16_prepare_kernel(const float* __restrict__ w, uint4* __restrict__ img, const int* __restrict__ ex, int M, int K, long long zw, int mtiles, int kslices,
-                                       long long total) {
+                                       long long total, int taps = 1) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per (z, m tile, k slice, k group, row)
   if (i >= total) return;
   const int g = i % 4; const int r = (i / 4) % 128; const long long t = i / 512;      // k group fastest: four lanes read 128 contiguous bytes of one weight row
@@ -244,8 +246,13 @@ __global__ void split16_prepare_kernel(const float* __restrict__ w, uint4* __res
   const int m = mt * 128 + r, k0 = ks * 32 + g * 8;
   const int sh = 14 - ex[z * (mtiles * 128) + m];
   float v[8];
+  const int C = K / taps;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (m < M && k0 + j < K) ? ldexpf(w[z * zw + (long long)m * K + k0 + j], sh) : 0.f;
+  for (int j = 0; j < 8; ++j) {
+    const int kp = k0 + j;                                       // position on the images' K axis
+    const int ksrc = taps > 1 ? (kp % C) * taps + kp / C : kp;
+    v[j] = (m < M && kp < K) ? ldexpf(w[z * zw + (long long)m * K + ksrc], sh) : 0.f;
+  }
   uint4 h, l;
   split2_f16(v[0], v[1], h.x, l.x); split2_f16(v[2], v[3], h.y, l.y); split2_f16(v[4], v[5], h.z, l.z); split2_f16(v[6], v[7], h.w, l.w);
   uint4* o = img + t * IMG16_U4;
@@ -286,9 +293,12 @@ struct Split16Args {
   int wide;                       // epilogue through the LDS transpose (float4 stores): HW % 4 == 0 and 16-byte aligned output / addend / partial planes
   int store_policy;
   long long zx, zy, slice;
+  // TAPS (a KH x KW convolution with zero padding as a GEMM over the tap-major K axis of its images): x is [B][C][XH][XW], the GEMM's HW pixels are
+  // the Ho x Wo outputs, K = KH * KW * C with C % 32 == 0 -- slice ks is channels (32 ks) % C .. + 31 of tap (32 ks) / C
+  int C, XH, XW, Wo, KW, stride, pad;
 };
 
-template <int NP>      // 3: l*h, h*l, h*h   4: + l*l
+template <int NP, bool TAPS = false>      // NP 3: l*h, h*l, h*h   4: + l*l;  TAPS: the activation operand is a zero-padded KH x KW gather (see Split16Args)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void split16_gemm_kernel(const Split16Args a) {
   __shared__ uint4 lds[2 * IMG16_U4];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -308,12 +318,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #endif
   const int px = pt * 128 + wave * 32 + r;
   const int pxc = px < HW ? px : HW - 1;
-  const float* xb = a.x + (long long)z * a.zx + (long long)b * a.K * HW;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.K * HW * 4, 0x00020000);
+  const int XHW = TAPS ? a.XH * a.XW : HW;                         // elements of one activation channel plane
+  const int XK = TAPS ? a.C : a.K;                                 // channel planes of one image
+  const float* xb = a.x + (long long)z * a.zx + (long long)b * XK * XHW;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, XK * XHW * 4, 0x00020000);
   const int xoff = (pxc + gs * 8 * HW) * 4;
   int choff[16];                                                   // scalar byte offsets of a lane's 16 channels within a slice, clamped to the buffer: the range check
 #pragma unroll                                                     // subtracts the scalar offset from the size, which must not wrap (K < 32)
-  for (int j = 0; j < 16; ++j) choff[j] = __builtin_amdgcn_readfirstlane(min(((j >> 3) * 16 + (j & 7)) * HW * 4, a.K * HW * 4));
+  for (int j = 0; j < 16; ++j) choff[j] = __builtin_amdgcn_readfirstlane(min(((j >> 3) * 16 + (j & 7)) * XHW * 4, XK * XHW * 4));
+  // TAPS: top-left input position of this lane's output pixel; a slice's byte offset is that of its tap (or the out-of-range marker: zero padding)
+  const int t_oi = TAPS ? pxc / a.Wo : 0, t_oj = TAPS ? pxc - t_oi * a.Wo : 0;
+  const int t_iy0 = t_oi * a.stride - a.pad, t_ix0 = t_oj * a.stride - a.pad;
+  auto tap_vo = [&](int ks_) -> int {
+    const int k0 = ks_ * BK, tp = __builtin_amdgcn_readfirstlane(k0 / a.C), c0 = __builtin_amdgcn_readfirstlane(k0 - tp * a.C);
+    const int ty = __builtin_amdgcn_readfirstlane(tp / a.KW), tx = __builtin_amdgcn_readfirstlane(tp - ty * a.KW);
+    const int iy = t_iy0 + ty, ix = t_ix0 + tx;
+    const bool ok = (unsigned)iy < (unsigned)a.XH && (unsigned)ix < (unsigned)a.XW && k0 < a.K;
+    return ok ? (iy * a.XW + ix + (c0 + gs * 8) * XHW) * 4 : (int)0x80000000u;
+  };
   const uint4* ag = a.img + ((long long)(z * a.mtiles + mt) * a.kslices) * IMG16_U4;
   const i32x4_t adesc = make_desc(ag, (unsigned)a.kslices * IMG16_U4 * 16u);
   const unsigned lds0 = (unsigned)(unsigned long long)(void*)lds;
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       lds_dma16(lds0 + (unsigned)(st_) * (IMG16_U4 * 16) + (unsigned)(i * 4 + wave) * 1024u, adesc, (unsigned)lane * 16u, ((ks_) * IMG16_U4 + (i * 4 + wave) * 64) * 16); \
   } while (0)
 #define S16_LOADB(ks_) do { \
-    const int vo = xoff + (ks_) * (BK * 4) * HW;                   /* one vector add per slice; the 16 channel offsets are scalars */ \
+    const int vo = TAPS ? tap_vo(ks_) : xoff + (ks_) * (BK * 4) * HW;   /* one vector add per slice; the 16 channel offsets are scalars */ \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) \
         rn[s2 * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, choff[s2 * 8 + j], 0)); \
@@ -636,14 +658,14 @@ extern "C" int prn_split_prepare_batched(const void* items_dev, int n_items, int
 }
 namespace {
 // cuts w[nz][M][K] (z stride zw) into `images` in the given piece format
-int cut_weight(const float* w, void* images, int M, int K, int nz, long long zw, int kind, hipStream_t st, const char* who) {
+int cut_weight(const float* w, void* images, int M, int K, int nz, long long zw, int kind, hipStream_t st, const char* who, int taps = 1) {
   const int mtiles = cdiv(M, 128), kslices = cdiv(K, 32);
   const long long ptotal = (long long)nz * mtiles * kslices * 512;
   if (kind == PRN_PIECES_F16) {
     int* ex = (int*)((char*)images + (int64_t)nz * mtiles * kslices * IMG16_U4 * 16);
     const long long rows = (long long)nz * mtiles * 128;
     hipLaunchKernelGGL(split16_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, ex, M, K, zw, mtiles * 128, rows);
-    hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, zw, mtiles, kslices, ptotal);
+    hipLaunchKernelGGL(split16_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, (const int*)ex, M, K, zw, mtiles, kslices, ptotal, taps);
   } else {
     hipLaunchKernelGGL(split_prepare_kernel, dim3(cdiv(ptotal, 256)), dim3(256), 0, st, w, (uint4*)images, M, K, zw, mtiles, kslices, ptotal);
   }
@@ -693,6 +715,7 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
       a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
       a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
       a.total = mtiles * ptiles * B * nz; a.splits = splits; a.zx = zx; a.zy = zy; a.slice = (long long)nz * B * M * HW;
+      a.C = K; a.XH = 1; a.XW = HW; a.Wo = HW; a.KW = 1; a.stride = 1; a.pad = 0;
       {
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         static int wide_on = -1;                                 // PRN_SPLIT_WIDE_STORE=0: the per-element epilogue (A/B)
@@ -718,5 +741,37 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
     PRN_REQUIRE(nz == 1 || (zy == (int64_t)B * M * HW), "prn_split_gemm: K splits need a dense output");
     return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)nz * B * M * HW, M, HW, splits, epi, st);
   }
+  return 0;
+}
+
+// A zero-padded KH x KW convolution y[b][m][oh][ow] = sum_{c,r,s} w[m][c][r][s] x[b][c][oh * stride - pad + r][ow * stride - pad + s] on the 16-bit pipe
+// (fp16 pieces only): the GEMM of prn_split_gemm over a TAP-major K axis (C % 32 == 0: every 32-deep slice is 32 channels of one tap, fetched like a
+// 1x1 layer's slice at that tap's pixel shift, out-of-image positions through the descriptor's range check).  The weight is cut per call into
+// images_ws (prn_split_gemm_image_bytes(M, KH * KW * C, 1)); partial: prn_split_gemm_partial_bytes(M, B, Ho * Wo, 1, splits).
+// Used for the 4x4 / stride-2 input gradient of the depth decoder's sub-pixel upsample-convolutions (planerecnet.py:540-566).
+int prn_split_conv_taps(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images_ws, float* partial, int M, int C, int B, int XH,
+                        int XW, int Ho, int Wo, int KH, int KW, int stride, int pad, int epi, int splits, const prn_gemm_opts* o, hipStream_t st, int phase) {
+  PRN_REQUIRE(o != nullptr && w && x && y && images_ws && (splits == 1 || partial), "prn_split_conv_taps: null operand");
+  PRN_REQUIRE(o->split_kind == PRN_PIECES_F16 && (C & 31) == 0 && KH > 0 && KW > 0, "prn_split_conv_taps: fp16 pieces and C %% 32 == 0 only");
+  const int K = KH * KW * C, HW = Ho * Wo;
+  const int mtiles = cdiv(M, 128), kslices = K / 32, ptiles = cdiv(HW, 128);
+  PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)C * XH * XW < (1LL << 29) && (int64_t)M * HW < (1LL << 29),
+              "prn_split_conv_taps: operand larger than a buffer descriptor");
+  if (phase != 2) {
+    if (int e = cut_weight(w, images_ws, M, K, 1, (long long)M * K, PRN_PIECES_F16, st, "prn_split_conv_taps/prepare", KH * KW)) return e;
+    Split16Args a;
+    a.img = (const uint4*)images_ws; a.ex = (const int*)((const char*)images_ws + (int64_t)mtiles * kslices * IMG16_U4 * 16);
+    a.x = x; a.bias = bias; a.addend = addend; a.y = y; a.partial = partial;
+    a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
+    a.total = mtiles * ptiles * B; a.splits = splits; a.zx = 0; a.zy = 0; a.slice = (long long)B * M * HW;
+    a.C = C; a.XH = XH; a.XW = XW; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    a.wide = (HW & 3) == 0 && ((int64_t)M * HW & 3) == 0 && al16(y) && al16(addend) && al16(partial);
+    a.store_policy = 1;
+    if (o->split_products >= 4) hipLaunchKernelGGL((split16_gemm_kernel<4, true>), dim3(a.total, splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((split16_gemm_kernel<3, true>), dim3(a.total, splits), dim3(256), 0, st, a);
+    PRN_CHECK_LAUNCH("prn_split_conv_taps");
+  }
+  if (splits > 1 && phase != 1) return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)B * M * HW, M, HW, splits, epi, st);
   return 0;
 }

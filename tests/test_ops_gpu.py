@@ -115,6 +115,32 @@ def test_up2_subpixel_form_matches_gather_form():
         close(a, r.double().cpu(), "up2 subpixel vs gather " + name, rtol=2e-5)
 
 
+@pytest.mark.parametrize("C,M,H,W,pad", [(64, 160, 22, 30, 3), (32, 96, 17, 12, 1), (96, 130, 10, 16, 2)])
+def test_conv4x4_stride2_on_the_16bit_pipe_is_the_fp32_conv(C, M, H, W, pad):
+    """The 4x4 / stride-2 zero-padded convolution (input gradient of the sub-pixel upsample-convolutions, ops._ConvUp2.backward) with the split kernel's
+    tap gather (csrc/prn_gemm_split.hip: TAPS, tap-major weight images): forced onto the 16-bit pipe (mode 2) it must agree with the fp64 convolution as
+    closely as the fp32 MFMA kernel does, tails in M, in the pixel tiles and at every image border included."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, C, H, W, seed=1)
+    w = rnd(M, C, 4, 4, seed=2, scale=(16 * C) ** -0.5)
+    Ho, Wo = (H + 2 * pad - 4) // 2 + 1, (W + 2 * pad - 4) // 2 + 1
+    ref = F.conv2d(x, w, None, stride=2, padding=pad)
+    got = {}
+    old = ops.set_split_gemm(mode=0)
+    try:
+        for mode in (0, 2):
+            ops.set_split_gemm(mode=mode)
+            got[mode] = ops.conv_fwd_raw(x.float().to(d), w.float().to(d), None, None, M, 4, 2, pad, Ho, Wo)
+    finally:
+        ops.set_split_gemm(**old)
+    e0 = (got[0].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    e2 = (got[2].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert not torch.equal(got[0], got[2]), "mode 2 did not reach the 16-bit-pipe kernel"
+    assert e2 <= max(2.0 * e0, 2e-6), (e0, e2)
+    close(got[2], ref, "conv 4x4 s2 on the 16-bit pipe", rtol=2e-5)
+
+
 @pytest.mark.parametrize("relu", [False, True])
 def test_conv_up2_inference_equals_upsample_pad_conv(relu):
     """The no-autograd sub-pixel form with bias + ReLU epilogue (eval-mode decoder blocks with folded BatchNorm) against

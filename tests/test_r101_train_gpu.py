@@ -105,7 +105,10 @@ _REPORT_ONLY = {("all-bf16", False), ("all-bf16", True)}
 # that own channel 202 of inst_head.kernel_tower.0 (its 3x3 weight rows and its GroupNorm scale / shift) are therefore checked in two parts: every
 # OTHER channel under the calibrated bound of the parameter, like all 450 remaining tensors; channel 202 itself under the size of the event
 # (measured 3.3e-3 .. 4.8e-3 of the tensor's norm when the set crosses, ~1e-5 when it does not).  Whether it crossed is printed.
-RELU_BOUNDARY_CHANNEL = {"inst_head.kernel_tower.0.weight": 202, "inst_head.kernel_tower.1.weight": 202, "inst_head.kernel_tower.1.bias": 202}
+# (The convolution's weight gradient sees the event in the whole GroupNorm group of the channel -- 32 groups of 8: channels 200 .. 207 -- because the
+# group's backward couples its channels; the GroupNorm shift / scale gradients see it in channel 202 alone: measured 4.6e-3 in channel 202 and 1.4e-3
+# in the other rows of the weight gradient with the group in, 3.5e-5 in the other channels of the shift gradient.)
+RELU_BOUNDARY_CHANNEL = {"inst_head.kernel_tower.0.weight": list(range(200, 208)), "inst_head.kernel_tower.1.weight": [202], "inst_head.kernel_tower.1.bias": [202]}
 RELU_BOUNDARY_EVENT = 1.5e-2
 
 
@@ -206,7 +209,7 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
         if l2 > bound:
             bad.append((n, l2, bound))
         if l2_event is not None:
-            print("ReLU-boundary channel %d of %s: error %.2e of the tensor's norm (%s; the other channels: %.2e, bound %.2e)"
+            print("ReLU-boundary channel(s) %s of %s: error %.2e of the tensor's norm (%s; the other channels: %.2e, bound %.2e)"
                   % (RELU_BOUNDARY_CHANNEL[n], n, l2_event, "the near-zero set CROSSED" if l2_event > bound else "same side as the oracle", l2, bound))
             if l2_event > RELU_BOUNDARY_EVENT:
                 bad.append((n + " (ReLU-boundary channel)", l2_event, RELU_BOUNDARY_EVENT))
@@ -215,7 +218,7 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
         smp = digest_samples(got, 64)[4:]
         if n in RELU_BOUNDARY_CHANNEL:                              # samples inside the boundary channel are not part of this comparison
             idx = torch.randint(0, got.numel(), (64,), generator=torch.Generator().manual_seed(123))
-            keep = ((idx // (got.numel() // got.shape[0])) != RELU_BOUNDARY_CHANNEL[n]).numpy()
+            keep = ~np.isin((idx // (got.numel() // got.shape[0])).numpy(), RELU_BOUNDARY_CHANNEL[n])
             ref, smp = ref[keep], smp[keep]
         d2 = float(np.linalg.norm(smp - ref) / (np.linalg.norm(ref) + 1e-30))
         worst_ref.append((d2 / bound, n, d2))
