@@ -99,6 +99,9 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
 // the same kernel with a zero-padded KH x KW gather as activation operand (tap-major weight images cut per call; fp16 pieces, C % 32 == 0)
 int prn_split_conv_taps(const float* w, const float* x, const float* bias, const float* addend, float* y, void* images_ws, float* partial, int M, int C, int B, int XH,
                         int XW, int Ho, int Wo, int KH, int KW, int stride, int pad, int epi, int splits, const prn_gemm_opts* o, hipStream_t st, int phase);
+// ... and with the four sub-pixel phases of PRN_IN_UP2_PHASE as its z axis (wp [4][M][C][2][2] -> y [B][M][2H][2W]; no K split)
+int prn_split_conv_up2(const float* wp, const float* x, const float* bias, float* y, void* images_ws, int M, int C, int B, int H, int W, int epi, const prn_gemm_opts* o,
+                       hipStream_t st);
 // weight-gradient plan knobs of a call (NULL opts: zeros)
 static inline prn_gemm_opts prn_opts_or_zero(const prn_gemm_opts* o) {
   prn_gemm_opts z;

@@ -1551,6 +1551,13 @@ int taps_plan_of(const prn_conv_desc* d) {
   if (!on || !(d->KH == 4 && d->in_mode == PRN_IN_ZERO && d->stride == 2 && d->ystride <= 1 && (d->C & 31) == 0 && d->opts.split_kind == PRN_PIECES_F16)) return 0;
   return prn_split_gemm_plan(d->M, d->C * 16, d->B, d->Ho * d->Wo, 1, &d->opts);
 }
+// the sub-pixel phases themselves (forward of the upsample-convolutions): 1 = on the 16-bit pipe (four phases as the z axis of one launch), 0 = fp32
+int up2_plan_of(const prn_conv_desc* d) {
+  static int on = -1;                                      // PRN_SPLIT_UP2=0: off (A/B)
+  if (on < 0) { const char* e = getenv("PRN_SPLIT_UP2"); on = e ? atoi(e) : 1; }
+  if (!on || !(d->KH == 2 && d->in_mode == PRN_IN_UP2_PHASE && (d->C & 31) == 0 && (d->W & 3) == 0 && d->opts.split_kind == PRN_PIECES_F16 && d->ystride <= 1)) return 0;
+  return prn_split_gemm_plan(d->M, d->C * 4, d->B, d->H * d->W, 4, &d->opts) == 1 ? 1 : 0;
+}
 int64_t taps_ws_bytes(const prn_conv_desc* d, int splits) {
   return ((prn_split_gemm_image_bytes(d->M, d->C * 16, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->Ho * d->Wo, 1, splits);
 }
@@ -1578,6 +1585,7 @@ extern "C" int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d) {
   if (direct_small_m(d) || direct_one_c(d)) return 0;
   if (const int ss = split_plan_of(d)) return split_ws_bytes(d, ss);
   if (const int st = taps_plan_of(d)) return taps_ws_bytes(d, st);
+  if (up2_plan_of(d)) return (prn_split_gemm_image_bytes(d->M, d->C * 4, 4) + 255) & ~255LL;
   const Geo g = geo_of(d);
   const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
                              wide_ks(d->KH, d->in_mode));
@@ -1632,6 +1640,7 @@ extern "C" int prn_conv2d_kernel_kind(const prn_conv_desc* d) {
   if (direct_small_m(d) || direct_one_c(d)) return 1;
   int ss = split_plan_of(d);
   if (ss == 0) ss = taps_plan_of(d);
+  if (ss == 0) ss = up2_plan_of(d);
   return ss == 0 ? 0 : (ss == 1 ? 2 : 3);
 }
 
@@ -1683,6 +1692,10 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
       const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL;
       return prn_split_gemm(w, w_images, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H * d->W, 1, 0, 0, 0, d->epilogue, ss, &d->opts,
                             (hipStream_t)stream, phase);
+    }
+    if (up2_plan_of(d) && addend == nullptr && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+      if (phase == 2) return 0;
+      return prn_split_conv_up2(w, x, bias, y, ws, d->M, d->C, d->B, d->H, d->W, d->epilogue, &d->opts, (hipStream_t)stream);
     }
     if (const int st = taps_plan_of(d)) {
       const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C * 16, 1) + 255) & ~255LL;

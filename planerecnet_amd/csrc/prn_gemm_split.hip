@@ -296,9 +296,12 @@ struct Split16Args {
   // TAPS (a KH x KW convolution with zero padding as a GEMM over the tap-major K axis of its images): x is [B][C][XH][XW], the GEMM's HW pixels are
   // the Ho x Wo outputs, K = KH * KW * C with C % 32 == 0 -- slice ks is channels (32 ks) % C .. + 31 of tap (32 ks) / C
   int C, XH, XW, Wo, KW, stride, pad;
+  // TAPS = 2 (PRN_IN_UP2_PHASE): z = output phase (py, px) with its own [M x 4C] images; the GEMM's pixels are the SOURCE grid, tap (ty, tx) of
+  // pixel (i, j) reads source (i + py - 1 + ty, j + px - 1 + tx) clamped to the map (replicate border), the result is stored at (2i + py, 2j + px) of a
+  // [B][M][2 XH][2 XW] tensor; no K split, no addend
 };
 
-template <int NP, bool TAPS = false>      // NP 3: l*h, h*l, h*h   4: + l*l;  TAPS: the activation operand is a zero-padded KH x KW gather (see Split16Args)
+template <int NP, int TAPS = 0>      // NP 3: l*h, h*l, h*h   4: + l*l;  TAPS 1: the activation operand is a zero-padded KH x KW gather, 2: a sub-pixel phase (see Split16Args)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void split16_gemm_kernel(const Split16Args a) {
   __shared__ uint4 lds[2 * IMG16_U4];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -332,8 +335,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   auto tap_vo = [&](int ks_) -> int {
     const int k0 = ks_ * BK, tp = __builtin_amdgcn_readfirstlane(k0 / a.C), c0 = __builtin_amdgcn_readfirstlane(k0 - tp * a.C);
     const int ty = __builtin_amdgcn_readfirstlane(tp / a.KW), tx = __builtin_amdgcn_readfirstlane(tp - ty * a.KW);
-    const int iy = t_iy0 + ty, ix = t_ix0 + tx;
-    const bool ok = (unsigned)iy < (unsigned)a.XH && (unsigned)ix < (unsigned)a.XW && k0 < a.K;
+    int iy = t_iy0 + ty, ix = t_ix0 + tx;
+    bool ok = (unsigned)iy < (unsigned)a.XH && (unsigned)ix < (unsigned)a.XW && k0 < a.K;
+    if (TAPS == 2) {
+      iy = min(max(t_oi + (z >> 1) - 1 + ty, 0), a.XH - 1); ix = min(max(t_oj + (z & 1) - 1 + tx, 0), a.XW - 1);
+      ok = k0 < a.K;
+    }
     return ok ? (iy * a.XW + ix + (c0 + gs * 8) * XHW) * 4 : (int)0x80000000u;
   };
   const uint4* ag = a.img + ((long long)(z * a.mtiles + mt) * a.kslices) * IMG16_U4;
@@ -475,6 +482,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float4 v = *reinterpret_cast<const float4*>(&cw[rl * 36 + ccol]);
         if (!pok || row >= M) continue;
         const long long idx = (long long)row * HW + px4;
+        if (TAPS == 2) {                                             // phase-interleaved store: four source pixels of one row -> every second output pixel
+          if (a.bias) { const float bm = a.bias[row]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+          if (a.epi == PRN_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          const int oi4 = px4 / a.Wo, oj4 = px4 - oi4 * a.Wo;
+          float* yp = a.y + (((long long)b * M + row) * (2 * a.XH) + 2 * oi4 + (z >> 1)) * (2 * a.XW) + 2 * oj4 + (z & 1);
+          yp[0] = v.x; yp[2] = v.y; yp[4] = v.z; yp[6] = v.w;
+          continue;
+        }
         if (fin) {
           if (a.bias) { const float bm = a.bias[row]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
           if (ab) { const float4 t4 = *reinterpret_cast<const float4*>(ab + idx); v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w; }
@@ -768,10 +783,33 @@ int prn_split_conv_taps(const float* w, const float* x, const float* bias, const
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     a.wide = (HW & 3) == 0 && ((int64_t)M * HW & 3) == 0 && al16(y) && al16(addend) && al16(partial);
     a.store_policy = 1;
-    if (o->split_products >= 4) hipLaunchKernelGGL((split16_gemm_kernel<4, true>), dim3(a.total, splits), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((split16_gemm_kernel<3, true>), dim3(a.total, splits), dim3(256), 0, st, a);
+    if (o->split_products >= 4) hipLaunchKernelGGL((split16_gemm_kernel<4, 1>), dim3(a.total, splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((split16_gemm_kernel<3, 1>), dim3(a.total, splits), dim3(256), 0, st, a);
     PRN_CHECK_LAUNCH("prn_split_conv_taps");
   }
   if (splits > 1 && phase != 1) return prn_launch_reduce_epilogue(partial, bias, addend, y, (int64_t)B * M * HW, M, HW, splits, epi, st);
+  return 0;
+}
+
+// Upsample(x2, nearest) -> ReflectionPad2d(1) -> Conv3x3 in its sub-pixel form (PRN_IN_UP2_PHASE: wp [4][M][C][2][2], y [B][M][2H][2W]) on the 16-bit pipe:
+// the four phases are the z axis of ONE launch (tap-major images per phase, cut per call into images_ws: prn_split_gemm_image_bytes(M, 4 C, 4)).
+int prn_split_conv_up2(const float* wp, const float* x, const float* bias, float* y, void* images_ws, int M, int C, int B, int H, int W, int epi, const prn_gemm_opts* o,
+                       hipStream_t st) {
+  PRN_REQUIRE(o != nullptr && wp && x && y && images_ws, "prn_split_conv_up2: null operand");
+  PRN_REQUIRE(o->split_kind == PRN_PIECES_F16 && (C & 31) == 0 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "prn_split_conv_up2: fp16 pieces, C %% 32 == 0, W %% 4 == 0");
+  const int K = 4 * C, HW = H * W;
+  const int mtiles = cdiv(M, 128), kslices = K / 32, ptiles = cdiv(HW, 128);
+  PRN_REQUIRE((int64_t)kslices * IMG_U4 * 16 < (1LL << 31) && (int64_t)C * HW < (1LL << 29) && (int64_t)B * M * HW * 4 < (1LL << 31), "prn_split_conv_up2: operand too large");
+  if (int e = cut_weight(wp, images_ws, M, K, 4, (long long)M * K, PRN_PIECES_F16, st, "prn_split_conv_up2/prepare", 4)) return e;
+  Split16Args a;
+  a.img = (const uint4*)images_ws; a.ex = (const int*)((const char*)images_ws + (int64_t)4 * mtiles * kslices * IMG16_U4 * 16);
+  a.x = x; a.bias = bias; a.addend = nullptr; a.y = y; a.partial = nullptr;
+  a.M = M; a.K = K; a.B = B; a.HW = HW; a.epi = epi; a.mtiles = mtiles; a.kslices = kslices; a.ptiles = ptiles;
+  a.total = mtiles * ptiles * B * 4; a.splits = 1; a.zx = 0; a.zy = 0; a.slice = 0;
+  a.C = C; a.XH = H; a.XW = W; a.Wo = W; a.KW = 2; a.stride = 1; a.pad = 0;
+  a.wide = 1; a.store_policy = 1;
+  if (o->split_products >= 4) hipLaunchKernelGGL((split16_gemm_kernel<4, 2>), dim3(a.total, 1), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((split16_gemm_kernel<3, 2>), dim3(a.total, 1), dim3(256), 0, st, a);
+  PRN_CHECK_LAUNCH("prn_split_conv_up2");
   return 0;
 }

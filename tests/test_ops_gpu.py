@@ -115,6 +115,38 @@ def test_up2_subpixel_form_matches_gather_form():
         close(a, r.double().cpu(), "up2 subpixel vs gather " + name, rtol=2e-5)
 
 
+@pytest.mark.parametrize("C,M,H,W", [(64, 128, 13, 16), (32, 96, 9, 20)])
+def test_up2_subpixel_phases_on_the_16bit_pipe(C, M, H, W):
+    """Upsample(x2) -> ReflectionPad2d(1) -> Conv3x3 (+ bias) in its sub-pixel form with the four phases on the split kernel (csrc/prn_gemm_split.hip: TAPS = 2,
+    phase = z axis, replicate-border tap gather, phase-interleaved store) and its 4x4 / stride-2 input gradient (TAPS = 1): forced onto the 16-bit pipe, output and
+    input gradient must agree with the fp64 operator as closely as the fp32 kernels do."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(2, C, H, W, seed=1)
+    w = rnd(M, C, 3, 3, seed=2, scale=(9 * C) ** -0.5)
+    b = rnd(M, seed=3)
+    go = rnd(2, M, 2 * H, 2 * W, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(F.interpolate(xr, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), w, b)
+    (gr,) = torch.autograd.grad(yr, [xr], go)
+    res = {}
+    old = ops.set_split_gemm(mode=0)
+    try:
+        for mode in (0, 2):
+            ops.set_split_gemm(mode=mode)
+            xd = x.float().to(d).requires_grad_(True)
+            yd = ops.conv2d(xd, w.float().to(d), b.float().to(d), 1, 1, ops.IN_UP2_REFLECT)
+            (gd,) = torch.autograd.grad(yd, [xd], go.float().to(d))
+            res[mode] = (yd.detach(), gd)
+    finally:
+        ops.set_split_gemm(**old)
+    assert not torch.equal(res[0][0], res[2][0]) and not torch.equal(res[0][1], res[2][1]), "mode 2 did not reach the 16-bit-pipe kernels"
+    for k, (ref, what) in enumerate(((yr, "y"), (gr, "dx"))):
+        e0 = (res[0][k].double().cpu() - ref.detach()).abs().max().item() / ref.abs().max().item()
+        e2 = (res[2][k].double().cpu() - ref.detach()).abs().max().item() / ref.abs().max().item()
+        assert e2 <= max(2.0 * e0, 2e-6), (what, e0, e2)
+
+
 @pytest.mark.parametrize("C,M,H,W,pad", [(64, 160, 22, 30, 3), (32, 96, 17, 12, 1), (96, 130, 10, 16, 2)])
 def test_conv4x4_stride2_on_the_16bit_pipe_is_the_fp32_conv(C, M, H, W, pad):
     """The 4x4 / stride-2 zero-padded convolution (input gradient of the sub-pixel upsample-convolutions, ops._ConvUp2.backward) with the split kernel's
