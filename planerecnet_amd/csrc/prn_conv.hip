@@ -1548,8 +1548,10 @@ int wgrad16_plan_of(const prn_conv_desc* d, int G) {
 int taps_plan_of(const prn_conv_desc* d) {
   static int on = -1;                                      // PRN_SPLIT_TAPS=0: off (A/B)
   if (on < 0) { const char* e = getenv("PRN_SPLIT_TAPS"); on = e ? atoi(e) : 1; }
-  if (!on || !(d->KH == 4 && d->in_mode == PRN_IN_ZERO && d->stride == 2 && d->ystride <= 1 && (d->C & 31) == 0 && d->opts.split_kind == PRN_PIECES_F16)) return 0;
-  return prn_split_gemm_plan(d->M, d->C * 16, d->B, d->Ho * d->Wo, 1, &d->opts);
+  // (also the stride-2 1x1 downsample convolutions of the backbone's stage entries, models/backbone.py:45: one tap, every second pixel)
+  const bool shape = (d->KH == 4 && d->stride == 2) || (d->KH == 1 && d->stride == 2 && d->pad == 0);
+  if (!on || !(shape && d->in_mode == PRN_IN_ZERO && d->ystride <= 1 && (d->C & 31) == 0 && d->opts.split_kind == PRN_PIECES_F16)) return 0;
+  return prn_split_gemm_plan(d->M, d->C * d->KH * d->KW, d->B, d->Ho * d->Wo, 1, &d->opts);
 }
 // the sub-pixel phases themselves (forward of the upsample-convolutions): 1 = on the 16-bit pipe (four phases as the z axis of one launch), 0 = fp32
 int up2_plan_of(const prn_conv_desc* d) {
@@ -1559,7 +1561,7 @@ int up2_plan_of(const prn_conv_desc* d) {
   return prn_split_gemm_plan(d->M, d->C * 4, d->B, d->H * d->W, 4, &d->opts) == 1 ? 1 : 0;
 }
 int64_t taps_ws_bytes(const prn_conv_desc* d, int splits) {
-  return ((prn_split_gemm_image_bytes(d->M, d->C * 16, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->Ho * d->Wo, 1, splits);
+  return ((prn_split_gemm_image_bytes(d->M, d->C * d->KH * d->KW, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->Ho * d->Wo, 1, splits);
 }
 int64_t split_ws_bytes(const prn_conv_desc* d, int splits) {
   return ((prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL) + prn_split_gemm_partial_bytes(d->M, d->B, d->H * d->W, 1, splits);
@@ -1698,8 +1700,8 @@ int conv_fwd_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* x,
       return prn_split_conv_up2(w, x, bias, y, ws, d->M, d->C, d->B, d->H, d->W, d->epilogue, &d->opts, (hipStream_t)stream);
     }
     if (const int st = taps_plan_of(d)) {
-      const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C * 16, 1) + 255) & ~255LL;
-      return prn_split_conv_taps(w, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H, d->W, d->Ho, d->Wo, 4, 4, d->stride, d->pad, d->epilogue,
+      const int64_t ib = (prn_split_gemm_image_bytes(d->M, d->C * d->KH * d->KW, 1) + 255) & ~255LL;
+      return prn_split_conv_taps(w, x, bias, addend, y, ws, (float*)((char*)ws + ib), d->M, d->C, d->B, d->H, d->W, d->Ho, d->Wo, d->KH, d->KW, d->stride, d->pad, d->epilogue,
                                  st, &d->opts, (hipStream_t)stream, phase);
     }
   }

@@ -610,7 +610,7 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     if scatter2 is None:
         y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
         d_, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
-        wimg = split_images(w2d, M, C, 1, (B, Ho * Wo)) if (d_.kind >= 2 and K == 1) else None      # (4x4 / stride-2 tap gather: images cut per call, tap-major)
+        wimg = split_images(w2d, M, C, 1, (B, Ho * Wo)) if (d_.kind >= 2 and K == 1 and stride == 1) else None      # (tap gather -- 4x4 / stride 2, 1x1 / stride 2 --: images cut per call, tap-major)
     else:
         wimg = None
         y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)

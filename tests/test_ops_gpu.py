@@ -147,23 +147,23 @@ def test_up2_subpixel_phases_on_the_16bit_pipe(C, M, H, W):
         assert e2 <= max(2.0 * e0, 2e-6), (what, e0, e2)
 
 
-@pytest.mark.parametrize("C,M,H,W,pad", [(64, 160, 22, 30, 3), (32, 96, 17, 12, 1), (96, 130, 10, 16, 2)])
-def test_conv4x4_stride2_on_the_16bit_pipe_is_the_fp32_conv(C, M, H, W, pad):
+@pytest.mark.parametrize("C,M,H,W,pad,K", [(64, 160, 22, 30, 3, 4), (32, 96, 17, 12, 1, 4), (96, 130, 10, 16, 2, 4), (64, 160, 21, 30, 0, 1), (32, 72, 16, 16, 0, 1)])
+def test_conv4x4_stride2_on_the_16bit_pipe_is_the_fp32_conv(C, M, H, W, pad, K):
     """The 4x4 / stride-2 zero-padded convolution (input gradient of the sub-pixel upsample-convolutions, ops._ConvUp2.backward) with the split kernel's
     tap gather (csrc/prn_gemm_split.hip: TAPS, tap-major weight images): forced onto the 16-bit pipe (mode 2) it must agree with the fp64 convolution as
     closely as the fp32 MFMA kernel does, tails in M, in the pixel tiles and at every image border included."""
     from planerecnet_amd import ops
     d = dev()
     x = rnd(2, C, H, W, seed=1)
-    w = rnd(M, C, 4, 4, seed=2, scale=(16 * C) ** -0.5)
-    Ho, Wo = (H + 2 * pad - 4) // 2 + 1, (W + 2 * pad - 4) // 2 + 1
+    w = rnd(M, C, K, K, seed=2, scale=(K * K * C) ** -0.5)             # (K = 1: the stride-2 downsample convolutions, one tap)
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
     ref = F.conv2d(x, w, None, stride=2, padding=pad)
     got = {}
     old = ops.set_split_gemm(mode=0)
     try:
         for mode in (0, 2):
             ops.set_split_gemm(mode=mode)
-            got[mode] = ops.conv_fwd_raw(x.float().to(d), w.float().to(d), None, None, M, 4, 2, pad, Ho, Wo)
+            got[mode] = ops.conv_fwd_raw(x.float().to(d), w.float().to(d), None, None, M, K, 2, pad, Ho, Wo)
     finally:
         ops.set_split_gemm(**old)
     e0 = (got[0].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
