@@ -130,6 +130,8 @@ def pmc_traffic(kernel):
     fam = fams.get(kernel)
     if fam is None and kernel == "split_gemm_kernel":           # (the profiler family of both piece formats; the fp16 one's kernel is split16_gemm_kernel)
         fam = fams.get("split16_gemm_kernel")
+    if fam is None and kernel == "dcnv2_fwd_kernel":            # (round 5: the windowed forward is dcnv2_fwd2_kernel; the PMC summary keys it by the common prefix)
+        fam = fams.get("dcnv2_fwd")
     if fam is not None and "hbm_bytes_per_launch" not in fam:
         fam = None
     return None if fam is None else {"bytes_per_launch": fam["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}

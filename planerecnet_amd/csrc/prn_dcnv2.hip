@@ -55,8 +55,8 @@ struct TabArgs {
   int N, Npad;
 };
 
-__global__ __launch_bounds__(256) void dcnv2_table_kernel(TabArgs a) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void dcnv2_table_body(const TabArgs& a, int block) {
+  const int gid = block * 256 + threadIdx.x;
   if (gid >= a.Npad * 9) return;
   const int p = gid & 15, t = (gid >> 4) % 9, chunk = gid / 144;
   const int n = chunk * 16 + p;
@@ -434,9 +434,9 @@ struct Tab2Args {
   int PH, PW, tilesY, tilesX;
 };
 
-__global__ __launch_bounds__(256) void dcnv2_table2_kernel(Tab2Args a) {
+__device__ __forceinline__ void dcnv2_table2_body(const Tab2Args& a, int tile) {
   __shared__ int wbb[4][4];
-  const int tid = threadIdx.x, tile = blockIdx.x;
+  const int tid = threadIdx.x;
   const int tx = tile % a.tilesX, ty = (tile / a.tilesX) % a.tilesY, b = tile / (a.tilesX * a.tilesY);
   int bb[4] = {0x7fffffff, -0x7fffffff, 0x7fffffff, -0x7fffffff};      // this thread's y0 min, y0 + 1 max, x0 min, x0 + 1 max
   const int plane = a.Ho * a.Wo;
@@ -506,6 +506,13 @@ __global__ __launch_bounds__(256) void dcnv2_table2_kernel(Tab2Args a) {
     tp[2 + e] = make_float4(__uint_as_float(meta), __uint_as_float(goff), 0.f, 0.f);
     tp[2 + 576 + e] = wv[i];
   }
+}
+
+__global__ __launch_bounds__(256) void dcnv2_table_kernel(TabArgs a) { dcnv2_table_body(a, blockIdx.x); }
+// both tables of a call in ONE launch: blocks [0, n1) the per-pixel gather table, the rest one patch each of the window table
+__global__ __launch_bounds__(256) void dcnv2_tables_kernel(TabArgs a, Tab2Args t, int n1) {
+  if ((int)blockIdx.x < n1) dcnv2_table_body(a, blockIdx.x);
+  else dcnv2_table2_body(t, (int)blockIdx.x - n1);
 }
 
 struct Fwd2Args {
@@ -977,17 +984,19 @@ extern "C" int prn_dcnv2_table(const prn_dcn_desc* d, const float* offset, const
   a.off_bs = (d->raw ? 27 : 18) * plane; a.msk_bs = 9 * plane;
   a.maxoff = d->max_offset;
   a.N = d->B * d->Ho * d->Wo; a.Npad = npad(d);
-  hipLaunchKernelGGL(dcnv2_table_kernel, dim3(cdiv((int64_t)a.Npad * 9, 256)), dim3(256), 0, (hipStream_t)stream, a);
-  PRN_CHECK_LAUNCH("prn_dcnv2_table");
   const F2Plan p2 = plan_dcn_fwd2(d);
-  if (p2.on) {
+  if (!p2.on) {
+    hipLaunchKernelGGL(dcnv2_table_kernel, dim3(cdiv((int64_t)a.Npad * 9, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    PRN_CHECK_LAUNCH("prn_dcnv2_table");
+  } else {
     Tab2Args t;
     t.off = offset; t.msk = a.msk; t.tab = (float4*)((char*)table + table1_bytes(d));
     t.B = d->B; t.C = d->C; t.H = d->H; t.W = d->W; t.Ho = d->Ho; t.Wo = d->Wo; t.stride = d->stride; t.pad = d->pad; t.raw = d->raw;
     t.off_bs = a.off_bs; t.msk_bs = a.msk_bs; t.maxoff = d->max_offset;
     t.PH = p2.PH; t.PW = p2.PW; t.tilesY = p2.tilesY; t.tilesX = p2.tilesX;
-    hipLaunchKernelGGL(dcnv2_table2_kernel, dim3(p2.ptiles), dim3(256), 0, (hipStream_t)stream, t);
-    PRN_CHECK_LAUNCH("prn_dcnv2_table/windows");
+    const int n1 = cdiv((int64_t)a.Npad * 9, 256);
+    hipLaunchKernelGGL(dcnv2_tables_kernel, dim3(n1 + p2.ptiles), dim3(256), 0, (hipStream_t)stream, a, t, n1);
+    PRN_CHECK_LAUNCH("prn_dcnv2_table");
   }
   return 0;
 }

@@ -15,7 +15,7 @@ cnt = collections.Counter()
 for r in csv.DictReader(open(f[0])):
     k = r['Kernel_Name']
     fam = None
-    for key in ("wgrad16_kernel", "split16_gemm_kernel", "split_gemm_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel"):
+    for key in ("wgrad16_kernel", "split16_gemm_kernel", "split_gemm_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd", "dcnv2_wgrad_kernel"):
         if key in k:
             fam = key
     if fam is None:

@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r['Counter_Name'] != c: continue
         k = r['Kernel_Name']
         fam = None
-        for key in ("dcnv2_fwd_kernel", "dcnv2_wgrad_kernel", "dcnv2_table_kernel", "mask_loss_partial", "mask_loss_bwd", "vnl_triplet_kernel", "vnl_scatter_kernel", "wgrad16_kernel", "split16_gemm_kernel", "split16_prepare_batched_kernel", "split16_rowmax_batched_kernel", "split_gemm_kernel", "split_prepare_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "reduce_epilogue_kernel", "reduce_splits_kernel", "bn_small_fwd_kernel", "bn_small_bwd_kernel", "bn_partial_kernel", "bn_apply_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "dcn_dom_partial_kernel", "dcn_dx_gather_kernel", "dcn_csr_fill_kernel", "dcn_csr_count_kernel", "dcn_sample_kernel", "gn_relu_fwd", "gn_relu_bwd", "resize_fwd", "resize_bwd", "flip_transpose_batched", "space_to_depth2", "replicate_fold", "winograd_input_kernel", "winograd_output_kernel", "winograd_dy_kernel", "winograd_dw_kernel", "winograd_weights_kernel"):
+        for key in ("dcnv2_fwd", "dcnv2_wgrad_kernel", "dcnv2_table", "dcnv2_patch_reduce", "mask_loss_partial", "mask_loss_bwd", "vnl_triplet_kernel", "vnl_scatter_kernel", "wgrad16_kernel", "split16_gemm_kernel", "split16_prepare_batched_kernel", "split16_rowmax_batched_kernel", "split_gemm_kernel", "split_prepare_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "reduce_epilogue_kernel", "reduce_splits_kernel", "bn_small_fwd_kernel", "bn_small_bwd_kernel", "bn_partial_kernel", "bn_apply_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "dcn_dom_partial_kernel", "dcn_dx_gather_kernel", "dcn_csr_fill_kernel", "dcn_csr_count_kernel", "dcn_sample_kernel", "gn_relu_fwd", "gn_relu_bwd", "resize_fwd", "resize_bwd", "flip_transpose_batched", "space_to_depth2", "replicate_fold", "winograd_input_kernel", "winograd_output_kernel", "winograd_dy_kernel", "winograd_dw_kernel", "winograd_weights_kernel"):
             if key in k: fam = key; break
         if fam: acc[fam].append(float(r['Counter_Value']))
     out[c] = {k: {"launches": len(v), "sum_kb": sum(v), "avg_kb": sum(v)/len(v)} for k, v in acc.items()}

@@ -28,7 +28,7 @@ for mode in ("serial", "default"):
     for r in rows:
         nm = r["Name"]
         key = "ATen / rocprim / copies"
-        for k in ("wgrad16_kernel", "split16_gemm_kernel", "split_gemm_kernel", "split16_", "split_prepare", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel", "dcnv2_table", "dcn_", "winograd_", "bn_", "gn_relu", "reduce_splits", "reduce_epilogue", "resize_", "mask_loss", "maxpool", "channel_sum", "flip_transpose", "pad_fold", "replicate_fold", "space_to_depth", "up2_", "conv3x3_"):
+        for k in ("wgrad16_kernel", "split16_gemm_kernel", "split_gemm_kernel", "split16_", "split_prepare", "conv_igemm_kernel", "conv_wgrad_kernel", "dcnv2_fwd", "dcnv2_wgrad_kernel", "dcnv2_table", "dcnv2_patch_reduce", "dcn_", "winograd_", "bn_", "gn_relu", "reduce_splits", "reduce_epilogue", "resize_", "mask_loss", "maxpool", "channel_sum", "flip_transpose", "pad_fold", "replicate_fold", "space_to_depth", "up2_", "conv3x3_"):
             if k in nm and "at::" not in nm:
                 key = k
                 break
