@@ -935,10 +935,13 @@ F2Plan plan_dcn_fwd2(const prn_dcn_desc* d) {
     const double waves = (double)(tiles * s) / (256.0 * res);
     double eff = waves / (double)((int64_t)(waves + 0.999999));
     if (waves < 1.0) eff = waves;
-    const double score = eff * (1.0 - 0.03 * (s - 1));
+    const double score = eff * (1.0 - 0.08 * (s - 1));      // (a split costs a prologue, a partial tile and its share of the reduction: sweep in profiles/r05_*_dcn_fwd2_sweep.txt)
     if (score > bs + 1e-9) { bs = score; p.splits = s; }
   }
   if (forced[0] > 0 && forced[1] > 0) p.splits = forced[1] < S ? forced[1] : S;
+  // patches that do not tile the map well leave lanes idle through the whole K loop (15 x 20 outputs: six 8 x 8 patches = 384 lanes for 300 pixels;
+  // the gather kernel's linear 64-pixel tiles waste 1 %): such a layer keeps the gather kernel
+  if ((int64_t)p.ptiles * 64 * 8 > (int64_t)d->B * d->Ho * d->Wo * 9 && forced[0] <= 0) p.on = 0;
   return p;
 }
 inline int64_t table1_bytes(const prn_dcn_desc* d) { return ((int64_t)npad(d) * 9 * 32 + 255) & ~255LL; }
