@@ -52,7 +52,9 @@ enum { PRN_EPI_NONE = 0, PRN_EPI_RELU = 1, PRN_EPI_SIGMOID = 2 };
  * A plain value the caller fills (or zeroes) per call / per descriptor; the library keeps nothing between calls.
  *   split_mode      PRN_SPLIT_OFF: every contraction on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).  PRN_SPLIT_PLAN: plain GEMMs
  *                   (stride-1 1x1 convolutions, the 36 transform-domain products of the Winograd path, the DCNv2 column gradient) of at
- *                   least split_min_tiles 128 x 128 output tiles and split_min_gflop GFLOP take the split kernel of prn_gemm_pipe below.
+ *                   least split_min_tiles 128 x 128 output tiles and split_min_gflop GFLOP take the split kernel of prn_gemm_pipe below;
+ *                   so do, with the fp16 pieces and C % 32 == 0, three convolution shapes the same kernel walks by TAP (its weight images cut
+ *                   tap-major per call): 4x4 / stride 2 / zero padding, 1x1 / stride 2, and the four 2x2 phases of PRN_IN_UP2_PHASE.
  *                   PRN_SPLIT_ALWAYS: wherever that kernel applies (tests: small batches then exercise what batch 8 runs).
  *   split_kind      PRN_PIECES_F16: two fp16 pieces per operand element after an exact power-of-two scaling per weight row / activation
  *                   column, split_products = 3 (l*h, h*l, h*h) or 4 (+ l*l) v_mfma_f32_32x32x16_f16 per multiply-add.  PRN_PIECES_BF16:
@@ -304,8 +306,12 @@ int prn_dcn_sample_bwd(const float* x, const float* om, const float* dcols, floa
  *   raw = 1: `offset` is the raw [B,27,Ho,Wo] output of the merged offset(18)|modulator(9) conv and `mask` is ignored:
  *            offsets are clamped to +-max_offset and the modulation is 2*sigmoid(raw[18+k]) (models/dcn.py:53-57 folded
  *            in); gradients come back for the raw tensor ([B,27,Ho,Wo] in d_offset, d_mask unused).
- * Call order:  prn_dcnv2_table (offset, mask -> gather table, prn_dcnv2_table_bytes; valid until offset / mask change)
- *   forward :  prn_dcnv2_fwd(x, table, w [M,C,3,3], bias) -> y [B,M,Ho,Wo]        (ws: prn_dcnv2_fwd_ws_bytes, K-split partials)
+ * Call order:  prn_dcnv2_table (offset, mask -> gather table, prn_dcnv2_table_bytes; valid until offset / mask change).  The table is opaque: a
+ *              per-pixel part (byte offsets of the 2 x 2 footprint + weights, read by the weight gradient and by the forward of layers it keeps) and,
+ *              for even C, a per-PATCH part (64 output pixels of one image: bounds of the input window they sample, LDS offsets + weights) from
+ *              which the forward stages that window in LDS -- zero-padded where it leaves the image, which IS deform_conv2d's border rule -- and
+ *              gathers from there; a patch whose offsets spread its window beyond 32 x 40 pixels gathers from global memory, bit-identically.
+ *   forward :  prn_dcnv2_fwd(x, table, w [M,C,3,3], bias) -> y [B,M,Ho,Wo]        (ws: prn_dcnv2_fwd_ws_bytes, K-split partials; w 8-byte aligned)
  *   backward:  prn_dcnv2_bwd_weight(x, table, dy) -> dw [M,C,3,3]                 (re-samples in the operand loader)
  *              prn_dcnv2_bwd_input(dy, wt [9C,M] = w^T, offset, mask) -> dx       (W^T dy into the head of ws, CSR gather;
  *                                                                                  dx may be NULL: column gradient only)
