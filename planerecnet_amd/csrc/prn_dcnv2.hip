@@ -252,6 +252,7 @@ struct WgArgs {
   int B, C, HW, M, K, N, HoWo;
   int tilesM, tilesJ, splits, chunks;
   int xbytes, dybytes, tabbytes;
+  int ilv;                    // reduction loop with the staging work issued inside the MFMA loop
 };
 
 // dW tile (64 * TM) x 64 (output channels x (c, tap) columns), reduction over 16-pixel chunks; thread (nl = tid & 15,
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_
   constexpr int BM = 64 * TM, BJ = 64, LD = 17, NBJ = 4;
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
-  __shared__ uint2 toff[2][9 * 16];
-  __shared__ float4 twt[2][9 * 16];
+  __shared__ uint2 toff[3][9 * 16];                 // (two buffers in the phase-separated loop, a ring of three in the interleaved one)
+  __shared__ float4 twt[3][9 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wj = wave & 1;
   const int m0 = (blockIdx.x % a.tilesM) * BM, j0 = (blockIdx.x / a.tilesM) * BJ;
@@ -370,7 +371,67 @@ __global__ __launch_bounds__(256, (TM == 1 ? 4 : (TM == 2 ? 3 : 2))) void dcnv2_
     }
   };
 
-  if (cbeg < cend) {
+  if (N4 && a.ilv && cend - cbeg >= 2) {
+    // Interleaved schedule: under every k step of chunk ch's MFMAs one operand piece of chunk ch + 1 goes from registers to LDS (a dY float4
+    // group as it is; a sampled column after its four corners are weighted with the table of chunk ch + 1) and is re-fetched for chunk ch + 2 (the
+    // gather offsets come from the table of chunk ch + 2).  Tables therefore live in a ring of three LDS buffers: chunk c's table is written in iteration
+    // c - 3 (from registers loaded an iteration earlier), its offsets are read in iteration c - 2, its weights in iteration c - 1.
+    constexpr int NP = TM + NBJ;
+    load_table(cbeg); write_table(0);
+    load_table(cbeg + 1); write_table(1);
+    load_table(cbeg + 2); write_table(2);
+    __syncthreads();
+    load_chunk(cbeg, 0);
+    store_chunk(0, 0);
+    load_chunk(cbeg + 1, 1);
+    load_table(cbeg + 3);
+    __syncthreads();
+    for (int ch = cbeg; ch + 1 < cend; ++ch) {
+      const int it = ch - cbeg, buf = it & 1, nbuf = buf ^ 1;
+      const int t1 = (it + 1) % 3, t2 = (it + 2) % 3;        // table buffers of chunks ch + 1 (weights) and ch + 2 (offsets)
+      const bool aok = (ch + 2) * 16 + anq < a.N;
+      const unsigned abase2 = (unsigned)((a_b * a.M + m0 + arow) * a.HoWo + a_p) * 4u;
+      float av[2][TM], bv[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[0][i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + (lane >> 5)];
+      bv[0] = Bs[buf][(wj * 32 + (lane & 31)) * LD + (lane >> 5)];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk + 1 < 8) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[(kk + 1) & 1][i] = As[buf][(wm * TM * 32 + i * 32 + (lane & 31)) * LD + (kk + 1) * 2 + (lane >> 5)];
+          bv[(kk + 1) & 1] = Bs[buf][(wj * 32 + (lane & 31)) * LD + (kk + 1) * 2 + (lane >> 5)];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          if ((p * 8) / NP == kk) {
+            if (p < TM) {
+              const int i = p < TM ? p : 0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) As[nbuf][(arow + 64 * i) * LD + anq + q] = ra[i][q];
+              const float4 v = bload4(dyr, (aok && mok[i]) ? abase2 : OOB, i * 64 * a.HoWo * 4);
+              ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+            } else {
+              const int i = p >= TM ? p - TM : 0;
+              const float4 wq = twt[t1][jt[i] * 16 + nl];
+              Bs[nbuf][(jrow + 16 * i) * LD + nl] = (wq.x * rb[i][0] + wq.y * rb[i][1]) + (wq.z * rb[i][2] + wq.w * rb[i][3]);
+              const uint2 o = toff[t2][jt[i] * 16 + nl];
+              const float2 r0 = bload2(xr, o.x + jcoff[i], 0), r1 = bload2(xr, o.y + jcoff[i], 0);
+              rb[i][0] = r0.x; rb[i][1] = r0.y; rb[i][2] = r1.x; rb[i][3] = r1.y;
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      a_p += 16;
+      while (a_p >= a.HoWo) { a_p -= a.HoWo; ++a_b; }
+      write_table(it % 3);                                   // table of chunk ch + 3 (its buffer held chunk ch's: done with since the previous iteration)
+      load_table(ch + 4);
+      __syncthreads();
+    }
+    mma_chunk((cend - 1 - cbeg) & 1);
+  } else if (cbeg < cend) {
     load_table(cbeg);
     write_table(0);
     load_table(cbeg + 1);
@@ -1089,6 +1150,11 @@ extern "C" int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x,
   a.xbytes = d->B * d->C * a.HW * 4; a.dybytes = d->B * d->M * a.HoWo * 4; a.tabbytes = (int)((int64_t)npad(d) * 9 * 32);
   const WPlan p = plan_dcn_wgrad(d->opts, a.M, a.K, a.N);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
+  {
+    static int ilv = -1;                                   // PRN_DCN_WGRAD_ILV=0: the phase-separated loop (A/B)
+    if (ilv < 0) { const char* e = getenv("PRN_DCN_WGRAD_ILV"); ilv = e ? atoi(e) : 1; }
+    a.ilv = ilv;
+  }
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_dcnv2_bwd_weight: workspace required (%d splits)", p.splits);
   a.out = p.splits > 1 ? (float*)ws : dw;
   hipStream_t st = (hipStream_t)stream;
