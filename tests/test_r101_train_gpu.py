@@ -336,7 +336,7 @@ def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
     l64, g64 = oracle(torch.float64)
     _, g32 = oracle(torch.float32)
     rel = lambda a, n: ((a - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()      # noqa: E731
-    bound = {n: WINOGRAD_SENSITIVE.get(n, GRAD_K_WINOGRAD * max(fix_spread[n], rel(g32[n], n)) + GRAD_FLOOR_WINOGRAD) for n in names if n not in zero}
+    bound = {n: max(WINOGRAD_SENSITIVE.get(n, 0.0), GRAD_K_WINOGRAD * max(fix_spread[n], rel(g32[n], n)) + GRAD_FLOOR_WINOGRAD) for n in names if n not in zero}
     err, msgs, bad = {}, [], []
     for arith in ("default", "fp32"):
         losses, g = product(arith)
