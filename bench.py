@@ -689,10 +689,10 @@ def main():
                 "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
                 "dtype": ("f32" if ops.split_mode() == 0 else
-                          "f32 (tensors and accumulation fp32; plain GEMMs >= %d tiles: %s split MFMA, fp32 accumulate; fp32-only rate in fp32_only_run)"
+                          "f32 (tensors and accumulation fp32; plain GEMMs and the tap-walked 4x4/s2, 1x1/s2 and sub-pixel convolutions >= %d tiles: %s split MFMA, fp32 accumulate; fp32-only rate in fp32_only_run)"
                           % (ops._POLICY["min_tiles"], "2xfp16-piece" if ops.split_products() <= 4.0 else "3xbf16-piece")),
                 "data": "synthetic",
-                "arithmetic": "fp32 tensors, fp32 accumulation, fp32 MFMA; plain GEMMs of >= %d output tiles run on the 16-bit matrix pipe with every fp32 operand cut "
+                "arithmetic": "fp32 tensors, fp32 accumulation, fp32 MFMA; plain GEMMs (and, since round 5, the 4x4 / stride-2, 1x1 / stride-2 and sub-pixel-phase convolutions, walked tap by tap) of >= %d output tiles run on the 16-bit matrix pipe with every fp32 operand cut "
                               "into %s (error vs fp64 at the fp32 MFMA's level; DESIGN.md 9.1b / 9.1c; PRN_SPLIT_GEMM=0 turns it off)"
                               % (ops._POLICY["min_tiles"], "two fp16 pieces after an exact power-of-two scaling" if ops.split_products() <= 4.0 else "three exact bf16 pieces"),
                 "config": {"workload": "%s: %s %s, per-GPU batch %d, %dx%d synthetic %s, random-init weights"
