@@ -266,6 +266,63 @@ __global__ __launch_bounds__(256) void dcn_csr_fill_kernel(OmView om, const int*
   put(t.i00, t.w00); put(t.i01, t.w01); put(t.i10, t.w10); put(t.i11, t.w11);
 }
 
+// The same CSR structure in ONE launch (round 5): workgroup (b, k) owns the H*W bins of its tap plane in LDS -- count (LDS atomics), exclusive
+// scan, fill (the LDS words turned into cursors) -- and its entries go to a FIXED segment of the entry buffer, [(b*9+k) * 4*plane, +4*plane): a
+// plane's points have at most four corners each, so no scan across planes is needed and `starts` is written directly.  Replaces memset + count +
+// block sums + scan + fill (five launches of ~5 us, i.e. five launch boundaries on the input-gradient chain per DCN layer).  H*W <= CSR1_MAX_BINS.
+constexpr int CSR1_THREADS = 1024;
+constexpr int CSR1_MAX_BINS = 15360;                    // 60 KB of LDS words (+ the scan scratch): 30x40 .. 96x160 input maps
+
+__global__ __launch_bounds__(CSR1_THREADS) void dcn_csr_build_kernel(OmView om, int* __restrict__ starts, int* __restrict__ counts,
+                                                                      CsrEntry* __restrict__ entries, int H, int W, int Ho, int Wo, int stride) {
+  extern __shared__ int csr_bins[];                     // [HW] counts, then cursors
+  __shared__ int wave_tot[CSR1_THREADS / 64];
+  const int bk = blockIdx.x, b = bk / 9, k = bk - b * 9;
+  const int HW = H * W, plane = Ho * Wo, tid = threadIdx.x;
+  for (int i = tid; i < HW; i += CSR1_THREADS) csr_bins[i] = 0;
+  __syncthreads();
+  for (int p = tid; p < plane; p += CSR1_THREADS) {
+    const int ho = p / Wo, wo = p - ho * Wo;
+    const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, false);
+    if (t.w00 != 0.f) atomicAdd(csr_bins + t.i00, 1);
+    if (t.w01 != 0.f) atomicAdd(csr_bins + t.i01, 1);
+    if (t.w10 != 0.f) atomicAdd(csr_bins + t.i10, 1);
+    if (t.w11 != 0.f) atomicAdd(csr_bins + t.i11, 1);
+  }
+  __syncthreads();
+  // exclusive scan: thread t owns bins [t * per, (t + 1) * per)
+  const int per = (HW + CSR1_THREADS - 1) / CSR1_THREADS;
+  const int b0 = tid * per, b1 = min(HW, b0 + per);
+  int mine = 0;
+  for (int i = b0; i < b1; ++i) mine += csr_bins[i];
+  const int lane = tid & 63, wv = tid >> 6;
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int off = incl - mine;
+  for (int w = 0; w < wv; ++w) off += wave_tot[w];
+  const int seg = bk * 4 * plane;                       // first entry of this plane's segment
+  const size_t gb = (size_t)bk * HW;
+  for (int i = b0; i < b1; ++i) {
+    const int c = csr_bins[i];
+    starts[gb + i] = seg + off;
+    counts[gb + i] = c;
+    csr_bins[i] = off;                                  // cursor (segment-relative)
+    off += c;
+  }
+  __syncthreads();
+  for (int p = tid; p < plane; p += CSR1_THREADS) {
+    const int ho = p / Wo, wo = p - ho * Wo;
+    const Tap t = make_tap(om, b, k, ho, wo, Ho, Wo, H, W, stride, false);
+    const int src = k * plane + p;
+    if (t.w00 != 0.f) entries[seg + atomicAdd(csr_bins + t.i00, 1)] = CsrEntry{src, t.w00 * t.mod};
+    if (t.w01 != 0.f) entries[seg + atomicAdd(csr_bins + t.i01, 1)] = CsrEntry{src, t.w01 * t.mod};
+    if (t.w10 != 0.f) entries[seg + atomicAdd(csr_bins + t.i10, 1)] = CsrEntry{src, t.w10 * t.mod};
+    if (t.w11 != 0.f) entries[seg + atomicAdd(csr_bins + t.i11, 1)] = CsrEntry{src, t.w11 * t.mod};
+  }
+}
+
 template <int CH>
 __global__ __launch_bounds__(256) void dcn_dx_gather_kernel(const float* __restrict__ dcols, const int* __restrict__ starts,
                                                             const int* __restrict__ counts, const CsrEntry* __restrict__ entries,
@@ -380,11 +437,17 @@ int launch_dx(const OmView& v, const float* dcols, float* dx, char* wsb, const B
   int* starts = (int*)(wsb + l.starts);
   int* bsum = (int*)(wsb + l.bsum);
   CsrEntry* entries = (CsrEntry*)(wsb + l.entries);
-  if (hipMemsetAsync(counts, 0, (size_t)l.nbins * 4, st) != hipSuccess) { prn_set_error("dcn d-input: memset failed"); return 1; }
-  hipLaunchKernelGGL(dcn_csr_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, counts, B, H, W, Ho, Wo, stride);
-  hipLaunchKernelGGL(dcn_csr_block_sums_kernel, dim3(l.nblocks), dim3(256), 0, st, (const int*)counts, bsum, l.nbins);
-  hipLaunchKernelGGL(dcn_csr_scan_kernel, dim3(l.nblocks), dim3(256), 0, st, counts, starts, (const int*)bsum, l.nbins);
-  hipLaunchKernelGGL(dcn_csr_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, (const int*)starts, counts, entries, B, H, W, Ho, Wo, stride);
+  static int one = -1;                                   // PRN_DCN_CSR1=0: the five-launch construction (A/B)
+  if (one < 0) { const char* e = getenv("PRN_DCN_CSR1"); one = e ? atoi(e) : 1; }
+  if (one && H * W <= CSR1_MAX_BINS) {
+    hipLaunchKernelGGL(dcn_csr_build_kernel, dim3(B * 9), dim3(CSR1_THREADS), (size_t)H * W * sizeof(int), st, v, starts, counts, entries, H, W, Ho, Wo, stride);
+  } else {
+    if (hipMemsetAsync(counts, 0, (size_t)l.nbins * 4, st) != hipSuccess) { prn_set_error("dcn d-input: memset failed"); return 1; }
+    hipLaunchKernelGGL(dcn_csr_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, counts, B, H, W, Ho, Wo, stride);
+    hipLaunchKernelGGL(dcn_csr_block_sums_kernel, dim3(l.nblocks), dim3(256), 0, st, (const int*)counts, bsum, l.nbins);
+    hipLaunchKernelGGL(dcn_csr_scan_kernel, dim3(l.nblocks), dim3(256), 0, st, counts, starts, (const int*)bsum, l.nbins);
+    hipLaunchKernelGGL(dcn_csr_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, (const int*)starts, counts, entries, B, H, W, Ho, Wo, stride);
+  }
   PRN_CHECK_LAUNCH("dcn d-input csr");
   const int HW = H * W;
   // channels per thread: 8, or 4 when that leaves fewer than ~4 blocks per CU
