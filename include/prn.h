@@ -106,6 +106,12 @@ int64_t prn_conv2d_fwd_ws_bytes(const prn_conv_desc* d);
  * output channels, or one input channel, over large maps: the depth head); 2 / 3: on the split GEMM kernel (prn_gemm_pipe below, per d->opts)
  * without / with a K split (3: a reduce launch follows, as for a split fp32 launch) -- for profilers that attribute launches to a roofline. */
 int prn_conv2d_kernel_kind(const prn_conv_desc* d);
+/* Where phase 1 of prn_conv2d_fwd_phase / prn_conv2d_fwd_counted leaves the K-split partial sums of the descriptor's forward: returns s > 1 when
+ * ws + *offset_bytes holds s dense [B][M][Ho][Wo] tensors, B*M*Ho*Wo elements apart, whose sum in split order (+ bias + addend) is the result phase 2
+ * would write; 0: no K split (or only the tail tiles are split).  A consumer that reads the output exactly once -- the BatchNorm behind a 1x1
+ * convolution, models/backbone.py:56-66 -- may take the partial sums instead (prn_bn_train_fwd_partials, prn_bn_bwd_partials): one launch and one
+ * pass over the tensor less.  Phase 1 is then called with counters == NULL. */
+int prn_conv2d_fwd_partials(const prn_conv_desc* d, int64_t* offset_bytes);
 /* Which matrix pipe the plain GEMM y[z][b][m][p] = sum_k w[z][m][k] x[z][b][k][p] (a stride-1 1x1 convolution: nz = 1, HW = H*W; a
  * prn_gemm_batched call: B = 1, HW = P, nz = nb) runs on under `opts`.  0: the fp32 MFMA kernel (v_mfma_f32_32x32x2_f32).  s >= 1: the
  * split kernel with s K splits -- fp32 operands cut into 16-bit pieces whose products are exact in fp32 and accumulated in fp32:
@@ -382,6 +388,17 @@ int prn_bn_train_fwd_into(const float* x, float* stats, const float* gamma, cons
 int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const float* x, const float* y, const float* stats, const float* gamma,
                     const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
                     int B, int C, int HW, int relu, int frozen, void* stream);
+
+/* The one-launch forms (prn_bn_kernel_kind(B, HW) == 1 required) with the layer's input (forward) / output gradient (backward) given as the `nparts`
+ * K-split partial sums of the GEMM that produces it (prn_conv2d_fwd_partials: parts + i * part_stride, i < nparts, dense [B][C][HW], 16-byte aligned):
+ * the kernel sums them in split order while loading -- bit for bit the tensor the producer's own sum launch would have written -- so that launch and one
+ * pass over the tensor disappear.  Forward: the summed input is also written to x_out (the backward reads it).  conv1 -> bn1 and conv3's input
+ * gradient -> bn2's backward of every stage-3 / stage-4 Bottleneck (models/backbone.py:56-66).  nparts == 1: the plain one-launch forms. */
+int prn_bn_train_fwd_partials(const float* parts, int nparts, int64_t part_stride, float* x_out, float* stats, const float* gamma, const float* beta,
+                              const float* residual, float* y, float* running_mean, float* running_var, int B, int C, int HW, float eps, float momentum,
+                              int relu, void* stream);
+int prn_bn_bwd_partials(const float* dparts, int nparts, int64_t part_stride, const float* x, const float* y, const float* stats, const float* gamma,
+                        const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu, int frozen, void* stream);
 
 /* ---- GroupNorm(32) + ReLU ---------------------------------------------------------------------------------------
  * replaces ATen group_norm fwd/bwd + ReLU: planerecnet.py:340-342,419-421,436-437,450-451,463-464           */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "prn_last_error": (ctypes.c_char_p, []),
     "prn_conv2d_fwd_ws_bytes": (c_i64, [_DP]),
     "prn_conv2d_kernel_kind": (c_int, [_DP]),
+    "prn_conv2d_fwd_partials": (c_int, [_DP, ctypes.POINTER(c_i64)]),
     "prn_gemm_opts_default": (None, [_OP]),
     "prn_gemm_pipe": (c_int, [c_int, c_int, c_int, c_int, c_int, _OP]),
     "prn_split_images_bytes": (c_i64, [c_int, c_int, c_int]),
@@ -165,6 +166,8 @@ SIGNATURES = {
     "prn_bn_bwd": (c_int, [P] * 11 + [c_int] * 5 + [P]),
     "prn_bn_train_fwd_into": (c_int, [P] * 6 + [c_i64] + [P] * 3 + [c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "prn_bn_bwd_from": (c_int, [P, c_i64] + [P] * 10 + [c_int] * 5 + [P]),
+    "prn_bn_train_fwd_partials": (c_int, [P, c_int, c_i64] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    "prn_bn_bwd_partials": (c_int, [P, c_int, c_i64] + [P] * 9 + [c_int] * 5 + [P]),
     "prn_gn_relu_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "prn_gn_relu_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),
     "prn_resize_bilinear_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),

@@ -1646,6 +1646,26 @@ extern "C" int prn_conv2d_kernel_kind(const prn_conv_desc* d) {
   return ss == 0 ? 0 : (ss == 1 ? 2 : 3);
 }
 
+// Where phase 1 of the descriptor's forward leaves its K-split partial sums: returns s > 1 when ws + *offset_bytes holds s dense [B][M][Ho][Wo]
+// tensors (B*M*Ho*Wo elements apart) whose sum in split order, + bias + addend, is the result (what phase 2 computes); 0 when the launch has no
+// K split, or splits only its tail tiles.  A consumer that reads the operator's output exactly once may sum the partials itself instead of
+// running phase 2 (prn_bn_train_fwd_partials / prn_bn_bwd_partials); phase 1 is then called with counters == NULL (no in-launch sum).
+extern "C" int prn_conv2d_fwd_partials(const prn_conv_desc* d, int64_t* offset_bytes) {
+  if (check_desc(d, "prn_conv2d_fwd_partials")) return -1;
+  PRN_REQUIRE(offset_bytes != nullptr, "prn_conv2d_fwd_partials: null offset");
+  *offset_bytes = 0;
+  if (direct_small_m(d) || direct_one_c(d)) return 0;
+  if (const int ss = split_plan_of(d)) {
+    *offset_bytes = (prn_split_gemm_image_bytes(d->M, d->C, 1) + 255) & ~255LL;
+    return ss > 1 ? ss : 0;
+  }
+  if (taps_plan_of(d) || up2_plan_of(d)) return 0;
+  const Geo g = geo_of(d);
+  const FwdPlan p = plan_fwd(d->M, (int64_t)d->B * g.gH * g.gW, d->C * d->KH * d->KW, narrow_available(d->KH, d->in_mode), g.phases, g.nosplit,
+                             wide_ks(d->KH, d->in_mode));
+  return p.splits > 1 ? p.splits : 0;
+}
+
 extern "C" int prn_conv2d_fwd_phase(const prn_conv_desc* d, const float* x, const float* w, const float* bias,
                                     const float* addend, float* y, void* ws, void* stream, int phase) {
   return conv_fwd_impl(d, nullptr, x, w, bias, addend, y, ws, stream, phase);

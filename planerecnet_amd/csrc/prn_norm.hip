@@ -246,7 +246,9 @@ template <int NV>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
                                                            float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, int HW, float eps,
-                                                           float momentum, int relu, int64_t ybs) {
+                                                           float momentum, int relu, int64_t ybs, int nparts, int64_t pstride, float* __restrict__ xsum) {
+  // nparts > 1: x is the first of `nparts` K-split partial sums of the producing GEMM (pstride elements apart); they are summed here in split
+  // order -- bit for bit what reduce_epilogue_kernel would have written -- and the sum goes to xsum (the BatchNorm input the backward reads).
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
   const int64_t ydelta = ybs - (int64_t)C * HW;             // y as a channel slice of a wider tensor: extra elements per image
   // All NV loads are issued before anything is consumed: they are UNCONDITIONAL (a lane past the end re-reads element 0 and
@@ -264,6 +266,19 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(x + off[i]);
   __builtin_amdgcn_sched_barrier(0);
+  for (int s = 1; s < nparts; ++s) {
+    float4 t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = *reinterpret_cast<const float4*>(x + (size_t)s * pstride + off[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i].x += t[i].x; v[i].y += t[i].y; v[i].z += t[i].z; v[i].w += t[i].w; }
+  }
+  if (xsum) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (threadIdx.x + i * 256 < n4) *reinterpret_cast<float4*>(xsum + off[i]) = v[i];
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     if (threadIdx.x + i * 256 >= n4) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -314,7 +329,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int HW, int relu,
-                                                           int frozen, int64_t dbs) {
+                                                           int frozen, int64_t dbs, int nparts, int64_t pstride) {
+  // nparts > 1: dy is the first of `nparts` dense K-split partial sums of the input-gradient GEMM that produced it (see bn_small_fwd_kernel)
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
   const int64_t ddelta = dbs - (int64_t)C * HW;
   const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
@@ -336,6 +352,14 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     xv[i] = *reinterpret_cast<const float4*>(x + off[i]);
   }
   __builtin_amdgcn_sched_barrier(0);
+  for (int s = 1; s < nparts; ++s) {
+    float4 t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = *reinterpret_cast<const float4*>(dy + (size_t)s * pstride + off[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g[i].x += t[i].x; g[i].y += t[i].y; g[i].z += t[i].z; g[i].w += t[i].w; }
+  }
   if (relu == 1) {                                         // mask from the forward output (a residual was added)
     float4 yv[NV];
 #pragma unroll
@@ -598,7 +622,7 @@ extern "C" int prn_bn_train_fwd_into(const float* x, float* stats, const float* 
   if (bn_small_ok(B, HW)) {                                // whole channel in one workgroup's registers: one launch, one read
     const int nv = cdiv(B * HW / 4, 256);
 #define PRN_BN_SMALL_FWD(NV_) hipLaunchKernelGGL((bn_small_fwd_kernel<NV_>), dim3(C), dim3(256), 0, st, x, stats, gamma, beta, residual, y, \
-                                                 running_mean, running_var, B, C, HW, eps, momentum, relu, ybs)
+                                                 running_mean, running_var, B, C, HW, eps, momentum, relu, ybs, 1, (int64_t)0, (float*)nullptr)
     if (nv <= 3) PRN_BN_SMALL_FWD(3); else if (nv <= 6) PRN_BN_SMALL_FWD(6); else if (nv <= 10) PRN_BN_SMALL_FWD(10); else PRN_BN_SMALL_FWD(12);
 #undef PRN_BN_SMALL_FWD
     PRN_CHECK_LAUNCH("prn_bn_train_fwd/small");
@@ -635,7 +659,7 @@ extern "C" int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const f
   if (bn_small_ok(B, HW)) {
     const int nv = cdiv(B * HW / 4, 256);
 #define PRN_BN_SMALL_BWD(NV_) hipLaunchKernelGGL((bn_small_bwd_kernel<NV_>), dim3(C), dim3(256), 0, st, dy, x, y, stats, gamma, beta, dx, dres, dgamma, \
-                                                 dbeta, B, C, HW, relu, frozen, dbs)
+                                                 dbeta, B, C, HW, relu, frozen, dbs, 1, (int64_t)0)
     if (nv <= 3) PRN_BN_SMALL_BWD(3); else if (nv <= 6) PRN_BN_SMALL_BWD(6); else if (nv <= 10) PRN_BN_SMALL_BWD(10); else PRN_BN_SMALL_BWD(12);
 #undef PRN_BN_SMALL_BWD
     PRN_CHECK_LAUNCH("prn_bn_bwd/small");
@@ -652,6 +676,50 @@ extern "C" int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const f
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, st, dy, x, y, stats, gamma, (const double*)ws, dx, dres, C, HW,
                      S, 1.f / ((float)B * HW), relu, frozen, have, dgamma, dbeta, beta, dbs);
   PRN_CHECK_LAUNCH("prn_bn_bwd/apply");
+  return 0;
+}
+
+// The one-pass kernels fed with the K-split partial sums of the GEMM that produces their input (include/prn.h: prn_conv2d_fwd_partials): the
+// separate sum launch of the producer and one read of its output disappear (models/backbone.py:56-66: conv1 -> bn1 in the forward, conv3's
+// input gradient -> bn2's backward).  Only where prn_bn_kernel_kind(B, HW) == 1.
+extern "C" int prn_bn_train_fwd_partials(const float* parts, int nparts, int64_t part_stride, float* x_out, float* stats, const float* gamma, const float* beta,
+                                         const float* residual, float* y, float* running_mean, float* running_var, int B, int C, int HW, float eps,
+                                         float momentum, int relu, void* stream) {
+  PRN_REQUIRE(parts && x_out && stats && gamma && beta && y && B > 0 && C > 0 && HW > 0, "prn_bn_train_fwd_partials: bad arguments");
+  PRN_REQUIRE(nparts >= 1 && nparts <= 64 && (nparts == 1 || part_stride >= (int64_t)B * C * HW) && (part_stride & 3) == 0,
+              "prn_bn_train_fwd_partials: 1..64 partial sums, a multiple of four elements and at least B*C*HW apart");
+  PRN_REQUIRE(bn_small_ok(B, HW), "prn_bn_train_fwd_partials: only for maps the one-pass kernel takes (prn_bn_kernel_kind(B, HW) == 1)");
+  PRN_REQUIRE(((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+              "prn_bn_train_fwd_partials: tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = cdiv(B * HW / 4, 256);
+  const int64_t ybs = (int64_t)C * HW;
+#define PRN_BN_SMALL_FWD(NV_) hipLaunchKernelGGL((bn_small_fwd_kernel<NV_>), dim3(C), dim3(256), 0, st, parts, stats, gamma, beta, residual, y, \
+                                                 running_mean, running_var, B, C, HW, eps, momentum, relu, ybs, nparts, part_stride, x_out)
+  if (nv <= 3) PRN_BN_SMALL_FWD(3); else if (nv <= 6) PRN_BN_SMALL_FWD(6); else if (nv <= 10) PRN_BN_SMALL_FWD(10); else PRN_BN_SMALL_FWD(12);
+#undef PRN_BN_SMALL_FWD
+  PRN_CHECK_LAUNCH("prn_bn_train_fwd_partials");
+  return 0;
+}
+
+extern "C" int prn_bn_bwd_partials(const float* dparts, int nparts, int64_t part_stride, const float* x, const float* y, const float* stats, const float* gamma,
+                                   const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu, int frozen,
+                                   void* stream) {
+  PRN_REQUIRE(dparts && x && stats && gamma && dx && B > 0 && C > 0 && HW > 0, "prn_bn_bwd_partials: bad arguments");
+  PRN_REQUIRE(nparts >= 1 && nparts <= 64 && (nparts == 1 || part_stride >= (int64_t)B * C * HW) && (part_stride & 3) == 0,
+              "prn_bn_bwd_partials: 1..64 partial sums, a multiple of four elements and at least B*C*HW apart");
+  PRN_REQUIRE(bn_small_ok(B, HW), "prn_bn_bwd_partials: only for maps the one-pass kernel takes (prn_bn_kernel_kind(B, HW) == 1)");
+  PRN_REQUIRE((reinterpret_cast<uintptr_t>(dparts) & 15) == 0, "prn_bn_bwd_partials: partial sums must be 16-byte aligned");
+  PRN_REQUIRE(!relu || y || (beta && !dres), "prn_bn_bwd_partials: relu needs the forward output, or beta (and no residual) to recompute its sign");
+  if (relu) relu = y ? 1 : 2;
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = cdiv(B * HW / 4, 256);
+  const int64_t dbs = (int64_t)C * HW;
+#define PRN_BN_SMALL_BWD(NV_) hipLaunchKernelGGL((bn_small_bwd_kernel<NV_>), dim3(C), dim3(256), 0, st, dparts, x, y, stats, gamma, beta, dx, dres, dgamma, \
+                                                 dbeta, B, C, HW, relu, frozen, dbs, nparts, part_stride)
+  if (nv <= 3) PRN_BN_SMALL_BWD(3); else if (nv <= 6) PRN_BN_SMALL_BWD(6); else if (nv <= 10) PRN_BN_SMALL_BWD(10); else PRN_BN_SMALL_BWD(12);
+#undef PRN_BN_SMALL_BWD
+  PRN_CHECK_LAUNCH("prn_bn_bwd_partials");
   return 0;
 }
 

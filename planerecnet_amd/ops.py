@@ -126,6 +126,10 @@ def wgrad_streams():
 def wgrad_join():
     """Make the current stream wait for the deferred weight gradients.  Call after backward(), before reading any `.grad`."""
     wgrad_flush()
+    if _LAZY_SUMS:                                           # a convolution left partial sums for a BatchNorm that never ran: its "result" was garbage
+        n = len(_LAZY_SUMS)
+        _LAZY_SUMS.clear()
+        raise RuntimeError("%d lazily summed convolution result(s) were never consumed by a BatchNorm kernel (ops.conv2d lazy_sum / lazy_dgrad misuse)" % n)
     if _SIDE:
         main = torch.cuda.current_stream()
         for st in _SIDE.values():
@@ -350,8 +354,31 @@ def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NO
         if fb < 0 or wb < 0:
             raise RuntimeError(lib.prn_last_error().decode())
         d.kind = lib.prn_conv2d_kernel_kind(ref)             # 2 / 3: plain GEMM on the split kernel
-        e = _DESC[key] = (d, ref, fb, wb)
+        off = ctypes.c_int64(0)
+        parts = lib.prn_conv2d_fwd_partials(ref, ctypes.byref(off)) if ystride <= 1 else 0
+        e = _DESC[key] = (d, ref, fb, wb, (parts, off.value // 4) if parts > 1 else None)
     return e
+
+
+# A K-split GEMM whose ONLY consumer is a one-launch BatchNorm kernel does not sum its partial results: the BatchNorm kernel does, while loading
+# (include/prn.h: prn_conv2d_fwd_partials, prn_bn_train_fwd_partials / prn_bn_bwd_partials) -- conv1 -> bn1 in the forward, conv3's input gradient ->
+# bn2's backward of the stage-3 / stage-4 Bottlenecks.  The tensor the producer returns is then NOT YET WRITTEN; its data pointer is the key under
+# which the consumer finds the partial sums.  Producers go lazy only when the caller says that a BatchNorm (training mode, small map) follows
+# (conv2d(..., lazy_sum=True) / lazy_dgrad=True); wgrad_join() -- called once per step -- fails loudly if a registered tensor was never consumed.
+LAZY_SPLIT_SUM = os.environ.get("PRN_LAZY_SPLIT_SUM", "1") == "1"
+_LAZY_SUMS = {}      # data_ptr -> (workspace tensor, number of partial sums, offset of the first one in floats, elements per partial sum)
+LAZY_STATS = {"fwd": 0, "bwd": 0}
+
+
+def _take_partials(t):
+    """The partial sums registered for tensor t (and forget them), or None: t holds its values."""
+    if not _LAZY_SUMS:
+        return None
+    return _LAZY_SUMS.pop(t.data_ptr(), None)
+
+
+def lazy_bn_ok(B, HW):
+    return LAZY_SPLIT_SUM and not profiling._enabled and lib.prn_bn_kernel_kind(int(B), int(HW)) == 1
 
 
 def _out_hw(H, W, K, stride, pad, mode):
@@ -604,18 +631,25 @@ def split_refresh_all():
 
 
 # ------------------------------------------------------------------------------------------ raw launches
-def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None):
-    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor."""
+def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None, lazy=False):
+    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor.
+    lazy: the caller vouches that the result's only reader is a BatchNorm kernel that can sum K-split partial results itself (_LAZY_SUMS)."""
     B, C, H, W = x.shape
+    parts = None
     if scatter2 is None:
         y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
-        d_, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+        d_, ref, nbytes, _, parts = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
         wimg = split_images(w2d, M, C, 1, (B, Ho * Wo)) if (d_.kind >= 2 and K == 1 and stride == 1) else None      # (tap gather -- 4x4 / stride 2, 1x1 / stride 2 --: images cut per call, tap-major)
     else:
         wimg = None
         y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
-        _, ref, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
+        _, ref, nbytes, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    if lazy and parts is not None and bias is None and addend is None and epi == EPI_NONE and lazy_bn_ok(B, Ho * Wo) and (y.numel() & 3) == 0:
+        # GEMM launch only; the partial sums stay in ws, which the registry keeps alive until the consumer has been launched
+        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), wimg, None, None, _p(y), _p(ws), None, _stream(), 1), "prn_conv2d_fwd")
+        _LAZY_SUMS[y.data_ptr()] = (ws, parts[0], parts[1], y.numel())
+        return y
     cnt = _counters(x.device) if (nbytes and FUSED_SPLIT_SUM) else None      # K-split layers: the sum inside the GEMM launch (opt-in)
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
@@ -645,7 +679,7 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
     else:
         Ho, Wo = dy.shape[2:]
         dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
-    _, ref, _, nbytes = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
+    _, ref, _, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     if profiling._enabled:
         wkind = lib.prn_conv2d_wgrad_kernel_kind(ref, 1)               # 1: the one- / two-channel 3x3 layers (direct HBM-bound kernel); 2: fp16-piece kernel
@@ -673,7 +707,7 @@ def conv_wgrad_grouped_raw(xs, dys, M, K, stride, pad, mode):
     B, C, H, W = xs[0].shape
     Ho, Wo = dys[0].shape[2:]
     dev = xs[0].device
-    _, ref, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
+    _, ref, _, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
     nbytes = lib.prn_conv2d_wgrad_grouped_ws_bytes(ref, G)
     if nbytes < 0:
         raise RuntimeError(lib.prn_last_error().decode())
@@ -939,7 +973,7 @@ def channel_sum(g):
     return out
 
 
-def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
+def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None, lazy=False):
     """Gradient w.r.t. the conv input: the same implicit-GEMM kernel run over dy with flipped/transposed weights.
     `addend` (another gradient of the same input, e.g. the residual branch) is summed in the kernel epilogue."""
     B, C, H, W = x_shape
@@ -961,7 +995,7 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
         check(lib.prn_pad_fold(_p(dp), _p(dx), B, C, H, W, 1 if mode == IN_UP2_REFLECT else 0, _stream()), "prn_pad_fold")
         return dx if addend is None else dx + addend
     if stride == 1:
-        return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W)
+        return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W, lazy=lazy and K == 1)
     if stride != 2:
         raise RuntimeError("conv dgrad: stride %d not implemented" % stride)
     if K == 1 and pad == 0 and addend is None:
@@ -974,7 +1008,7 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
 # ------------------------------------------------------------------------------------------ conv2d
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi, fork=False):
+    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi, fork=False, lazy_sum=False, lazy_dgrad=False):
         _dev(x, w, bias, addend)
         x0, bias_param = x, bias
         x, w, bias, addend = _c(x), _c(w), _c(bias), _c(addend)
@@ -988,9 +1022,10 @@ class _Conv2d(torch.autograd.Function):
             if keep:
                 ctx.wino_v = keep[0]
         else:
-            y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
+            y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi, lazy=lazy_sum and K == 1)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
         ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
+        ctx.lazy_dgrad = lazy_dgrad and K == 1 and stride == 1
         ctx.bias = bias_param
         ctx.fork = fork
         if fork:
@@ -1005,7 +1040,8 @@ class _Conv2d(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         stride, pad, mode, epi, has_bias, has_add = ctx.cfg
         if dy is None:                                      # only the forked identity was used
-            return (dfork,) + (None,) * 8
+            return (dfork,) + (None,) * 10
+        lazy = ctx.lazy_dgrad and dfork is None
         dy = _c(dy)
         dfork = _c(dfork)
         if epi == EPI_RELU:
@@ -1030,18 +1066,18 @@ class _Conv2d(torch.autograd.Function):
             if V is None and K in (1, 3, 7) and mode in (IN_ZERO, IN_REFLECT) and M > 2 and dy.shape[0] * dy.shape[2] * dy.shape[3] <= WGRAD_GROUP_PIXELS:
                 gkey = ("conv", tuple(x.shape), tuple(dy.shape[2:]), M, K, stride, pad, mode)
             _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad, gkey)
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork, lazy) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None
         else:
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork, lazy) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = wgrad() if ctx.needs_input_grad[1] else None
         if dfork is not None and dx is not None:
             dx = dx + dfork
         db = _bias_grad(has_bias and ctx.needs_input_grad[2], ctx.bias, dy)
         da = dy if (has_add and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, da, None, None, None, None, None
+        return dx, dw, db, da, None, None, None, None, None, None, None
 
 
 class _ConvUp2(torch.autograd.Function):
@@ -1096,11 +1132,13 @@ class _ConvUp2(torch.autograd.Function):
 UP2_SUBPIXEL = bool(int(os.environ.get("PRN_UP2_SUBPIXEL", "1")))      # 0: the PRN_IN_UP2_REFLECT gather at output resolution
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
-    """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list)."""
+def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None, lazy_sum=False, lazy_dgrad=False):
+    """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list).
+    lazy_sum: the result goes to batch_norm_module (training mode) and nowhere else; lazy_dgrad: x comes from batch_norm_module and goes nowhere
+    else -- a K-split launch may then leave its partial sums to that BatchNorm kernel (_LAZY_SUMS above)."""
     if in_mode == IN_UP2_REFLECT and UP2_SUBPIXEL and epilogue == EPI_NONE and addend is None and x.shape[2] > 1 and x.shape[3] > 1:
         return _ConvUp2.apply(x, w, bias)
-    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue)
+    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, False, lazy_sum, lazy_dgrad)
 
 
 _UP2_PHASE = {}     # weight data_ptr -> (weakref(weight), version, phase weights): inference only
@@ -1127,11 +1165,11 @@ def conv_up2_inference(x, w, bias=None, relu=False):
     return conv_fwd_raw(x, e[2], bias, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE, 1, EPI_RELU if relu else EPI_NONE)
 
 
-def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
+def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None, lazy_sum=False):
     """conv2d that also hands its input back: `y, x_id = conv2d_fork(x, w)`.  Use x_id wherever else x is consumed
     (the identity branch of a residual block): the two gradients of x are then summed inside the input-gradient GEMM's
     epilogue rather than by autograd's separate accumulation kernel (one full-tensor read-read-write pass per block)."""
-    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, True)
+    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, True, lazy_sum, False)
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
@@ -1467,7 +1505,19 @@ class _BatchNorm(torch.autograd.Function):
         B, C, H, W = x.shape
         HW = H * W
         y = torch.empty_like(x)
-        if training:
+        pend = _take_partials(x)
+        if pend is not None:                                # x is not written yet: its producer left K-split partial sums (see _LAZY_SUMS)
+            if not training:
+                raise RuntimeError("a lazily summed convolution result reached an eval-mode BatchNorm")
+            pws, nparts, poff, pn = pend
+            assert pn == x.numel()
+            stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            check(lib.prn_bn_train_fwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean),
+                                                _p(rvar), B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_partials")
+            LAZY_STATS["fwd"] += 1
+            torch.autograd.graph.increment_version(rmean)
+            torch.autograd.graph.increment_version(rvar)
+        elif training:
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
             if profiling._enabled:
@@ -1504,6 +1554,14 @@ class _BatchNorm(torch.autograd.Function):
         need_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dg = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
+        pend = _take_partials(dy)
+        if pend is not None:                                # dy is not written: the input-gradient GEMM behind it left its K-split partial sums
+            pws, nparts, poff, pn = pend
+            assert pn == dy.numel() and training
+            check(lib.prn_bn_bwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
+                                          B, C, H * W, int(relu), 0, _stream()), "prn_bn_bwd_partials")
+            LAZY_STATS["bwd"] += 1
+            return dx, dg, db, None, None, dres, None, None, None, None
         ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
         # executed bytes: dy and x (and y, when the ReLU mask comes from the output) are read once by the one-pass kernel, twice by the
         # two-pass pair; dx (and the residual's gradient) written once.  ref = the reference operator chain (ReLU bwd + BN bwd + add)

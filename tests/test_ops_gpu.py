@@ -627,6 +627,58 @@ def test_batch_norm_fwd_bwd(B, C, H, W, res, relu, training):
         close(g1, g0, "bn " + n, rtol=5e-4)
 
 
+@pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (2, 512, 128, 12, 20)])
+def test_k_split_sums_left_to_the_batchnorm_kernels_are_bit_identical(B, Cin, Cmid, H, W):
+    """conv1 -> bn1 (forward) and conv3's input gradient -> bn2's backward of a Bottleneck (models/backbone.py:56-66): where the GEMM runs with a K split
+    and the map is small enough for the one-launch BatchNorm kernels, the partial sums are summed by the BatchNorm kernel itself
+    (prn_conv2d_fwd_partials / prn_bn_train_fwd_partials / prn_bn_bwd_partials) -- same values, bit for bit, as with the separate sum launch; and against
+    the fp64 reference.  The third case has no K split under any plan it is run with: the flags must then change nothing."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = (rnd(B, Cin, H, W, seed=1).relu() * 0.7).float()
+    w1 = rnd(Cmid, Cin, 1, 1, seed=2, scale=Cin ** -0.5).float()
+    w3 = rnd(Cin, Cmid, 1, 1, seed=3, scale=Cmid ** -0.5).float()
+    g1, b1 = (rnd(Cmid, seed=4) * 0.2 + 1).float(), rnd(Cmid, seed=5, scale=0.2).float()
+    go = rnd(B, Cin, H, W, seed=6).float().to(d)
+
+    def run(lazy):
+        ops.LAZY_SPLIT_SUM = lazy
+        before = dict(ops.LAZY_STATS)
+        leaves = [t.to(d).requires_grad_(True) for t in (x, w1, w3, g1, b1)]
+        rm, rv = torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d)
+        y1 = ops.conv2d(leaves[0], leaves[1], lazy_sum=True)
+        z1 = ops.batch_norm(y1, leaves[3], leaves[4], rm, rv, True, 1e-5, 0.1, None, True)
+        out = ops.conv2d(z1, leaves[2], lazy_dgrad=True)
+        grads = torch.autograd.grad(out, leaves, go)
+        ops.wgrad_join()
+        took = (ops.LAZY_STATS["fwd"] - before["fwd"], ops.LAZY_STATS["bwd"] - before["bwd"])
+        return [out.detach(), rm, rv] + [g_.detach() for g_ in grads], took
+
+    try:
+        eager, took0 = run(False)
+        lazy, took1 = run(True)
+    finally:
+        ops.LAZY_SPLIT_SUM = True
+    assert took0 == (0, 0)
+    # (the forward GEMM and conv3's input-gradient GEMM have the same descriptor here: Cin -> Cmid, 1x1)
+    split = ops._desc(B, Cin, H, W, Cmid, 1, 1, 0, H, W)[4] is not None and ops.lib.prn_bn_kernel_kind(B, H * W) == 1
+    assert took1 == ((1, 1) if split else (0, 0)), (took1, split)
+    if Cin >= 1024:
+        assert split, "the stage-3 / stage-4 shapes are the ones this exists for"
+    names = ["out", "running_mean", "running_var", "dx", "dw1", "dw3", "dgamma", "dbeta"]
+    for n, a, b in zip(names, eager, lazy):
+        assert torch.equal(a, b), "%s differs between the eager and the lazily summed path (max %.3e)" % (n, (a - b).abs().max().item())
+    # ... and the values themselves against fp64
+    xr, w1r, w3r, g1r, b1r = [t.double().requires_grad_(True) for t in (x, w1, w3, g1, b1)]
+    z = F.relu(F.batch_norm(F.conv2d(xr, w1r), None, None, g1r, b1r, True, 0.1, 1e-5))
+    outr = F.conv2d(z, w3r)
+    gr = torch.autograd.grad(outr, [xr, w1r, w3r, g1r, b1r], go.double().cpu())
+    close(lazy[0], outr, "lazy out", rtol=5e-4)
+    for n, a, b in zip(names[3:], lazy[3:], gr):         # (r.m.s.: a BatchNorm output within rounding of the ReLU's zero flips single elements of dx by O(1))
+        a, b = a.double().cpu(), b.double()
+        assert (a - b).norm().item() <= 2e-3 * b.norm().item(), "lazy %s: rms error %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
+
+
 @pytest.mark.parametrize("B,Ca,Cb,H,W", [(4, 64, 32, 15, 20), (2, 128, 128, 60, 80), (3, 5, 9, 7, 9), (8, 16, 24, 30, 40)])
 def test_batch_norm_relu_cat_equals_two_layers_and_cat(B, Ca, Cb, H, W):
     """cat([relu(bn_a(xa)), relu(bn_b(xb))], 1) with both layers writing into / reading from channel slices of one buffer

@@ -22,7 +22,8 @@ def main():
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), r.get("Stream_Id", "0"), short(r["Kernel_Name"])))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), r.get("Stream_Id", "0"), short(r["Kernel_Name"]),
+                         r.get("Grid_Size", r.get("Grid_Size_X", "?"))))
     rows.sort()
     ends = [i for i, r in enumerate(rows) if r[4].startswith("adam_kernel")]
     if len(ends) < steps + 1:
@@ -60,6 +61,16 @@ def main():
         print("%-20s %9.1f %10.2f %12.2f" % ("%s/%s" % q, len(v) / steps, busy / 1e6 / steps, sum(e - s for s, e, *_ in v) / 1e6 / steps))
         if main_q is None:
             main_q = q
+    if len(sys.argv) > 3:                                   # neighbours of the launches whose name matches argv[3], per queue
+        pat = re.compile(sys.argv[3])
+        ctx = collections.Counter()
+        for q, v in byq.items():
+            for i, r in enumerate(v):
+                if pat.search(r[4]):
+                    ctx[("%s/%s" % q, v[i - 1][4] if i else "-", r[4], r[5], v[i + 1][4] if i + 1 < len(v) else "-")] += 1
+        print("launches matching %r with their neighbours on the same queue (queue | previous | kernel | grid | next):" % sys.argv[3])
+        for k, n in sorted(ctx.items(), key=lambda kv: -kv[1])[:80]:
+            print("  %5.1f /step  %-5s %-40s | %-40s %9s | %-40s" % (n / steps, k[0], k[1][:40], k[2][:40], k[3], k[4][:40]))
     v = byq[main_q]
     gaps = []
     for a, b in zip(v, v[1:]):
