@@ -220,6 +220,16 @@ int64_t prn_gemm_batched_ws_bytes(int M, int C, int P, int nb, const prn_gemm_op
 int prn_gemm_batched(int M, int C, int P, int nb, const float* U, const void* u_images, const float* V, float* Y, void* ws, const prn_gemm_opts* opts,
                      void* stream);
 int prn_winograd_output(const float* Y, const float* bias, const float* addend, float* y, int B, int M, int H, int W, int epilogue, void* stream);
+/* The output transform fused with the operator that consumes the convolution's result, for maps whose channel fits one workgroup's registers
+ * (prn_bn_kernel_kind(B, H * W) == 1: stages 3 / 4 of the backbone) -- one launch and one pass over the tensor less each:
+ *   _bn_fwd: x_out = A^T Y' A (the convolution's result, kept for the backward), then training-mode BatchNorm (+ ReLU) of it -> y, statistics -> stats
+ *            [2M] and the running buffers: conv2 -> bn2 of a Bottleneck (models/backbone.py:60-62).
+ *   _bn_bwd: Y' is the transform-domain result of the input-gradient convolution of conv2, i.e. the gradient of bn1's output; dx = backward of
+ *            BatchNorm (+ ReLU, its sign recomputed from x, stats, gamma, beta) w.r.t. bn1's input x, dgamma / dbeta [M] (models/backbone.py:57-58). */
+int prn_winograd_output_bn_fwd(const float* Yt, float* x_out, float* stats, const float* gamma, const float* beta, float* y, float* running_mean,
+                               float* running_var, int B, int M, int H, int W, float eps, float momentum, int relu, void* stream);
+int prn_winograd_output_bn_bwd(const float* Yt, const float* x, const float* stats, const float* gamma, const float* beta, float* dx, float* dgamma,
+                               float* dbeta, int B, int M, int H, int W, int relu, void* stream);
 /* Weight gradient on the same path: dw = G^T [ sum over tiles (A dy A^T) .* (B^T x B) ] G.
  *   prn_winograd_dy    : dy [B][M][H][W] -> dY' [36][M][P]
  *   prn_gemm_batched_nt: out_z [M][C] = A_z [M][P] * B_z [C][P]^T for z < nb; partial sums [splits][nb][M][C] go to ws

@@ -80,6 +80,8 @@ SIGNATURES = {
     "prn_gemm_batched_ws_bytes": (c_i64, [c_int, c_int, c_int, c_int, _OP]),
     "prn_gemm_batched": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, _OP, P]),
     "prn_winograd_output": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "prn_winograd_output_bn_fwd": (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, c_int, P]),
+    "prn_winograd_output_bn_bwd": (c_int, [P] * 8 + [c_int] * 5 + [P]),
     "prn_winograd_wgrad_ws_bytes": (c_i64, [c_int] * 5 + [_OP]),
     "prn_winograd_dy": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "prn_gemm_batched_nt_splits": (c_int, [c_int] * 4 + [_OP]),

@@ -77,14 +77,14 @@ class Bottleneck(nn.Module):
             return conv_bn(out, self.conv3, self.bn3, relu=True, residual=res)
         # x has a second consumer (the identity branch or the downsample conv): hand it on through the fork so that both
         # gradients of x meet in conv1's input-gradient epilogue instead of in a separate accumulation kernel
-        # (lazy_sum / lazy_dgrad: conv1's result is read by bn1 only, bn2's output by conv3 only -- a K-split GEMM then leaves its partial
-        # sums to the BatchNorm kernel behind it, ops._LAZY_SUMS)
+        # (lazy_sum / lazy_dgrad: a convolution's result is read by the BatchNorm behind it only, a BatchNorm's output by the convolution behind
+        # it only -- a K-split GEMM then leaves its partial sums, a Winograd convolution its output transform, to that BatchNorm kernel: ops._LAZY_SUMS)
         out, x = ops.conv2d_fork(x, self.conv1.weight, lazy_sum=self.bn1.training)
         out = _bn(self.bn1, out, relu=True)
         if isinstance(self.conv2, DeformableConv2d):
             out = self.conv2(out)
         else:
-            out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1)
+            out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, lazy_sum=self.bn2.training, lazy_dgrad=self.bn1.training)
         out = _bn(self.bn2, out, relu=True)
         out = ops.conv2d(out, self.conv3.weight, lazy_dgrad=self.bn2.training)
         res = x

@@ -75,6 +75,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// (a, b) summed over the workgroup in a fixed order (wave shuffles, then the waves' totals in wave order); sm: 2 * (waves per block) doubles
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[nw + w] = b; }
+  __syncthreads();
+  double ra = 0.0, rb = 0.0;
+  for (int i = 0; i < nw; ++i) { ra += sm[i]; rb += sm[nw + i]; }
+  a = ra; b = rb;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Internal (not part of the C ABI): the fixed-order split reductions of prn_conv.hip, shared with prn_dcnv2.hip.

@@ -6,17 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
-  a = wave_sum_d(a);
-  b = wave_sum_d(b);
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[nw + w] = b; }           // sm: 2 * (waves per block) doubles
-  __syncthreads();
-  double ra = 0.0, rb = 0.0;
-  for (int i = 0; i < nw; ++i) { ra += sm[i]; rb += sm[nw + i]; }
-  a = ra; b = rb;
-}
 
 // ------------------------------------------------------------------------------------------- BatchNorm
 // grid (C, S): block (c, s) reduces slice s of every image plane of channel c.  S is chosen by the launcher so that a

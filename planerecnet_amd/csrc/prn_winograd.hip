@@ -177,6 +177,154 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
   }
 }
 
+// ---- output transform + BatchNorm in one launch (small maps) ---------------------------------------------------------------------
+// The layers of the backbone's stages 3 / 4 have <= 12288 values per channel: ONE workgroup owns a channel, transforms all of its tiles
+// (<= 768: three per thread) and keeps the 4x4 outputs in registers, so what follows the 3x3 convolution in the reference -- BatchNorm in
+// training mode (models/backbone.py:60-62), or, in the backward pass, the backward of the BatchNorm + ReLU in front of it (:57-58) --
+// needs no second kernel and no second pass over the tensor.  Dense batches only; the transform arithmetic is winograd_output_kernel's.
+template <int NT>
+__device__ __forceinline__ void wino_tiles_out(const float* __restrict__ Y, int m, int M, int P, int P4, int H, int W, float4 (&o)[NT][4], size_t (&off)[NT],
+                                               int (&rows)[NT]) {
+  const int TW = W >> 2, TH = (H + 3) >> 2;
+  const size_t zs = (size_t)M * P4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int p = threadIdx.x + t * 256;
+    const bool live = p < P;
+    const int q = live ? p : 0;
+    const int tx = q % TW, ty = (q / TW) % TH, b = q / (TW * TH);
+    const float* in = Y + (size_t)m * P4 + q;
+    float v[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) v[k] = in[(size_t)k * zs];          // (unconditional: a dead slot re-reads tile 0)
+    float tt[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float c6[6], r4[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) c6[i] = v[i * 6 + j];
+      at6(c6, r4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tt[i][j] = r4[i];
+    }
+    rows[t] = live ? min(4, H - 4 * ty) : 0;                         // valid rows of the tile (the last tile row may hang over the map)
+    off[t] = (((size_t)b * M + m) * H + 4 * ty) * W + 4 * tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float r4[4];
+      at6(tt[i], r4);
+      o[t][i] = i < rows[t] ? make_float4(r4[0], r4[1], r4[2], r4[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void winograd_output_bn_fwd_kernel(const float* __restrict__ Y, float* __restrict__ xout, float* __restrict__ stats,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ z,
+                                                                     float* __restrict__ rmean, float* __restrict__ rvar, int B, int M, int P, int P4, int H, int W,
+                                                                     float eps, float momentum, int relu) {
+  const int m = blockIdx.x;
+  float4 o[NT][4];
+  size_t off[NT];
+  int rows[NT];
+  wino_tiles_out<NT>(Y, m, M, P, P4, H, W, o, off, rows);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                    // (rows outside the map are zero)
+      const float4 v = o[t][i];
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  __shared__ double sm[16];
+  double d1 = s1, d2 = s2;
+  block_sum2(d1, d2, sm);
+  const double count = (double)B * H * W, mean = d1 / count;
+  double var = d2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mean_f = (float)mean, istd_f = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    stats[m] = mean_f;
+    stats[M + m] = istd_f;
+    if (rmean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[m] = (1.f - momentum) * rmean[m] + momentum * mean_f;
+      rvar[m] = (1.f - momentum) * rvar[m] + momentum * (float)unbiased;
+    }
+  }
+  const float sc = istd_f * gamma[m], sh = beta[m] - mean_f * sc;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= rows[t]) continue;
+      const float4 v = o[t][i];
+      *reinterpret_cast<float4*>(xout + off[t] + (size_t)i * W) = v;
+      float4 r;
+      r.x = fmaf(v.x, sc, sh); r.y = fmaf(v.y, sc, sh); r.z = fmaf(v.z, sc, sh); r.w = fmaf(v.w, sc, sh);
+      if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+      *reinterpret_cast<float4*>(z + off[t] + (size_t)i * W) = r;
+    }
+}
+
+// backward of BatchNorm (+ ReLU, mask recomputed from x as bn_small_bwd_kernel's relu == 2) whose output gradient is the result of a Winograd
+// input-gradient convolution still in the transform domain: dx = gamma * istd * (g - mean(g) - xhat * mean(g * xhat))
+template <int NT>
+__global__ __launch_bounds__(256) void winograd_output_bn_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ x, const float* __restrict__ stats,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int M, int P, int P4, int H,
+                                                                     int W, int relu) {
+  const int m = blockIdx.x;
+  float4 g[NT][4];
+  size_t off[NT];
+  int rows[NT];
+  wino_tiles_out<NT>(Y, m, M, P, P4, H, W, g, off, rows);
+  const float mean = stats[m], istd = stats[M + m], gi = gamma[m] * istd;
+  const float sc = relu ? gi : 0.f, sh = relu ? beta[m] - mean * sc : 0.f;
+  float4 xv[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      xv[t][i] = *reinterpret_cast<const float4*>(x + (i < rows[t] ? off[t] + (size_t)i * W : 0));      // (dead rows re-read element 0; their g is zero)
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4& q = g[t][i];
+      const float4 v = xv[t][i];
+      if (relu) {
+        q.x = fmaf(v.x, sc, sh) > 0.f ? q.x : 0.f; q.y = fmaf(v.y, sc, sh) > 0.f ? q.y : 0.f;
+        q.z = fmaf(v.z, sc, sh) > 0.f ? q.z : 0.f; q.w = fmaf(v.w, sc, sh) > 0.f ? q.w : 0.f;
+      }
+      s1 += (q.x + q.y) + (q.z + q.w);
+      s2 += (q.x * (v.x - mean) + q.y * (v.y - mean)) + (q.z * (v.z - mean) + q.w * (v.w - mean));
+    }
+  s2 *= istd;
+  __shared__ double sm[16];
+  double t1 = s1, t2 = s2;
+  block_sum2(t1, t2, sm);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[m] = (float)t1;
+    if (dgamma) dgamma[m] = (float)t2;
+  }
+  const float inv_count = 1.f / ((float)B * H * W);
+  const float m1 = (float)t1 * inv_count, m2 = (float)t2 * inv_count;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= rows[t]) continue;
+      const float4 q = g[t][i], v = xv[t][i];
+      float4 r;
+      r.x = gi * (q.x - m1 - (v.x - mean) * istd * m2); r.y = gi * (q.y - m1 - (v.y - mean) * istd * m2);
+      r.z = gi * (q.z - m1 - (v.z - mean) * istd * m2); r.w = gi * (q.w - m1 - (v.w - mean) * istd * m2);
+      *reinterpret_cast<float4*>(dx + off[t] + (size_t)i * W) = r;
+    }
+}
+
 // One workgroup = one 32 x 32 (m, c) block of one weight tensor (items are located by bisection over `first`, as in
 // flip_transpose_batched_kernel).  Pass A writes U[z][m][c] with c along the lanes; pass B re-reads the same 36 KiB block
 // (L1/L2 hits) with m along the lanes and writes the rotated-tap transform U'[z][c][m] -- both stores coalesced.
@@ -482,6 +630,40 @@ extern "C" int prn_winograd_output(const float* Y, const float* bias, const floa
 }
 extern "C" int prn_winograd_dy(const float* dy, float* Y, int B, int M, int H, int W, void* stream) {
   return dy_impl(dy, Y, nullptr, B, M, H, W, stream);
+}
+// Output transform of Y' [36][M][P] fused with what consumes the convolution's result when a whole channel fits one workgroup's registers
+// (prn_bn_kernel_kind(B, H * W) == 1, i.e. <= 768 tiles): see winograd_output_bn_fwd_kernel / _bwd_kernel.
+extern "C" int prn_winograd_output_bn_fwd(const float* Yt, float* x_out, float* stats, const float* gamma, const float* beta, float* y, float* running_mean,
+                                          float* running_var, int B, int M, int H, int W, float eps, float momentum, int relu, void* stream) {
+  PRN_REQUIRE(Yt && x_out && stats && gamma && beta && y && M > 0 && M < 65536, "prn_winograd_output_bn_fwd: bad arguments");
+  PRN_REQUIRE(((reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "prn_winograd_output_bn_fwd: tensors must be 16-byte aligned");
+  WSeg g;
+  const int64_t P = make_seg(g, nullptr, B, H, W, "prn_winograd_output_bn_fwd");
+  if (P < 0) return 2;
+  PRN_REQUIRE(prn_bn_kernel_kind(B, H * W) == 1 && P <= 768, "prn_winograd_output_bn_fwd: only for maps the one-launch BatchNorm kernels take");
+  hipStream_t st = (hipStream_t)stream;
+#define PRN_WOB(NT_) hipLaunchKernelGGL((winograd_output_bn_fwd_kernel<NT_>), dim3(M), dim3(256), 0, st, Yt, x_out, stats, gamma, beta, y, running_mean, running_var, \
+                                        B, M, (int)P, (int)pad4(P), H, W, eps, momentum, relu)
+  if (P <= 256) PRN_WOB(1); else if (P <= 512) PRN_WOB(2); else PRN_WOB(3);
+#undef PRN_WOB
+  PRN_CHECK_LAUNCH("prn_winograd_output_bn_fwd");
+  return 0;
+}
+extern "C" int prn_winograd_output_bn_bwd(const float* Yt, const float* x, const float* stats, const float* gamma, const float* beta, float* dx, float* dgamma,
+                                          float* dbeta, int B, int M, int H, int W, int relu, void* stream) {
+  PRN_REQUIRE(Yt && x && stats && gamma && dx && (beta || !relu) && M > 0 && M < 65536, "prn_winograd_output_bn_bwd: bad arguments");
+  PRN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0, "prn_winograd_output_bn_bwd: tensors must be 16-byte aligned");
+  WSeg g;
+  const int64_t P = make_seg(g, nullptr, B, H, W, "prn_winograd_output_bn_bwd");
+  if (P < 0) return 2;
+  PRN_REQUIRE(prn_bn_kernel_kind(B, H * W) == 1 && P <= 768, "prn_winograd_output_bn_bwd: only for maps the one-launch BatchNorm kernels take");
+  hipStream_t st = (hipStream_t)stream;
+#define PRN_WOB(NT_) hipLaunchKernelGGL((winograd_output_bn_bwd_kernel<NT_>), dim3(M), dim3(256), 0, st, Yt, x, stats, gamma, beta, dx, dgamma, dbeta, B, M, (int)P, \
+                                        (int)pad4(P), H, W, relu)
+  if (P <= 256) PRN_WOB(1); else if (P <= 512) PRN_WOB(2); else PRN_WOB(3);
+#undef PRN_WOB
+  PRN_CHECK_LAUNCH("prn_winograd_output_bn_bwd");
+  return 0;
 }
 extern "C" int prn_winograd_dw(const float* partials, float* dw, int M, int C, int splits, void* stream) {
   PRN_REQUIRE(partials && dw && M > 0 && C > 0 && splits > 0, "prn_winograd_dw: bad arguments");

@@ -366,8 +366,11 @@ def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NO
 # which the consumer finds the partial sums.  Producers go lazy only when the caller says that a BatchNorm (training mode, small map) follows
 # (conv2d(..., lazy_sum=True) / lazy_dgrad=True); wgrad_join() -- called once per step -- fails loudly if a registered tensor was never consumed.
 LAZY_SPLIT_SUM = os.environ.get("PRN_LAZY_SPLIT_SUM", "1") == "1"
-_LAZY_SUMS = {}      # data_ptr -> (workspace tensor, number of partial sums, offset of the first one in floats, elements per partial sum)
-LAZY_STATS = {"fwd": 0, "bwd": 0}
+# data_ptr -> ("sum", workspace tensor, number of partial sums, offset of the first one in floats, elements per partial sum): K-split partial sums of a GEMM
+#          -> ("wino", workspace tensor, offset of Y' [36][M][P] in floats, elements of the result): a Winograd convolution before its output transform, which
+#             the BatchNorm kernel applies itself (prn_winograd_output_bn_fwd / _bwd: conv2 -> bn2, conv2's input gradient -> bn1's backward)
+_LAZY_SUMS = {}
+LAZY_STATS = {"fwd": 0, "bwd": 0, "wino_fwd": 0, "wino_bwd": 0}
 
 
 def _take_partials(t):
@@ -648,7 +651,7 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
     if lazy and parts is not None and bias is None and addend is None and epi == EPI_NONE and lazy_bn_ok(B, Ho * Wo) and (y.numel() & 3) == 0:
         # GEMM launch only; the partial sums stay in ws, which the registry keeps alive until the consumer has been launched
         check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), wimg, None, None, _p(y), _p(ws), None, _stream(), 1), "prn_conv2d_fwd")
-        _LAZY_SUMS[y.data_ptr()] = (ws, parts[0], parts[1], y.numel())
+        _LAZY_SUMS[y.data_ptr()] = ("sum", ws, parts[0], parts[1], y.numel())
         return y
     cnt = _counters(x.device) if (nbytes and FUSED_SPLIT_SUM) else None      # K-split layers: the sum inside the GEMM launch (opt-in)
     if profiling._enabled:
@@ -898,7 +901,7 @@ SPLIT_SKIP = set(filter(None, os.environ.get("PRN_SPLIT_SKIP", "").split(","))) 
 WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
 
 
-def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep=None):
+def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep=None, lazy=False):
     """3x3 / stride 1 / pad 1 convolution of x [B,C,H,W] with transform-domain weights U [36,M,C].
     keep: a list that receives the workspace (whose head is V = B^T x B) for conv3x3_winograd_wgrad_raw(..., V=...).
     mode IN_EMBED1: x is the block at (1, 1) of a virtual zero tensor [B,C,H+2,W+4]; the result has that size (include/prn.h)."""
@@ -917,6 +920,15 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         if nb_ws < 0:
             raise RuntimeError(lib.prn_last_error().decode())
     ws = torch.empty(nb_ws // 4, device=x.device, dtype=torch.float32)
+    if lazy and bias is None and addend is None and epi == EPI_NONE and mode == IN_ZERO and P <= 768 and lazy_bn_ok(B, H * W):
+        # input transform and the 36 products only: the output transform is left to the BatchNorm kernel that follows (_LAZY_SUMS)
+        gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
+        check(lib.prn_winograd_input(_p(x), _p(ws), B, C, H, W, mode, _stream()), "prn_winograd_input")
+        check(lib.prn_gemm_batched(M, C, P, 36, _p(U), uimg, _p(ws), ws.data_ptr() + 4 * 36 * C * P, _p(gws) if gws.numel() else None, oref, _stream()), "prn_gemm_batched")
+        _LAZY_SUMS[y.data_ptr()] = ("wino", ws, 36 * C * P, y.numel())
+        if keep is not None and 4 * 36 * C * P <= WINOGRAD_KEEP_V:
+            keep.append(ws)
+        return y
     if profiling._enabled:
         V, Yt = ws[:36 * C * P], ws[36 * C * P:36 * (C + M) * P]
         gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
@@ -979,7 +991,7 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None, lazy=False):
     B, C, H, W = x_shape
     M, _, K, _ = w.shape
     if mode == IN_ZERO and winograd_ok(B, M, H, W, C, K, stride, pad, IN_ZERO, EPI_NONE) and tuple(dy.shape[2:]) == (H, W):
-        return conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, addend, C)
+        return conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, addend, C, lazy=lazy)
     wt = flip_transpose(w)                                  # [C, M, K, K]
     if mode == IN_REFLECT and W % 4 == 0 and tuple(dy.shape[2:]) == (H, W) and winograd_ok(B, M, H + 2, W + 4, C, K, 1, 1, IN_ZERO, EPI_NONE):
         # gradient of the reflect-padded tensor = FULL correlation of dy, on the Winograd path (dy embedded at (1, 1) of a
@@ -1018,14 +1030,14 @@ class _Conv2d(torch.autograd.Function):
         ctx.wino_v = None
         if winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, epi):
             keep = [] if (WINOGRAD_WGRAD and ctx.needs_input_grad[1]) else None
-            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi, keep)
+            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi, keep, lazy=lazy_sum)
             if keep:
                 ctx.wino_v = keep[0]
         else:
             y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi, lazy=lazy_sum and K == 1)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
         ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
-        ctx.lazy_dgrad = lazy_dgrad and K == 1 and stride == 1
+        ctx.lazy_dgrad = lazy_dgrad and K in (1, 3) and stride == 1
         ctx.bias = bias_param
         ctx.fork = fork
         if fork:
@@ -1509,12 +1521,19 @@ class _BatchNorm(torch.autograd.Function):
         if pend is not None:                                # x is not written yet: its producer left K-split partial sums (see _LAZY_SUMS)
             if not training:
                 raise RuntimeError("a lazily summed convolution result reached an eval-mode BatchNorm")
-            pws, nparts, poff, pn = pend
-            assert pn == x.numel()
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-            check(lib.prn_bn_train_fwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean),
-                                                _p(rvar), B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_partials")
-            LAZY_STATS["fwd"] += 1
+            if pend[0] == "wino":
+                _, pws, poff, pn = pend
+                assert pn == x.numel() and residual is None
+                check(lib.prn_winograd_output_bn_fwd(pws.data_ptr() + 4 * poff, _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(rmean), _p(rvar), B, C, H, W,
+                                                     eps, momentum, int(relu), _stream()), "prn_winograd_output_bn_fwd")
+                LAZY_STATS["wino_fwd"] += 1
+            else:
+                _, pws, nparts, poff, pn = pend
+                assert pn == x.numel()
+                check(lib.prn_bn_train_fwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean),
+                                                    _p(rvar), B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_partials")
+                LAZY_STATS["fwd"] += 1
             torch.autograd.graph.increment_version(rmean)
             torch.autograd.graph.increment_version(rvar)
         elif training:
@@ -1556,11 +1575,19 @@ class _BatchNorm(torch.autograd.Function):
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         pend = _take_partials(dy)
         if pend is not None:                                # dy is not written: the input-gradient GEMM behind it left its K-split partial sums
-            pws, nparts, poff, pn = pend
-            assert pn == dy.numel() and training
-            check(lib.prn_bn_bwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
-                                          B, C, H * W, int(relu), 0, _stream()), "prn_bn_bwd_partials")
-            LAZY_STATS["bwd"] += 1
+            assert training
+            if pend[0] == "wino":
+                _, pws, poff, pn = pend
+                assert pn == dy.numel() and not has_res and y is None
+                check(lib.prn_winograd_output_bn_bwd(pws.data_ptr() + 4 * poff, _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dg), _p(db), B, C, H, W,
+                                                     int(relu), _stream()), "prn_winograd_output_bn_bwd")
+                LAZY_STATS["wino_bwd"] += 1
+            else:
+                _, pws, nparts, poff, pn = pend
+                assert pn == dy.numel()
+                check(lib.prn_bn_bwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
+                                              B, C, H * W, int(relu), 0, _stream()), "prn_bn_bwd_partials")
+                LAZY_STATS["bwd"] += 1
             return dx, dg, db, None, None, dres, None, None, None, None
         ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
         # executed bytes: dy and x (and y, when the ReLU mask comes from the output) are read once by the one-pass kernel, twice by the

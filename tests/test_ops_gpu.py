@@ -679,6 +679,62 @@ def test_k_split_sums_left_to_the_batchnorm_kernels_are_bit_identical(B, Cin, Cm
         assert (a - b).norm().item() <= 2e-3 * b.norm().item(), "lazy %s: rms error %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
 
 
+@pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (4, 256, 64, 18, 28)])
+def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kernels(B, Cin, Cmid, H, W):
+    """conv1 -> bn1 -> conv2 (3x3, Winograd) -> bn2 -> conv3 as models/backbone.py:56-66 chains them, once with every launch of its own and once with
+    (i) the K-split sums of conv1 / of conv3's input gradient and (ii) the Winograd OUTPUT TRANSFORM of conv2 / of conv2's input gradient left to the
+    one-launch BatchNorm kernels behind them (prn_winograd_output_bn_fwd / _bwd).  (ii) sums the channel statistics in another order, so the two runs agree
+    to fp32 rounding, not bit for bit; both against fp64.  The last case is too small for any K split: only (ii) is exercised."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = (rnd(B, Cin, H, W, seed=1).relu() * 0.7).float()
+    w1 = rnd(Cmid, Cin, 1, 1, seed=2, scale=Cin ** -0.5).float()
+    w2 = rnd(Cmid, Cmid, 3, 3, seed=8, scale=(9 * Cmid) ** -0.5).float()
+    w3 = rnd(Cin, Cmid, 1, 1, seed=3, scale=Cmid ** -0.5).float()
+    g1, b1 = (rnd(Cmid, seed=4) * 0.2 + 1).float(), rnd(Cmid, seed=5, scale=0.2).float()
+    g2, b2 = (rnd(Cmid, seed=9) * 0.2 + 1).float(), rnd(Cmid, seed=10, scale=0.2).float()
+    go = rnd(B, Cin, H, W, seed=6).float().to(d)
+    assert ops.winograd_ok(B, Cmid, H, W, Cmid, 3, 1, 1, ops.IN_ZERO, ops.EPI_NONE)
+
+    def run(lazy):
+        ops.LAZY_SPLIT_SUM = lazy
+        before = dict(ops.LAZY_STATS)
+        leaves = [t.to(d).requires_grad_(True) for t in (x, w1, w2, w3, g1, b1, g2, b2)]
+        rms = [torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d), torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d)]
+        y1 = ops.conv2d(leaves[0], leaves[1], lazy_sum=True)
+        z1 = ops.batch_norm(y1, leaves[4], leaves[5], rms[0], rms[1], True, 1e-5, 0.1, None, True)
+        y2 = ops.conv2d(z1, leaves[2], pad=1, lazy_sum=True, lazy_dgrad=True)
+        z2 = ops.batch_norm(y2, leaves[6], leaves[7], rms[2], rms[3], True, 1e-5, 0.1, None, True)
+        out = ops.conv2d(z2, leaves[3], lazy_dgrad=True)
+        grads = torch.autograd.grad(out, leaves, go)
+        ops.wgrad_join()
+        took = {k: ops.LAZY_STATS[k] - before[k] for k in before}
+        return [out.detach()] + rms + [g_.detach() for g_ in grads], took
+
+    try:
+        eager, took0 = run(False)
+        lazy, took1 = run(True)
+    finally:
+        ops.LAZY_SPLIT_SUM = True
+    assert not any(took0.values())
+    assert took1["wino_fwd"] == 1 and took1["wino_bwd"] == 1, took1
+    if Cin >= 1024:
+        assert took1["fwd"] == 1 and took1["bwd"] == 1, took1
+    names = ["out", "rm1", "rv1", "rm2", "rv2", "dx", "dw1", "dw2", "dw3", "dg1", "db1", "dg2", "db2"]
+    for n, a, b in zip(names, eager, lazy):
+        a, b = a.double(), b.double()
+        assert (a - b).norm().item() <= 2e-5 * b.norm().item() + 1e-12, "%s: eager vs lazy rms difference %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
+    xr, w1r, w2r, w3r, g1r, b1r, g2r, b2r = [t.double().requires_grad_(True) for t in (x, w1, w2, w3, g1, b1, g2, b2)]
+    z = F.relu(F.batch_norm(F.conv2d(xr, w1r), None, None, g1r, b1r, True, 0.1, 1e-5))
+    z = F.relu(F.batch_norm(F.conv2d(z, w2r, padding=1), None, None, g2r, b2r, True, 0.1, 1e-5))
+    outr = F.conv2d(z, w3r)
+    gr = torch.autograd.grad(outr, [xr, w1r, w2r, w3r, g1r, b1r, g2r, b2r], go.double().cpu())
+    close(lazy[0], outr, "lazy out", rtol=1e-3)
+    for n, a, b in zip(names[5:], lazy[5:], gr):
+        a, b = a.double().cpu(), b.double()
+        assert (a - b).norm().item() <= 3e-3 * b.norm().item(), "lazy %s: rms error %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
+
+
 @pytest.mark.parametrize("B,Ca,Cb,H,W", [(4, 64, 32, 15, 20), (2, 128, 128, 60, 80), (3, 5, 9, 7, 9), (8, 16, 24, 30, 40)])
 def test_batch_norm_relu_cat_equals_two_layers_and_cat(B, Ca, Cb, H, W):
     """cat([relu(bn_a(xa)), relu(bn_b(xb))], 1) with both layers writing into / reading from channel slices of one buffer
