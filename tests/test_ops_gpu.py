@@ -265,7 +265,7 @@ def test_conv_split_sum_inside_the_gemm_is_bit_identical(shape, monkeypatch):
     w = (torch.randn(M, C * K * K, generator=g) * (C * K * K) ** -0.5).cuda()
     bias = torch.randn(M, generator=g).cuda() if has_b else None
     add = torch.randn(B, M, H, W, generator=g).cuda() if has_a else None
-    _, ref, nbytes, _ = ops._desc(B, C, H, W, M, K, 1, pad, H, W, mode, 1, epi)
+    _, ref, nbytes, _, _ = ops._desc(B, C, H, W, M, K, 1, pad, H, W, mode, 1, epi)
     ws = torch.empty(max(nbytes, 16) // 4, device="cuda")
     cnt = torch.zeros(ops.TILE_COUNTERS, device="cuda", dtype=torch.int32)
     y_two, y_one = torch.empty(B, M, H, W, device="cuda"), torch.empty(B, M, H, W, device="cuda")
@@ -1150,7 +1150,7 @@ def test_split_gemm_is_an_fp32_gemm(M, K, B, HW, bias, add, epi, split_everywher
     out = {}
     for mode in (2, 0):
         ops.set_split_gemm(mode=mode)
-        _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, epi)
+        _, ref, nbytes, _, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, epi)
         assert lib.prn_conv2d_kernel_kind(ref) == (0 if mode == 0 else (3 if ops.gemm_pipe(M, K, B, HW, 1) > 1 else 2))
         ws = torch.full((max(nbytes, 16) // 4,), float("nan"), device="cuda")
         y = torch.full((B, M, HW), float("nan"), device="cuda")
@@ -1200,7 +1200,7 @@ def test_split_gemm_on_operands_spanning_twelve_decades(split_everywhere, split_
     out = {}
     for mode in (2, 0):
         ops.set_split_gemm(mode=mode)
-        _, ref, nbytes, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
+        _, ref, nbytes, _, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
         ws = torch.empty(max(nbytes, 16) // 4, device="cuda")
         y = torch.empty(B, M, HW, device="cuda")
         check(lib.prn_conv2d_fwd(ref, _p(x), _p(w), None, None, _p(y), _p(ws), _stream()), "conv")

@@ -24,7 +24,7 @@ for (M, K, B, HW, dist) in [(1024,256,2,1200,"uniform"),(256,1024,2,1200,"unifor
     out = {}
     for mode in (2, 0):
         ops.set_split_gemm(mode=mode)
-        _, ref, nb, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
+        _, ref, nb, _, _ = ops._desc(B, K, 1, HW, M, 1, 1, 0, 1, HW, 0, 1, 0)
         ws = torch.empty(max(nb,16)//4, device="cuda"); y = torch.full((B,M,HW), float("nan"), device="cuda")
         check(lib.prn_conv2d_fwd(ref, _p(x), _p(w), None, None, _p(y), _p(ws), _s()), "conv"); torch.cuda.synchronize()
         assert bool(torch.isfinite(y).all())
