@@ -409,6 +409,17 @@ int prn_bn_train_fwd_partials(const float* parts, int nparts, int64_t part_strid
                               int relu, void* stream);
 int prn_bn_bwd_partials(const float* dparts, int nparts, int64_t part_stride, const float* x, const float* y, const float* stats, const float* gamma,
                         const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu, int frozen, void* stream);
+/* ... and with the layer's OUTPUT leaving a second time in the form its consumer wants: V = B^T . B [36][C][P4] (P4 = prn_winograd_tiles(B, H, W)), the Winograd
+ * input transform (prn_winograd_input, PRN_IN_ZERO) of y (forward: for the 3x3 / pad-1 convolution that follows, bn1 -> conv2, models/backbone.py:57-60)
+ * or of dx (backward: for the input-gradient convolution of the 3x3 layer in front, bn2 <- conv2) -- the channel's plane goes through LDS, the transform launch
+ * and its pass over the tensor disappear.  [B, C, H, W], W % 4 == 0, prn_bn_kernel_kind(B, H * W) == 1; nparts == 1: `parts` / `dparts` is the tensor itself
+ * (x_out may then be NULL). */
+int prn_bn_train_fwd_winograd(const float* parts, int nparts, int64_t part_stride, float* x_out, float* stats, const float* gamma, const float* beta,
+                              const float* residual, float* y, float* running_mean, float* running_var, float* V, int B, int C, int H, int W, float eps,
+                              float momentum, int relu, void* stream);
+int prn_bn_bwd_winograd(const float* dparts, int nparts, int64_t part_stride, const float* x, const float* y, const float* stats, const float* gamma,
+                        const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, float* V, int B, int C, int H, int W, int relu, int frozen,
+                        void* stream);
 
 /* ---- GroupNorm(32) + ReLU ---------------------------------------------------------------------------------------
  * replaces ATen group_norm fwd/bwd + ReLU: planerecnet.py:340-342,419-421,436-437,450-451,463-464           */

@@ -170,6 +170,8 @@ SIGNATURES = {
     "prn_bn_bwd_from": (c_int, [P, c_i64] + [P] * 10 + [c_int] * 5 + [P]),
     "prn_bn_train_fwd_partials": (c_int, [P, c_int, c_i64] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "prn_bn_bwd_partials": (c_int, [P, c_int, c_i64] + [P] * 9 + [c_int] * 5 + [P]),
+    "prn_bn_train_fwd_winograd": (c_int, [P, c_int, c_i64] + [P] * 9 + [c_int] * 4 + [c_float, c_float, c_int, P]),
+    "prn_bn_bwd_winograd": (c_int, [P, c_int, c_i64] + [P] * 10 + [c_int] * 6 + [P]),
     "prn_gn_relu_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "prn_gn_relu_bwd": (c_int, [P] * 8 + [c_int] * 4 + [P]),
     "prn_resize_bilinear_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),

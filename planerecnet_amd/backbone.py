@@ -12,8 +12,8 @@ from . import ops
 from .dcn import DeformableConv2d
 
 
-def _bn(m, x, residual=None, relu=False):
-    return ops.batch_norm_module(m, x, residual, relu)
+def _bn(m, x, residual=None, relu=False, wino_out=False, wino_grad=False):
+    return ops.batch_norm_module(m, x, residual, relu, wino_out, wino_grad)
 
 
 def folded_bn(conv_w, conv_b, m):
@@ -80,12 +80,13 @@ class Bottleneck(nn.Module):
         # (lazy_sum / lazy_dgrad: a convolution's result is read by the BatchNorm behind it only, a BatchNorm's output by the convolution behind
         # it only -- a K-split GEMM then leaves its partial sums, a Winograd convolution its output transform, to that BatchNorm kernel: ops._LAZY_SUMS)
         out, x = ops.conv2d_fork(x, self.conv1.weight, lazy_sum=self.bn1.training)
-        out = _bn(self.bn1, out, relu=True)
+        plain = self.stride == 1 and not isinstance(self.conv2, DeformableConv2d)    # conv2 may take the Winograd path: the BatchNorm kernels on either side
+        out = _bn(self.bn1, out, relu=True, wino_out=plain)                          # of it then also write its operands' input transforms (ops._WINO_V)
         if isinstance(self.conv2, DeformableConv2d):
             out = self.conv2(out)
         else:
             out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, lazy_sum=self.bn2.training, lazy_dgrad=self.bn1.training)
-        out = _bn(self.bn2, out, relu=True)
+        out = _bn(self.bn2, out, relu=True, wino_grad=plain)
         out = ops.conv2d(out, self.conv3.weight, lazy_dgrad=self.bn2.training)
         res = x
         if self.downsample is not None:

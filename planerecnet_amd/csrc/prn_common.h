@@ -88,6 +88,23 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
   a = ra; b = rb;
 }
 
+// Winograd F(4x4, 3x3), one pass over a row or column of a 6-vector (prn_winograd.hip): o = B^T v (input side), o = A^T m (output side)
+__device__ __forceinline__ void bt6(const float* v, float* o) {
+  o[0] = 4.f * v[0] - 5.f * v[2] + v[4];
+  o[1] = -4.f * (v[1] + v[2]) + v[3] + v[4];
+  o[2] = 4.f * (v[1] - v[2]) - v[3] + v[4];
+  o[3] = -2.f * v[1] - v[2] + 2.f * v[3] + v[4];
+  o[4] = 2.f * v[1] - v[2] - 2.f * v[3] + v[4];
+  o[5] = 4.f * v[1] - 5.f * v[3] + v[5];
+}
+__device__ __forceinline__ void at6(const float* m, float* o) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Internal (not part of the C ABI): the fixed-order split reductions of prn_conv.hip, shared with prn_dcnv2.hip.

@@ -231,13 +231,60 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // launches were ~10 us each, i.e. launch-bound.  NV = float4 groups per thread; needs HW % 4 == 0.
 constexpr int BN_SMALL_MAX = 12288;
 
-template <int NV>
+// The Winograd INPUT transform of a channel whose plane (all B images, <= BN_SMALL_MAX floats) a one-launch BatchNorm kernel has just put in LDS: what
+// winograd_input_kernel<PRN_IN_ZERO> (prn_winograd.hip) computes from global memory -- V[(i*6+j)][c][p] = (B^T d B)[i][j] of the 6x6 patch of tile p -- for
+// the 3x3 / pad-1 convolution that consumes the kernel's output (models/backbone.py:57-60: bn1 -> conv2; in the backward pass bn2's input gradient ->
+// conv2's input-gradient convolution).  Dense batch, W % 4 == 0.
+__device__ __forceinline__ void plane_to_winograd_v(const float* __restrict__ plane, float* __restrict__ V, int c, int C, int B, int H, int W) {
+  const int TW = W >> 2, TH = (H + 3) >> 2, P = B * TH * TW, P4 = (P + 3) & ~3, HW = H * W;
+  const size_t zs = (size_t)C * P4;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const int tx = p % TW, ty = (p / TW) % TH, b = p / (TW * TH);
+    const float* pb = plane + b * HW;
+    const int w0 = 4 * tx;
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int ih = 4 * ty - 1 + i;
+      const bool ok = (unsigned)ih < (unsigned)H;
+      const float* row = pb + (ok ? ih : 0) * W;
+      const float4 q = *reinterpret_cast<const float4*>(row + w0);
+      const bool okl = w0 > 0, okr = w0 + 4 < W;
+      const float l = row[okl ? w0 - 1 : 0], r = row[okr ? w0 + 4 : 0];
+      d[i][0] = (ok && okl) ? l : 0.f;
+      d[i][1] = ok ? q.x : 0.f; d[i][2] = ok ? q.y : 0.f; d[i][3] = ok ? q.z : 0.f; d[i][4] = ok ? q.w : 0.f;
+      d[i][5] = (ok && okr) ? r : 0.f;
+    }
+    float t[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float v[6], o[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = d[i][j];
+      bt6(v, o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+    }
+    float* out = V + (size_t)c * P4 + p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float o[6];
+      bt6(t[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) out[(size_t)(i * 6 + j) * zs] = o[j];
+    }
+  }
+}
+
+template <int NV, bool WINO = false>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
                                                            float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, int HW, float eps,
-                                                           float momentum, int relu, int64_t ybs, int nparts, int64_t pstride, float* __restrict__ xsum) {
+                                                           float momentum, int relu, int64_t ybs, int nparts, int64_t pstride, float* __restrict__ xsum,
+                                                           float* __restrict__ V = nullptr, int H = 0, int W = 0) {
   // nparts > 1: x is the first of `nparts` K-split partial sums of the producing GEMM (pstride elements apart); they are summed here in split
   // order -- bit for bit what reduce_epilogue_kernel would have written -- and the sum goes to xsum (the BatchNorm input the backward reads).
+  __shared__ float wino_plane[WINO ? BN_SMALL_MAX : 4];
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
   const int64_t ydelta = ybs - (int64_t)C * HW;             // y as a channel slice of a wider tensor: extra elements per image
   // All NV loads are issued before anything is consumed: they are UNCONDITIONAL (a lane past the end re-reads element 0 and
@@ -309,17 +356,24 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     size_t oy = off[i];
     if (ydelta) oy += (size_t)(((threadIdx.x + i * 256) * 4) / HW) * ydelta;
     *reinterpret_cast<float4*>(y + oy) = o;
+    if constexpr (WINO) *reinterpret_cast<float4*>(&wino_plane[(threadIdx.x + i * 256) * 4]) = o;
+  }
+  if constexpr (WINO) {                                      // WINO: the output also leaves as B^T y B for the 3x3 convolution behind this layer
+    __syncthreads();
+    plane_to_winograd_v(wino_plane, V, c, C, B, H, W);
   }
 }
 
 // relu: 0 none | 1 mask from y | 2 mask from fmaf(x, sc, sh) (no residual)
-template <int NV>
+template <int NV, bool WINO = false>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int HW, int relu,
-                                                           int frozen, int64_t dbs, int nparts, int64_t pstride) {
+                                                           int frozen, int64_t dbs, int nparts, int64_t pstride, float* __restrict__ V = nullptr, int H = 0,
+                                                           int W = 0) {
   // nparts > 1: dy is the first of `nparts` dense K-split partial sums of the input-gradient GEMM that produced it (see bn_small_fwd_kernel)
+  __shared__ float wino_plane[WINO ? BN_SMALL_MAX : 4];
   const int c = blockIdx.x, n4 = (B * HW) >> 2;
   const int64_t ddelta = dbs - (int64_t)C * HW;
   const float mean = stats[c], istd = stats[C + c], gi = gamma[c] * istd;
@@ -390,6 +444,11 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     o.x = gi * (g[i].x - m1 - (xv[i].x - mean) * istd * m2); o.y = gi * (g[i].y - m1 - (xv[i].y - mean) * istd * m2);
     o.z = gi * (g[i].z - m1 - (xv[i].z - mean) * istd * m2); o.w = gi * (g[i].w - m1 - (xv[i].w - mean) * istd * m2);
     *reinterpret_cast<float4*>(dx + off[i]) = o;
+    if constexpr (WINO) *reinterpret_cast<float4*>(&wino_plane[(threadIdx.x + i * 256) * 4]) = o;
+  }
+  if constexpr (WINO) {                                      // WINO: dx also leaves as B^T dx B for the input-gradient convolution of the 3x3 layer in front
+    __syncthreads();
+    plane_to_winograd_v(wino_plane, V, c, C, B, H, W);
   }
 }
 
@@ -709,6 +768,52 @@ extern "C" int prn_bn_bwd_partials(const float* dparts, int nparts, int64_t part
   if (nv <= 3) PRN_BN_SMALL_BWD(3); else if (nv <= 6) PRN_BN_SMALL_BWD(6); else if (nv <= 10) PRN_BN_SMALL_BWD(10); else PRN_BN_SMALL_BWD(12);
 #undef PRN_BN_SMALL_BWD
   PRN_CHECK_LAUNCH("prn_bn_bwd_partials");
+  return 0;
+}
+
+// ... and with the layer's OUTPUT (forward: y; backward: dx) leaving a second time as the Winograd input transform V = B^T . B [36][C][P4] that the 3x3 /
+// pad-1 convolution behind (forward) / in front of (backward) the layer would compute from it (prn_winograd_input, PRN_IN_ZERO): that launch and its pass
+// over the tensor disappear (models/backbone.py:57-60).  [B, C, H, W] with W % 4 == 0; otherwise the two calls above (nparts >= 1).
+extern "C" int prn_bn_train_fwd_winograd(const float* parts, int nparts, int64_t part_stride, float* x_out, float* stats, const float* gamma, const float* beta,
+                                         const float* residual, float* y, float* running_mean, float* running_var, float* V, int B, int C, int H, int W,
+                                         float eps, float momentum, int relu, void* stream) {
+  const int HW = H * W;
+  PRN_REQUIRE(parts && stats && gamma && beta && y && V && B > 0 && C > 0 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_bn_train_fwd_winograd: bad arguments");
+  PRN_REQUIRE(nparts >= 1 && nparts <= 64 && (nparts == 1 || (x_out && part_stride >= (int64_t)B * C * HW)) && (part_stride & 3) == 0,
+              "prn_bn_train_fwd_winograd: 1..64 partial sums (x_out required beyond one), a multiple of four elements and at least B*C*HW apart");
+  PRN_REQUIRE(bn_small_ok(B, HW), "prn_bn_train_fwd_winograd: only for maps the one-pass kernel takes (prn_bn_kernel_kind(B, HW) == 1)");
+  PRN_REQUIRE(((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+              "prn_bn_train_fwd_winograd: tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = cdiv(B * HW / 4, 256);
+  const int64_t ybs = (int64_t)C * HW;
+#define PRN_BN_SMALL_FWD(NV_) hipLaunchKernelGGL((bn_small_fwd_kernel<NV_, true>), dim3(C), dim3(256), 0, st, parts, stats, gamma, beta, residual, y, \
+                                                 running_mean, running_var, B, C, HW, eps, momentum, relu, ybs, nparts, part_stride, x_out, V, H, W)
+  if (nv <= 3) PRN_BN_SMALL_FWD(3); else if (nv <= 6) PRN_BN_SMALL_FWD(6); else if (nv <= 10) PRN_BN_SMALL_FWD(10); else PRN_BN_SMALL_FWD(12);
+#undef PRN_BN_SMALL_FWD
+  PRN_CHECK_LAUNCH("prn_bn_train_fwd_winograd");
+  return 0;
+}
+
+extern "C" int prn_bn_bwd_winograd(const float* dparts, int nparts, int64_t part_stride, const float* x, const float* y, const float* stats, const float* gamma,
+                                   const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, float* V, int B, int C, int H, int W, int relu,
+                                   int frozen, void* stream) {
+  const int HW = H * W;
+  PRN_REQUIRE(dparts && x && stats && gamma && dx && V && B > 0 && C > 0 && H >= 5 && W >= 4 && (W & 3) == 0, "prn_bn_bwd_winograd: bad arguments");
+  PRN_REQUIRE(nparts >= 1 && nparts <= 64 && (nparts == 1 || part_stride >= (int64_t)B * C * HW) && (part_stride & 3) == 0,
+              "prn_bn_bwd_winograd: 1..64 partial sums, a multiple of four elements and at least B*C*HW apart");
+  PRN_REQUIRE(bn_small_ok(B, HW), "prn_bn_bwd_winograd: only for maps the one-pass kernel takes (prn_bn_kernel_kind(B, HW) == 1)");
+  PRN_REQUIRE((reinterpret_cast<uintptr_t>(dparts) & 15) == 0, "prn_bn_bwd_winograd: the gradient must be 16-byte aligned");
+  PRN_REQUIRE(!relu || y || (beta && !dres), "prn_bn_bwd_winograd: relu needs the forward output, or beta (and no residual) to recompute its sign");
+  if (relu) relu = y ? 1 : 2;
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = cdiv(B * HW / 4, 256);
+  const int64_t dbs = (int64_t)C * HW;
+#define PRN_BN_SMALL_BWD(NV_) hipLaunchKernelGGL((bn_small_bwd_kernel<NV_, true>), dim3(C), dim3(256), 0, st, dparts, x, y, stats, gamma, beta, dx, dres, dgamma, \
+                                                 dbeta, B, C, HW, relu, frozen, dbs, nparts, part_stride, V, H, W)
+  if (nv <= 3) PRN_BN_SMALL_BWD(3); else if (nv <= 6) PRN_BN_SMALL_BWD(6); else if (nv <= 10) PRN_BN_SMALL_BWD(10); else PRN_BN_SMALL_BWD(12);
+#undef PRN_BN_SMALL_BWD
+  PRN_CHECK_LAUNCH("prn_bn_bwd_winograd");
   return 0;
 }
 

@@ -43,23 +43,7 @@ __device__ __forceinline__ TilePos locate(const WSeg& g, int p, int channels) {
   return r;
 }
 
-// o = B^T v
-__device__ __forceinline__ void bt6(const float* v, float* o) {
-  o[0] = 4.f * v[0] - 5.f * v[2] + v[4];
-  o[1] = -4.f * (v[1] + v[2]) + v[3] + v[4];
-  o[2] = 4.f * (v[1] - v[2]) - v[3] + v[4];
-  o[3] = -2.f * v[1] - v[2] + 2.f * v[3] + v[4];
-  o[4] = 2.f * v[1] - v[2] - 2.f * v[3] + v[4];
-  o[5] = 4.f * v[1] - 5.f * v[3] + v[5];
-}
-// o = A^T m
-__device__ __forceinline__ void at6(const float* m, float* o) {
-  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-  o[0] = m[0] + s12 + s34;
-  o[1] = d12 + 2.f * d34;
-  o[2] = s12 + 4.f * s34;
-  o[3] = d12 + 8.f * d34 + m[5];
-}
+// (bt6 / at6, the B^T and A^T passes of the transforms: prn_common.h -- the one-launch BatchNorm kernels of prn_norm.hip use bt6 too)
 // o = G g
 __device__ __forceinline__ void g6(float g0, float g1, float g2, float* o) {
   o[0] = 0.25f * g0;

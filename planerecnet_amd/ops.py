@@ -130,6 +130,7 @@ def wgrad_join():
         n = len(_LAZY_SUMS)
         _LAZY_SUMS.clear()
         raise RuntimeError("%d lazily summed convolution result(s) were never consumed by a BatchNorm kernel (ops.conv2d lazy_sum / lazy_dgrad misuse)" % n)
+    _WINO_V.clear()
     if _SIDE:
         main = torch.cuda.current_stream()
         for st in _SIDE.values():
@@ -370,7 +371,12 @@ LAZY_SPLIT_SUM = os.environ.get("PRN_LAZY_SPLIT_SUM", "1") == "1"
 #          -> ("wino", workspace tensor, offset of Y' [36][M][P] in floats, elements of the result): a Winograd convolution before its output transform, which
 #             the BatchNorm kernel applies itself (prn_winograd_output_bn_fwd / _bwd: conv2 -> bn2, conv2's input gradient -> bn1's backward)
 _LAZY_SUMS = {}
-LAZY_STATS = {"fwd": 0, "bwd": 0, "wino_fwd": 0, "wino_bwd": 0}
+# data_ptr of a WRITTEN tensor -> (V = its Winograd input transform [36][C][P], (B, C, H, W)): left by the BatchNorm kernel that produced the tensor for the 3x3
+# convolution that reads it next (prn_bn_train_fwd_winograd: bn1 -> conv2; prn_bn_bwd_winograd: bn2's input gradient -> conv2's input-gradient convolution).  A
+# consumer that does not find its input here transforms it itself; entries nobody took are dropped at wgrad_join().
+_WINO_V = {}
+BN_WINO_V = os.environ.get("PRN_BN_WINO_V", "1") == "1"      # 0: the consumers transform their inputs themselves (A/B)
+LAZY_STATS = {"fwd": 0, "bwd": 0, "wino_fwd": 0, "wino_bwd": 0, "v_fwd": 0, "v_bwd": 0, "v_used": 0}
 
 
 def _take_partials(t):
@@ -920,14 +926,27 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         if nb_ws < 0:
             raise RuntimeError(lib.prn_last_error().decode())
     ws = torch.empty(nb_ws // 4, device=x.device, dtype=torch.float32)
-    if lazy and bias is None and addend is None and epi == EPI_NONE and mode == IN_ZERO and P <= 768 and lazy_bn_ok(B, H * W):
-        # input transform and the 36 products only: the output transform is left to the BatchNorm kernel that follows (_LAZY_SUMS)
+    pre = _WINO_V.pop(x.data_ptr(), None) if _WINO_V else None
+    if pre is not None and not (pre[1] == (B, C, H, W) and mode == IN_ZERO and not profiling._enabled):
+        pre = None
+    go_lazy = lazy and bias is None and addend is None and epi == EPI_NONE and mode == IN_ZERO and P <= 768 and lazy_bn_ok(B, H * W)
+    if pre is not None or go_lazy:
+        # staged calls: the input transform is skipped when the producer of x left V (_WINO_V); the output transform is left to the BatchNorm kernel
+        # that follows when the caller vouches for one (_LAZY_SUMS)
         gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
-        check(lib.prn_winograd_input(_p(x), _p(ws), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        check(lib.prn_gemm_batched(M, C, P, 36, _p(U), uimg, _p(ws), ws.data_ptr() + 4 * 36 * C * P, _p(gws) if gws.numel() else None, oref, _stream()), "prn_gemm_batched")
-        _LAZY_SUMS[y.data_ptr()] = ("wino", ws, 36 * C * P, y.numel())
+        Vt = ws if pre is None else pre[0]
+        if pre is None:
+            check(lib.prn_winograd_input(_p(x), _p(ws), B, C, H, W, mode, _stream()), "prn_winograd_input")
+        else:
+            LAZY_STATS["v_used"] += 1
+        yt = ws.data_ptr() + 4 * 36 * C * P
+        check(lib.prn_gemm_batched(M, C, P, 36, _p(U), uimg, _p(Vt), yt, _p(gws) if gws.numel() else None, oref, _stream()), "prn_gemm_batched")
+        if go_lazy:
+            _LAZY_SUMS[y.data_ptr()] = ("wino", ws, 36 * C * P, y.numel())
+        else:
+            check(lib.prn_winograd_output(yt, _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
         if keep is not None and 4 * 36 * C * P <= WINOGRAD_KEEP_V:
-            keep.append(ws)
+            keep.append(Vt)                                    # (its head is V: all the weight gradient reads of it)
         return y
     if profiling._enabled:
         V, Yt = ws[:36 * C * P], ws[36 * C * P:36 * (C + M) * P]
@@ -1511,14 +1530,34 @@ def fpn_level(x, w_lat, b_lat, prev, w_out, b_out, relu):
 # ------------------------------------------------------------------------------------------ BatchNorm
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, eps, momentum, relu, wino_out=False, wino_grad=False):
         _dev(x, gamma, beta, rmean, rvar, residual)
         x, residual = _c(x), _c(residual)
         B, C, H, W = x.shape
         HW = H * W
         y = torch.empty_like(x)
         pend = _take_partials(x)
-        if pend is not None:                                # x is not written yet: its producer left K-split partial sums (see _LAZY_SUMS)
+        # wino_out / wino_grad: the 3x3 convolution that reads this layer's output is on the Winograd path -- the kernel then also writes the input transform
+        # of its output (forward) / of its input gradient (backward) for it (_WINO_V)
+        v_ok = BN_WINO_V and training and W % 4 == 0 and residual is None and lazy_bn_ok(B, HW) and winograd_ok(B, C, H, W, C, 3, 1, 1, IN_ZERO, EPI_NONE)
+        ctx.wino_grad = bool(wino_grad and v_ok)
+        if wino_out and v_ok and (pend is None or pend[0] == "sum"):
+            stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            V = torch.empty(36 * C * lib.prn_winograd_tiles(B, H, W), device=x.device, dtype=torch.float32)
+            if pend is None:
+                check(lib.prn_bn_train_fwd_winograd(_p(x), 1, 0, None, _p(stats), _p(gamma), _p(beta), None, _p(y), _p(rmean), _p(rvar), _p(V), B, C, H, W, eps,
+                                                    momentum, int(relu), _stream()), "prn_bn_train_fwd_winograd")
+            else:
+                _, pws, nparts, poff, pn = pend
+                assert pn == x.numel()
+                check(lib.prn_bn_train_fwd_winograd(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(stats), _p(gamma), _p(beta), None, _p(y), _p(rmean), _p(rvar),
+                                                    _p(V), B, C, H, W, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_winograd")
+                LAZY_STATS["fwd"] += 1
+            LAZY_STATS["v_fwd"] += 1
+            _WINO_V[y.data_ptr()] = (V, (B, C, H, W))
+            torch.autograd.graph.increment_version(rmean)
+            torch.autograd.graph.increment_version(rvar)
+        elif pend is not None:                              # x is not written yet: its producer left K-split partial sums (see _LAZY_SUMS)
             if not training:
                 raise RuntimeError("a lazily summed convolution result reached an eval-mode BatchNorm")
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
@@ -1574,6 +1613,20 @@ class _BatchNorm(torch.autograd.Function):
         dg = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         pend = _take_partials(dy)
+        if ctx.wino_grad and (pend is None or pend[0] == "sum"):      # dx also leaves as the input transform conv2's input-gradient convolution wants
+            V = torch.empty(36 * C * lib.prn_winograd_tiles(B, H, W), device=x.device, dtype=torch.float32)
+            if pend is None:
+                check(lib.prn_bn_bwd_winograd(_p(dy), 1, 0, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(V), B, C, H, W,
+                                              int(relu), 0, _stream()), "prn_bn_bwd_winograd")
+            else:
+                _, pws, nparts, poff, pn = pend
+                assert pn == dy.numel()
+                check(lib.prn_bn_bwd_winograd(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
+                                              _p(V), B, C, H, W, int(relu), 0, _stream()), "prn_bn_bwd_winograd")
+                LAZY_STATS["bwd"] += 1
+            LAZY_STATS["v_bwd"] += 1
+            _WINO_V[dx.data_ptr()] = (V, (B, C, H, W))
+            return dx, dg, db, None, None, dres, None, None, None, None, None, None
         if pend is not None:                                # dy is not written: the input-gradient GEMM behind it left its K-split partial sums
             assert training
             if pend[0] == "wino":
@@ -1588,7 +1641,7 @@ class _BatchNorm(torch.autograd.Function):
                 check(lib.prn_bn_bwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
                                               B, C, H * W, int(relu), 0, _stream()), "prn_bn_bwd_partials")
                 LAZY_STATS["bwd"] += 1
-            return dx, dg, db, None, None, dres, None, None, None, None
+            return dx, dg, db, None, None, dres, None, None, None, None, None, None
         ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
         # executed bytes: dy and x (and y, when the ReLU mask comes from the output) are read once by the one-pass kernel, twice by the
         # two-pass pair; dx (and the residual's gradient) written once.  ref = the reference operator chain (ReLU bwd + BN bwd + add)
@@ -1598,7 +1651,7 @@ class _BatchNorm(torch.autograd.Function):
                             ref=4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
             check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
                                  B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
-        return dx, dg, db, None, None, dres, None, None, None, None
+        return dx, dg, db, None, None, dres, None, None, None, None, None, None
 
 
 class _BatchNormCat(torch.autograd.Function):
@@ -1676,19 +1729,20 @@ def batch_norm_relu_cat(ma, xa, mb, xb):
                                float(ma.eps), float(ma.momentum), float(mb.eps), float(mb.momentum))
 
 
-def batch_norm_module(m, x, residual=None, relu=False):
+def batch_norm_module(m, x, residual=None, relu=False, wino_out=False, wino_grad=False):
     """nn.BatchNorm2d.forward (+ residual add + ReLU) on the HIP kernels, including the module's bookkeeping: in training mode
     `num_batches_tracked` advances like nn.BatchNorm2d's (counted on the host and written to the buffer when a state dict
     is read, see _count_batch)."""
     if m.training and m.track_running_stats:
         _count_batch(m)
-    return batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
+    return batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu, wino_out, wino_grad)
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, residual=None, relu=False):
+def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, residual=None, relu=False, wino_out=False, wino_grad=False):
     """F.batch_norm (+ residual add + ReLU) replacement. training=True uses batch statistics and updates the
     running buffers in place (momentum, unbiased variance) like nn.BatchNorm2d."""
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps), float(momentum), bool(relu))
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps), float(momentum), bool(relu), bool(wino_out),
+                            bool(wino_grad))
 
 
 # ------------------------------------------------------------------------------------------ GroupNorm + ReLU

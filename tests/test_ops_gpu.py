@@ -683,7 +683,8 @@ def test_k_split_sums_left_to_the_batchnorm_kernels_are_bit_identical(B, Cin, Cm
 def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kernels(B, Cin, Cmid, H, W):
     """conv1 -> bn1 -> conv2 (3x3, Winograd) -> bn2 -> conv3 as models/backbone.py:56-66 chains them, once with every launch of its own and once with
     (i) the K-split sums of conv1 / of conv3's input gradient and (ii) the Winograd OUTPUT TRANSFORM of conv2 / of conv2's input gradient left to the
-    one-launch BatchNorm kernels behind them (prn_winograd_output_bn_fwd / _bwd).  (ii) sums the channel statistics in another order, so the two runs agree
+    one-launch BatchNorm kernels behind them (prn_winograd_output_bn_fwd / _bwd), and (iii) the Winograd INPUT transforms of conv2's operands written by the
+    BatchNorm kernels in front of them (prn_bn_train_fwd_winograd / prn_bn_bwd_winograd: the consumer's loader work done where the data is in registers).  (ii) sums the channel statistics in another order, so the two runs agree
     to fp32 rounding, not bit for bit; both against fp64.  The last case is too small for any K split: only (ii) is exercised."""
     from planerecnet_amd import ops
     d = dev()
@@ -702,9 +703,9 @@ def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kerne
         leaves = [t.to(d).requires_grad_(True) for t in (x, w1, w2, w3, g1, b1, g2, b2)]
         rms = [torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d), torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d)]
         y1 = ops.conv2d(leaves[0], leaves[1], lazy_sum=True)
-        z1 = ops.batch_norm(y1, leaves[4], leaves[5], rms[0], rms[1], True, 1e-5, 0.1, None, True)
+        z1 = ops.batch_norm(y1, leaves[4], leaves[5], rms[0], rms[1], True, 1e-5, 0.1, None, True, wino_out=True)
         y2 = ops.conv2d(z1, leaves[2], pad=1, lazy_sum=True, lazy_dgrad=True)
-        z2 = ops.batch_norm(y2, leaves[6], leaves[7], rms[2], rms[3], True, 1e-5, 0.1, None, True)
+        z2 = ops.batch_norm(y2, leaves[6], leaves[7], rms[2], rms[3], True, 1e-5, 0.1, None, True, wino_grad=True)
         out = ops.conv2d(z2, leaves[3], lazy_dgrad=True)
         grads = torch.autograd.grad(out, leaves, go)
         ops.wgrad_join()
@@ -718,6 +719,7 @@ def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kerne
         ops.LAZY_SPLIT_SUM = True
     assert not any(took0.values())
     assert took1["wino_fwd"] == 1 and took1["wino_bwd"] == 1, took1
+    assert took1["v_fwd"] == 1 and took1["v_bwd"] == 1 and took1["v_used"] == 2, took1      # (iii) bn1 / bn2's backward also wrote conv2's input transforms
     if Cin >= 1024:
         assert took1["fwd"] == 1 and took1["bwd"] == 1, took1
     names = ["out", "rm1", "rv1", "rm2", "rv2", "dx", "dw1", "dw2", "dw3", "dg1", "db1", "dg2", "db2"]
