@@ -371,7 +371,7 @@ LAZY_SPLIT_SUM = os.environ.get("PRN_LAZY_SPLIT_SUM", "1") == "1"
 #          -> ("wino", workspace tensor, offset of Y' [36][M][P] in floats, elements of the result): a Winograd convolution before its output transform, which
 #             the BatchNorm kernel applies itself (prn_winograd_output_bn_fwd / _bwd: conv2 -> bn2, conv2's input gradient -> bn1's backward)
 _LAZY_SUMS = {}
-# data_ptr of a WRITTEN tensor -> (V = its Winograd input transform [36][C][P], (B, C, H, W)): left by the BatchNorm kernel that produced the tensor for the 3x3
+# data_ptr of a WRITTEN tensor -> (V = its Winograd input transform [36][C][P], (B, C, H, W), weakref to the tensor): left by the BatchNorm kernel that produced the tensor for the 3x3
 # convolution that reads it next (prn_bn_train_fwd_winograd: bn1 -> conv2; prn_bn_bwd_winograd: bn2's input gradient -> conv2's input-gradient convolution).  A
 # consumer that does not find its input here transforms it itself; entries nobody took are dropped at wgrad_join().
 _WINO_V = {}
@@ -927,7 +927,8 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
             raise RuntimeError(lib.prn_last_error().decode())
     ws = torch.empty(nb_ws // 4, device=x.device, dtype=torch.float32)
     pre = _WINO_V.pop(x.data_ptr(), None) if _WINO_V else None
-    if pre is not None and not (pre[1] == (B, C, H, W) and mode == IN_ZERO and not profiling._enabled):
+    # (valid only while the tensor it was computed from is alive -- its address cannot have been handed to another tensor then -- and for this very geometry)
+    if pre is not None and not (pre[2]() is not None and pre[1] == (B, C, H, W) and mode == IN_ZERO and not profiling._enabled):
         pre = None
     go_lazy = lazy and bias is None and addend is None and epi == EPI_NONE and mode == IN_ZERO and P <= 768 and lazy_bn_ok(B, H * W)
     if pre is not None or go_lazy:
@@ -1539,7 +1540,8 @@ class _BatchNorm(torch.autograd.Function):
         pend = _take_partials(x)
         # wino_out / wino_grad: the 3x3 convolution that reads this layer's output is on the Winograd path -- the kernel then also writes the input transform
         # of its output (forward) / of its input gradient (backward) for it (_WINO_V)
-        v_ok = BN_WINO_V and training and W % 4 == 0 and residual is None and lazy_bn_ok(B, HW) and winograd_ok(B, C, H, W, C, 3, 1, 1, IN_ZERO, EPI_NONE)
+        v_ok = ((wino_out or wino_grad) and BN_WINO_V and training and W % 4 == 0 and residual is None and lazy_bn_ok(B, HW)
+                and winograd_ok(B, C, H, W, C, 3, 1, 1, IN_ZERO, EPI_NONE))
         ctx.wino_grad = bool(wino_grad and v_ok)
         if wino_out and v_ok and (pend is None or pend[0] == "sum"):
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
@@ -1554,7 +1556,7 @@ class _BatchNorm(torch.autograd.Function):
                                                     _p(V), B, C, H, W, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_winograd")
                 LAZY_STATS["fwd"] += 1
             LAZY_STATS["v_fwd"] += 1
-            _WINO_V[y.data_ptr()] = (V, (B, C, H, W))
+            _WINO_V[y.data_ptr()] = (V, (B, C, H, W), weakref.ref(y))
             torch.autograd.graph.increment_version(rmean)
             torch.autograd.graph.increment_version(rvar)
         elif pend is not None:                              # x is not written yet: its producer left K-split partial sums (see _LAZY_SUMS)
@@ -1625,7 +1627,7 @@ class _BatchNorm(torch.autograd.Function):
                                               _p(V), B, C, H, W, int(relu), 0, _stream()), "prn_bn_bwd_winograd")
                 LAZY_STATS["bwd"] += 1
             LAZY_STATS["v_bwd"] += 1
-            _WINO_V[dx.data_ptr()] = (V, (B, C, H, W))
+            _WINO_V[dx.data_ptr()] = (V, (B, C, H, W), weakref.ref(dx))
             return dx, dg, db, None, None, dres, None, None, None, None, None, None
         if pend is not None:                                # dy is not written: the input-gradient GEMM behind it left its K-split partial sums
             assert training
