@@ -92,7 +92,8 @@ typedef struct prn_conv_desc {
   int32_t dil;             /* PRN_IN_DILATED: dilation factor of the virtual input                     */
   int32_t epilogue;        /* PRN_EPI_* (fwd only)                                                     */
   int32_t ystride;         /* 0/1: dense output.  2 (fwd only): output pixel (oh,ow) is stored at (2*oh, 2*ow) of  */
-  int32_t yH, yW;          /*    a caller-zeroed [B,M,yH,yW] tensor (input gradient of a stride-2 1x1 conv)    */
+  int32_t yH, yW;          /*    a caller-zeroed [B,M,yH,yW] tensor (input gradient of a stride-2 1x1 conv); `addend` is then read at the OUTPUT's index, and
+                            *    addend == y adds the result into a tensor that already holds another gradient of the same input (no zero fill, no separate sum) */
   int32_t reserved;
   prn_gemm_opts opts;      /* which kernels this descriptor's calls (and its workspace sizes) are planned for  */
 } prn_conv_desc;

@@ -5,11 +5,16 @@ Module tree, parameter names and the plugin contract (`.channels`, `.layers`, `.
 nn.Conv2d / nn.BatchNorm2d instances are used as parameter containers only -- the arithmetic runs in the HIP
 operators (planerecnet_amd.ops): every BatchNorm launch also applies the ReLU and, for bn3, the residual add.
 """
+import os
+
 import torch
 from torch import nn
 
 from . import ops
 from .dcn import DeformableConv2d
+
+
+STAGE_FORK = os.environ.get("PRN_STAGE_FORK", "1") == "1"      # 0: the stage outputs' gradients meet in autograd's accumulation pass (A/B)
 
 
 def _bn(m, x, residual=None, relu=False, wino_out=False, wino_grad=False):
@@ -66,7 +71,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, hand_back=False):
+        """hand_back (training path, blocks with a downsample branch): also return the block's INPUT as handed on by the downsample convolution's fork --
+        whoever else reads that tensor (the FPN / the depth decoder read the stage outputs) takes it from there, so that its gradient joins the
+        downsample convolution's input gradient inside that launch instead of in autograd's separate accumulation pass."""
         if can_fold(self.bn1):                                 # inference: every conv + BN (+ residual + ReLU) is one launch
             out = conv_bn(x, self.conv1, self.bn1, relu=True)
             if isinstance(self.conv2, DeformableConv2d):
@@ -74,7 +82,8 @@ class Bottleneck(nn.Module):
             else:
                 out = conv_bn(out, self.conv2, self.bn2, self.stride, 1, relu=True)
             res = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], self.downsample[0].stride[0])
-            return conv_bn(out, self.conv3, self.bn3, relu=True, residual=res)
+            out = conv_bn(out, self.conv3, self.bn3, relu=True, residual=res)
+            return (out, x) if hand_back else out
         # x has a second consumer (the identity branch or the downsample conv): hand it on through the fork so that both
         # gradients of x meet in conv1's input-gradient epilogue instead of in a separate accumulation kernel
         # (lazy_sum / lazy_dgrad: a convolution's result is read by the BatchNorm behind it only, a BatchNorm's output by the convolution behind
@@ -90,8 +99,13 @@ class Bottleneck(nn.Module):
         out = ops.conv2d(out, self.conv3.weight, lazy_dgrad=self.bn2.training)
         res = x
         if self.downsample is not None:
-            res = _bn(self.downsample[1], ops.conv2d(x, self.downsample[0].weight, stride=self.downsample[0].stride[0]))
-        return _bn(self.bn3, out, residual=res, relu=True)
+            if hand_back:
+                r, x = ops.conv2d_fork(x, self.downsample[0].weight, stride=self.downsample[0].stride[0])
+            else:
+                r = ops.conv2d(x, self.downsample[0].weight, stride=self.downsample[0].stride[0])
+            res = _bn(self.downsample[1], r)
+        out = _bn(self.bn3, out, residual=res, relu=True)
+        return (out, x) if hand_back else out
 
 
 class ResNetBackbone(nn.Module):
@@ -138,7 +152,13 @@ class ResNetBackbone(nn.Module):
         x = ops.max_pool_3x3_s2(x)
         outs = []
         for layer in self.layers:
-            x = layer(x)
+            blocks = list(layer)
+            if STAGE_FORK and outs and isinstance(blocks[0], Bottleneck) and blocks[0].downsample is not None:
+                # the previous stage's output has readers outside the backbone (FPN, depth decoder): they get it from the first block's fork
+                x, outs[-1] = blocks[0](x, hand_back=True)
+                blocks = blocks[1:]
+            for block in blocks:
+                x = block(x)
             outs.append(x)
         return tuple(outs)
 

@@ -367,6 +367,7 @@ def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NO
 # which the consumer finds the partial sums.  Producers go lazy only when the caller says that a BatchNorm (training mode, small map) follows
 # (conv2d(..., lazy_sum=True) / lazy_dgrad=True); wgrad_join() -- called once per step -- fails loudly if a registered tensor was never consumed.
 LAZY_SPLIT_SUM = os.environ.get("PRN_LAZY_SPLIT_SUM", "1") == "1"
+SCATTER_ACCUMULATE = os.environ.get("PRN_SCATTER_ACC", "1") == "1"      # stride-2 1x1 input gradients add into the forked identity's gradient in place (A/B)
 # data_ptr -> ("sum", workspace tensor, number of partial sums, offset of the first one in floats, elements per partial sum): K-split partial sums of a GEMM
 #          -> ("wino", workspace tensor, offset of Y' [36][M][P] in floats, elements of the result): a Winograd convolution before its output transform, which
 #             the BatchNorm kernel applies itself (prn_winograd_output_bn_fwd / _bwd: conv2 -> bn2, conv2's input gradient -> bn1's backward)
@@ -376,7 +377,7 @@ _LAZY_SUMS = {}
 # consumer that does not find its input here transforms it itself; entries nobody took are dropped at wgrad_join().
 _WINO_V = {}
 BN_WINO_V = os.environ.get("PRN_BN_WINO_V", "1") == "1"      # 0: the consumers transform their inputs themselves (A/B)
-LAZY_STATS = {"fwd": 0, "bwd": 0, "wino_fwd": 0, "wino_bwd": 0, "v_fwd": 0, "v_bwd": 0, "v_used": 0}
+LAZY_STATS = {"fwd": 0, "bwd": 0, "wino_fwd": 0, "wino_bwd": 0, "v_fwd": 0, "v_bwd": 0, "v_used": 0, "scatter_acc": 0}
 
 
 def _take_partials(t):
@@ -640,8 +641,9 @@ def split_refresh_all():
 
 
 # ------------------------------------------------------------------------------------------ raw launches
-def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None, lazy=False):
-    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor.
+def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None, lazy=False, scatter_into=None):
+    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor -- or, scatter_into given, ADD it to that
+    position of scatter_into (a dense [B, M, yH, yW] tensor, modified in place and returned: the strided epilogue reads its addend at the output's own index).
     lazy: the caller vouches that the result's only reader is a BatchNorm kernel that can sum K-split partial results itself (_LAZY_SUMS)."""
     B, C, H, W = x.shape
     parts = None
@@ -651,7 +653,11 @@ def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, 
         wimg = split_images(w2d, M, C, 1, (B, Ho * Wo)) if (d_.kind >= 2 and K == 1 and stride == 1) else None      # (tap gather -- 4x4 / stride 2, 1x1 / stride 2 --: images cut per call, tap-major)
     else:
         wimg = None
-        y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
+        if scatter_into is not None:
+            assert addend is None and scatter_into.is_contiguous() and tuple(scatter_into.shape) == (B, M, scatter2[0], scatter2[1])
+            y = addend = scatter_into
+        else:
+            y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
         _, ref, nbytes, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     if lazy and parts is not None and bias is None and addend is None and epi == EPI_NONE and lazy_bn_ok(B, Ho * Wo) and (y.numel() & 3) == 0:
@@ -1034,6 +1040,11 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None, lazy=False):
         # only the even positions of dx are non-zero: run the GEMM over dy's own pixel grid and scatter (4x fewer MACs
         # than gathering through the zero-dilated view)
         return conv_fwd_raw(dy, wt, None, None, C, 1, 1, 0, dy.shape[2], dy.shape[3], scatter2=(H, W))
+    if K == 1 and pad == 0 and SCATTER_ACCUMULATE and addend.is_contiguous() and addend._base is None and tuple(addend.shape) == (B, C, H, W):
+        # ... and with another gradient of the same input (the forked identity's): added INTO that tensor at the even positions -- no zero fill, no
+        # separate sum (the stage outputs of the backbone: FPN / decoder gradient + the next stage's downsample convolution, models/backbone.py:45)
+        LAZY_STATS["scatter_acc"] += 1
+        return conv_fwd_raw(dy, wt, None, None, C, 1, 1, 0, dy.shape[2], dy.shape[3], scatter2=(H, W), scatter_into=addend)
     return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W, IN_DILATED, 2)
 
 

@@ -627,6 +627,38 @@ def test_batch_norm_fwd_bwd(B, C, H, W, res, relu, training):
         close(g1, g0, "bn " + n, rtol=5e-4)
 
 
+@pytest.mark.parametrize("B,C,H,W,M", [(2, 24, 15, 21, 40), (2, 64, 30, 40, 128), (1, 256, 120, 160, 512)])
+def test_stride2_1x1_input_gradient_adds_into_the_forked_gradient_in_place(B, C, H, W, M):
+    """The downsample convolution of a stage's first Bottleneck (1x1, stride 2, models/backbone.py:45) as a fork: the gradient of its input's other readers
+    (FPN lateral, depth decoder) arrives as the forked identity's gradient, and the input gradient of the convolution -- non-zero at the even positions only --
+    is ADDED INTO that tensor by the GEMM's strided epilogue (addend == y): no zero fill, no separate sum.  Against fp64, odd sizes included."""
+    from planerecnet_amd import ops
+    d = dev()
+    x = rnd(B, C, H, W, seed=1)
+    w = rnd(M, C, 1, 1, seed=2, scale=C ** -0.5)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g1, g2 = rnd(B, M, Ho, Wo, seed=3), rnd(B, C, H, W, seed=4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = torch.autograd.grad([F.conv2d(xr, wr, stride=2), xr * 1.0], [xr, wr], [g1, g2])
+    results = {}
+    for acc in (False, True):
+        ops.SCATTER_ACCUMULATE = acc
+        before = ops.LAZY_STATS["scatter_acc"]
+        xd, wd = x.float().to(d).requires_grad_(True), w.float().to(d).requires_grad_(True)
+        try:
+            y, xid = ops.conv2d_fork(xd, wd, stride=2)
+            got = torch.autograd.grad([y, xid * 1.0], [xd, wd], [g1.float().to(d), g2.float().to(d)])
+        finally:
+            ops.SCATTER_ACCUMULATE = True
+        ops.wgrad_join()
+        assert ops.LAZY_STATS["scatter_acc"] - before == (1 if acc else 0)
+        close(got[0], ref[0], "dx (accumulate=%s)" % acc)
+        close(got[1], ref[1], "dw (accumulate=%s)" % acc, rtol=5e-4)
+        results[acc] = got[0]
+    # (the two paths run the products through different launch plans: equal to fp32 rounding of a C-term sum, not bit for bit)
+    assert (results[False] - results[True]).abs().max().item() <= 1e-5 * results[False].abs().max().item()
+
+
 @pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (2, 512, 128, 12, 20)])
 def test_k_split_sums_left_to_the_batchnorm_kernels_are_bit_identical(B, Cin, Cmid, H, W):
     """conv1 -> bn1 (forward) and conv3's input gradient -> bn2's backward of a Bottleneck (models/backbone.py:56-66): where the GEMM runs with a K split
