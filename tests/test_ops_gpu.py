@@ -711,6 +711,31 @@ def test_k_split_sums_left_to_the_batchnorm_kernels_are_bit_identical(B, Cin, Cm
         assert (a - b).norm().item() <= 2e-3 * b.norm().item(), "lazy %s: rms error %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
 
 
+def test_a_handed_over_result_that_no_batchnorm_takes_fails_loudly():
+    """A producer called with lazy_sum=True leaves its result unwritten for the BatchNorm kernel behind it (ops._LAZY_SUMS).  If the caller's promise is
+    broken -- nothing, or an eval-mode BatchNorm, follows -- the mistake must not pass silently: wgrad_join() (called once per training step) raises for a
+    hand-over nobody took, and an eval-mode BatchNorm refuses one."""
+    from planerecnet_amd import ops
+    d = dev()
+    B, Cin, Cmid, H, W = 8, 1024, 256, 30, 40
+    x = rnd(B, Cin, H, W, seed=1).float().to(d)
+    w = rnd(Cmid, Cin, 1, 1, seed=2, scale=Cin ** -0.5).float().to(d)
+    assert ops._desc(B, Cin, H, W, Cmid, 1, 1, 0, H, W)[4] is not None, "this shape runs with a K split: the case the hand-over exists for"
+    with torch.no_grad():
+        y = ops.conv2d(x, w, lazy_sum=True)
+        assert y.data_ptr() in ops._LAZY_SUMS
+        with pytest.raises(RuntimeError, match="never consumed"):
+            ops.wgrad_join()
+        assert not ops._LAZY_SUMS                              # (the registry is clean again)
+        y = ops.conv2d(x, w, lazy_sum=True)
+        g, b_ = torch.ones(Cmid, device=d), torch.zeros(Cmid, device=d)
+        with pytest.raises(RuntimeError, match="eval-mode"):
+            ops.batch_norm(y, g, b_, torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d), False)
+        ops.wgrad_join()                                       # (the refused hand-over was taken out of the registry)
+        # ... and without the flag the same call writes its own result
+        close(ops.conv2d(x, w), F.conv2d(x.double().cpu(), w.double().cpu()), "conv2d without hand-over")
+
+
 @pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (4, 256, 64, 18, 28)])
 def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kernels(B, Cin, Cmid, H, W):
     """conv1 -> bn1 -> conv2 (3x3, Winograd) -> bn2 -> conv3 as models/backbone.py:56-66 chains them, once with every launch of its own and once with
