@@ -637,8 +637,9 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
   if (tiles < 300) {
     splits = (int)(640 / (tiles > 0 ? tiles : 1));
     if (splits > kslices / 8) splits = kslices / 8;
-    static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 4.  Training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; 3 and 4 are within the
-    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 4; }     // noise of a box -- a performance choice only (the fixture's ReLU-boundary channel that 3 splits once tipped is bounded separately by the parity test since round 5)
+    static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 3.  Round 4: training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; since the partial sums of
+    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 3; }     // the stage-3 layers are summed by the BatchNorm kernel that reads them (round 5: one partial tensor less to read there) 43.51 / 43.52 (4) -> 43.35 / 43.30 (3), 43.40 / 43.50 (2).
+                                                                 // A performance choice only (the fixture's ReLU-boundary channel that 3 splits once tipped is bounded separately by the parity test since round 5)
     if (splits > smax) splits = smax;
     if (splits < 1) splits = 1;
   }
