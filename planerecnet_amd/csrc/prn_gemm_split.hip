@@ -640,7 +640,10 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
     static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 3.  Round 4: training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; since the partial sums of
     if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 3; }     // the stage-3 layers are summed by the BatchNorm kernel that reads them (round 5: one partial tensor less to read there) 43.51 / 43.52 (4) -> 43.35 / 43.30 (3), 43.40 / 43.50 (2).
                                                                  // A performance choice only (the fixture's ReLU-boundary channel that 3 splits once tipped is bounded separately by the parity test since round 5)
+    // ... but a launch that reaches the tile floor only with four splits keeps four (the stage-4 reducing layers, 96 tiles: 288 < 300 with three)
+    const int wide = splits > 4 ? 4 : splits;
     if (splits > smax) splits = smax;
+    if (o->split_mode == PRN_SPLIT_PLAN && tiles * splits < o->split_min_tiles && tiles * wide >= o->split_min_tiles) splits = wide;
     if (splits < 1) splits = 1;
   }
   if (o->split_mode == PRN_SPLIT_ALWAYS) return splits;

@@ -56,8 +56,8 @@ def test_split_gemm_plan_is_host_logic():
     lib = _lib.lib
     _, o = _opts()
     assert lib.prn_gemm_pipe(1024, 256, 8, 1200, 1, o) == 1          # stage-3 expand: 640 tiles
-    assert lib.prn_gemm_pipe(256, 1024, 8, 1200, 1, o) == 4          # stage-3 reduce: 160 tiles -> 4 K splits (>= 8 slices each)
-    assert lib.prn_gemm_pipe(512, 2048, 8, 300, 1, o) == 4           # stage-4 reduce: 96 tiles, K = 2048 -> at most 4 splits
+    assert lib.prn_gemm_pipe(256, 1024, 8, 1200, 1, o) == 3          # stage-3 reduce: 160 tiles -> 3 K splits (the cap; >= 8 slices each)
+    assert lib.prn_gemm_pipe(512, 2048, 8, 300, 1, o) == 4           # stage-4 reduce: 96 tiles reach the 300-tile floor only with 4 splits: the cap yields
     assert lib.prn_gemm_pipe(64, 256, 8, 19200, 1, o) == 0           # half-empty row tile
     assert lib.prn_gemm_pipe(256, 256, 1, 1200, 1, o) == 0           # batch-1 launch below the FLOP floor
     assert lib.prn_gemm_pipe(256, 256, 1, 9600, 36, o) == 1          # Winograd products, 36 batched GEMMs
