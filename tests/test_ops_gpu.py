@@ -736,7 +736,7 @@ def test_a_handed_over_result_that_no_batchnorm_takes_fails_loudly():
         close(ops.conv2d(x, w), F.conv2d(x.double().cpu(), w.double().cpu()), "conv2d without hand-over")
 
 
-@pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (4, 256, 64, 18, 28)])
+@pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (4, 256, 64, 18, 28), (5, 256, 64, 20, 28)])     # (last: 175 tiles, a padded tile axis)
 def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kernels(B, Cin, Cmid, H, W):
     """conv1 -> bn1 -> conv2 (3x3, Winograd) -> bn2 -> conv3 as models/backbone.py:56-66 chains them, once with every launch of its own and once with
     (i) the K-split sums of conv1 / of conv3's input gradient and (ii) the Winograd OUTPUT TRANSFORM of conv2 / of conv2's input gradient left to the
