@@ -62,16 +62,28 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const float* __res
   red[threadIdx.x] = dice;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (gsum) {
+    // lava numerators: one wave per image, lanes over the rows (any row order), a shuffle tree -- fixed order; the one-thread loop over P * ML_SPLITS
+    // dependent loads that stood here took 75 us of the loss phase
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B && b < 64; b += 4) {
+      double acc = 0.0;
+      for (int i = lane; i < P; i += 64) {
+        if ((int)img[i] != b) continue;
+        double l = 0;
+        for (int s = 0; s < ML_SPLITS; ++s) l += part[((size_t)i * ML_SPLITS + s) * 4 + 3];
+        acc += l;
+      }
+      acc = wave_sum_d(acc);
+      if (lane == 0) num[b] = acc;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     out[0] = (float)(red[0] / P * w_ins);
     // lava: rows are sorted by image (the loss lays them out image by image): fixed-order sums
     int ok = 0;
     if (gsum) {
-      for (int i = 0; i < P; ++i) {
-        double l = 0;
-        for (int s = 0; s < ML_SPLITS; ++s) l += part[((size_t)i * ML_SPLITS + s) * 4 + 3];
-        num[img[i]] += l;
-      }
       double tot = 0.0;
       for (int b = 0; b < B; ++b)
         if (gsum[b] > 0.f && npos[b] > 0.f) { ++ok; tot += num[b] / fmax((double)gsum[b] * npos[b], 1e-30); }
@@ -400,12 +412,11 @@ __global__ __launch_bounds__(256) void focal_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-__global__ void sum_partials_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int b = 0; b < nb; ++b) t += part[b];
-    out[0] = (float)t;
-  }
+__global__ void sum_partials_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {      // one wave: lanes over the partial sums, a shuffle tree
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 64) t += part[b];
+  t = wave_sum_d(t);
+  if (threadIdx.x == 0) out[0] = (float)t;
 }
 
 __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ label, const float* __restrict__ g,
@@ -443,17 +454,39 @@ __global__ __launch_bounds__(256) void rmse_log_partial_kernel(const float* __re
 }
 
 // out[0] = mean_b sqrt(S_b / n_b); coef[b] = 1 / (B * sqrt(S_b / n_b) * n_b): d out / d pred[b][i] = coef[b] * (log p - log g) / p on valid pixels
-__global__ void rmse_log_final_kernel(const double* __restrict__ part, int nb, int B, float* __restrict__ out, float* __restrict__ coef) {
-  if (threadIdx.x != 0) return;
-  double tot = 0.0;
-  for (int b = 0; b < B; ++b) {
-    double s = 0.0, c = 0.0;
-    for (int k = 0; k < nb; ++k) { s += part[((size_t)b * nb + k) * 2]; c += part[((size_t)b * nb + k) * 2 + 1]; }
-    const double r = sqrt(s / c);
-    tot += r;
-    coef[b] = (float)(1.0 / ((double)B * r * c));
+// (one wave per image, lanes over the partial sums, a shuffle tree: the one-thread loop over B * nb * 2 dependent loads took 83 us of the loss phase)
+__global__ __launch_bounds__(256) void rmse_log_final_kernel(const double* __restrict__ part, int nb, int B, float* __restrict__ out, float* __restrict__ coef) {
+  __shared__ double rs[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (B > 64) {                                            // (no LDS slot per image: the serial form)
+    if (threadIdx.x != 0) return;
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) {
+      double s = 0.0, c = 0.0;
+      for (int k = 0; k < nb; ++k) { s += part[((size_t)b * nb + k) * 2]; c += part[((size_t)b * nb + k) * 2 + 1]; }
+      const double r = sqrt(s / c);
+      tot += r;
+      coef[b] = (float)(1.0 / ((double)B * r * c));
+    }
+    out[0] = (float)(tot / B);
+    return;
   }
-  out[0] = (float)(tot / B);
+  for (int b = wave; b < B; b += 4) {
+    double s = 0.0, c = 0.0;
+    for (int k = lane; k < nb; k += 64) { s += part[((size_t)b * nb + k) * 2]; c += part[((size_t)b * nb + k) * 2 + 1]; }
+    s = wave_sum_d(s); c = wave_sum_d(c);
+    if (lane == 0) {
+      const double r = sqrt(s / c);
+      rs[b] = r;
+      coef[b] = (float)(1.0 / ((double)B * r * c));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) tot += rs[b];
+    out[0] = (float)(tot / B);
+  }
 }
 
 __global__ __launch_bounds__(256) void rmse_log_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ coef,
@@ -499,7 +532,7 @@ extern "C" int prn_rmse_log_fwd(const float* pred, const float* gt, float* out, 
   int nb = cdiv(HW, 256 * 8);
   nb = nb > RED_BLOCKS ? RED_BLOCKS : (nb < 1 ? 1 : nb);
   hipLaunchKernelGGL(rmse_log_partial_kernel, dim3(nb, B), dim3(256), 0, st, pred, gt, ws, HW, min_depth, clamp);
-  hipLaunchKernelGGL(rmse_log_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, B, out, coef);
+  hipLaunchKernelGGL(rmse_log_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, B, out, coef);
   PRN_CHECK_LAUNCH("prn_rmse_log_fwd");
   return 0;
 }
@@ -555,22 +588,24 @@ __global__ __launch_bounds__(256) void vnl_trim_region_kernel(const double* __re
 
 // out[b] = sum over the image's counted regions of seg_sum / (m - drop)  /  (planes + [non-planar region counted]);
 // seg_coef[s] = d out[img] / d (a kept loss of region s)
-__global__ void vnl_trim_final_kernel(const double* __restrict__ seg_sum, const int* __restrict__ seg_m, const unsigned char* __restrict__ seg_is_plane,
-                                      const int64_t* __restrict__ seg_img, const double* __restrict__ nplanes, int nseg, int B, double* __restrict__ out,
-                                      double* __restrict__ seg_coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int b = 0; b < B; ++b) {
+// (one wave per image, lanes over the regions: the one-thread double loop over B * nseg took 64 us of the loss phase)
+__global__ __launch_bounds__(256) void vnl_trim_final_kernel(const double* __restrict__ seg_sum, const int* __restrict__ seg_m, const unsigned char* __restrict__ seg_is_plane,
+                                                             const int64_t* __restrict__ seg_img, const double* __restrict__ nplanes, int nseg, int B, double* __restrict__ out,
+                                                             double* __restrict__ seg_coef) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < B; b += 4) {
     double tot = 0.0, extra = 0.0;
-    for (int s = 0; s < nseg; ++s) {
+    for (int s = lane; s < nseg; s += 64) {
       if (seg_img[s] != b) continue;
       const int m = seg_m[s], drop = m / 4;
       const bool np_ok = !seg_is_plane[s] && m > 0, use = seg_is_plane[s] || np_ok;
       if (use) tot += seg_sum[s] / (double)(m - drop);      // (a plane without a valid triplet: 0 / 0 = NaN like the reference)
       if (np_ok) extra += 1.0;
     }
+    tot = wave_sum_d(tot); extra = wave_sum_d(extra);
     const double den = nplanes[b] + extra;
-    out[b] = tot / den;
-    for (int s = 0; s < nseg; ++s) {
+    if (lane == 0) out[b] = tot / den;
+    for (int s = lane; s < nseg; s += 64) {
       if (seg_img[s] != b) continue;
       const int m = seg_m[s], drop = m / 4;
       const bool use = seg_is_plane[s] || m > 0;
@@ -608,7 +643,7 @@ extern "C" int prn_vnl_trim_fwd(const double* loss, const unsigned char* valid, 
               "prn_vnl_trim_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(vnl_trim_region_kernel, dim3(nseg), dim3(256), 0, st, loss, valid, order, seg_start, nseg, n, seg_sum, seg_m);
-  hipLaunchKernelGGL(vnl_trim_final_kernel, dim3(1), dim3(64), 0, st, (const double*)seg_sum, (const int*)seg_m, seg_is_plane, seg_img, nplanes, nseg, B, out,
+  hipLaunchKernelGGL(vnl_trim_final_kernel, dim3(1), dim3(256), 0, st, (const double*)seg_sum, (const int*)seg_m, seg_is_plane, seg_img, nplanes, nseg, B, out,
                      seg_coef);
   PRN_CHECK_LAUNCH("prn_vnl_trim_fwd");
   return 0;
