@@ -539,12 +539,14 @@ int prn_rmse_log_bwd(const float* pred, const float* gt, const float* coef, cons
  * quarter dropped, the rest averaged (NaN losses count as kept zeros); per image the regions' means summed over (planes + 1 if the non-planar
  * region had a valid triplet).  loss [n] double, valid [n], seg [n] region of each triplet (contiguous runs), seg_start [nseg];
  *   prn_vnl_trim_key: key = 4 seg + (valid ? (NaN ? 1.5 : loss) : 2) -- sort it (any sort), order = the permutation;
- *   prn_vnl_trim_fwd: out [B]; seg_sum / seg_m / seg_coef [nseg] are kept for the backward pass;
+ *   prn_vnl_trim_fwd: out [B]; seg_sum / seg_m / seg_coef [nseg] are kept for the backward pass; ws: prn_vnl_trim_ws_bytes(nseg) bytes (every region
+ *                     is summed in 16 chunks, added in chunk order: the regions' sizes differ by three orders of magnitude);
  *   prn_vnl_trim_bwd: dloss [n] = g_out[image] * d out / d loss (one coefficient per kept triplet, 0 elsewhere). */
 int prn_vnl_trim_key(const double* loss, const unsigned char* valid, const int64_t* seg, double* key, int n, void* stream);
 int prn_vnl_trim_fwd(const double* loss, const unsigned char* valid, const int64_t* order, const int64_t* seg_start, const unsigned char* seg_is_plane,
                      const int64_t* seg_img, const double* nplanes, int nseg, int n, int B, double* out, double* seg_sum, int* seg_m, double* seg_coef,
-                     void* stream);
+                     void* ws, void* stream);
+int64_t prn_vnl_trim_ws_bytes(int nseg);
 int prn_vnl_trim_bwd(const double* loss, const int64_t* order, const int64_t* seg_start, const int* seg_m, const double* seg_coef, const int64_t* seg_img,
                      const double* g_out, int nseg, int n, double* dloss, void* stream);
 

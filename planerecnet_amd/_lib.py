@@ -142,7 +142,8 @@ SIGNATURES = {
     "prn_depth_metrics_ws_doubles": (c_int, []),
     "prn_depth_metrics": (c_int, [P, P, P, P, c_i64, c_float, c_float, P]),
     "prn_vnl_trim_key": (c_int, [P, P, P, P, c_int, P]),
-    "prn_vnl_trim_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P]),
+    "prn_vnl_trim_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "prn_vnl_trim_ws_bytes": (c_i64, [c_int]),
     "prn_vnl_trim_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P]),
     "prn_loss_ws_doubles": (c_int, [c_int]),
     "prn_focal_sum_fwd": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),

@@ -559,40 +559,73 @@ __global__ __launch_bounds__(256) void vnl_trim_key_kernel(const double* __restr
   key[i] = (double)seg[i] * 4.0 + (valid[i] ? (isnan(l) ? 1.5 : l) : 2.0);      // valid ascending (losses are in [0, 1]), NaN, invalid
 }
 
-// one workgroup per region s: sorted positions [seg_start[s], seg_start[s+1]) hold its triplets, the m valid ones first
-__global__ __launch_bounds__(256) void vnl_trim_region_kernel(const double* __restrict__ loss, const unsigned char* __restrict__ valid,
-                                                              const int64_t* __restrict__ order, const int64_t* __restrict__ seg_start, int nseg, int n,
-                                                              double* __restrict__ seg_sum, int* __restrict__ seg_m) {
-  const int s = blockIdx.x;
-  const int a = (int)seg_start[s], b = s + 1 < nseg ? (int)seg_start[s + 1] : n;
-  __shared__ int cnt[4];
-  __shared__ double part[4];
+// Region s: sorted positions [seg_start[s], seg_start[s+1]) hold its triplets, the m valid ones first.  The regions differ in size by three orders of
+// magnitude (a non-planar region: ~1e5 triplets, a small plane: a few hundred), and one workgroup per region took as long as the largest one (187 us): every
+// region is cut into VT_CH chunks of max(1024, size / VT_CH) positions, grid (nseg, VT_CH) -- first the valid counts per chunk (the kept range [drop, m) needs the
+// region's total), then the kept sums per chunk; the chunks are added in chunk order by vnl_trim_final_kernel (fixed order: deterministic).
+constexpr int VT_CH = 16;
+__device__ __forceinline__ void vt_chunk(const int64_t* __restrict__ seg_start, int nseg, int n, int s, int c, int& a, int& lo, int& hi) {
+  a = (int)seg_start[s];
+  const int b = s + 1 < nseg ? (int)seg_start[s + 1] : n, size = b - a;
+  const int chk = max(1024, (size + VT_CH - 1) / VT_CH);
+  lo = min(b, a + c * chk);
+  hi = min(b, lo + chk);
+}
+__global__ __launch_bounds__(256) void vnl_trim_count_kernel(const unsigned char* __restrict__ valid, const int64_t* __restrict__ order,
+                                                             const int64_t* __restrict__ seg_start, int nseg, int n, int* __restrict__ cnt) {
+  const int s = blockIdx.x, c = blockIdx.y;
+  int a, lo, hi;
+  vt_chunk(seg_start, nseg, n, s, c, a, lo, hi);
+  __shared__ int wc[4];
   int m = 0;
-  for (int j = a + threadIdx.x; j < b; j += 256) m += valid[order[j]] ? 1 : 0;
+  for (int j = lo + threadIdx.x; j < hi; j += 256) m += valid[order[j]] ? 1 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
-  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = m;
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = m;
   __syncthreads();
-  m = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  if (threadIdx.x == 0) cnt[s * VT_CH + c] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+__global__ __launch_bounds__(256) void vnl_trim_sum_kernel(const double* __restrict__ loss, const int64_t* __restrict__ order, const int64_t* __restrict__ seg_start,
+                                                           int nseg, int n, const int* __restrict__ cnt, double* __restrict__ part, int* __restrict__ seg_m) {
+  const int s = blockIdx.x, c = blockIdx.y;
+  int a, lo, hi;
+  vt_chunk(seg_start, nseg, n, s, c, a, lo, hi);
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < VT_CH; ++k) m += cnt[s * VT_CH + k];
   const int drop = m / 4;
+  lo = max(lo, a + drop);
+  hi = min(hi, a + m);
+  __shared__ double wp[4];
   double acc = 0.0;
-  for (int j = a + drop + threadIdx.x; j < a + m; j += 256) {
+  for (int j = lo + threadIdx.x; j < hi; j += 256) {
     const double l = loss[order[j]];
     acc += isnan(l) ? 0.0 : l;
   }
   acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  if ((threadIdx.x & 63) == 0) wp[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) { seg_sum[s] = (part[0] + part[1]) + (part[2] + part[3]); seg_m[s] = m; }
+  if (threadIdx.x == 0) {
+    part[s * VT_CH + c] = (wp[0] + wp[1]) + (wp[2] + wp[3]);
+    if (c == 0) seg_m[s] = m;
+  }
 }
 
 // out[b] = sum over the image's counted regions of seg_sum / (m - drop)  /  (planes + [non-planar region counted]);
 // seg_coef[s] = d out[img] / d (a kept loss of region s)
 // (one wave per image, lanes over the regions: the one-thread double loop over B * nseg took 64 us of the loss phase)
-__global__ __launch_bounds__(256) void vnl_trim_final_kernel(const double* __restrict__ seg_sum, const int* __restrict__ seg_m, const unsigned char* __restrict__ seg_is_plane,
-                                                             const int64_t* __restrict__ seg_img, const double* __restrict__ nplanes, int nseg, int B, double* __restrict__ out,
+__global__ __launch_bounds__(256) void vnl_trim_final_kernel(const double* __restrict__ part, double* __restrict__ seg_sum, const int* __restrict__ seg_m,
+                                                             const unsigned char* __restrict__ seg_is_plane, const int64_t* __restrict__ seg_img,
+                                                             const double* __restrict__ nplanes, int nseg, int B, double* __restrict__ out,
                                                              double* __restrict__ seg_coef) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = threadIdx.x; s < nseg; s += 256) {            // the regions' kept sums: their chunks in chunk order
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < VT_CH; ++k) t += part[s * VT_CH + k];
+    seg_sum[s] = t;
+  }
+  __syncthreads();
   for (int b = wave; b < B; b += 4) {
     double tot = 0.0, extra = 0.0;
     for (int s = lane; s < nseg; s += 64) {
@@ -614,18 +647,24 @@ __global__ __launch_bounds__(256) void vnl_trim_final_kernel(const double* __res
   }
 }
 
+// One thread per SORTED position j (its region by bisection over seg_start): the regions differ in size by three orders of magnitude -- a non-planar region
+// holds ~1e5 triplets, a small plane a few hundred -- and the one-workgroup-per-region form of this kernel took as long as its largest region (146 us).
 __global__ __launch_bounds__(256) void vnl_trim_bwd_kernel(const double* __restrict__ loss, const int64_t* __restrict__ order, const int64_t* __restrict__ seg_start,
                                                            const int* __restrict__ seg_m, const double* __restrict__ seg_coef, const int64_t* __restrict__ seg_img,
                                                            const double* __restrict__ g, int nseg, int n, double* __restrict__ dloss) {
-  const int s = blockIdx.x;
-  const int a = (int)seg_start[s], b = s + 1 < nseg ? (int)seg_start[s + 1] : n;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  int lo = 0, hi = nseg - 1;                                 // largest s with seg_start[s] <= j (seg_start[0] == 0; empty regions share a start: the last one wins,
+  while (lo < hi) {                                          //  and it is the one that owns position j)
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)seg_start[mid] <= j) lo = mid; else hi = mid - 1;
+  }
+  const int s = lo, a = (int)seg_start[s];
   const int m = seg_m[s], drop = m / 4;
   const double c = seg_coef[s] * g[seg_img[s]];
-  for (int j = a + threadIdx.x; j < b; j += 256) {
-    const int64_t i = order[j];
-    const bool kept = j - a >= drop && j - a < m && !isnan(loss[i]);
-    dloss[i] = kept ? c : 0.0;
-  }
+  const int64_t i = order[j];
+  const bool kept = j - a >= drop && j - a < m && !isnan(loss[i]);
+  dloss[i] = kept ? c : 0.0;
 }
 }  // namespace
 
@@ -636,14 +675,20 @@ extern "C" int prn_vnl_trim_key(const double* loss, const unsigned char* valid, 
   return 0;
 }
 
+extern "C" int64_t prn_vnl_trim_ws_bytes(int nseg) { return nseg > 0 ? (int64_t)nseg * VT_CH * (8 + 4) : -1; }
+
 extern "C" int prn_vnl_trim_fwd(const double* loss, const unsigned char* valid, const int64_t* order, const int64_t* seg_start,
                                 const unsigned char* seg_is_plane, const int64_t* seg_img, const double* nplanes, int nseg, int n, int B, double* out,
-                                double* seg_sum, int* seg_m, double* seg_coef, void* stream) {
-  PRN_REQUIRE(loss && valid && order && seg_start && seg_is_plane && seg_img && nplanes && out && seg_sum && seg_m && seg_coef && nseg > 0 && n > 0 && B > 0,
+                                double* seg_sum, int* seg_m, double* seg_coef, void* ws, void* stream) {
+  PRN_REQUIRE(loss && valid && order && seg_start && seg_is_plane && seg_img && nplanes && out && seg_sum && seg_m && seg_coef && ws && nseg > 0 && n > 0 && B > 0,
               "prn_vnl_trim_fwd: bad arguments");
+  PRN_REQUIRE(nseg <= 65535 && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, "prn_vnl_trim_fwd: at most 65535 regions, 8-byte aligned workspace");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(vnl_trim_region_kernel, dim3(nseg), dim3(256), 0, st, loss, valid, order, seg_start, nseg, n, seg_sum, seg_m);
-  hipLaunchKernelGGL(vnl_trim_final_kernel, dim3(1), dim3(256), 0, st, (const double*)seg_sum, (const int*)seg_m, seg_is_plane, seg_img, nplanes, nseg, B, out,
+  double* part = (double*)ws;                              // [nseg][VT_CH] kept sums, then [nseg][VT_CH] valid counts
+  int* cnt = (int*)(part + (size_t)nseg * VT_CH);
+  hipLaunchKernelGGL(vnl_trim_count_kernel, dim3(nseg, VT_CH), dim3(256), 0, st, valid, order, seg_start, nseg, n, cnt);
+  hipLaunchKernelGGL(vnl_trim_sum_kernel, dim3(nseg, VT_CH), dim3(256), 0, st, loss, order, seg_start, nseg, n, (const int*)cnt, part, seg_m);
+  hipLaunchKernelGGL(vnl_trim_final_kernel, dim3(1), dim3(256), 0, st, (const double*)part, seg_sum, (const int*)seg_m, seg_is_plane, seg_img, nplanes, nseg, B, out,
                      seg_coef);
   PRN_CHECK_LAUNCH("prn_vnl_trim_fwd");
   return 0;
@@ -652,7 +697,7 @@ extern "C" int prn_vnl_trim_fwd(const double* loss, const unsigned char* valid, 
 extern "C" int prn_vnl_trim_bwd(const double* loss, const int64_t* order, const int64_t* seg_start, const int* seg_m, const double* seg_coef,
                                 const int64_t* seg_img, const double* g_out, int nseg, int n, double* dloss, void* stream) {
   PRN_REQUIRE(loss && order && seg_start && seg_m && seg_coef && seg_img && g_out && dloss && nseg > 0 && n > 0, "prn_vnl_trim_bwd: bad arguments");
-  hipLaunchKernelGGL(vnl_trim_bwd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, loss, order, seg_start, seg_m, seg_coef, seg_img, g_out, nseg, n, dloss);
+  hipLaunchKernelGGL(vnl_trim_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, loss, order, seg_start, seg_m, seg_coef, seg_img, g_out, nseg, n, dloss);
   PRN_CHECK_LAUNCH("prn_vnl_trim_bwd");
   return 0;
 }

@@ -436,8 +436,9 @@ class _TrimmedMeans(torch.autograd.Function):
             seg_sum, seg_coef = torch.empty(nseg, device=dev, dtype=torch.float64), torch.empty(nseg, device=dev, dtype=torch.float64)
             seg_m = torch.empty(nseg, device=dev, dtype=torch.int32)
             plane8 = t.seg_is_plane.view(torch.uint8) if t.seg_is_plane.dtype == torch.bool else t.seg_is_plane
+            ws = torch.empty(ops.lib.prn_vnl_trim_ws_bytes(nseg) // 8, device=dev, dtype=torch.float64)
             ops.check(ops.lib.prn_vnl_trim_fwd(ops._p(loss_c), ops._p(v8), ops._p(order), ops._p(t.seg_start), ops._p(plane8), ops._p(t.seg_img), ops._p(t.N),
-                                               nseg, n, t.B, ops._p(out), ops._p(seg_sum), ops._p(seg_m), ops._p(seg_coef), ops._stream()), "prn_vnl_trim_fwd")
+                                               nseg, n, t.B, ops._p(out), ops._p(seg_sum), ops._p(seg_m), ops._p(seg_coef), ops._p(ws), ops._stream()), "prn_vnl_trim_fwd")
             ctx.save_for_backward(loss_c, order, seg_m, seg_coef)
             ctx.t = t
             ctx.fused = True
