@@ -1100,8 +1100,11 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
 // LDS: rows of w are read along (c, tap) and rows of wt written along (m, tap), both contiguous -- the element-wise version
 // read with stride C*KH*KW and fetched 6x the bytes it needed (PMC FETCH_SIZE: 1.0 GB for 172 MB of weights, 0.53 ms).
 // `first` = running count of 32x32 blocks of the preceding items; kernels larger than 3x3 take the element-wise path.
+// (LDS: a 32 x 32 block of a 1x1 weight, or ONE 16 x 16 quarter of a 3x3 block at a time -- 9.3 KB instead of the 37 KB of a whole 3x3 block, which capped every workgroup
+//  of the launch at four per CU: 175 -> 161 us for 460 MB.  Round 5 also tried several blocks per workgroup with one bisection of the item table in the two split-image
+//  kernels: 120 -> 122 / 108 us, i.e. neither the bisection nor the occupancy is what holds these three passes at 1.5-3 TB/s; not kept)
 __global__ __launch_bounds__(256) void flip_transpose_batched_kernel(const prn_flip_item* __restrict__ items, int n, int64_t total) {
-  __shared__ float tile[32 * (32 * 9 + 1)];
+  __shared__ float tile[16 * (16 * 9 + 1)];
   const int64_t blk = blockIdx.x;
   if (blk >= total) return;
   int lo = 0, hi = n - 1;                                  // last item with first <= blk
@@ -1121,17 +1124,24 @@ __global__ __launch_bounds__(256) void flip_transpose_batched_kernel(const prn_f
     }
     return;
   }
-  const int rowlen = ct * KK, pitch = 32 * KK + 1;
-  for (int i = threadIdx.x; i < mt * rowlen; i += 256) {   // read: row m of w, columns (c0 .. c0+ct) x taps, contiguous
-    const int m = i / rowlen, j = i - m * rowlen;
-    tile[m * pitch + j] = it.src[((size_t)(m0 + m) * it.C + c0) * KK + j];
-  }
-  __syncthreads();
-  const int orow = mt * KK;
-  for (int i = threadIdx.x; i < ct * orow; i += 256) {     // write: row c of wt, columns (m0 .. m0+mt) x flipped taps, contiguous
-    const int c = i / orow, j = i - c * orow, m = j / KK, k = j - m * KK;
-    it.dst[((size_t)(c0 + c) * it.M + m0) * KK + j] = tile[m * pitch + c * KK + (KK - 1 - k)];
-  }
+  const int sub = KK == 1 ? 32 : 16;                         // (m, c) extent of one pass through LDS
+  const int pitch = sub * KK + 1;
+  for (int ms = 0; ms < mt; ms += sub)
+    for (int cs = 0; cs < ct; cs += sub) {
+      const int mq = min(sub, mt - ms), cq = min(sub, ct - cs);
+      const int rowlen = cq * KK;
+      __syncthreads();                                       // (the previous pass has been written out)
+      for (int i = threadIdx.x; i < mq * rowlen; i += 256) { // read: row m of w, columns (c0+cs .. +cq) x taps, contiguous
+        const int m = i / rowlen, j = i - m * rowlen;
+        tile[m * pitch + j] = it.src[((size_t)(m0 + ms + m) * it.C + c0 + cs) * KK + j];
+      }
+      __syncthreads();
+      const int orow = mq * KK;
+      for (int i = threadIdx.x; i < cq * orow; i += 256) {   // write: row c of wt, columns (m0+ms .. +mq) x flipped taps, contiguous
+        const int c = i / orow, j = i - c * orow, m = j / KK, k = j - m * KK;
+        it.dst[((size_t)(c0 + cs + c) * it.M + m0 + ms) * KK + j] = tile[m * pitch + c * KK + (KK - 1 - k)];
+      }
+    }
 }
 
 // dx[b,c,h,w] = sum over the virtual padded positions that gather from (h,w)
