@@ -378,7 +378,8 @@ int prn_bn_apply(const float* x, const float* stats, const float* gamma, const f
 /* training forward in two launches (per-channel partial sums, then normalise with the statistics finalised inside the apply
  * kernel): equivalent to prn_bn_stats + prn_bn_apply; stats[2C] receives mean / invstd for the backward. */
 /* 1: training-mode forward / backward of a [B, C, HW] layer run as ONE launch each that reads the activation once (small maps: the
- * channel lives in a workgroup's registers), 0: statistics pass + apply pass -- lets a profiler credit the bytes actually moved. */
+ * channel lives in a workgroup's registers), 0: statistics pass + apply pass -- lets a profiler credit the bytes actually moved; `ws` of
+ * prn_bn_train_fwd[_into] / prn_bn_bwd[_from] may be NULL where this returns 1. */
 int prn_bn_kernel_kind(int B, int HW);
 int prn_bn_train_fwd(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
                      float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps, float momentum,

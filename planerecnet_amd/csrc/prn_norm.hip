@@ -661,7 +661,8 @@ extern "C" int prn_bn_train_fwd(const float* x, float* stats, const float* gamma
 extern "C" int prn_bn_train_fwd_into(const float* x, float* stats, const float* gamma, const float* beta, const float* residual, float* y,
                                      int64_t y_batch_stride, float* running_mean, float* running_var, double* ws, int B, int C, int HW, float eps,
                                      float momentum, int relu, void* stream) {
-  PRN_REQUIRE(x && stats && gamma && beta && y && ws && B > 0 && C > 0 && HW > 0, "prn_bn_train_fwd: bad arguments");
+  PRN_REQUIRE(x && stats && gamma && beta && y && B > 0 && C > 0 && HW > 0, "prn_bn_train_fwd: bad arguments");
+  PRN_REQUIRE(ws || bn_small_ok(B, HW), "prn_bn_train_fwd: the two-launch path needs its workspace (prn_bn_kernel_kind(B, HW) == 0)");
   PRN_REQUIRE(y_batch_stride >= (int64_t)C * HW && ((HW & 3) || ((y_batch_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)),
               "prn_bn_train_fwd_into: bad output batch stride / alignment");
   const int64_t ybs = y_batch_stride;
@@ -696,7 +697,8 @@ extern "C" int prn_bn_bwd(const float* dy, const float* x, const float* y, const
 extern "C" int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const float* x, const float* y, const float* stats, const float* gamma,
                                const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* ws,
                                int B, int C, int HW, int relu, int frozen, void* stream) {
-  PRN_REQUIRE(dy && x && stats && gamma && dx && ws && B > 0 && C > 0 && HW > 0, "prn_bn_bwd: bad arguments");
+  PRN_REQUIRE(dy && x && stats && gamma && dx && B > 0 && C > 0 && HW > 0, "prn_bn_bwd: bad arguments");
+  PRN_REQUIRE(ws || bn_small_ok(B, HW), "prn_bn_bwd: the two-launch path needs its workspace (prn_bn_kernel_kind(B, HW) == 0)");
   PRN_REQUIRE(dy_batch_stride >= (int64_t)C * HW && ((HW & 3) || ((dy_batch_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)),
               "prn_bn_bwd_from: bad gradient batch stride / alignment");
   const int64_t dbs = dy_batch_stride;

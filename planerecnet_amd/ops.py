@@ -191,25 +191,25 @@ _DEFER_SEQ = [0]
 
 
 def _deferred_wgrad(w, inputs, compute, group=None):
-    main = torch.cuda.current_stream()
-    e = _PENDING.get(main.cuda_stream)
+    handle = _raw_stream(_cur_dev())                        # (the Stream object is built once per stream: torch.cuda.current_stream() costs ~4 us per call)
+    e = _PENDING.get(handle)
     if e is None:
-        e = _PENDING[main.cuda_stream] = (main, [])
+        e = _PENDING[handle] = (torch.cuda.current_stream(), [])
     _DEFER_SEQ[0] += 1
-    groups = _GROUPS.get(main.cuda_stream)
+    groups = _GROUPS.get(handle)
     if group is not None and WGRAD_GROUP > 1:
         if groups is None:
-            groups = _GROUPS[main.cuda_stream] = {}
+            groups = _GROUPS[handle] = {}
         pend = groups.setdefault(group, [[], 0])
         pend[0].append((w, inputs))
         pend[1] = _DEFER_SEQ[0]
         if len(pend[0]) >= WGRAD_GROUP:
-            _emit_group(e, main.cuda_stream, group)
+            _emit_group(e, handle, group)
     else:
         e[1].append((w, inputs, compute))
     if groups:
         for key in [k for k, v in groups.items() if _DEFER_SEQ[0] - v[1] >= WGRAD_GROUP_AGE]:       # the backward pass has left that stage
-            _emit_group(e, main.cuda_stream, key)
+            _emit_group(e, handle, key)
     if len(e[1]) >= WGRAD_BATCH:
         _flush_one(e)
 
@@ -321,8 +321,11 @@ def _side_stream(device, main=None):
 _raw_stream = torch._C._cuda_getCurrentRawStream      # raw hipStream_t of the calling thread's current stream (0.3 us vs 10 us)
 
 
+_cur_dev = torch._C._cuda_getDevice                       # (torch.cuda.current_device() without its lazy-init check: 0.2 against 0.9 us, once per launch)
+
+
 def _stream():
-    return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
+    return ctypes.c_void_p(_raw_stream(_cur_dev()))
 
 
 def _p(t):
@@ -1590,7 +1593,8 @@ class _BatchNorm(torch.autograd.Function):
             torch.autograd.graph.increment_version(rvar)
         elif training:
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-            ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
+            # (the fp64 partial sums exist only on the two-launch path; the library checks the pointer there)
+            ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64) if lib.prn_bn_kernel_kind(B, HW) != 1 else None
             if profiling._enabled:
                 small = lib.prn_bn_kernel_kind(B, HW) == 1        # one pass (x read once) or statistics pass + apply pass
                 r_ = 1 if residual is not None else 0
@@ -1655,10 +1659,10 @@ class _BatchNorm(torch.autograd.Function):
                                               B, C, H * W, int(relu), 0, _stream()), "prn_bn_bwd_partials")
                 LAZY_STATS["bwd"] += 1
             return dx, dg, db, None, None, dres, None, None, None, None, None, None
-        ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64)
         # executed bytes: dy and x (and y, when the ReLU mask comes from the output) are read once by the one-pass kernel, twice by the
         # two-pass pair; dx (and the residual's gradient) written once.  ref = the reference operator chain (ReLU bwd + BN bwd + add)
         small = training and lib.prn_bn_kernel_kind(B, H * W) == 1
+        ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64) if not small else None      # (only the two-launch path writes partial sums)
         reads = 2 + (1 if y is not None else 0)
         with profiling.span("bn_small_bwd" if small else "bn_bwd", "hbm", 4.0 * x.numel() * (reads * (1 if small else 2) + 1 + (1 if has_res else 0)),
                             ref=4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
