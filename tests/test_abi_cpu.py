@@ -191,3 +191,36 @@ def test_one_default_plan_in_one_place():
             "print('ok')\n")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
+
+
+def test_producer_to_batchnorm_hand_overs_are_host_logic_until_the_launch():
+    """prn_conv2d_fwd_partials (where phase 1 of a K-split forward leaves its partial sums) is a function of the descriptor alone; the consumers
+    (prn_bn_*_partials / _winograd, prn_winograd_output_bn_*) validate shapes, counts and the one-launch map size on the host before any launch."""
+    from planerecnet_amd import _lib
+    lib = _lib.lib
+    o, _ = _opts()
+    off = ctypes.c_int64(-1)
+
+    def desc(C, M, H, W, opts, B=8):
+        return _lib.ConvDesc(B, C, H, W, M, 1, 1, 1, 0, H, W, 0, 1, 0, 0, 0, 0, 0, opts)
+
+    d = desc(1024, 256, 30, 40, o)                                 # stage-3 reducing layer: three K splits on the split kernel, behind its weight images
+    assert lib.prn_conv2d_fwd_partials(ctypes.byref(d), ctypes.byref(off)) == 3
+    assert off.value == (lib.prn_split_images_bytes(256, 1024, 1) + 255) // 256 * 256 and off.value % 16 == 0
+    d = desc(256, 1024, 30, 40, o)                                 # the expanding layer fills the GPU without a split: nothing to hand over
+    assert lib.prn_conv2d_fwd_partials(ctypes.byref(d), ctypes.byref(off)) == 0
+    zero = _lib.GemmOpts(0, 0, 0, 0, 0.0, 0, 0, 0)
+    d = desc(1024, 256, 30, 40, zero)                              # fp32 kernels only: their own K split, partial sums at the head of the workspace
+    n = lib.prn_conv2d_fwd_partials(ctypes.byref(d), ctypes.byref(off))
+    assert n > 1 and off.value == 0 and lib.prn_conv2d_fwd_ws_bytes(ctypes.byref(d)) == n * 8 * 256 * 1200 * 4
+    assert lib.prn_conv2d_fwd_partials(ctypes.byref(d), None) != 0 and b"null offset" in lib.prn_last_error()
+    # one-launch map sizes: 8 x 30x40 and 8 x 15x20 yes, 8 x 60x80 no; W % 4 != 0 no
+    assert lib.prn_bn_kernel_kind(8, 1200) == 1 and lib.prn_bn_kernel_kind(8, 300) == 1 and lib.prn_bn_kernel_kind(8, 4800) == 0
+    p = ctypes.c_void_p(4096)                                      # (never dereferenced: validation precedes the launch)
+    assert lib.prn_bn_train_fwd_partials(p, 3, 8 * 256 * 4800, p, p, p, p, None, p, None, None, 8, 256, 4800, 1e-5, 0.1, 1, None) != 0
+    assert b"one-pass" in lib.prn_last_error()
+    assert lib.prn_bn_train_fwd_partials(p, 0, 0, p, p, p, p, None, p, None, None, 8, 256, 1200, 1e-5, 0.1, 1, None) != 0      # no partial sums at all
+    assert lib.prn_bn_bwd_partials(p, 3, 100, p, None, p, p, p, p, None, None, None, 8, 256, 1200, 1, 0, None) != 0           # partial sums overlap
+    assert lib.prn_bn_train_fwd_winograd(p, 1, 0, None, p, p, p, None, p, None, None, p, 8, 256, 30, 42, 1e-5, 0.1, 1, None) != 0   # W % 4 != 0
+    assert lib.prn_winograd_output_bn_fwd(p, p, p, p, p, p, None, None, 8, 256, 60, 80, 1e-5, 0.1, 1, None) != 0                    # 2400 tiles: not a one-launch map
+    assert lib.prn_vnl_trim_ws_bytes(600) == 600 * 16 * 12 and lib.prn_vnl_trim_ws_bytes(0) == -1
