@@ -563,3 +563,47 @@ def test_fused_virtual_normal_kernel_equals_operator_chain():
     assert torch.allclose(outs[True][0], outs[False][0], rtol=1e-6, atol=1e-9), (outs[True][0], outs[False][0])
     a, b = outs[True][1].double(), outs[False][1].double()
     assert ((a - b).norm() / b.norm()).item() < 1e-4 and (a - b).abs().max().item() <= 1e-3 * b.abs().max().item()
+
+
+def test_frozen_batchnorm_training_path_ignores_the_hand_overs(setup):
+    """`freeze_bn` (models/planerecnet.py freeze_bn: BatchNorm modules in eval mode while the rest trains -- train.py switches it on for small batches): the
+    backbone then runs its per-operator training path with eval-mode statistics.  None of the round-5 producer -> BatchNorm hand-overs may engage there (they
+    exist for training-mode statistics only); the stage-output fork does.  Outputs and gradients must equal the path with every switch off, and the running
+    statistics must not move."""
+    import copy
+    from planerecnet_amd import backbone as bb, ops
+    net, _, _ = setup
+    net = copy.deepcopy(net)
+    net.train()
+    net.freeze_bn()
+    x = torch.randn(2, 3, 256, 320, generator=torch.Generator().manual_seed(3)).cuda()
+    bns = [m for m in net.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    rm0 = [m.running_mean.clone() for m in bns]
+    params = [p for p in net.backbone.parameters() if p.requires_grad]
+    assert params and all(not m.training and not m.weight.requires_grad for m in bns)
+
+    def run():
+        before = dict(ops.LAZY_STATS)
+        outs = net.backbone(x)
+        loss = sum((o * o).mean() for o in outs)
+        g = torch.autograd.grad(loss, params)
+        ops.wgrad_join()
+        took = {k: ops.LAZY_STATS[k] - before[k] for k in before}
+        return [o.detach() for o in outs], [t.detach() for t in g], took
+
+    saved = (ops.LAZY_SPLIT_SUM, ops.SCATTER_ACCUMULATE, bb.STAGE_FORK)
+    try:
+        ops.LAZY_SPLIT_SUM, ops.SCATTER_ACCUMULATE, bb.STAGE_FORK = False, False, False
+        o0, g0, t0 = run()
+        ops.LAZY_SPLIT_SUM, ops.SCATTER_ACCUMULATE, bb.STAGE_FORK = True, True, True
+        o1, g1, t1 = run()
+    finally:
+        ops.LAZY_SPLIT_SUM, ops.SCATTER_ACCUMULATE, bb.STAGE_FORK = saved
+    assert not any(t0.values())
+    assert t1["scatter_acc"] == 3 and not any(v for k, v in t1.items() if k != "scatter_acc"), t1
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)                                    # the forward pass is the same sequence of launches
+    for a, b in zip(g0, g1):
+        close(b, a, 2e-4, "frozen-BN gradient with / without the stage fork")
+    for m, r in zip(bns, rm0):
+        assert torch.equal(m.running_mean, r)
