@@ -570,10 +570,13 @@ def test_frozen_batchnorm_training_path_ignores_the_hand_overs(setup):
     backbone then runs its per-operator training path with eval-mode statistics.  None of the round-5 producer -> BatchNorm hand-overs may engage there (they
     exist for training-mode statistics only); the stage-output fork does.  Outputs and gradients must equal the path with every switch off, and the running
     statistics must not move."""
-    import copy
     from planerecnet_amd import backbone as bb, ops
-    net, _, _ = setup
-    net = copy.deepcopy(net)
+    from planerecnet_amd.config import cfg
+    from planerecnet_amd.planerecnet import PlaneRecNet
+    _, sd, _ = setup
+    net = PlaneRecNet(cfg)                                         # (a fresh instance: the module-scoped one carries launch caches that do not deep-copy)
+    net.load_state_dict(sd)
+    net = net.cuda()
     net.train()
     net.freeze_bn()
     x = torch.randn(2, 3, 256, 320, generator=torch.Generator().manual_seed(3)).cuda()
