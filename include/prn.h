@@ -487,6 +487,74 @@ int prn_fpn_level_fwd(const float* x, const float* w_lat, const float* b_lat, co
                       const float* b_out, float* lateral, float* p_out, void* ws, int B, int C, int H, int W, int F, int relu, const prn_gemm_opts* opts,
                       void* stream);
 
+/* ---- one residual block of the backbone per call (csrc/prn_bottleneck.hip) -------------------------------------------------------
+ * replaces Bottleneck.forward and its backward (models/backbone.py:53-73; with the deformable conv2 of models/dcn.py:52-67), the unit the
+ * reference's backbone calls 33 times per batch (PlaneRecNet_101), in TRAINING mode (batch statistics):
+ *   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity),  identity = x  or  bn_d(conv_d(x)) (1x1, the block's stride)
+ * A block call issues the launch sequence of the operators above from C -- same launches, same arguments, same results as calling them one by
+ * one -- with the producer -> BatchNorm hand-overs as internal state (PRN_BLK_HANDOVER: a K-split GEMM's partial sums are summed by the
+ * BatchNorm kernel that reads them, a Winograd convolution's output transform is applied by it, and it writes the input transform the next
+ * 3x3 convolution wants; small maps only, prn_bn_kernel_kind == 1).  The caller owns these buffers (save / gsave / ws 256-byte aligned):
+ *   save   (PRN_BLK_SAVE_BYTES)   forward -> backward: conv / BatchNorm results the backward pass reads, the statistics, the DCNv2 offset map and gather
+ *                                 table, conv2's Winograd input transform (PRN_BLK_KEEP_V); the weight gradients read a1, a2, V from it
+ *   gsave  (PRN_BLK_GSAVE_BYTES)  backward -> the caller's weight-gradient launches: d1, d2, d3, dd (gradients of conv1 / conv2 / conv3 / conv_d's
+ *                                 results), dom (of the raw offset | modulator map)
+ *   bn_grads (PRN_BLK_BN_GRAD_FLOATS floats) the BatchNorm parameter gradients dgamma1 | dbeta1 | dgamma2 | dbeta2 | dgamma3 | dbeta3 [| dgamma_d | dbeta_d]
+ *   ws     (PRN_BLK_FWD_WS_BYTES / PRN_BLK_BWD_WS_BYTES) scratch, dead when the call returns (one buffer per stream serves every block)
+ * The weight gradients are the caller's (prn_conv2d_wgrad[_grouped], prn_conv3x3_winograd_wgrad_v, prn_dcnv2_bwd_weight, prn_channel_sum on the
+ * operands above): nothing inside the backward pass reads them, and the caller batches them across blocks on its own stream.
+ * prn_bottleneck_plan fills a caller-owned, relocatable plan (prn_bottleneck_plan_bytes() bytes; no pointers inside) from the descriptor: built
+ * once per shape.  prn_bottleneck_plan_info reports sizes, offsets and which derived operands the plan reads (PRN_BLK_* indices). */
+enum { PRN_BLK_WINOGRAD = 1,      /* conv2 (plain 3x3, stride 1) and its input gradient take the F(4x4,3x3) path where the operator layer's rule allows (W % 4 == 0, H >= 8, >= 64 channels, >= 128 tiles) */
+       PRN_BLK_HANDOVER = 2,      /* the producer -> BatchNorm hand-overs described above */
+       PRN_BLK_KEEP_V = 4,        /* conv2's Winograd input transform stays in `save` for its weight gradient (up to 128 MB) */
+       PRN_BLK_SCATTER_ACC = 8 }; /* stride-2 downsample blocks: prn_bottleneck_train_bwd may be asked to ADD into a dx that holds another gradient */
+enum { PRN_BLK_CONV2_DIRECT = 0, PRN_BLK_CONV2_WINOGRAD = 1, PRN_BLK_CONV2_DCN = 2 };
+typedef struct prn_bottleneck_desc {
+  int32_t B, C, H, W;        /* block input [B,C,H,W] */
+  int32_t planes;            /* bottleneck width P; the block's output is [B, 4P, Ho, Wo] */
+  int32_t stride;            /* of conv2 and of the downsample convolution: 1 or 2 */
+  int32_t dcn;               /* conv2 = offset|modulator conv (27 channels) + DCNv2 on its raw output (models/dcn.py:52-67) */
+  int32_t downsample;        /* identity path = conv1x1(stride) + BatchNorm (models/backbone.py:156-166) */
+  int32_t flags;             /* PRN_BLK_* */
+  float eps[4], momentum[4]; /* bn1, bn2, bn3, downsample BatchNorm */
+  float max_offset;          /* dcn: the offset clamp, max(h, w) / 4 of the block's conv2 input */
+  int32_t reserved;
+  prn_gemm_opts opts;
+} prn_bottleneck_desc;
+/* Device pointers of a block's parameters and of the derived operand layouts the CALLER keeps current (NULL where the plan does not read one:
+ * prn_bottleneck_plan_info's PRN_BLK_NEEDS_* say which images a plan uses; a NULL image makes the launch cut the weight itself, into ws). */
+typedef struct prn_bottleneck_params {
+  const float *w1, *w2, *w3, *wd;                 /* [P,C,1,1], [P,P,3,3] (dcn: regular_conv.weight), [4P,P,1,1], [4P,C,1,1] */
+  const float *b2;                                /* dcn: regular_conv.bias or NULL */
+  const void *w1_img, *w3_img, *wd_img;           /* split-kernel images (prn_split_prepare) of w1 / w3 / wd (stride 1 only) */
+  const float* u2; const void* u2_img;            /* conv2 in the Winograd domain [36][P][P] (prn_winograd_weights_batched: u) and its images */
+  const float *w1_t, *w2_t, *w3_t, *wd_t;         /* input-gradient layouts (prn_weight_flip_transpose): [C,P,1,1], [P,P,3,3], [P,4P,1,1], [C,4P,1,1] */
+  const void *w1_t_img, *w3_t_img, *wd_t_img;
+  const float* ut2; const void* ut2_img;          /* prn_winograd_weights_batched: ut */
+  const float *w27, *b27, *w27_t;                 /* dcn: merged offset(18) | modulator(9) weights [27,P,3,3], bias [27], input-gradient layout [P,27,3,3] */
+  const float* w2_cols_t; const void* w2_cols_t_img;   /* dcn: regular_conv.weight as [9P, P] transposed (the column-gradient GEMM's operand) and its images */
+  const float *gamma[4], *beta[4];
+  float *running_mean[4], *running_var[4];
+} prn_bottleneck_params;
+enum { PRN_BLK_SAVE_BYTES = 0, PRN_BLK_GSAVE_BYTES, PRN_BLK_FWD_WS_BYTES, PRN_BLK_BWD_WS_BYTES, PRN_BLK_HO, PRN_BLK_WO, PRN_BLK_CONV2_PATH, PRN_BLK_KEEPS_V,
+       PRN_BLK_OFF_A1, PRN_BLK_OFF_V, PRN_BLK_OFF_A2, PRN_BLK_OFF_OM, PRN_BLK_OFF_TABLE,        /* byte offsets into save: bn1's / bn2's outputs, V, the raw offset map, the gather table */
+       PRN_BLK_OFF_D1, PRN_BLK_OFF_D2, PRN_BLK_OFF_D3, PRN_BLK_OFF_DD, PRN_BLK_OFF_DOM,   /* byte offsets into gsave */
+       PRN_BLK_BN_GRAD_FLOATS,
+       PRN_BLK_HANDOVERS,         /* bit 0: conv1 sums in bn1, 1: bn1 writes V, 2: conv2's output transform in bn2, 3 / 4 / 5: their backward counterparts */
+       PRN_BLK_NEEDS_W1_IMG, PRN_BLK_NEEDS_W3_IMG, PRN_BLK_NEEDS_WD_IMG, PRN_BLK_NEEDS_W1T_IMG, PRN_BLK_NEEDS_W3T_IMG, PRN_BLK_NEEDS_WDT_IMG, PRN_BLK_NEEDS_U_IMG,
+       PRN_BLK_NEEDS_COLT_IMG, PRN_BLK_INFO_COUNT };
+int64_t prn_bottleneck_plan_bytes(void);
+int64_t prn_bottleneck_params_bytes(void);
+int prn_bottleneck_plan(const prn_bottleneck_desc* d, void* plan);
+int prn_bottleneck_plan_info(const void* plan, int64_t* out, int n);
+int prn_bottleneck_train_fwd(const void* plan, const prn_bottleneck_params* p, const float* x, float* y, void* save, void* ws, void* stream);
+/* dy: gradient of y.  dx: gradient of x, fully written -- or, dx_accumulate != 0 (stride-2 downsample blocks planned with PRN_BLK_SCATTER_ACC): dx already
+ * holds the gradient the block's other readers sent back (models/backbone.py:45: the stage outputs also feed the FPN and the depth decoder) and the
+ * block's own gradient is added to it in place (no zero fill of the strided input gradient, no separate sum over the full-size map). */
+int prn_bottleneck_train_bwd(const void* plan, const prn_bottleneck_params* p, const float* x, const float* y, const float* dy, float* dx, int dx_accumulate,
+                             const void* save, void* gsave, float* bn_grads, void* ws, void* stream);
+
 /* prn_frame_to_input -- input staging of the inference entry point in ONE launch (simple_inference.py:143-152): src = the decoded
  *   uint8 BGR frame [Hs][Ws][3] on the device (uploaded as bytes); cv2.resize(INTER_LINEAR) to Hr x Wr in OpenCV's fixed-point
  *   arithmetic, zero padding to Hp x Wp (funcs.py:204-210), FastBaseTransform (augmentations.py:496-530): mode 0 (x - mean) / std,

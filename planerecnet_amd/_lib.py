@@ -45,6 +45,19 @@ class DcnDesc(ctypes.Structure):
                                                                                                               ("opts", GemmOpts)]
 
 
+class BottleneckDesc(ctypes.Structure):
+    """mirror of prn_bottleneck_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "H", "W", "planes", "stride", "dcn", "downsample", "flags")] + [
+        ("eps", ctypes.c_float * 4), ("momentum", ctypes.c_float * 4), ("max_offset", ctypes.c_float), ("reserved", ctypes.c_int32), ("opts", GemmOpts)]
+
+
+class BottleneckParams(ctypes.Structure):
+    """mirror of prn_bottleneck_params: device addresses (or None) of a block's parameters and derived operands"""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "w1", "w2", "w3", "wd", "b2", "w1_img", "w3_img", "wd_img", "u2", "u2_img", "w1_t", "w2_t", "w3_t", "wd_t", "w1_t_img", "w3_t_img", "wd_t_img", "ut2", "ut2_img",
+        "w27", "b27", "w27_t", "w2_cols_t", "w2_cols_t_img")] + [(n, ctypes.c_void_p * 4) for n in ("gamma", "beta", "running_mean", "running_var")]
+
+
 IN_ZERO, IN_REFLECT, IN_UP2_REFLECT, IN_DILATED, IN_UP2_PHASE, IN_EMBED1 = 0, 1, 2, 3, 4, 5
 EPI_NONE, EPI_RELU, EPI_SIGMOID = 0, 1, 2
 BN_SPLITS = 32
@@ -181,6 +194,12 @@ SIGNATURES = {
     "prn_resize_bilinear_bwd_add": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_bwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+    "prn_bottleneck_plan_bytes": (c_i64, []),
+    "prn_bottleneck_params_bytes": (c_i64, []),
+    "prn_bottleneck_plan": (c_int, [ctypes.POINTER(BottleneckDesc), P]),
+    "prn_bottleneck_plan_info": (c_int, [P, ctypes.POINTER(c_i64), c_int]),
+    "prn_bottleneck_train_fwd": (c_int, [P, ctypes.POINTER(BottleneckParams), P, P, P, P, P]),
+    "prn_bottleneck_train_bwd": (c_int, [P, ctypes.POINTER(BottleneckParams), P, P, P, P, c_int, P, P, P, P, P]),
 }
 
 
@@ -197,6 +216,8 @@ def load():
 
 
 lib = load()
+if lib.prn_bottleneck_params_bytes() != ctypes.sizeof(BottleneckParams):
+    raise ImportError("libprn_hip.so and planerecnet_amd._lib disagree about prn_bottleneck_params (rebuild the library)")
 
 
 def check(rc, what):

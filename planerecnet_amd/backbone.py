@@ -10,7 +10,7 @@ import os
 import torch
 from torch import nn
 
-from . import ops
+from . import blocks, ops
 from .dcn import DeformableConv2d
 
 
@@ -71,6 +71,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def _apply(self, fn, recurse=True):                    # .to() / .cuda() / .float() replace parameter and buffer objects: drop what blocks.py derived from them
+        r = super()._apply(fn, recurse)
+        blocks.invalidate(self)
+        return r
+
     def forward(self, x, hand_back=False):
         """hand_back (training path, blocks with a downsample branch): also return the block's INPUT as handed on by the downsample convolution's fork --
         whoever else reads that tensor (the FPN / the depth decoder read the stage outputs) takes it from there, so that its gradient joins the
@@ -84,6 +89,8 @@ class Bottleneck(nn.Module):
             res = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], self.downsample[0].stride[0])
             out = conv_bn(out, self.conv3, self.bn3, relu=True, residual=res)
             return (out, x) if hand_back else out
+        if blocks.usable(self, x):                             # training mode on the device: the whole block is ONE call each way (blocks.py, include/prn.h: prn_bottleneck_*)
+            return blocks.bottleneck_train(self, x, hand_back)
         # x has a second consumer (the identity branch or the downsample conv): hand it on through the fork so that both
         # gradients of x meet in conv1's input-gradient epilogue instead of in a separate accumulation kernel
         # (lazy_sum / lazy_dgrad: a convolution's result is read by the BatchNorm behind it only, a BatchNorm's output by the convolution behind

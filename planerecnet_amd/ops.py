@@ -190,7 +190,11 @@ _GROUPS = {}        # raw stream handle -> {shape key: [[(weight, (x, dy)), ...]
 _DEFER_SEQ = [0]
 
 
-def _deferred_wgrad(w, inputs, compute, group=None):
+def _deferred_wgrad(w, inputs, compute, group=None, hold=None):
+    """inputs: what `compute` reads -- for a shape group (x, dy) of the layer, tensors or blocks._Ref (pointer + shape).  hold: the tensors that
+    own that memory (default: the inputs themselves); they are told about the side stream when the launch goes out."""
+    if hold is None:
+        hold = inputs
     handle = _raw_stream(_cur_dev())                        # (the Stream object is built once per stream: torch.cuda.current_stream() costs ~4 us per call)
     e = _PENDING.get(handle)
     if e is None:
@@ -201,12 +205,12 @@ def _deferred_wgrad(w, inputs, compute, group=None):
         if groups is None:
             groups = _GROUPS[handle] = {}
         pend = groups.setdefault(group, [[], 0])
-        pend[0].append((w, inputs))
+        pend[0].append((w, inputs, hold))
         pend[1] = _DEFER_SEQ[0]
         if len(pend[0]) >= WGRAD_GROUP:
             _emit_group(e, handle, group)
     else:
-        e[1].append((w, inputs, compute))
+        e[1].append((w, hold, compute))
     if groups:
         for key in [k for k, v in groups.items() if _DEFER_SEQ[0] - v[1] >= WGRAD_GROUP_AGE]:       # the backward pass has left that stage
             _emit_group(e, handle, key)
@@ -214,12 +218,44 @@ def _deferred_wgrad(w, inputs, compute, group=None):
         _flush_one(e)
 
 
+def queue_wgrads(items, hold, need, base, grads):
+    """The parameter gradients of a composite node (blocks._BottleneckFn.backward).  items: (index | [indices] into the node's parameter list,
+    parameter | [parameters], inputs, compute, shape-group key); need[base + index]: autograd wants that gradient.  Each is deferred to the side
+    stream where the training loop allows it (then `.grad` is written there and autograd gets None) or computed now into grads[index]."""
+    for idx, w, inputs, compute, gkey in items:
+        if isinstance(idx, list):                           # one launch pair, several parameters (a DCN block's offset | modulator convolution)
+            if not any(need[base + k] for k in idx):
+                continue
+            if BIAS_ASYNC and all(need[base + k] for k in idx) and all(_defer(True, p_) for p_ in w):
+                _deferred_wgrad(list(w), inputs, compute, None, hold)
+            else:
+                for k, g in zip(idx, compute()):
+                    grads[k] = g
+        elif need[base + idx]:
+            if _defer(True, w) and (BIAS_ASYNC or w.dim() != 1):
+                _deferred_wgrad(w, inputs, compute, gkey, hold)
+            else:
+                grads[idx] = compute()
+
+
+# What the model's per-step refresh vouches for (PlaneRecNet._refresh_dgrad_weights -> vouch_refreshed): id(weight) -> the version its derived layouts
+# were last rewritten for, and the addresses of the buffers those batch refreshers rewrite in place (FlippedWeights / WinogradWeights views).
+REFRESHED = {}
+BATCHED = {}
+
+
+def vouch_refreshed(weights):
+    """Call after FlippedWeights.refresh / WinogradWeights.refresh / split_refresh_all ran for `weights` at their current versions."""
+    for w in weights:
+        REFRESHED[id(w)] = w._version
+
+
 def _emit_group(e, handle, key):
     """Move a shape group to the launch queue as ONE item (its compute returns the [G, ...] gradient stack)."""
     pend = _GROUPS[handle].pop(key)[0]
-    ws_, ins = [w for w, _ in pend], [i for _, i in pend]
+    ws_, ins = [w for w, _, _ in pend], [i for _, i, _ in pend]
     M, K, stride, pad, mode = key[-5:]
-    e[1].append((ws_, tuple(t for i in ins for t in i), lambda: conv_wgrad_grouped_raw([i[0] for i in ins], [i[1] for i in ins], M, K, stride, pad, mode)))
+    e[1].append((ws_, tuple(t for _, _, h in pend for t in h), lambda: conv_wgrad_grouped_raw([i[0] for i in ins], [i[1] for i in ins], M, K, stride, pad, mode)))
 
 
 def _flush_one(e, everything=False):
@@ -330,6 +366,15 @@ def _stream():
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# Bumped whenever a cache of derived operands (cut images, input-gradient layouts, Winograd-domain weights) gains, drops or re-allocates an entry:
+# whoever holds raw pointers into those caches (blocks._State: the parameter table of a Bottleneck call) looks them up again.
+OPERAND_EPOCH = [0]
 
 
 def _dev(*ts):
@@ -543,6 +588,7 @@ def _split_drop(ptr, stamp=True):
         _STAMP.pop(ptr, None)
     if _SPLIT_IMG.pop(ptr, None) is not None:
         _SPLIT_ITEMS[0] = None
+        OPERAND_EPOCH[0] += 1
 
 
 def _split_state(e):
@@ -606,6 +652,7 @@ def split_images(t, M, K, nz, cols=None):
         e.images = torch.empty(nb, device=t.device, dtype=torch.uint8)
         _SPLIT_IMG[ptr] = e
         _SPLIT_ITEMS[0] = None
+        OPERAND_EPOCH[0] += 1
         if owner is not None:
             weakref.finalize(owner, lambda p=ptr, r=e: _split_drop(p) if _SPLIT_IMG.get(p) is r else None)
     check(lib.prn_split_prepare(ctypes.c_void_p(ptr), _p(e.images), M, K, nz, kind, _stream()), "prn_split_prepare")
@@ -614,6 +661,12 @@ def split_images(t, M, K, nz, cols=None):
     if os.environ.get("PRN_SPLIT_DEBUG"):
         SPLIT_STATS.setdefault("who", {}).setdefault((M, K, nz, "param" if e.owner is not None else "derived"), []).append(SPLIT_STATS["refreshes"])
     return _p(e.images)
+
+
+def split_images_ptr(t, M, K, nz, cols=None):
+    """split_images as a plain integer address (or None): for parameter tables filled field by field."""
+    r = split_images(t, M, K, nz, cols)
+    return None if r is None else r.value
 
 
 def split_refresh_all():
@@ -786,6 +839,11 @@ class FlippedWeights:
         self.items = torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev)
         self.total = blocks
         self.ptrs = [w.data_ptr() for w in self.data]
+        OPERAND_EPOCH[0] += 1
+        for k in [k for k, o in BATCHED.items() if o == id(self)]:
+            del BATCHED[k]
+        for v in self.views:                                    # rewritten in place by every refresh(): see blocks.py
+            BATCHED[v.data_ptr()] = id(self)
 
     def refresh(self):
         """Call after the weights changed (once per step, before backward)."""
@@ -836,6 +894,8 @@ def _wino_store(w, U, Ut):
     old = _WINO.get(ptr)
     if old is not None and (old[2] is not U or old[3] is not Ut):
         _split_drop(old[2].data_ptr()); _split_drop(old[3].data_ptr())
+    if old is None or old[2] is not U or old[3] is not Ut:
+        OPERAND_EPOCH[0] += 1
     _WINO[ptr] = (weakref.ref(w), w._version, U, Ut)
     _stamp(U); _stamp(Ut)
     if new:
@@ -845,6 +905,7 @@ def _wino_store(w, U, Ut):
 def _wino_pop(ptr):
     e = _WINO.pop(ptr, None)
     if e is not None:
+        OPERAND_EPOCH[0] += 1
         _split_drop(e[2].data_ptr()); _split_drop(e[3].data_ptr())
 
 
@@ -895,6 +956,11 @@ class WinogradWeights:
             first += n
         self.items, self.total = _winograd_items(entries, dev)
         self.ptrs = [w.data_ptr() for w in self.weights]
+        OPERAND_EPOCH[0] += 1
+        for k in [k for k, o in BATCHED.items() if o == id(self)]:
+            del BATCHED[k]
+        for U, Ut in self.views:
+            BATCHED[U.data_ptr()] = BATCHED[Ut.data_ptr()] = id(self)
 
     def refresh(self):
         """Call after the weights changed (once per step, before forward)."""

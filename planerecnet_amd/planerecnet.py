@@ -133,6 +133,10 @@ class PlaneRecNet(nn.Module):
         if ww is not None:
             ww.refresh()
         ops.split_refresh_all()          # weight images of the bf16-split GEMM launches (parameters, flipped and transform-domain layouts): one launch
+        # every derived layout these three keep is now current for the weights' versions: the block calls re-use their parameter tables (blocks.py)
+        ops.vouch_refreshed([t for gd in fw.guards for t in gd])
+        if ww is not None:
+            ops.vouch_refreshed(ww.weights)
 
     def forward(self, x):
         if x.is_cuda:

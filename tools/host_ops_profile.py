@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from planerecnet_amd import ops, timer, losses as L  # noqa: E402
+from planerecnet_amd import blocks, ops, timer, losses as L  # noqa: E402
 from planerecnet_amd.config import cfg, set_cfg  # noqa: E402
 from planerecnet_amd.losses import PlaneRecNetLoss, TargetPrefetcher  # noqa: E402
 from planerecnet_amd.planerecnet import PlaneRecNet  # noqa: E402
@@ -51,7 +51,7 @@ def wrap(cls, name):
     setattr(cls, name, staticmethod(timed))
 
 
-for mod in (ops, L):
+for mod in (ops, L, blocks):
     for v in list(vars(mod).values()):
         if isinstance(v, type) and issubclass(v, torch.autograd.Function) and v is not torch.autograd.Function:
             wrap(v, "forward")
@@ -82,6 +82,7 @@ class _TimedLib:
 
 
 ops.lib = _TimedLib(ops.lib)
+blocks.lib = ops.lib
 _te, _tel = torch.empty, torch.empty_like
 
 
