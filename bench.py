@@ -398,21 +398,60 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(n_warm, n_steps):
+    BLOCK = 5
+    blocks_log = {}
+
+    def timed(n_warm, n_steps, tag=None):
+        """n_warm untimed steps, then EXACTLY n_steps timed ones between two fences (the contract).  tag: also stamp the stream every BLOCK steps (event records,
+        no synchronisation) -> blocks_log[tag] = ms per step of each block, read after the closing fence."""
         out = None
         for _ in range(n_warm):
             out = step()
         fence()
+        marks = []
         t0 = time.perf_counter()
-        for _ in range(n_steps):
+        for i in range(n_steps):
+            if tag is not None and i % BLOCK == 0:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((i, ev))
             out = step()
+        if tag is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((n_steps, ev))
         fence()
         el = time.perf_counter() - t0
+        if tag is not None and len(marks) > 1:
+            blocks_log[tag] = [round(a[1].elapsed_time(b[1]) / (b[0] - a[0]), 3) for a, b in zip(marks[:-1], marks[1:])]
         if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
+
+    def condition(max_steps=40, tol=0.01):
+        """Untimed conditioning BEFORE the contract's warm-up: blocks of BLOCK steps until two consecutive blocks agree within `tol` (at most max_steps).
+        A fresh lease pays its first-use costs here -- code-object loads of every kernel, the caching allocator's growth to the step's working set,
+        the per-shape plans / descriptors / block states of the host layer, the board's clock ramp -- instead of inside the first timed steps
+        (round 5: the driver's 5 + 20 steps read 45.7 ms where later legs of the same process read 42.2-43.4)."""
+        ms, used = [], 0
+        while used < max_steps:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(BLOCK):
+                step()
+            fence()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            ms.append(round(1e3 * el / BLOCK, 3))
+            used += BLOCK
+            if len(ms) >= 2 and abs(ms[-1] - ms[-2]) <= tol * ms[-2]:
+                break
+        return ms
 
     # which plain GEMMs take the bf16-split kernel is a trade against this board's clock management: time the alternative (untimed steps,
     # before the warm-up proper; every rank decides on the slowest rank's times)
@@ -427,16 +466,37 @@ def main():
         for _ in range(3):
             step()
         tune = ops.autotune_split_policy(step, "train" if train else "eval", reduce_max=rmax)
+    conditioning = condition() if not os.environ.get("PRN_BENCH_NO_CONDITIONING") else []
     n_host0 = len(ph.get("host_ms_per_step", []))
     cpu0 = time.process_time()
-    elapsed, last = timed(args.warmup, args.steps)
+    elapsed, last = timed(args.warmup, args.steps, tag="headline")
     # host side of the timed steps on this rank: wall time the trainer thread needs to enqueue a step, and CPU time of the whole
     # process (trainer + autograd + receiver threads; the target workers are separate processes) -- at N ranks per host these add up
     host = None
     if train:
         hs = ph.get("host_ms_per_step", [])[n_host0 + args.warmup:]
-        host = {"enqueue_ms_per_step": (sum(hs) / len(hs)) if hs else None,
-                "process_cpu_ms_per_step": 1e3 * (time.process_time() - cpu0) / max(args.steps + args.warmup, 1),
+        cpu_free = 1e3 * (time.process_time() - cpu0) / max(args.steps + args.warmup, 1)
+        # What the trainer needs to ENQUEUE a step: each probe step is issued while the stream is parked behind a spin kernel, so no launch waits for queue
+        # space and no event wait absorbs slack -- in the free-running, GPU-bound loop above the host is throttled by the device (a full hardware queue blocks
+        # inside the launches, the target hand-over waits for an event), and the wall time of a step's host phases then measures the GPU, not the host
+        # (tools/wait_probe.py: 16-20 ms of host phases against 11 ms for the same work with the GPU parked).  Same steps, same process, after the timed leg.
+        park, park_cpu = [], []
+        for _ in range(0 if (graphed or os.environ.get("PRN_BENCH_NO_ENQUEUE_PROBE")) else 5):
+            fence()
+            torch.cuda._sleep(int(0.12 * 2.4e9))
+            c0, t0 = time.process_time(), time.perf_counter()
+            step()
+            park.append(1e3 * (time.perf_counter() - t0))
+            park_cpu.append(1e3 * (time.process_time() - c0))
+        fence()
+        med = lambda v: sorted(v)[len(v) // 2] if v else None      # noqa: E731
+        host = {"enqueue_ms_per_step": med(park) if park else ((sum(hs) / len(hs)) if hs else None),
+                "enqueue_probe": {"method": "whole step (zero_grad, forward, loss, backward, join, exchange, Adam, next targets) enqueued against a stream parked behind a "
+                                            "spin kernel; median of the probes", "ms": [round(v, 2) for v in park], "process_cpu_ms": [round(v, 2) for v in park_cpu]},
+                "free_running_trainer_ms_per_step": (sum(hs) / len(hs)) if hs else None,
+                "process_cpu_ms_per_step": cpu_free,
+                "process_cpu_note": "all threads of the process over the timed leg, free-running: trainer + autograd thread + the HIP / ROCr runtime's own threads "
+                                    "(one of which polls completion signals at ~100 % of a core while the GPU is busy: tools/thread_probe.py)",
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "targets": args.targets,
                 "target_prep_host_cpu_ms_per_step": (prefetch.host_cpu_ms / max(getattr(prefetch, "calls", 1), 1)) if hasattr(prefetch, "host_cpu_ms") else None,
                 "target_prep_host_wall_ms_per_step": (prefetch.host_ms / max(getattr(prefetch, "calls", 1), 1)) if hasattr(prefetch, "host_ms") else None}
@@ -463,7 +523,10 @@ def main():
             exchange = plain
             if hasattr(opt, "exchange"):
                 opt.exchange = plain
-            exch = {"ms_per_step_with_exchange": 1e3 * el2 / n2, "exchange_overhead_ms": 1e3 * el2 / n2 - 1e3 * elapsed / args.steps, "steps": n2,
+            el3, _ = timed(3, n2)                                # the plain step again, ADJACENT to the exchange leg: the difference below is between neighbours,
+            exch = {"ms_per_step_with_exchange": 1e3 * el2 / n2,   # not against the headline leg minutes earlier (round 5 read -2.2 ms that way)
+                    "ms_per_step_plain_adjacent": 1e3 * el3 / n2, "exchange_overhead_ms": max(1e3 * (el2 - el3) / n2, 0.0),
+                    "exchange_overhead_raw_ms": 1e3 * (el2 - el3) / n2, "steps": n2,
                     "buckets": None, "note": "one-rank RCCL group: hooks + pack + all-reduce launch + unpack, no wire time"}
         except Exception as e:                                   # noqa: BLE001
             exch = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -704,6 +767,11 @@ def main():
                 "hip_graph": graphed, "losses_finite": finite, "losses": None if loss_means is None else dict(zip(sorted(losses), loss_means)),
                 "detections_last_batch": detections, "roofline": roof, "cpu_baseline": cpu, "fp32_only_run": fp32_run, "conditioned_run": cond_run,
                 "dcn_offsets_run": dcn_run, "host": host,
+                # steady state: untimed conditioning blocks (ms per step) before the contract's warm-up, and the timed leg resolved into blocks of five steps
+                # (stream stamps, no synchronisation inside the leg): the headline is the whole leg; its blocks' median / min / max show whether it was steady
+                "steady_state": {"conditioning_blocks_ms_per_step": conditioning, "timed_blocks_ms_per_step": blocks_log.get("headline"),
+                                 "timed_blocks_median_min_max": (lambda b: [sorted(b)[len(b) // 2], min(b), max(b)] if b else None)(blocks_log.get("headline")),
+                                 "block_steps": BLOCK},
                 "exchange_probe": exch, "split_gemm_policy": tune,
                 "device": {"name": torch.cuda.get_device_name(dev), "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", None))},   # boxes differ by +-2 %
                 "kernels": kernels}

@@ -10,6 +10,7 @@ CPU path in the product.
 import ctypes
 
 import os
+import threading
 import weakref
 
 import torch
@@ -135,6 +136,7 @@ def wgrad_join():
         main = torch.cuda.current_stream()
         for st in _SIDE.values():
             main.wait_stream(st)
+    del _HELD[:]                                            # (inputs of the fast deferred launches: the current stream is now ordered behind their readers)
 
 
 def _defer(needs_grad, w):
@@ -160,7 +162,7 @@ def _bias_grad(needs_grad, bias, dy):
     if not needs_grad or bias is None:
         return None
     if BIAS_ASYNC and _defer(True, bias):
-        _deferred_wgrad(bias, (dy,), lambda: channel_sum(dy))
+        _deferred_wgrad(bias, (dy,), lambda: channel_sum(dy), fast=True)
         return None
     return channel_sum(dy)
 
@@ -190,9 +192,12 @@ _GROUPS = {}        # raw stream handle -> {shape key: [[(weight, (x, dy)), ...]
 _DEFER_SEQ = [0]
 
 
-def _deferred_wgrad(w, inputs, compute, group=None, hold=None):
+def _deferred_wgrad(w, inputs, compute, group=None, hold=None, fast=False):
     """inputs: what `compute` reads -- for a shape group (x, dy) of the layer, tensors or blocks._Ref (pointer + shape).  hold: the tensors that
-    own that memory (default: the inputs themselves); they are told about the side stream when the launch goes out."""
+    own that memory (default: the inputs themselves).  fast: `compute` consists of this library's launches only (no ATen kernels, no temporaries
+    besides its results and workspaces taken through _wspace): it is then issued on the side stream's raw handle WITHOUT switching PyTorch's current
+    stream -- results come from the calling stream's pool, workspaces from the side stream's persistent scratch, `hold` stays referenced until
+    wgrad_join() (see _flush_one)."""
     if hold is None:
         hold = inputs
     handle = _raw_stream(_cur_dev())                        # (the Stream object is built once per stream: torch.cuda.current_stream() costs ~4 us per call)
@@ -205,12 +210,12 @@ def _deferred_wgrad(w, inputs, compute, group=None, hold=None):
         if groups is None:
             groups = _GROUPS[handle] = {}
         pend = groups.setdefault(group, [[], 0])
-        pend[0].append((w, inputs, hold))
+        pend[0].append((w, inputs, hold, fast))
         pend[1] = _DEFER_SEQ[0]
         if len(pend[0]) >= WGRAD_GROUP:
             _emit_group(e, handle, group)
     else:
-        e[1].append((w, hold, compute))
+        e[1].append((w, hold, compute, fast))
     if groups:
         for key in [k for k, v in groups.items() if _DEFER_SEQ[0] - v[1] >= WGRAD_GROUP_AGE]:       # the backward pass has left that stage
             _emit_group(e, handle, key)
@@ -227,13 +232,13 @@ def queue_wgrads(items, hold, need, base, grads):
             if not any(need[base + k] for k in idx):
                 continue
             if BIAS_ASYNC and all(need[base + k] for k in idx) and all(_defer(True, p_) for p_ in w):
-                _deferred_wgrad(list(w), inputs, compute, None, hold)
+                _deferred_wgrad(list(w), inputs, compute, None, hold, True)
             else:
                 for k, g in zip(idx, compute()):
                     grads[k] = g
         elif need[base + idx]:
             if _defer(True, w) and (BIAS_ASYNC or w.dim() != 1):
-                _deferred_wgrad(w, inputs, compute, gkey, hold)
+                _deferred_wgrad(w, inputs, compute, gkey, hold, True)
             else:
                 grads[idx] = compute()
 
@@ -253,9 +258,66 @@ def vouch_refreshed(weights):
 def _emit_group(e, handle, key):
     """Move a shape group to the launch queue as ONE item (its compute returns the [G, ...] gradient stack)."""
     pend = _GROUPS[handle].pop(key)[0]
-    ws_, ins = [w for w, _, _ in pend], [i for _, i, _ in pend]
+    ws_, ins = [w for w, _, _, _ in pend], [i for _, i, _, _ in pend]
     M, K, stride, pad, mode = key[-5:]
-    e[1].append((ws_, tuple(t for _, _, h in pend for t in h), lambda: conv_wgrad_grouped_raw([i[0] for i in ins], [i[1] for i in ins], M, K, stride, pad, mode)))
+    e[1].append((ws_, tuple(t for _, _, h, _ in pend for t in h), lambda: conv_wgrad_grouped_raw([i[0] for i in ins], [i[1] for i in ins], M, K, stride, pad, mode),
+                 all(f for _, _, _, f in pend)))
+
+
+# Launching a deferred gradient used to mean: switch PyTorch's current stream to the side stream (a context manager, ~10 us), allocate result and
+# workspace there, tell the allocator about every input (`record_stream`, ~1.2 us each; a block has three per layer) -- ~50 times per step.  A `fast`
+# item needs none of it: it only calls this library, which takes the stream as an argument (_stream() returns the side stream's handle while
+# _TLS.side is set); its RESULT is allocated from the calling stream's pool -- the first write on the side stream is ordered after everything the
+# calling stream had enqueued when the block was released (side waits for an event recorded on it first), the readers come after wgrad_join();
+# its WORKSPACE is the side stream's persistent scratch (launches on one stream are ordered); its INPUTS stay referenced in _HELD until
+# wgrad_join() has made the calling stream wait for the side stream -- whoever re-uses their memory afterwards is ordered behind the last reader.
+_TLS = threading.local()
+_HELD = []
+_SIDE_SCRATCH = {}      # raw side-stream handle -> float32 tensor
+_SIDE_EVENTS = {}       # raw handle of the originating stream -> reusable event
+FAST_WGRAD = os.environ.get("PRN_WGRAD_FAST", "1") == "1"      # 0: every deferred launch under a PyTorch stream context (A/B)
+
+
+class _Ws:
+    __slots__ = ("ptr",)
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def data_ptr(self):
+        return self.ptr
+
+
+def _wspace(nbytes, dev, dtype=torch.float32):
+    """Workspace of a weight-gradient launch: the side stream's scratch inside a fast deferred launch, a fresh allocation otherwise."""
+    side = getattr(_TLS, "side", None)
+    if side is None:
+        return torch.empty(max((nbytes + dtype.itemsize - 1) // dtype.itemsize, 1), device=dev, dtype=dtype)
+    t = _SIDE_SCRATCH.get(side)
+    if t is None or t.numel() * 4 < nbytes:
+        with torch.cuda.stream(_TLS.side_obj):
+            t = _SIDE_SCRATCH[side] = torch.empty((int(nbytes * 1.5) + (1 << 20)) // 4, device=dev, dtype=torch.float32)
+    return _Ws(t.data_ptr())
+
+
+def _assign_grads(w, dw, main, side_ctx):
+    # a list of weights: a shape group (one weight per slice of the gradient stack) or a node with several parameters
+    pairs = zip(w, dw if isinstance(dw, (tuple, list)) else dw.unbind(0)) if isinstance(w, list) else [(w, dw)]
+    for w_, dw_ in pairs:
+        if dw_.shape != w_.shape:
+            dw_ = dw_.view_as(w_)
+        if GRAD_RECORD_STREAM and side_ctx:
+            dw_.record_stream(main)                 # read by the optimizer on the main stream after wgrad_join()
+        if w_.grad is None:
+            w_.grad = dw_
+        elif side_ctx:
+            w_.grad.add_(dw_)
+        else:                                       # (gradient accumulation: the sum is an ATen kernel and must follow the launch on the side stream)
+            with torch.cuda.stream(_TLS.side_obj):
+                w_.grad.add_(dw_)
+            _HELD.append(dw_)
+    # (post-accumulate-grad hooks still fire: the engine runs the parameter's AccumulateGrad node -- a no-op for the
+    # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
 
 
 def _flush_one(e, everything=False):
@@ -269,27 +331,28 @@ def _flush_one(e, everything=False):
     del items[:]
     first = todo[0][0][0] if isinstance(todo[0][0], list) else todo[0][0]
     side = _side_stream(first.device, main)                 # (keyed by the originating stream)
-    side.wait_stream(main)
-    with torch.cuda.stream(side), torch.no_grad():
-        for w, _, compute in todo:
-            dw = compute()
-            # a list of weights: a shape group (one weight per slice of the gradient stack) or a node with several parameters
-            pairs = zip(w, dw if isinstance(dw, (tuple, list)) else dw.unbind(0)) if isinstance(w, list) else [(w, dw)]
-            for w_, dw_ in pairs:
-                if dw_.shape != w_.shape:
-                    dw_ = dw_.view_as(w_)
-                if GRAD_RECORD_STREAM:
-                    dw_.record_stream(main)                 # read by the optimizer on the main stream after wgrad_join()
-                if w_.grad is None:
-                    w_.grad = dw_
-                else:
-                    w_.grad.add_(dw_)
-            # (post-accumulate-grad hooks still fire: the engine runs the parameter's AccumulateGrad node -- a no-op for the
-            # undefined gradient this op returns -- and its hooks once all uses of the parameter have been processed)
-    for _, inputs, _ in todo:
-        for t in inputs:
-            t.record_stream(side)                          # (their release puts marker packets on the SIDE stream; holding them back
-                                                            # until wgrad_join() instead changed nothing: 51.49 vs 51.55 ms)
+    ev = _SIDE_EVENTS.get(main.cuda_stream)
+    if ev is None:
+        ev = _SIDE_EVENTS[main.cuda_stream] = torch.cuda.Event()
+    ev.record(main)
+    side.wait_event(ev)
+    slow = [t for t in todo if not (t[3] and FAST_WGRAD)]
+    if len(slow) < len(todo):
+        _TLS.side, _TLS.side_obj = side.cuda_stream, side
+        try:
+            for w, hold, compute, fast in todo:
+                if fast and FAST_WGRAD:
+                    _assign_grads(w, compute(), main, False)
+                    _HELD.append(hold)
+        finally:
+            _TLS.side = None
+    if slow:
+        with torch.cuda.stream(side), torch.no_grad():
+            for w, _, compute, _ in slow:
+                _assign_grads(w, compute(), main, True)
+        for _, inputs, _, _ in slow:
+            for t in inputs:
+                t.record_stream(side)                      # (their release puts marker packets on the SIDE stream)
 
 
 def wgrad_flush():
@@ -361,7 +424,8 @@ _cur_dev = torch._C._cuda_getDevice                       # (torch.cuda.current_
 
 
 def _stream():
-    return ctypes.c_void_p(_raw_stream(_cur_dev()))
+    side = getattr(_TLS, "side", None)                      # inside a fast deferred launch: the side stream (see _flush_one)
+    return ctypes.c_void_p(side if side is not None else _raw_stream(_cur_dev()))
 
 
 def _p(t):
@@ -751,7 +815,7 @@ def conv_wgrad_raw(x, dy, M, K, stride, pad, mode):
         Ho, Wo = dy.shape[2:]
         dw = torch.empty(M, C, K, K, device=x.device, dtype=torch.float32)
     _, ref, _, nbytes, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode)
-    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    ws = _wspace(nbytes, x.device)
     if profiling._enabled:
         wkind = lib.prn_conv2d_wgrad_kernel_kind(ref, 1)               # 1: the one- / two-channel 3x3 layers (direct HBM-bound kernel); 2: fp16-piece kernel
         direct = wkind == 1
@@ -783,7 +847,7 @@ def conv_wgrad_grouped_raw(xs, dys, M, K, stride, pad, mode):
     if nbytes < 0:
         raise RuntimeError(lib.prn_last_error().decode())
     dw = torch.empty(G, M, C, K, K, device=dev, dtype=torch.float32)
-    ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    ws = _wspace(nbytes, dev)
     px = (ctypes.c_void_p * G)(*[t.data_ptr() for t in xs])
     pdy = (ctypes.c_void_p * G)(*[t.data_ptr() for t in dys])
     check(lib.prn_conv2d_wgrad_grouped(ref, G, px, pdy, _p(dw), _p(ws), _stream()), "prn_conv2d_wgrad_grouped")
@@ -1051,7 +1115,7 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
     nbytes = _WINO_WG_WS.get(key)
     if nbytes is None:
         nbytes = _WINO_WG_WS[key] = lib.prn_winograd_wgrad_ws_bytes(B, C, H, W, M, oref)
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    ws = _wspace(nbytes, x.device)
     dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
     if V is not None and not profiling._enabled:
         check(lib.prn_conv3x3_winograd_wgrad_v(_p(V), _p(dy), _p(dw), _p(ws), B, C, H, W, M, oref, _stream()), "prn_conv3x3_winograd_wgrad_v")
@@ -1075,7 +1139,7 @@ def conv3x3_winograd_wgrad_raw(x, dy, M, mode=IN_ZERO, V=None):
 def channel_sum(g):
     B, C, H, W = g.shape
     out = torch.empty(C, device=g.device, dtype=torch.float32)
-    ws = torch.empty(C * _lib.BN_SPLITS, device=g.device, dtype=torch.float64)
+    ws = _wspace(8 * C * _lib.BN_SPLITS, g.device, torch.float64)
     check(lib.prn_channel_sum(_p(g), _p(out), _p(ws), B, C, H * W, _stream()), "prn_channel_sum")
     return out
 
@@ -1177,7 +1241,7 @@ class _Conv2d(torch.autograd.Function):
             gkey = None
             if V is None and K in (1, 3, 7) and mode in (IN_ZERO, IN_REFLECT) and M > 2 and dy.shape[0] * dy.shape[2] * dy.shape[3] <= WGRAD_GROUP_PIXELS:
                 gkey = ("conv", tuple(x.shape), tuple(dy.shape[2:]), M, K, stride, pad, mode)
-            _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad, gkey)
+            _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad, gkey, fast=True)
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork, lazy) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None
@@ -1341,7 +1405,7 @@ def dcn_wgrad_raw(x, table, dy, M, stride, pad, raw, max_offset):
     B, C, H, W = x.shape
     _, ref, _, _, wb, _ = _dcn_desc(B, C, H, W, M, stride, pad, raw, max_offset)
     dw = torch.empty(M, C, 3, 3, device=x.device, dtype=torch.float32)
-    ws = _f32(wb, x.device) if wb else None
+    ws = _wspace(wb, x.device) if wb else None
     if profiling._enabled:
         with profiling.span("dcnv2_wgrad_kernel", "mfma", 2.0 * M * C * 9 * dy.shape[0] * dy.shape[2] * dy.shape[3],
                             nbytes=4.0 * (x.numel() + dy.numel() + dw.numel()) + 32.0 * 9 * dy.shape[0] * dy.shape[2] * dy.shape[3]):
@@ -1418,7 +1482,7 @@ class _DeformConv(torch.autograd.Function):
         if ni[0] or ni[1] or ni[4]:
             dx, d_off, d_msk = dcn_data_grads_raw(x, offset, mask, w, dy, stride, pad, 0, 0.0, need_x=ni[0], need_om=ni[1] or ni[4])
         if _defer(ni[2], w):
-            _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0))
+            _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0), fast=True)
         elif ni[2]:
             dw = dcn_wgrad_raw(x, table, dy, M, stride, pad, 0, 0.0)
         db = _bias_grad(has_bias and ni[3], ctx.bias, dy)
@@ -1481,7 +1545,7 @@ class _DeformConvBlock(torch.autograd.Function):
         ni = ctx.needs_input_grad
         dx1, dom, _ = dcn_data_grads_raw(x, om, None, w, dy, stride, 1, 1, max_offset)
         if _defer(ni[7], w):
-            _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset))
+            _deferred_wgrad(w, (x, dy, table), lambda: dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset), fast=True)
             dw = None
         else:
             dw = dcn_wgrad_raw(x, table, dy, M, stride, 1, 1, max_offset) if ni[7] else None
@@ -1494,7 +1558,7 @@ class _DeformConvBlock(torch.autograd.Function):
                 dw27_ = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO)
                 db27_ = channel_sum(dom)
                 return dw27_[:18], dw27_[18:], db27_[:18], db27_[18:]
-            _deferred_wgrad([w_off, w_mod, b_off, b_mod], (x, dom), om_grads)
+            _deferred_wgrad([w_off, w_mod, b_off, b_mod], (x, dom), om_grads, fast=True)
             dw27 = db27 = None
         else:
             dw27 = conv_wgrad_raw(x, dom, 27, 3, stride, 1, IN_ZERO) if (ni[1] or ni[2]) else None
@@ -1567,14 +1631,14 @@ class _PlanePrior(torch.autograd.Function):
         def wgrad():
             dw = torch.empty(F, NK, 1, 1, device=d_out.device, dtype=torch.float32)
             oref = opts_ref()
-            ws = _f32(lib.prn_plane_prior_wgrad_ws_bytes(B, h, w, NK, F, oref), d_out.device)
+            ws = _wspace(lib.prn_plane_prior_wgrad_ws_bytes(B, h, w, NK, F, oref), d_out.device)
             with profiling.span("conv_wgrad_kernel", "mfma", 2.0 * F * NK * B * (h // 4) * (w // 4), nbytes=4.0 * (pooled.numel() + d_out.numel() + dw.numel()),
                                 tag=("wgrad", NK, h // 4, w // 4, F, 1, 1, 0, 1, B)):      # (GEMM + split sum in one bracket)
                 check(lib.prn_plane_prior_wgrad(_p(pooled), _p(d_out), _p(dw), _p(ws), B, h, w, NK, F, oref, _stream()), "prn_plane_prior_wgrad")
             return dw
         dw = None
         if _defer(ctx.needs_input_grad[2], w1):
-            _deferred_wgrad(w1, (pooled, d_out), wgrad)
+            _deferred_wgrad(w1, (pooled, d_out), wgrad, fast=True)
         elif ctx.needs_input_grad[2]:
             dw = wgrad().view_as(w1)
         db = _bias_grad(has_bias and ctx.needs_input_grad[3], ctx.bias, d_out)

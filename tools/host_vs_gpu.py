@@ -40,8 +40,13 @@ ops.set_wgrad_async(True)
 FIXED = [None]
 
 
+PH = {}
+
+
 def step():
+    t0 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
+    t1 = time.perf_counter()
     if os.environ.get("FIXED_TARGETS"):                 # targets computed once: no worker thread competing for the GIL
         if FIXED[0] is None:
             FIXED[0] = pf.get(depths, dev)
@@ -49,11 +54,20 @@ def step():
     else:
         t = pf.get(depths, dev, overlap=True)
         pf.submit(inst, (480, 640))
+    t2 = time.perf_counter()
     out = net(images)
+    t3 = time.perf_counter()
     losses = crit(net, *out, inst, depths, targets=t)
-    sum(losses.values()).sum().backward()
+    tot = sum(losses.values()).sum()
+    t4 = time.perf_counter()
+    tot.backward()
+    t5 = time.perf_counter()
     ops.wgrad_join()
+    t6 = time.perf_counter()
     opt.step()
+    t7 = time.perf_counter()
+    for k, v in (("zero_grad", t1 - t0), ("targets", t2 - t1), ("forward", t3 - t2), ("loss", t4 - t3), ("backward", t5 - t4), ("join", t6 - t5), ("adam", t7 - t6)):
+        PH.setdefault(k, []).append(v * 1e3)
 
 
 HOST_ONLY = bool(os.environ.get("HOST_ONLY"))          # several copies of this script share ONE GPU (tools/host_probe_8ranks.sh): only H means something
@@ -79,6 +93,7 @@ for _ in range(6):
     torch.cuda.synchronize()
     Gs.append(e0.elapsed_time(e1))
 print("free-running step S = %.1f ms" % S)
+print("host phases of the parked steps (ms): " + ", ".join("%s %.2f" % (k, sum(v[-6:]) / 6) for k, v in PH.items()))
 print("host enqueue H (GPU parked): " + " ".join("%.1f" % h for h in Hs))
 print("process CPU during the enqueue (all threads): " + " ".join("%.1f" % c for c in Cs))
 print("GPU drain    G (no host dep): " + " ".join("%.1f" % g for g in Gs))
