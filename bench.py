@@ -667,8 +667,8 @@ def main():
                                                     "winograd_dw_kernel", "conv3x3_winograd_wgrad_ragged", "dcnv2_fwd_kernel", "dcnv2_wgrad_kernel")]
         ref_flops = sum(f["ref_work"] for f in conv if f["bound"] == "mfma")
         conv_ms = sum(f["time_ms"] for f in conv)
-        # (the bracketed leg brackets every launch on its own, so it runs with the producer -> BatchNorm hand-overs of DESIGN 11.6 off -- ops.lazy_bn_ok is false under the
-        # profiler: every operator writes its own result there, ~160 launches more than the timed step issues; the MFMA families the roofline is about are the same launches)
+        # (the bracketed leg brackets every launch on its own, so it runs with the block entry points off (blocks.usable is false under the
+        # profiler): every operator writes its own result there, ~160 launches more than the timed step issues; the MFMA families the roofline is about are the same launches)
         roof["bracketed_leg"] = "every operator writes its own result (the timed step's producer -> BatchNorm hand-overs are off while launches are bracketed one by one)"
         roof["footnote_reference_operator_view"] = {"reference_flops_per_step": ref_flops, "time_ms": conv_ms,
                                                     "achieved": ref_flops / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",

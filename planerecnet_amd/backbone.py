@@ -17,8 +17,8 @@ from .dcn import DeformableConv2d
 STAGE_FORK = os.environ.get("PRN_STAGE_FORK", "1") == "1"      # 0: the stage outputs' gradients meet in autograd's accumulation pass (A/B)
 
 
-def _bn(m, x, residual=None, relu=False, wino_out=False, wino_grad=False):
-    return ops.batch_norm_module(m, x, residual, relu, wino_out, wino_grad)
+def _bn(m, x, residual=None, relu=False):
+    return ops.batch_norm_module(m, x, residual, relu)
 
 
 def folded_bn(conv_w, conv_b, m):
@@ -91,19 +91,17 @@ class Bottleneck(nn.Module):
             return (out, x) if hand_back else out
         if blocks.usable(self, x):                             # training mode on the device: the whole block is ONE call each way (blocks.py, include/prn.h: prn_bottleneck_*)
             return blocks.bottleneck_train(self, x, hand_back)
+        # operator by operator (frozen BatchNorm, profiler-bracketed runs, shapes the block entry points do not take): every operator writes its own result.
         # x has a second consumer (the identity branch or the downsample conv): hand it on through the fork so that both
         # gradients of x meet in conv1's input-gradient epilogue instead of in a separate accumulation kernel
-        # (lazy_sum / lazy_dgrad: a convolution's result is read by the BatchNorm behind it only, a BatchNorm's output by the convolution behind
-        # it only -- a K-split GEMM then leaves its partial sums, a Winograd convolution its output transform, to that BatchNorm kernel: ops._LAZY_SUMS)
-        out, x = ops.conv2d_fork(x, self.conv1.weight, lazy_sum=self.bn1.training)
-        plain = self.stride == 1 and not isinstance(self.conv2, DeformableConv2d)    # conv2 may take the Winograd path: the BatchNorm kernels on either side
-        out = _bn(self.bn1, out, relu=True, wino_out=plain)                          # of it then also write its operands' input transforms (ops._WINO_V)
+        out, x = ops.conv2d_fork(x, self.conv1.weight)
+        out = _bn(self.bn1, out, relu=True)
         if isinstance(self.conv2, DeformableConv2d):
             out = self.conv2(out)
         else:
-            out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1, lazy_sum=self.bn2.training, lazy_dgrad=self.bn1.training)
-        out = _bn(self.bn2, out, relu=True, wino_grad=plain)
-        out = ops.conv2d(out, self.conv3.weight, lazy_dgrad=self.bn2.training)
+            out = ops.conv2d(out, self.conv2.weight, stride=self.stride, pad=1)
+        out = _bn(self.bn2, out, relu=True)
+        out = ops.conv2d(out, self.conv3.weight)
         res = x
         if self.downsample is not None:
             if hand_back:

@@ -127,11 +127,6 @@ def wgrad_streams():
 def wgrad_join():
     """Make the current stream wait for the deferred weight gradients.  Call after backward(), before reading any `.grad`."""
     wgrad_flush()
-    if _LAZY_SUMS:                                           # a convolution left partial sums for a BatchNorm that never ran: its "result" was garbage
-        n = len(_LAZY_SUMS)
-        _LAZY_SUMS.clear()
-        raise RuntimeError("%d lazily summed convolution result(s) were never consumed by a BatchNorm kernel (ops.conv2d lazy_sum / lazy_dgrad misuse)" % n)
-    _WINO_V.clear()
     if _SIDE:
         main = torch.cuda.current_stream()
         for st in _SIDE.values():
@@ -473,34 +468,9 @@ def _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NO
     return e
 
 
-# A K-split GEMM whose ONLY consumer is a one-launch BatchNorm kernel does not sum its partial results: the BatchNorm kernel does, while loading
-# (include/prn.h: prn_conv2d_fwd_partials, prn_bn_train_fwd_partials / prn_bn_bwd_partials) -- conv1 -> bn1 in the forward, conv3's input gradient ->
-# bn2's backward of the stage-3 / stage-4 Bottlenecks.  The tensor the producer returns is then NOT YET WRITTEN; its data pointer is the key under
-# which the consumer finds the partial sums.  Producers go lazy only when the caller says that a BatchNorm (training mode, small map) follows
-# (conv2d(..., lazy_sum=True) / lazy_dgrad=True); wgrad_join() -- called once per step -- fails loudly if a registered tensor was never consumed.
-LAZY_SPLIT_SUM = os.environ.get("PRN_LAZY_SPLIT_SUM", "1") == "1"
-SCATTER_ACCUMULATE = os.environ.get("PRN_SCATTER_ACC", "1") == "1"      # stride-2 1x1 input gradients add into the forked identity's gradient in place (A/B)
-# data_ptr -> ("sum", workspace tensor, number of partial sums, offset of the first one in floats, elements per partial sum): K-split partial sums of a GEMM
-#          -> ("wino", workspace tensor, offset of Y' [36][M][P] in floats, elements of the result): a Winograd convolution before its output transform, which
-#             the BatchNorm kernel applies itself (prn_winograd_output_bn_fwd / _bwd: conv2 -> bn2, conv2's input gradient -> bn1's backward)
-_LAZY_SUMS = {}
-# data_ptr of a WRITTEN tensor -> (V = its Winograd input transform [36][C][P], (B, C, H, W), weakref to the tensor): left by the BatchNorm kernel that produced the tensor for the 3x3
-# convolution that reads it next (prn_bn_train_fwd_winograd: bn1 -> conv2; prn_bn_bwd_winograd: bn2's input gradient -> conv2's input-gradient convolution).  A
-# consumer that does not find its input here transforms it itself; entries nobody took are dropped at wgrad_join().
-_WINO_V = {}
-BN_WINO_V = os.environ.get("PRN_BN_WINO_V", "1") == "1"      # 0: the consumers transform their inputs themselves (A/B)
-LAZY_STATS = {"fwd": 0, "bwd": 0, "wino_fwd": 0, "wino_bwd": 0, "v_fwd": 0, "v_bwd": 0, "v_used": 0, "scatter_acc": 0}
-
-
-def _take_partials(t):
-    """The partial sums registered for tensor t (and forget them), or None: t holds its values."""
-    if not _LAZY_SUMS:
-        return None
-    return _LAZY_SUMS.pop(t.data_ptr(), None)
-
-
-def lazy_bn_ok(B, HW):
-    return LAZY_SPLIT_SUM and not profiling._enabled and lib.prn_bn_kernel_kind(int(B), int(HW)) == 1
+# (Round 6: the producer -> BatchNorm hand-overs of DESIGN.md 11.6 -- K-split sums summed by the BatchNorm kernel, Winograd transforms inside the BatchNorm
+# launches -- are internal to the block entry points now (include/prn.h: prn_bottleneck_train_fwd / _bwd, planerecnet_amd/blocks.py).  Every operator of this
+# module writes its own result: no tensor is ever handed out unwritten, and nothing is keyed by a data pointer between two call sites.)
 
 
 def _out_hw(H, W, K, stride, pad, mode):
@@ -761,30 +731,18 @@ def split_refresh_all():
 
 
 # ------------------------------------------------------------------------------------------ raw launches
-def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None, lazy=False, scatter_into=None):
-    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor -- or, scatter_into given, ADD it to that
-    position of scatter_into (a dense [B, M, yH, yW] tensor, modified in place and returned: the strided epilogue reads its addend at the output's own index).
-    lazy: the caller vouches that the result's only reader is a BatchNorm kernel that can sum K-split partial results itself (_LAZY_SUMS)."""
+def conv_fwd_raw(x, w2d, bias, addend, M, K, stride, pad, Ho, Wo, mode=IN_ZERO, dil=1, epi=EPI_NONE, scatter2=None):
+    """scatter2=(yH, yW): store output pixel (oh, ow) at (2*oh, 2*ow) of a zero-filled [B, M, yH, yW] tensor."""
     B, C, H, W = x.shape
-    parts = None
     if scatter2 is None:
         y = torch.empty(B, M, Ho, Wo, device=x.device, dtype=torch.float32)
-        d_, ref, nbytes, _, parts = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
+        d_, ref, nbytes, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi)
         wimg = split_images(w2d, M, C, 1, (B, Ho * Wo)) if (d_.kind >= 2 and K == 1 and stride == 1) else None      # (tap gather -- 4x4 / stride 2, 1x1 / stride 2 --: images cut per call, tap-major)
     else:
         wimg = None
-        if scatter_into is not None:
-            assert addend is None and scatter_into.is_contiguous() and tuple(scatter_into.shape) == (B, M, scatter2[0], scatter2[1])
-            y = addend = scatter_into
-        else:
-            y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
+        y = torch.zeros(B, M, scatter2[0], scatter2[1], device=x.device, dtype=torch.float32)
         _, ref, nbytes, _, _ = _desc(B, C, H, W, M, K, stride, pad, Ho, Wo, mode, dil, epi, 2, scatter2[0], scatter2[1])
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
-    if lazy and parts is not None and bias is None and addend is None and epi == EPI_NONE and lazy_bn_ok(B, Ho * Wo) and (y.numel() & 3) == 0:
-        # GEMM launch only; the partial sums stay in ws, which the registry keeps alive until the consumer has been launched
-        check(lib.prn_conv2d_fwd_counted(ref, _p(x), _p(w2d), wimg, None, None, _p(y), _p(ws), None, _stream(), 1), "prn_conv2d_fwd")
-        _LAZY_SUMS[y.data_ptr()] = ("sum", ws, parts[0], parts[1], y.numel())
-        return y
     cnt = _counters(x.device) if (nbytes and FUSED_SPLIT_SUM) else None      # K-split layers: the sum inside the GEMM launch (opt-in)
     if profiling._enabled:
         # algorithmic FLOPs of the reference convolution this launch evaluates (a dilated-input dgrad is credited with the
@@ -1046,7 +1004,7 @@ SPLIT_SKIP = set(filter(None, os.environ.get("PRN_SPLIT_SKIP", "").split(","))) 
 WINOGRAD_KEEP_V = int(os.environ.get("PRN_WINOGRAD_KEEP_V", str(128 << 20)))    # keep B^T x B for the weight gradient up to this many bytes per layer
 
 
-def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep=None, lazy=False):
+def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep=None):
     """3x3 / stride 1 / pad 1 convolution of x [B,C,H,W] with transform-domain weights U [36,M,C].
     keep: a list that receives the workspace (whose head is V = B^T x B) for conv3x3_winograd_wgrad_raw(..., V=...).
     mode IN_EMBED1: x is the block at (1, 1) of a virtual zero tensor [B,C,H+2,W+4]; the result has that size (include/prn.h)."""
@@ -1065,29 +1023,6 @@ def conv3x3_winograd_raw(x, U, bias, addend, M, mode=IN_ZERO, epi=EPI_NONE, keep
         if nb_ws < 0:
             raise RuntimeError(lib.prn_last_error().decode())
     ws = torch.empty(nb_ws // 4, device=x.device, dtype=torch.float32)
-    pre = _WINO_V.pop(x.data_ptr(), None) if _WINO_V else None
-    # (valid only while the tensor it was computed from is alive -- its address cannot have been handed to another tensor then -- and for this very geometry)
-    if pre is not None and not (pre[2]() is not None and pre[1] == (B, C, H, W) and mode == IN_ZERO and not profiling._enabled):
-        pre = None
-    go_lazy = lazy and bias is None and addend is None and epi == EPI_NONE and mode == IN_ZERO and P <= 768 and lazy_bn_ok(B, H * W)
-    if pre is not None or go_lazy:
-        # staged calls: the input transform is skipped when the producer of x left V (_WINO_V); the output transform is left to the BatchNorm kernel
-        # that follows when the caller vouches for one (_LAZY_SUMS)
-        gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
-        Vt = ws if pre is None else pre[0]
-        if pre is None:
-            check(lib.prn_winograd_input(_p(x), _p(ws), B, C, H, W, mode, _stream()), "prn_winograd_input")
-        else:
-            LAZY_STATS["v_used"] += 1
-        yt = ws.data_ptr() + 4 * 36 * C * P
-        check(lib.prn_gemm_batched(M, C, P, 36, _p(U), uimg, _p(Vt), yt, _p(gws) if gws.numel() else None, oref, _stream()), "prn_gemm_batched")
-        if go_lazy:
-            _LAZY_SUMS[y.data_ptr()] = ("wino", ws, 36 * C * P, y.numel())
-        else:
-            check(lib.prn_winograd_output(yt, _p(bias), _p(addend), _p(y), B, M, H, W, epi, _stream()), "prn_winograd_output")
-        if keep is not None and 4 * 36 * C * P <= WINOGRAD_KEEP_V:
-            keep.append(Vt)                                    # (its head is V: all the weight gradient reads of it)
-        return y
     if profiling._enabled:
         V, Yt = ws[:36 * C * P], ws[36 * C * P:36 * (C + M) * P]
         gws = ws[(36 * (C + M) * P + 63) // 64 * 64:]
@@ -1144,13 +1079,13 @@ def channel_sum(g):
     return out
 
 
-def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None, lazy=False):
+def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None):
     """Gradient w.r.t. the conv input: the same implicit-GEMM kernel run over dy with flipped/transposed weights.
     `addend` (another gradient of the same input, e.g. the residual branch) is summed in the kernel epilogue."""
     B, C, H, W = x_shape
     M, _, K, _ = w.shape
     if mode == IN_ZERO and winograd_ok(B, M, H, W, C, K, stride, pad, IN_ZERO, EPI_NONE) and tuple(dy.shape[2:]) == (H, W):
-        return conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, addend, C, lazy=lazy)
+        return conv3x3_winograd_raw(dy, winograd_weights(w)[1], None, addend, C)
     wt = flip_transpose(w)                                  # [C, M, K, K]
     if mode == IN_REFLECT and W % 4 == 0 and tuple(dy.shape[2:]) == (H, W) and winograd_ok(B, M, H + 2, W + 4, C, K, 1, 1, IN_ZERO, EPI_NONE):
         # gradient of the reflect-padded tensor = FULL correlation of dy, on the Winograd path (dy embedded at (1, 1) of a
@@ -1166,25 +1101,24 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad, mode, addend=None, lazy=False):
         check(lib.prn_pad_fold(_p(dp), _p(dx), B, C, H, W, 1 if mode == IN_UP2_REFLECT else 0, _stream()), "prn_pad_fold")
         return dx if addend is None else dx + addend
     if stride == 1:
-        return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W, lazy=lazy and K == 1)
+        return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W)
     if stride != 2:
         raise RuntimeError("conv dgrad: stride %d not implemented" % stride)
     if K == 1 and pad == 0 and addend is None:
         # only the even positions of dx are non-zero: run the GEMM over dy's own pixel grid and scatter (4x fewer MACs
         # than gathering through the zero-dilated view)
         return conv_fwd_raw(dy, wt, None, None, C, 1, 1, 0, dy.shape[2], dy.shape[3], scatter2=(H, W))
-    if K == 1 and pad == 0 and SCATTER_ACCUMULATE and addend.is_contiguous() and addend._base is None and tuple(addend.shape) == (B, C, H, W):
-        # ... and with another gradient of the same input (the forked identity's): added INTO that tensor at the even positions -- no zero fill, no
-        # separate sum (the stage outputs of the backbone: FPN / decoder gradient + the next stage's downsample convolution, models/backbone.py:45)
-        LAZY_STATS["scatter_acc"] += 1
-        return conv_fwd_raw(dy, wt, None, None, C, 1, 1, 0, dy.shape[2], dy.shape[3], scatter2=(H, W), scatter_into=addend)
+    if K == 1 and pad == 0:
+        # ... and with another gradient of the same input: scattered, then summed (the block entry points add INTO a gradient they provably own instead:
+        # blocks._BottleneckFn.backward; a plain operator does not write into a tensor autograd handed it)
+        return conv_fwd_raw(dy, wt, None, None, C, 1, 1, 0, dy.shape[2], dy.shape[3], scatter2=(H, W)) + addend
     return conv_fwd_raw(dy, wt, None, addend, C, K, 1, K - 1 - pad, H, W, IN_DILATED, 2)
 
 
 # ------------------------------------------------------------------------------------------ conv2d
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi, fork=False, lazy_sum=False, lazy_dgrad=False):
+    def forward(ctx, x, w, bias, addend, stride, pad, mode, epi, fork=False):
         _dev(x, w, bias, addend)
         x0, bias_param = x, bias
         x, w, bias, addend = _c(x), _c(w), _c(bias), _c(addend)
@@ -1194,14 +1128,13 @@ class _Conv2d(torch.autograd.Function):
         ctx.wino_v = None
         if winograd_ok(x.shape[0], C, x.shape[2], x.shape[3], M, K, stride, pad, mode, epi):
             keep = [] if (WINOGRAD_WGRAD and ctx.needs_input_grad[1]) else None
-            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi, keep, lazy=lazy_sum)
+            y = conv3x3_winograd_raw(x, winograd_weights(w)[0], bias, addend, M, mode, epi, keep)
             if keep:
                 ctx.wino_v = keep[0]
         else:
-            y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi, lazy=lazy_sum and K == 1)
+            y = conv_fwd_raw(x, w, bias, addend, M, K, stride, pad, Ho, Wo, mode, 1, epi)
         ctx.save_for_backward(x, w, y if epi != EPI_NONE else None)
         ctx.cfg = (stride, pad, mode, epi, bias is not None, addend is not None)
-        ctx.lazy_dgrad = lazy_dgrad and K in (1, 3) and stride == 1
         ctx.bias = bias_param
         ctx.fork = fork
         if fork:
@@ -1216,8 +1149,7 @@ class _Conv2d(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         stride, pad, mode, epi, has_bias, has_add = ctx.cfg
         if dy is None:                                      # only the forked identity was used
-            return (dfork,) + (None,) * 10
-        lazy = ctx.lazy_dgrad and dfork is None
+            return (dfork,) + (None,) * 8
         dy = _c(dy)
         dfork = _c(dfork)
         if epi == EPI_RELU:
@@ -1242,18 +1174,18 @@ class _Conv2d(torch.autograd.Function):
             if V is None and K in (1, 3, 7) and mode in (IN_ZERO, IN_REFLECT) and M > 2 and dy.shape[0] * dy.shape[2] * dy.shape[3] <= WGRAD_GROUP_PIXELS:
                 gkey = ("conv", tuple(x.shape), tuple(dy.shape[2:]), M, K, stride, pad, mode)
             _deferred_wgrad(w, (x, dy) if V is None else (x, dy, V), wgrad, gkey, fast=True)
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork, lazy) if ctx.needs_input_grad[0] else None
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = None
         else:
-            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork, lazy) if ctx.needs_input_grad[0] else None
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad, mode, dfork) if ctx.needs_input_grad[0] else None
             dfork = None
             dw = wgrad() if ctx.needs_input_grad[1] else None
         if dfork is not None and dx is not None:
             dx = dx + dfork
         db = _bias_grad(has_bias and ctx.needs_input_grad[2], ctx.bias, dy)
         da = dy if (has_add and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, da, None, None, None, None, None, None, None
+        return dx, dw, db, da, None, None, None, None, None
 
 
 class _ConvUp2(torch.autograd.Function):
@@ -1308,13 +1240,11 @@ class _ConvUp2(torch.autograd.Function):
 UP2_SUBPIXEL = bool(int(os.environ.get("PRN_UP2_SUBPIXEL", "1")))      # 0: the PRN_IN_UP2_REFLECT gather at output resolution
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None, lazy_sum=False, lazy_dgrad=False):
-    """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list).
-    lazy_sum: the result goes to batch_norm_module (training mode) and nowhere else; lazy_dgrad: x comes from batch_norm_module and goes nowhere
-    else -- a K-split launch may then leave its partial sums to that BatchNorm kernel (_LAZY_SUMS above)."""
+def conv2d(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
+    """F.conv2d replacement (reference: every nn.Conv2d call; see include/prn.h for the call-site list)."""
     if in_mode == IN_UP2_REFLECT and UP2_SUBPIXEL and epilogue == EPI_NONE and addend is None and x.shape[2] > 1 and x.shape[3] > 1:
         return _ConvUp2.apply(x, w, bias)
-    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, False, lazy_sum, lazy_dgrad)
+    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, False)
 
 
 _UP2_PHASE = {}     # weight data_ptr -> (weakref(weight), version, phase weights): inference only
@@ -1341,11 +1271,11 @@ def conv_up2_inference(x, w, bias=None, relu=False):
     return conv_fwd_raw(x, e[2], bias, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE, 1, EPI_RELU if relu else EPI_NONE)
 
 
-def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None, lazy_sum=False):
+def conv2d_fork(x, w, bias=None, stride=1, pad=0, in_mode=IN_ZERO, epilogue=EPI_NONE, addend=None):
     """conv2d that also hands its input back: `y, x_id = conv2d_fork(x, w)`.  Use x_id wherever else x is consumed
     (the identity branch of a residual block): the two gradients of x are then summed inside the input-gradient GEMM's
     epilogue rather than by autograd's separate accumulation kernel (one full-tensor read-read-write pass per block)."""
-    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, True, lazy_sum, False)
+    return _Conv2d.apply(x, w, bias, addend, stride, pad, in_mode, epilogue, True)
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
@@ -1675,53 +1605,13 @@ def fpn_level(x, w_lat, b_lat, prev, w_out, b_out, relu):
 # ------------------------------------------------------------------------------------------ BatchNorm
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, eps, momentum, relu, wino_out=False, wino_grad=False):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, eps, momentum, relu):
         _dev(x, gamma, beta, rmean, rvar, residual)
         x, residual = _c(x), _c(residual)
         B, C, H, W = x.shape
         HW = H * W
         y = torch.empty_like(x)
-        pend = _take_partials(x)
-        # wino_out / wino_grad: the 3x3 convolution that reads this layer's output is on the Winograd path -- the kernel then also writes the input transform
-        # of its output (forward) / of its input gradient (backward) for it (_WINO_V)
-        v_ok = ((wino_out or wino_grad) and BN_WINO_V and training and W % 4 == 0 and residual is None and lazy_bn_ok(B, HW)
-                and winograd_ok(B, C, H, W, C, 3, 1, 1, IN_ZERO, EPI_NONE))
-        ctx.wino_grad = bool(wino_grad and v_ok)
-        if wino_out and v_ok and (pend is None or pend[0] == "sum"):
-            stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-            V = torch.empty(36 * C * lib.prn_winograd_tiles(B, H, W), device=x.device, dtype=torch.float32)
-            if pend is None:
-                check(lib.prn_bn_train_fwd_winograd(_p(x), 1, 0, None, _p(stats), _p(gamma), _p(beta), None, _p(y), _p(rmean), _p(rvar), _p(V), B, C, H, W, eps,
-                                                    momentum, int(relu), _stream()), "prn_bn_train_fwd_winograd")
-            else:
-                _, pws, nparts, poff, pn = pend
-                assert pn == x.numel()
-                check(lib.prn_bn_train_fwd_winograd(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(stats), _p(gamma), _p(beta), None, _p(y), _p(rmean), _p(rvar),
-                                                    _p(V), B, C, H, W, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_winograd")
-                LAZY_STATS["fwd"] += 1
-            LAZY_STATS["v_fwd"] += 1
-            _WINO_V[y.data_ptr()] = (V, (B, C, H, W), weakref.ref(y))
-            torch.autograd.graph.increment_version(rmean)
-            torch.autograd.graph.increment_version(rvar)
-        elif pend is not None:                              # x is not written yet: its producer left K-split partial sums (see _LAZY_SUMS)
-            if not training:
-                raise RuntimeError("a lazily summed convolution result reached an eval-mode BatchNorm")
-            stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-            if pend[0] == "wino":
-                _, pws, poff, pn = pend
-                assert pn == x.numel() and residual is None
-                check(lib.prn_winograd_output_bn_fwd(pws.data_ptr() + 4 * poff, _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(rmean), _p(rvar), B, C, H, W,
-                                                     eps, momentum, int(relu), _stream()), "prn_winograd_output_bn_fwd")
-                LAZY_STATS["wino_fwd"] += 1
-            else:
-                _, pws, nparts, poff, pn = pend
-                assert pn == x.numel()
-                check(lib.prn_bn_train_fwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(stats), _p(gamma), _p(beta), _p(residual), _p(y), _p(rmean),
-                                                    _p(rvar), B, C, HW, eps, momentum, int(relu), _stream()), "prn_bn_train_fwd_partials")
-                LAZY_STATS["fwd"] += 1
-            torch.autograd.graph.increment_version(rmean)
-            torch.autograd.graph.increment_version(rvar)
-        elif training:
+        if training:
             stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             # (the fp64 partial sums exist only on the two-launch path; the library checks the pointer there)
             ws = torch.empty(2 * C * _lib.BN_SPLITS, device=x.device, dtype=torch.float64) if lib.prn_bn_kernel_kind(B, HW) != 1 else None
@@ -1759,36 +1649,6 @@ class _BatchNorm(torch.autograd.Function):
         need_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dg = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if need_affine else None
-        pend = _take_partials(dy)
-        if ctx.wino_grad and (pend is None or pend[0] == "sum"):      # dx also leaves as the input transform conv2's input-gradient convolution wants
-            V = torch.empty(36 * C * lib.prn_winograd_tiles(B, H, W), device=x.device, dtype=torch.float32)
-            if pend is None:
-                check(lib.prn_bn_bwd_winograd(_p(dy), 1, 0, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(V), B, C, H, W,
-                                              int(relu), 0, _stream()), "prn_bn_bwd_winograd")
-            else:
-                _, pws, nparts, poff, pn = pend
-                assert pn == dy.numel()
-                check(lib.prn_bn_bwd_winograd(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
-                                              _p(V), B, C, H, W, int(relu), 0, _stream()), "prn_bn_bwd_winograd")
-                LAZY_STATS["bwd"] += 1
-            LAZY_STATS["v_bwd"] += 1
-            _WINO_V[dx.data_ptr()] = (V, (B, C, H, W), weakref.ref(dx))
-            return dx, dg, db, None, None, dres, None, None, None, None, None, None
-        if pend is not None:                                # dy is not written: the input-gradient GEMM behind it left its K-split partial sums
-            assert training
-            if pend[0] == "wino":
-                _, pws, poff, pn = pend
-                assert pn == dy.numel() and not has_res and y is None
-                check(lib.prn_winograd_output_bn_bwd(pws.data_ptr() + 4 * poff, _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dg), _p(db), B, C, H, W,
-                                                     int(relu), _stream()), "prn_winograd_output_bn_bwd")
-                LAZY_STATS["wino_bwd"] += 1
-            else:
-                _, pws, nparts, poff, pn = pend
-                assert pn == dy.numel()
-                check(lib.prn_bn_bwd_partials(pws.data_ptr() + 4 * poff, nparts, pn, _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db),
-                                              B, C, H * W, int(relu), 0, _stream()), "prn_bn_bwd_partials")
-                LAZY_STATS["bwd"] += 1
-            return dx, dg, db, None, None, dres, None, None, None, None, None, None
         # executed bytes: dy and x (and y, when the ReLU mask comes from the output) are read once by the one-pass kernel, twice by the
         # two-pass pair; dx (and the residual's gradient) written once.  ref = the reference operator chain (ReLU bwd + BN bwd + add)
         small = training and lib.prn_bn_kernel_kind(B, H * W) == 1
@@ -1798,7 +1658,7 @@ class _BatchNorm(torch.autograd.Function):
                             ref=4.0 * x.numel() * ((3 if relu else 2) * 2 + 1 + (1 if has_res else 0))):
             check(lib.prn_bn_bwd(_p(dy), _p(x), _p(y), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dg), _p(db), _p(ws),
                                  B, C, H * W, int(relu), int(not training), _stream()), "prn_bn_bwd")
-        return dx, dg, db, None, None, dres, None, None, None, None, None, None
+        return dx, dg, db, None, None, dres, None, None, None, None
 
 
 class _BatchNormCat(torch.autograd.Function):
@@ -1876,20 +1736,19 @@ def batch_norm_relu_cat(ma, xa, mb, xb):
                                float(ma.eps), float(ma.momentum), float(mb.eps), float(mb.momentum))
 
 
-def batch_norm_module(m, x, residual=None, relu=False, wino_out=False, wino_grad=False):
+def batch_norm_module(m, x, residual=None, relu=False):
     """nn.BatchNorm2d.forward (+ residual add + ReLU) on the HIP kernels, including the module's bookkeeping: in training mode
     `num_batches_tracked` advances like nn.BatchNorm2d's (counted on the host and written to the buffer when a state dict
     is read, see _count_batch)."""
     if m.training and m.track_running_stats:
         _count_batch(m)
-    return batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu, wino_out, wino_grad)
+    return batch_norm(x, m.weight, m.bias, m.running_mean, m.running_var, m.training, m.eps, m.momentum, residual, relu)
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, residual=None, relu=False, wino_out=False, wino_grad=False):
+def batch_norm(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, residual=None, relu=False):
     """F.batch_norm (+ residual add + ReLU) replacement. training=True uses batch statistics and updates the
     running buffers in place (momentum, unbiased variance) like nn.BatchNorm2d."""
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps), float(momentum), bool(relu), bool(wino_out),
-                            bool(wino_grad))
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(eps), float(momentum), bool(relu))
 
 
 # ------------------------------------------------------------------------------------------ GroupNorm + ReLU

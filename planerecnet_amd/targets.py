@@ -183,10 +183,14 @@ class DeviceTargetBuilder:
         L = len(crit.num_grids)
         level_start = np.concatenate([[0], np.cumsum([g * g for g in crit.num_grids])])
         cell_ids, which_all, cate_rows, n_pos, num_ins = [], [], [[] for _ in range(L)], [], 0
+        # the float arithmetic of the assignment for all instances of the batch at once (losses.cell_regions); the per-image loop only places cells
+        regions = crit.cell_regions(np.concatenate([np.asarray(m["boxes"], dtype=np.float64).reshape(-1, 4) for m in job["meta"]]) if Ntot else np.zeros((0, 4)),
+                                    cx_all[:Ntot], cy_all[:Ntot], (fh, fw))
+        nonempty_all = (cnt_t > 0).numpy()
         for b in range(B):
             lo, hi = int(first[b]), int(first[b + 1])
             meta = job["meta"][b]
-            which_l, cate_l, ind_l, order_l = crit.assign_cells(meta["boxes"], meta["classes"], cx_all[lo:hi], cy_all[lo:hi], cnt_t[lo:hi] > 0, (fh, fw))
+            which_l, cate_l, ind_l, order_l = crit.assign_cells(None, meta["classes"], None, None, nonempty_all[lo:hi], (fh, fw), regions, lo)
             cell_ids.append(np.concatenate([level_start[lv] + np.asarray(order_l[lv], dtype=np.int64) for lv in range(L)]))
             which_all.append(np.concatenate([np.asarray(w, dtype=np.int64) for w in which_l]) + lo)
             n_pos.append(int(cell_ids[-1].shape[0]))

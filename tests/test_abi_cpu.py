@@ -224,3 +224,81 @@ def test_producer_to_batchnorm_hand_overs_are_host_logic_until_the_launch():
     assert lib.prn_bn_train_fwd_winograd(p, 1, 0, None, p, p, p, None, p, None, None, p, 8, 256, 30, 42, 1e-5, 0.1, 1, None) != 0   # W % 4 != 0
     assert lib.prn_winograd_output_bn_fwd(p, p, p, p, p, p, None, None, 8, 256, 60, 80, 1e-5, 0.1, 1, None) != 0                    # 2400 tiles: not a one-launch map
     assert lib.prn_vnl_trim_ws_bytes(600) == 600 * 16 * 12 and lib.prn_vnl_trim_ws_bytes(0) == -1
+
+
+def _block_desc(B=8, C=1024, H=30, W=40, P=256, stride=1, dcn=0, ds=0, flags=15, max_offset=0.0):
+    from planerecnet_amd import _lib
+    o, _ = _opts(wgrad=1)
+    f4 = ctypes.c_float * 4
+    return _lib.BottleneckDesc(B, C, H, W, P, stride, dcn, ds, flags, f4(1e-5, 1e-5, 1e-5, 1e-5), f4(0.1, 0.1, 0.1, 0.1), max_offset, 0, o)
+
+
+def _block_plan(d):
+    from planerecnet_amd import _lib, blocks
+    lib = _lib.lib
+    buf = ctypes.create_string_buffer(lib.prn_bottleneck_plan_bytes())
+    rc = lib.prn_bottleneck_plan(ctypes.byref(d), buf)
+    info = (ctypes.c_int64 * blocks.INFO_COUNT)()
+    if rc == 0:
+        assert lib.prn_bottleneck_plan_info(buf, info, blocks.INFO_COUNT) == 0
+    return rc, buf, list(info)
+
+
+def test_bottleneck_plan_is_host_logic():
+    """prn_bottleneck_plan (include/prn.h) is a function of the descriptor alone: which path conv2 takes, which producer -> BatchNorm hand-overs apply,
+    buffer sizes and operand offsets -- checked here without a GPU for the block shapes of the benchmark (PlaneRecNet_101, B = 8, 480x640)."""
+    from planerecnet_amd import blocks as bk
+    # stage 3, plain block: Winograd conv2, V kept, every hand-over (30x40 maps: one-launch BatchNorm kernels, conv1 / conv3-dgrad K-split)
+    rc, _, i = _block_plan(_block_desc())
+    assert rc == 0 and i[bk.I_CONV2] == bk.CONV2_WINOGRAD and i[bk.I_KEEPS_V] == 1 and i[bk.I_HANDOVERS] == 0b111111 and (i[bk.I_HO], i[bk.I_WO]) == (30, 40)
+    assert i[bk.I_BN_FLOATS] == 2 * 256 + 2 * 256 + 2 * 1024
+    # ... the same without the hand-over flag: nothing handed over, same sizes of what the backward pass keeps
+    rc, _, j = _block_plan(_block_desc(flags=15 & ~2))
+    assert rc == 0 and j[bk.I_HANDOVERS] == 0 and j[bk.I_SAVE] == i[bk.I_SAVE]
+    # stage 1 (120x160): two-launch BatchNorm kernels -> no hand-overs; Winograd with V kept (88 MB <= 128 MB)
+    rc, _, i = _block_plan(_block_desc(C=256, H=120, W=160, P=64))
+    assert rc == 0 and i[bk.I_CONV2] == bk.CONV2_WINOGRAD and i[bk.I_HANDOVERS] == 0 and i[bk.I_KEEPS_V] == 1
+    # first block of stage 3: deformable conv2 at stride 2 with a downsample branch (60x80 -> 30x40): only conv3's input gradient hands its sums over
+    rc, _, i = _block_plan(_block_desc(C=512, H=60, W=80, P=256, stride=2, dcn=1, ds=1, max_offset=20.0))
+    assert rc == 0 and i[bk.I_CONV2] == bk.CONV2_DCN and (i[bk.I_HO], i[bk.I_WO]) == (30, 40) and i[bk.I_HANDOVERS] == 0b001000
+    assert i[bk.I_BN_FLOATS] == 4 * 256 + 4 * 1024 and i[bk.I_OM] > 0 and i[bk.I_TABLE] > i[bk.I_OM] and i[bk.I_DD] > 0
+    # every offset lies inside its buffer and is 256-byte aligned
+    for k in (bk.I_A1, bk.I_V, bk.I_A2, bk.I_OM, bk.I_TABLE):
+        assert 0 <= i[k] < i[bk.I_SAVE] and i[k] % 256 == 0
+    for k in (bk.I_D1, bk.I_D2, bk.I_D3, bk.I_DD, bk.I_DOM):
+        assert 0 <= i[k] < i[bk.I_GSAVE] and i[k] % 256 == 0
+    # too few channels for F(4x4,3x3): the direct kernel
+    rc, _, i = _block_plan(_block_desc(B=2, C=64, H=12, W=16, P=16))
+    assert rc == 0 and i[bk.I_CONV2] == bk.CONV2_DIRECT
+
+
+def test_bottleneck_entry_points_validate_before_any_launch():
+    """Bad descriptors / plans / buffers are refused on the host (rc != 0 + message), nothing is launched."""
+    from planerecnet_amd import _lib
+    lib = _lib.lib
+    err = lambda: lib.prn_last_error().decode()      # noqa: E731
+    rc, _, _ = _block_plan(_block_desc(C=100))                         # no downsample branch, but the block would change the channel count
+    assert rc != 0 and "downsample" in err()
+    rc, _, _ = _block_plan(_block_desc(stride=3, ds=1))
+    assert rc != 0 and "stride" in err()
+    rc, _, _ = _block_plan(_block_desc(dcn=1))                         # deformable variant without its offset clamp
+    assert rc != 0 and "max_offset" in err()
+    assert lib.prn_bottleneck_plan(None, ctypes.create_string_buffer(64)) != 0
+    assert lib.prn_bottleneck_plan(ctypes.byref(_block_desc()), None) != 0
+    p = _lib.BottleneckParams()
+    junk = ctypes.create_string_buffer(lib.prn_bottleneck_plan_bytes())      # not a plan prn_bottleneck_plan filled
+    assert lib.prn_bottleneck_train_fwd(junk, ctypes.byref(p), 256, 256, 256, 256, None) != 0 and "plan" in err()
+    assert lib.prn_bottleneck_train_bwd(junk, ctypes.byref(p), 256, 256, 256, 256, 0, 256, 256, 256, 256, None) != 0 and "plan" in err()
+    rc, plan, _ = _block_plan(_block_desc())
+    assert rc == 0
+    assert lib.prn_bottleneck_train_fwd(plan, ctypes.byref(p), None, 256, 256, 256, None) != 0 and "null" in err()
+    assert lib.prn_bottleneck_train_fwd(plan, ctypes.byref(p), 256, 256, 256, 256, None) != 0 and "null" in err()      # the parameter table is empty
+    p.w1 = p.w3 = p.u2 = 4096
+    for k in range(3):
+        p.gamma[k] = p.beta[k] = p.running_mean[k] = p.running_var[k] = 4096
+    assert lib.prn_bottleneck_train_fwd(plan, ctypes.byref(p), 4096, 4096, 4096 + 16, 4096, None) != 0 and "aligned" in err()
+    assert lib.prn_bottleneck_train_bwd(plan, ctypes.byref(p), 4096, 4096, 4096, 4096, 0, 4096, 4096, 4096, 4096, None) != 0 and "layout" in err()
+    p.w1_t = p.w3_t = p.ut2 = 4096
+    assert lib.prn_bottleneck_train_bwd(plan, ctypes.byref(p), 4096, 4096, 4096, 4096, 1, 4096, 4096, 4096, 4096, None) != 0 and "dx_accumulate" in err()
+    info = (ctypes.c_int64 * 4)()
+    assert lib.prn_bottleneck_plan_info(plan, info, 4) != 0                  # too short an output array

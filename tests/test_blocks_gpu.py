@@ -82,6 +82,9 @@ CASES = [
     (2, 128, 64, 24, 32, 2, True, True),                     # deformable conv2, stride 2, downsample branch (first block of stages 2-4)
     (2, 256, 128, 30, 40, 2, True, True),
     (3, 64, 16, 7, 9, 1, False, False),                      # H*W % 4 != 0: nothing vectorised, nothing handed over
+    (8, 2048, 512, 15, 20, 1, False, False),                 # the stage-4 block of the benchmark
+    (4, 256, 64, 18, 28, 1, False, False),                   # H % 4 != 0
+    (5, 256, 64, 20, 28, 1, False, False),                   # 175 Winograd tiles: a padded tile axis
 ]
 
 
@@ -96,11 +99,10 @@ def test_block_call_equals_the_operator_sequence(B, Cin, P, H, W, stride, ds, dc
     go = rnd(B, 4 * P, Ho, Wo, seed=6).float().to(d)
     ext = rnd(B, Cin, H, W, seed=7).float().to(d)
     hb = bool(ds and stride == 2)
-    saved = (blocks.ENABLED, blocks.HANDOVER, ops.WGRAD_ASYNC, ops.LAZY_SPLIT_SUM)
+    saved = (blocks.ENABLED, blocks.HANDOVER, ops.WGRAD_ASYNC)
     try:
         ops.set_wgrad_async(deferred)
-        blocks.ENABLED = False
-        ops.LAZY_SPLIT_SUM = False                            # the operator sequence with every operator writing its own result
+        blocks.ENABLED = False                                # the operator sequence: ops.conv2d / batch_norm / deform_conv_block nodes
         ref = run(blk, x, go, hb, ext)
         blocks.ENABLED, blocks.HANDOVER = True, False
         n0 = dict(blocks.STATS)
@@ -113,7 +115,6 @@ def test_block_call_equals_the_operator_sequence(B, Cin, P, H, W, stride, ds, dc
     finally:
         blocks.ENABLED, blocks.HANDOVER = saved[0], saved[1]
         ops.set_wgrad_async(saved[2])
-        ops.LAZY_SPLIT_SUM = saved[3]
     assert set(ref) == set(plain) == set(handed)
     # the CSR bins of the deformable sampler's input gradient are filled through an atomic cursor: last-bit differences run to run in everything behind it
     loose = ("dx", "d conv1.weight", "d bn1.weight", "d bn1.bias") if dcn else ()

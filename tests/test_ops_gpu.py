@@ -628,10 +628,11 @@ def test_batch_norm_fwd_bwd(B, C, H, W, res, relu, training):
 
 
 @pytest.mark.parametrize("B,C,H,W,M", [(2, 24, 15, 21, 40), (2, 64, 30, 40, 128), (1, 256, 120, 160, 512)])
-def test_stride2_1x1_input_gradient_adds_into_the_forked_gradient_in_place(B, C, H, W, M):
+def test_stride2_1x1_fork_sums_the_two_gradients_of_its_input(B, C, H, W, M):
     """The downsample convolution of a stage's first Bottleneck (1x1, stride 2, models/backbone.py:45) as a fork: the gradient of its input's other readers
-    (FPN lateral, depth decoder) arrives as the forked identity's gradient, and the input gradient of the convolution -- non-zero at the even positions only --
-    is ADDED INTO that tensor by the GEMM's strided epilogue (addend == y): no zero fill, no separate sum.  Against fp64, odd sizes included."""
+    (FPN lateral, depth decoder) arrives as the forked identity's gradient; the convolution's input gradient -- non-zero at the even positions only -- is
+    scattered by the GEMM's strided epilogue and the two are summed.  Against fp64, odd sizes included.  (The block entry points add INTO the incoming
+    gradient in place when they own it: tests/test_blocks_gpu.py.)"""
     from planerecnet_amd import ops
     d = dev()
     x = rnd(B, C, H, W, seed=1)
@@ -640,158 +641,15 @@ def test_stride2_1x1_input_gradient_adds_into_the_forked_gradient_in_place(B, C,
     g1, g2 = rnd(B, M, Ho, Wo, seed=3), rnd(B, C, H, W, seed=4)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     ref = torch.autograd.grad([F.conv2d(xr, wr, stride=2), xr * 1.0], [xr, wr], [g1, g2])
-    results = {}
-    for acc in (False, True):
-        ops.SCATTER_ACCUMULATE = acc
-        before = ops.LAZY_STATS["scatter_acc"]
-        xd, wd = x.float().to(d).requires_grad_(True), w.float().to(d).requires_grad_(True)
-        try:
-            y, xid = ops.conv2d_fork(xd, wd, stride=2)
-            got = torch.autograd.grad([y, xid * 1.0], [xd, wd], [g1.float().to(d), g2.float().to(d)])
-        finally:
-            ops.SCATTER_ACCUMULATE = True
-        ops.wgrad_join()
-        assert ops.LAZY_STATS["scatter_acc"] - before == (1 if acc else 0)
-        close(got[0], ref[0], "dx (accumulate=%s)" % acc)
-        close(got[1], ref[1], "dw (accumulate=%s)" % acc, rtol=5e-4)
-        results[acc] = got[0]
-    # (the two paths run the products through different launch plans: equal to fp32 rounding of a C-term sum, not bit for bit)
-    assert (results[False] - results[True]).abs().max().item() <= 1e-5 * results[False].abs().max().item()
-
-
-@pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (2, 512, 128, 12, 20)])
-def test_k_split_sums_left_to_the_batchnorm_kernels_are_bit_identical(B, Cin, Cmid, H, W):
-    """conv1 -> bn1 (forward) and conv3's input gradient -> bn2's backward of a Bottleneck (models/backbone.py:56-66): where the GEMM runs with a K split
-    and the map is small enough for the one-launch BatchNorm kernels, the partial sums are summed by the BatchNorm kernel itself
-    (prn_conv2d_fwd_partials / prn_bn_train_fwd_partials / prn_bn_bwd_partials) -- same values, bit for bit, as with the separate sum launch; and against
-    the fp64 reference.  The third case has no K split under any plan it is run with: the flags must then change nothing."""
-    from planerecnet_amd import ops
-    d = dev()
-    x = (rnd(B, Cin, H, W, seed=1).relu() * 0.7).float()
-    w1 = rnd(Cmid, Cin, 1, 1, seed=2, scale=Cin ** -0.5).float()
-    w3 = rnd(Cin, Cmid, 1, 1, seed=3, scale=Cmid ** -0.5).float()
-    g1, b1 = (rnd(Cmid, seed=4) * 0.2 + 1).float(), rnd(Cmid, seed=5, scale=0.2).float()
-    go = rnd(B, Cin, H, W, seed=6).float().to(d)
-
-    def run(lazy):
-        ops.LAZY_SPLIT_SUM = lazy
-        before = dict(ops.LAZY_STATS)
-        leaves = [t.to(d).requires_grad_(True) for t in (x, w1, w3, g1, b1)]
-        rm, rv = torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d)
-        y1 = ops.conv2d(leaves[0], leaves[1], lazy_sum=True)
-        z1 = ops.batch_norm(y1, leaves[3], leaves[4], rm, rv, True, 1e-5, 0.1, None, True)
-        out = ops.conv2d(z1, leaves[2], lazy_dgrad=True)
-        grads = torch.autograd.grad(out, leaves, go)
-        ops.wgrad_join()
-        took = (ops.LAZY_STATS["fwd"] - before["fwd"], ops.LAZY_STATS["bwd"] - before["bwd"])
-        return [out.detach(), rm, rv] + [g_.detach() for g_ in grads], took
-
-    try:
-        eager, took0 = run(False)
-        lazy, took1 = run(True)
-    finally:
-        ops.LAZY_SPLIT_SUM = True
-    assert took0 == (0, 0)
-    # (the forward GEMM and conv3's input-gradient GEMM have the same descriptor here: Cin -> Cmid, 1x1)
-    split = ops._desc(B, Cin, H, W, Cmid, 1, 1, 0, H, W)[4] is not None and ops.lib.prn_bn_kernel_kind(B, H * W) == 1
-    assert took1 == ((1, 1) if split else (0, 0)), (took1, split)
-    if Cin >= 1024:
-        assert split, "the stage-3 / stage-4 shapes are the ones this exists for"
-    names = ["out", "running_mean", "running_var", "dx", "dw1", "dw3", "dgamma", "dbeta"]
-    for n, a, b in zip(names, eager, lazy):
-        assert torch.equal(a, b), "%s differs between the eager and the lazily summed path (max %.3e)" % (n, (a - b).abs().max().item())
-    # ... and the values themselves against fp64
-    xr, w1r, w3r, g1r, b1r = [t.double().requires_grad_(True) for t in (x, w1, w3, g1, b1)]
-    z = F.relu(F.batch_norm(F.conv2d(xr, w1r), None, None, g1r, b1r, True, 0.1, 1e-5))
-    outr = F.conv2d(z, w3r)
-    gr = torch.autograd.grad(outr, [xr, w1r, w3r, g1r, b1r], go.double().cpu())
-    close(lazy[0], outr, "lazy out", rtol=5e-4)
-    for n, a, b in zip(names[3:], lazy[3:], gr):         # (r.m.s.: a BatchNorm output within rounding of the ReLU's zero flips single elements of dx by O(1))
-        a, b = a.double().cpu(), b.double()
-        assert (a - b).norm().item() <= 2e-3 * b.norm().item(), "lazy %s: rms error %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
-
-
-def test_a_handed_over_result_that_no_batchnorm_takes_fails_loudly():
-    """A producer called with lazy_sum=True leaves its result unwritten for the BatchNorm kernel behind it (ops._LAZY_SUMS).  If the caller's promise is
-    broken -- nothing, or an eval-mode BatchNorm, follows -- the mistake must not pass silently: wgrad_join() (called once per training step) raises for a
-    hand-over nobody took, and an eval-mode BatchNorm refuses one."""
-    from planerecnet_amd import ops
-    d = dev()
-    B, Cin, Cmid, H, W = 8, 1024, 256, 30, 40
-    x = rnd(B, Cin, H, W, seed=1).float().to(d)
-    w = rnd(Cmid, Cin, 1, 1, seed=2, scale=Cin ** -0.5).float().to(d)
-    assert ops._desc(B, Cin, H, W, Cmid, 1, 1, 0, H, W)[4] is not None, "this shape runs with a K split: the case the hand-over exists for"
-    with torch.no_grad():
-        y = ops.conv2d(x, w, lazy_sum=True)
-        assert y.data_ptr() in ops._LAZY_SUMS
-        with pytest.raises(RuntimeError, match="never consumed"):
-            ops.wgrad_join()
-        assert not ops._LAZY_SUMS                              # (the registry is clean again)
-        y = ops.conv2d(x, w, lazy_sum=True)
-        g, b_ = torch.ones(Cmid, device=d), torch.zeros(Cmid, device=d)
-        with pytest.raises(RuntimeError, match="eval-mode"):
-            ops.batch_norm(y, g, b_, torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d), False)
-        ops.wgrad_join()                                       # (the refused hand-over was taken out of the registry)
-        # ... and without the flag the same call writes its own result
-        close(ops.conv2d(x, w), F.conv2d(x.double().cpu(), w.double().cpu()), "conv2d without hand-over")
-
-
-@pytest.mark.parametrize("B,Cin,Cmid,H,W", [(8, 1024, 256, 30, 40), (8, 2048, 512, 15, 20), (4, 256, 64, 18, 28), (5, 256, 64, 20, 28)])     # (last: 175 tiles, a padded tile axis)
-def test_bottleneck_chain_with_the_output_transforms_left_to_the_batchnorm_kernels(B, Cin, Cmid, H, W):
-    """conv1 -> bn1 -> conv2 (3x3, Winograd) -> bn2 -> conv3 as models/backbone.py:56-66 chains them, once with every launch of its own and once with
-    (i) the K-split sums of conv1 / of conv3's input gradient and (ii) the Winograd OUTPUT TRANSFORM of conv2 / of conv2's input gradient left to the
-    one-launch BatchNorm kernels behind them (prn_winograd_output_bn_fwd / _bwd), and (iii) the Winograd INPUT transforms of conv2's operands written by the
-    BatchNorm kernels in front of them (prn_bn_train_fwd_winograd / prn_bn_bwd_winograd: the consumer's loader work done where the data is in registers).  (ii) sums the channel statistics in another order, so the two runs agree
-    to fp32 rounding, not bit for bit; both against fp64.  The last case is too small for any K split: only (ii) is exercised."""
-    from planerecnet_amd import ops
-    d = dev()
-    x = (rnd(B, Cin, H, W, seed=1).relu() * 0.7).float()
-    w1 = rnd(Cmid, Cin, 1, 1, seed=2, scale=Cin ** -0.5).float()
-    w2 = rnd(Cmid, Cmid, 3, 3, seed=8, scale=(9 * Cmid) ** -0.5).float()
-    w3 = rnd(Cin, Cmid, 1, 1, seed=3, scale=Cmid ** -0.5).float()
-    g1, b1 = (rnd(Cmid, seed=4) * 0.2 + 1).float(), rnd(Cmid, seed=5, scale=0.2).float()
-    g2, b2 = (rnd(Cmid, seed=9) * 0.2 + 1).float(), rnd(Cmid, seed=10, scale=0.2).float()
-    go = rnd(B, Cin, H, W, seed=6).float().to(d)
-    assert ops.winograd_ok(B, Cmid, H, W, Cmid, 3, 1, 1, ops.IN_ZERO, ops.EPI_NONE)
-
-    def run(lazy):
-        ops.LAZY_SPLIT_SUM = lazy
-        before = dict(ops.LAZY_STATS)
-        leaves = [t.to(d).requires_grad_(True) for t in (x, w1, w2, w3, g1, b1, g2, b2)]
-        rms = [torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d), torch.zeros(Cmid, device=d), torch.ones(Cmid, device=d)]
-        y1 = ops.conv2d(leaves[0], leaves[1], lazy_sum=True)
-        z1 = ops.batch_norm(y1, leaves[4], leaves[5], rms[0], rms[1], True, 1e-5, 0.1, None, True, wino_out=True)
-        y2 = ops.conv2d(z1, leaves[2], pad=1, lazy_sum=True, lazy_dgrad=True)
-        z2 = ops.batch_norm(y2, leaves[6], leaves[7], rms[2], rms[3], True, 1e-5, 0.1, None, True, wino_grad=True)
-        out = ops.conv2d(z2, leaves[3], lazy_dgrad=True)
-        grads = torch.autograd.grad(out, leaves, go)
-        ops.wgrad_join()
-        took = {k: ops.LAZY_STATS[k] - before[k] for k in before}
-        return [out.detach()] + rms + [g_.detach() for g_ in grads], took
-
-    try:
-        eager, took0 = run(False)
-        lazy, took1 = run(True)
-    finally:
-        ops.LAZY_SPLIT_SUM = True
-    assert not any(took0.values())
-    assert took1["wino_fwd"] == 1 and took1["wino_bwd"] == 1, took1
-    assert took1["v_fwd"] == 1 and took1["v_bwd"] == 1 and took1["v_used"] == 2, took1      # (iii) bn1 / bn2's backward also wrote conv2's input transforms
-    if Cin >= 1024:
-        assert took1["fwd"] == 1 and took1["bwd"] == 1, took1
-    names = ["out", "rm1", "rv1", "rm2", "rv2", "dx", "dw1", "dw2", "dw3", "dg1", "db1", "dg2", "db2"]
-    for n, a, b in zip(names, eager, lazy):
-        a, b = a.double(), b.double()
-        assert (a - b).norm().item() <= 2e-5 * b.norm().item() + 1e-12, "%s: eager vs lazy rms difference %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
-    xr, w1r, w2r, w3r, g1r, b1r, g2r, b2r = [t.double().requires_grad_(True) for t in (x, w1, w2, w3, g1, b1, g2, b2)]
-    z = F.relu(F.batch_norm(F.conv2d(xr, w1r), None, None, g1r, b1r, True, 0.1, 1e-5))
-    z = F.relu(F.batch_norm(F.conv2d(z, w2r, padding=1), None, None, g2r, b2r, True, 0.1, 1e-5))
-    outr = F.conv2d(z, w3r)
-    gr = torch.autograd.grad(outr, [xr, w1r, w2r, w3r, g1r, b1r, g2r, b2r], go.double().cpu())
-    close(lazy[0], outr, "lazy out", rtol=1e-3)
-    for n, a, b in zip(names[5:], lazy[5:], gr):
-        a, b = a.double().cpu(), b.double()
-        assert (a - b).norm().item() <= 3e-3 * b.norm().item(), "lazy %s: rms error %.3e of %.3e" % (n, (a - b).norm().item(), b.norm().item())
+    xd, wd = x.float().to(d).requires_grad_(True), w.float().to(d).requires_grad_(True)
+    y, xid = ops.conv2d_fork(xd, wd, stride=2)
+    g2d = g2.float().to(d)
+    keep = g2d.clone()
+    got = torch.autograd.grad([y, xid * 1.0], [xd, wd], [g1.float().to(d), g2d])
+    ops.wgrad_join()
+    close(got[0], ref[0], "dx")
+    close(got[1], ref[1], "dw", rtol=5e-4)
+    assert torch.equal(g2d, keep), "a plain operator wrote into a gradient tensor autograd handed it"
 
 
 @pytest.mark.parametrize("B,Ca,Cb,H,W", [(4, 64, 32, 15, 20), (2, 128, 128, 60, 80), (3, 5, 9, 7, 9), (8, 16, 24, 30, 40)])

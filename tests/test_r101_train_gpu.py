@@ -284,31 +284,49 @@ def test_r101_b8_losses_equal_oracle(net101):
     assert not missing, missing[:5]
 
 
-@pytest.mark.skipif(not os.environ.get("PRN_TEST_B8"), reason="3-4 minutes of fp64 + fp32 oracle on the host (it would double the GPU suite): PRN_TEST_B8=1; logs of its runs are kept "
-                                                                "under profiles/ (r04_e_r101_b8_gradients_vs_fp64.txt, r04_f / r04_g_pytest_gpu.txt ran it as part of the suite)")
+def _b8_sample_index(numel, ns, seed):
+    """The sample positions of tests/golden/make_golden_r101_b8.py (all of a tensor of <= ns elements)."""
+    if numel <= ns:
+        return torch.arange(numel)
+    return torch.randint(0, numel, (ns,), generator=torch.Generator().manual_seed(seed + numel % 9973))
+
+
 def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
     """The benchmark's own configuration, directly: PlaneRecNet_101, B = 8, 480x640, DEFAULT options (the launch plan bench.py times: every plain
-    GEMM of >= 300 tiles / 4 GFLOP and its weight gradient on the fp16 pipe, Winograd, ragged instance head, deferred and grouped weight
-    gradients) against the fp64 oracle on the same batch.  The yardstick is measured on THIS batch: the oracle run in fp32 (the reference's
-    arithmetic) against the oracle in fp64; every parameter gradient of the product has to be within 2.5 x max(that spread, the B = 2 fixture's
-    spread) + 1e-3 -- the shipping bound -- under the default plan AND with the 16-bit pipe off, and the default plan may not be further from
-    fp64 than the fp32-only build by more than half the bound (measured: 0.24 at most, -0.05 on the median).  The `b8-plan` parametrisation above is the fast proxy of this test."""
-    from oracle import loss_ref, model_ref, synth
-    from planerecnet_amd import ops
+    GEMM of >= 300 tiles / 4 GFLOP and its weight gradient on the fp16 pipe, Winograd, ragged instance head, block entry points, deferred and grouped
+    weight gradients) against the fp64 oracle on the same batch -- from the committed fixture tests/golden/e2e_r101_b8_480x640.npz (written in the build
+    container by make_golden_r101_b8.py: real reference fp32 run, oracle fp32 == reference, oracle fp64; round 5 ran the two oracles here, 3-4 minutes,
+    and therefore kept this test opt-in).  The fixture holds, per parameter, the fp64 gradient at up to 2048 seeded positions and the rel-L2 distance of
+    the reference's fp32 gradient from fp64 on the FULL tensor (the spread on this batch); the error of the product is estimated over the sample
+    positions (the generator measured that estimate against the full-tensor value where both are known: 0.94 .. 1.07 of it at the 1st / 99th percentile).
+    Every parameter gradient has to be within 2.5 x max(spread on this batch, the B = 2 fixture's spread) + 1e-3 -- the shipping bound -- under the
+    default plan AND with the 16-bit pipe off, and the default plan may not be further from fp64 than the fp32-only build by more than half the bound
+    (measured: 0.24 at most, -0.05 on the median).  The `b8-plan` parametrisation above is the B = 2 proxy of this test."""
+    from oracle import synth
+    from planerecnet_amd import blocks, ops
     from planerecnet_amd.losses import PlaneRecNetLoss
     net, sd = net101
-    fx = np.load(os.path.join(golden_dir, "e2e_r101_480x640.npz"))
+    fx2 = np.load(os.path.join(golden_dir, "e2e_r101_480x640.npz"))
+    fx = np.load(os.path.join(golden_dir, "e2e_r101_b8_480x640.npz"))
     x, inst, gtd = synth.make_batch(8, 480, 640, seed=21)
     crit = PlaneRecNetLoss().cuda()
     names = [str(n) for n in fx["grad_names"]]
-    zero = set(str(n) for n in fx["grad_structurally_zero"])
-    fix_spread = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
+    ns, sseed = int(fx["ns"]), int(fx["sample_seed"])
+    off = fx["sample_offsets"]
+    s64 = {n: fx["grad_fp64_samples"][off[i]:off[i + 1]].astype(np.float64) for i, n in enumerate(names)}
+    sref = {n: fx["grad_ref_samples"][off[i]:off[i + 1]].astype(np.float64) for i, n in enumerate(names)}
+    spread8 = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
+    names2 = [str(n) for n in fx2["grad_names"]]
+    spread2 = dict(zip(names2, np.maximum(fx2["grad_spread_ref_vs_fp64"], fx2["grad_spread_oracle32_vs_fp64"])))
+    bound = {n: max(WINOGRAD_SENSITIVE.get(n, 0.0), GRAD_K_WINOGRAD * max(spread2.get(n, 0.0), spread8[n]) + GRAD_FLOOR_WINOGRAD) for n in names}
+    l64 = {k: float(fx["fp64_" + k]) for k in ("ins", "cat", "dpt", "pln", "lav")}
 
     def product(arith):
         net.load_state_dict(sd)
         net.train()
         old = ops.set_split_gemm(mode=0) if arith == "fp32" else None
         ops.set_wgrad_async(True)
+        n0 = blocks.STATS["bwd"]
         try:
             np.random.seed(5)
             out = net(x.cuda())
@@ -321,35 +339,34 @@ def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
             if old is not None:
                 ops.set_split_gemm(**old)
         torch.cuda.synchronize()
+        assert blocks.STATS["bwd"] - n0 == 33, "the backbone's 33 blocks did not run through the block entry points"
         params = dict(net.named_parameters())
-        return {k: float(v) for k, v in losses.items()}, {n: params[n].grad.detach().double().cpu() for n in names if n not in zero}
+        smp = {}
+        for n in names:
+            g = params[n].grad.detach().flatten()
+            smp[n] = g[_b8_sample_index(g.numel(), ns, sseed).to(g.device)].double().cpu().numpy()
+        return {k: float(v) for k, v in losses.items()}, smp
 
-    def oracle(dt):
-        sdg = {k: (v.to(dt).clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
-                   (v.to(dt).clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
-        np.random.seed(5)
-        oo = model_ref.forward(sdg, x.to(dt), model_ref.ARCH[CN], training=True)
-        ol = loss_ref.joint_loss(*oo, inst, gtd)
-        g = torch.autograd.grad(sum(ol.values()).sum(), [sdg[n] for n in names])
-        return {k: float(v) for k, v in ol.items()}, {n: t.double() for n, t in zip(names, g)}
-
-    l64, g64 = oracle(torch.float64)
-    _, g32 = oracle(torch.float32)
-    rel = lambda a, n: ((a - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()      # noqa: E731
-    bound = {n: max(WINOGRAD_SENSITIVE.get(n, 0.0), GRAD_K_WINOGRAD * max(fix_spread[n], rel(g32[n], n)) + GRAD_FLOOR_WINOGRAD) for n in names if n not in zero}
+    rel = lambda a, n: float(np.linalg.norm(a - s64[n]) / (np.linalg.norm(s64[n]) + 1e-30))      # noqa: E731
+    # the sampled estimate itself, checked on the one pair whose full-tensor value the fixture holds (reference fp32 vs fp64)
+    est = np.array([rel(sref[n], n) for n in names]) / np.maximum(fx["grad_spread_ref_vs_fp64"], 1e-12)
+    assert 0.8 < np.percentile(est, 1) and np.percentile(est, 99) < 1.25, np.percentile(est, [1, 50, 99])
     err, msgs, bad = {}, [], []
     for arith in ("default", "fp32"):
         losses, g = product(arith)
         for k in l64:
             assert abs(losses[k] - l64[k]) <= 1e-3 * abs(l64[k]) + 1e-4, (arith, k, losses[k], l64[k])
-        err[arith] = {n: rel(g[n], n) for n in bound}
-        ratios = sorted(((err[arith][n] / bound[n], n) for n in bound), reverse=True)
+            assert abs(losses[k] - float(fx[k])) <= 1e-3 * abs(float(fx[k])) + 1e-4, (arith, k, "vs the reference's value", losses[k], float(fx[k]))
+        err[arith] = {n: rel(g[n], n) for n in names}
+        ratios = sorted(((err[arith][n] / bound[n], n) for n in names), reverse=True)
         pct = np.round(np.percentile(np.array([r for r, _ in ratios]), [50, 90, 99, 100]), 3)
-        msgs.append("r101 B=8 %s vs fp64 oracle: error / bound percentiles 50/90/99/max = %s  worst: %s" % (arith, pct.tolist(), [(round(float(r), 2), n) for r, n in ratios[:4]]))
-        bad += [(arith, n, err[arith][n], bound[n]) for n in bound if err[arith][n] > bound[n]]
-    s32 = np.array([rel(g32[n], n) for n in bound])
-    msgs.append("oracle fp32 vs fp64 on this batch (the yardstick): spread percentiles 50/90/99/max = %s" % np.array2string(np.percentile(s32, [50, 90, 99, 100]), precision=5))
-    d = np.array([(err["default"][n] - err["fp32"][n]) / bound[n] for n in bound])
+        msgs.append("r101 B=8 %s vs fp64 oracle (fixture samples): error / bound percentiles 50/90/99/max = %s  worst: %s"
+                    % (arith, pct.tolist(), [(round(float(r), 2), n) for r, n in ratios[:4]]))
+        bad += [(arith, n, err[arith][n], bound[n]) for n in names if err[arith][n] > 1.1 * bound[n]]      # (1.1: the sampling error of the estimate)
+    s32 = np.array([spread8[n] for n in names])
+    msgs.append("reference / oracle fp32 vs fp64 on this batch (the yardstick, full tensors): spread percentiles 50/90/99/max = %s"
+                % np.array2string(np.percentile(s32, [50, 90, 99, 100]), precision=5))
+    d = np.array([(err["default"][n] - err["fp32"][n]) / bound[n] for n in names])
     msgs.append("default minus fp32-only error, in units of the bound: percentiles 1/50/99/max = %s" % np.round(np.percentile(d, [1, 50, 99, 100]), 3).tolist())
     print("\n".join(msgs))
     if os.environ.get("PRN_TEST_PCT_LOG"):
