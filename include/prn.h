@@ -438,6 +438,10 @@ int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* beta, c
                            float* dx, float* dgamma_part, float* dbeta_part, int B, int C, int nseg, const int* hw, int G,
                            void* stream);
 
+/* out[z][n] = sum over r < R of in[z][r][n] (r ascending), z < nb: the per-image partials dgamma_part / dbeta_part above -> dgamma / dbeta in one launch
+ * ([2][B][C] -> [2][C]; ragged: R = nseg * B). */
+int prn_sum_rows(const float* in, float* out, int nb, int R, int N, void* stream);
+
 /* ---- resampling ---------------------------------------------------------------------------------------------------
  * bilinear, align_corners=False (F.interpolate / nn.Upsample): models/fpn.py:54 ; planerecnet.py:115,381,439,453,594 ;
  * losses.py:143,299.  bwd is the exact adjoint in gather form (overwrites dx, deterministic). */

@@ -194,6 +194,7 @@ SIGNATURES = {
     "prn_resize_bilinear_bwd_add": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_fwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_maxpool3s2_bwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+    "prn_sum_rows": (c_int, [P, P, c_int, c_int, c_int, P]),
     "prn_bottleneck_plan_bytes": (c_i64, []),
     "prn_bottleneck_params_bytes": (c_i64, []),
     "prn_bottleneck_plan": (c_int, [ctypes.POINTER(BottleneckDesc), P]),

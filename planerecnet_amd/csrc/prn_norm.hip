@@ -872,3 +872,26 @@ extern "C" int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const flo
   PRN_CHECK_LAUNCH("prn_gn_relu_bwd_ragged");
   return 0;
 }
+
+// out[z][n] = sum_r in[z][r][n] (r ascending: fixed order), z < nb: the per-image partials of the GroupNorm parameter gradients ([2][B][C] -> [2][C]),
+// one launch instead of a framework reduction (so that the gradient can be issued on a side stream by pointer: planerecnet_amd.ops._small_param_grads).
+namespace {
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int N, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t z = i / N;
+  const int n = (int)(i - z * N);
+  const float* p = in + z * R * N + n;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += p[(int64_t)r * N];
+  out[i] = s;
+}
+}  // namespace
+
+extern "C" int prn_sum_rows(const float* in, float* out, int nb, int R, int N, void* stream) {
+  PRN_REQUIRE(in && out && nb > 0 && R > 0 && N > 0, "prn_sum_rows: bad arguments");
+  const int64_t total = (int64_t)nb * N;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, R, N, total);
+  PRN_CHECK_LAUNCH("prn_sum_rows");
+  return 0;
+}

@@ -143,13 +143,21 @@ def _defer(needs_grad, w):
 BIAS_ASYNC = bool(int(os.environ.get("PRN_BIAS_ASYNC", "1")))
 
 
-def _small_param_grads(leaves, inputs, compute):
+def _small_param_grads(leaves, inputs, compute, fast=False):
     """Gradients of a few small parameters (GroupNorm affine pairs, ragged-conv biases) from tensors the backward pass already holds:
     `compute()` -> tuple matching `leaves`.  Deferred to the side stream with the weight gradients when possible (then None)."""
     if BIAS_ASYNC and all(p_ is not None and _defer(True, p_) for p_ in leaves):
-        _deferred_wgrad(list(leaves), inputs, compute)
+        _deferred_wgrad(list(leaves), inputs, compute, fast=fast)
         return None
     return compute()
+
+
+def sum_rows(part):
+    """part [nb, R, N] -> [nb, N] (rows summed in order) in one library launch (include/prn.h: prn_sum_rows)."""
+    nb, R, N = part.shape
+    out = torch.empty(nb, N, device=part.device, dtype=torch.float32)
+    check(lib.prn_sum_rows(_p(part), _p(out), nb, R, N, _stream()), "prn_sum_rows")
+    return out
 
 
 def _bias_grad(needs_grad, bias, dy):
@@ -1228,9 +1236,11 @@ class _ConvUp2(torch.autograd.Function):
             dwp = conv_wgrad_raw(x, dyp, M, 2, 1, 0, IN_UP2_PHASE)
             dwo = torch.empty_like(w)
             check(lib.prn_up2_wgrad_combine(_p(dwp), _p(dwo), M, C, _stream()), "prn_up2_wgrad_combine")
+            if getattr(_TLS, "side", None) is not None:          # a fast deferred launch: its temporaries live until wgrad_join() like its inputs (_flush_one)
+                _HELD.append((dyp, dwp))
             return dwo
         if _defer(ctx.needs_input_grad[1], w):
-            _deferred_wgrad(w, (x, dy), wgrad)
+            _deferred_wgrad(w, (x, dy), wgrad, fast=True)
         elif ctx.needs_input_grad[1]:
             dw = wgrad()
         db = _bias_grad(ctx.has_bias and ctx.needs_input_grad[2], ctx.bias, dy)
@@ -1779,9 +1789,9 @@ class _GroupNormReLU(torch.autograd.Function):
             check(lib.prn_gn_relu_bwd(_p(dy), _p(x), _p(beta), _p(stats), _p(gamma), _p(dx), _p(part[0]), _p(part[1]), B, C, H * W, ctx.groups, _stream()),
                   "prn_gn_relu_bwd")
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            dgb = _small_param_grads(ctx.leaves, (part,), lambda: part.sum(1).unbind(0))
+            dgb = _small_param_grads(ctx.leaves, (part,), lambda: sum_rows(part).unbind(0), fast=True)
             return (dx, None, None, None, None) if dgb is None else (dx, dgb[0], dgb[1], None, None)
-        dgb = part.sum(1)
+        dgb = sum_rows(part)
         return dx, dgb[0], dgb[1], None, None
 
 
@@ -1917,7 +1927,12 @@ class _RaggedConv(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             dw = wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            r = _small_param_grads((ctx.bias,), (dy,), lambda: (torch.stack([t.sum((0, 2, 3)) for t in rs.unpack(dy, M)]).sum(0),))
+            def bias_grad():                                     # per segment a channel sum (library launches), then the segments' sums added in order
+                parts = torch.stack([channel_sum(t) for t in rs.unpack(dy, M)])
+                if getattr(_TLS, "side", None) is not None:
+                    _HELD.append(parts)
+                return (sum_rows(parts.unsqueeze(0))[0],)
+            r = _small_param_grads((ctx.bias,), (dy,), bias_grad)
             db = None if r is None else r[0]
         return dx, dw, db, None
 
@@ -1957,9 +1972,9 @@ class _RaggedGNReLU(torch.autograd.Function):
             check(lib.prn_gn_relu_bwd_ragged(_p(dy), _p(xp), _p(beta), _p(stats), _p(gamma), _p(dx), _p(part[0]), _p(part[1]), rs.B, C, n, rs.hw, groups,
                                              _stream()), "prn_gn_relu_bwd_ragged")
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            dgb = _small_param_grads(ctx.leaves, (part,), lambda: part.sum(1).unbind(0))
+            dgb = _small_param_grads(ctx.leaves, (part,), lambda: sum_rows(part).unbind(0), fast=True)
             return (dx, None, None, None, None, None) if dgb is None else (dx, dgb[0], dgb[1], None, None, None)
-        dgb = part.sum(1)
+        dgb = sum_rows(part)
         return dx, dgb[0], dgb[1], None, None, None
 
 

@@ -72,8 +72,7 @@ class FusedAdam(torch.optim.Optimizer):
             return super().zero_grad(set_to_none=False)
         for g in self.param_groups:
             for p in g["params"]:
-                if p.grad is not None:
-                    p.grad = None
+                p.grad = None
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -31,6 +31,15 @@ from oracle import ref_shim, synth, model_ref, loss_ref  # noqa: E402
 CN = "PlaneRecNet_101_config"
 B, H, W = 2, 480, 640
 SEED_W, SEED_X, SEED_NP = 3, 12, 13
+# A second, independent weight / input draw (python tests/golden/make_golden_r101.py --seed 4 -> e2e_r101_seed4_480x640.npz): the gradient gate of
+# tests/test_r101_train_gpu.py runs on both.  Seed 3 carries one degenerate GroupNorm channel (inst_head.kernel_tower.0, channel 202: a SET of its outputs
+# within ~1e-6 of the ReLU's zero, which any coherent 1e-6 shift of the tower's input moves across together -- DESIGN.md 10.4); the generator counts such
+# near-zero sets (a forward hook on every GroupNorm of the reference model) and refuses a second seed that has one.
+if "--seed" in sys.argv:
+    SEED_W = int(sys.argv[sys.argv.index("--seed") + 1])
+    SEED_X, SEED_NP = SEED_W + 9, SEED_W + 10
+OUT_NAME = "e2e_r101_480x640.npz" if SEED_W == 3 else "e2e_r101_seed%d_480x640.npz" % SEED_W
+NEAR_ZERO = 2e-6
 
 
 def digest(t, n=64, seed=123):
@@ -67,9 +76,24 @@ def main():
     crit = ref["losses"].PlaneRecNetLoss()
     x, inst, gtd = synth.make_batch(B, H, W, seed=SEED_X)
 
+    # near-zero sets behind the GroupNorm layers (their outputs feed a ReLU): per layer, the largest number of outputs of ONE channel within NEAR_ZERO of zero
+    near = {}
+
+    def gn_hook(name):
+        def hook(mod, inp, outp):
+            cnt = (outp.detach().abs() < NEAR_ZERO).sum((0, 2, 3))
+            near[name] = max(near.get(name, 0), int(cnt.max()))
+        return hook
+    hooks = [m.register_forward_hook(gn_hook(n)) for n, m in net.named_modules() if isinstance(m, torch.nn.GroupNorm)]
     t0 = time.time()
     np.random.seed(SEED_NP)
     out = net(x)
+    for h_ in hooks:
+        h_.remove()
+    worst_near = sorted(near.items(), key=lambda kv: -kv[1])[:4]
+    print("GroupNorm outputs within %.0e of the ReLU's zero, largest count in one channel per layer:" % NEAR_ZERO, worst_near)
+    if SEED_W != 3:
+        assert worst_near[0][1] <= 3, ("this seed has a coherent near-zero set behind a GroupNorm: pick another", worst_near)
     rl = crit(net, *out, inst, gtd)
     net.zero_grad()
     sum(rl.values()).sum().backward()
@@ -104,6 +128,21 @@ def main():
         print("   %.2e  %-60s |g| %.3e" % w)
     assert worst[0][0] < 1e-3, worst[0]
 
+    # the fp32 oracle once more with the 3x3 layers of the product's Winograd path evaluated by F(4x4, 3x3) (oracle/model_ref.py: CONV3X3): how far an fp32
+    # implementation of THAT algorithm lands from fp64, per parameter -- the yardstick of the GPU test's default (Winograd) build
+    t0 = time.time()
+    model_ref.CONV3X3 = "winograd"
+    try:
+        o32w, l32w, g32w = oracle_step(sd, x, inst, gtd, torch.float32)
+    finally:
+        model_ref.CONV3X3 = None
+    print("oracle fp32 step, Winograd restatement: %.1f s" % (time.time() - t0), {k: float(v) for k, v in l32w.items()})
+    for k in rl:
+        assert abs(float(rl[k]) - float(l32w[k])) <= 1e-3 * max(1.0, abs(float(rl[k]))), k
+    e = ((o32w[0].double() - out[0].double()).abs().max() / out[0].double().abs().max()).item()
+    print("Winograd oracle vs reference, mask features: %.1e" % e)
+    assert e < 5e-4, e
+
     t0 = time.time()
     o64, l64, g64 = oracle_step(sd, x, inst, gtd, torch.float64)
     print("oracle fp64 step: %.1f s" % (time.time() - t0), {k: float(v) for k, v in l64.items()})
@@ -123,13 +162,20 @@ def main():
     fix["grad_fp64_norm"] = np.array([g64[n].norm().item() for n in names])
     fix["grad_spread_ref_vs_fp64"] = np.array([rel_l2(rgrads[n], g64[n]) for n in names])
     fix["grad_spread_oracle32_vs_fp64"] = np.array([rel_l2(g32[n], g64[n]) for n in names])
+    fix["grad_spread_oracle32_winograd_vs_fp64"] = np.array([rel_l2(g32w[n], g64[n]) for n in names])
+    ratio = fix["grad_spread_oracle32_winograd_vs_fp64"] / np.maximum(np.maximum(fix["grad_spread_ref_vs_fp64"], fix["grad_spread_oracle32_vs_fp64"]), 1e-12)
+    print("Winograd-oracle spread over direct spread: median %.2f; parameters above 3x:" % np.median(ratio[[i for i, n in enumerate(names) if n not in zero]]))
+    for i in np.argsort(-ratio):
+        if names[i] not in zero and ratio[i] > 3:
+            print("   %-60s %.2e (direct %.2e)" % (names[i], fix["grad_spread_oracle32_winograd_vs_fp64"][i], fix["grad_spread_oracle32_vs_fp64"][i]))
     sp = np.maximum(fix["grad_spread_ref_vs_fp64"], fix["grad_spread_oracle32_vs_fp64"])
     order = np.argsort(-sp)
     print("fp32-vs-fp64 gradient spread: median %.1e, max %.1e" % (np.median(sp), sp.max()))
     for i in order[:12]:
         print("   %-60s %.2e" % (names[i], sp[i]))
-    np.savez_compressed(os.path.join(HERE, "e2e_r101_480x640.npz"), **fix)
-    print("written", os.path.join(HERE, "e2e_r101_480x640.npz"))
+    fix["groupnorm_near_zero_max_per_channel"] = np.array([worst_near[0][1]])
+    np.savez_compressed(os.path.join(HERE, OUT_NAME), **fix)
+    print("written", os.path.join(HERE, OUT_NAME))
 
 
 if __name__ == "__main__":

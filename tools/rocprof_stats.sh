@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out/prof
 for mode in serial default; do
   rm -rf /tmp/prof_$mode
   extra=""; [ $mode = serial ] && extra="--sync-wgrad"
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -o t -- env PRN_BENCH_NO_FP32_RUN=1 python $R/bench.py --no-exchange-probe --steps 10 --warmup 1 --no-cpu-baseline --no-roofline --dcn-offsets 0 $extra > /tmp/prof_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -o t -- env PRN_BENCH_NO_FP32_RUN=1 PRN_BENCH_NO_ENQUEUE_PROBE=1 python $R/bench.py --no-exchange-probe --steps 10 --warmup 1 --no-cpu-baseline --no-roofline --dcn-offsets 0 $extra > /tmp/prof_$mode.log 2>&1
   f=$(ls /tmp/prof_$mode/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $R/gpurun_out/prof/${TAG}_kernel_stats_$mode.csv
   tail -2 /tmp/prof_$mode.log | cut -c1-300
