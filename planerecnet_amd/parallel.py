@@ -57,6 +57,17 @@ class GradAllReduce:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
+        # The LAST bucket holds the first layers of the network, whose gradients arrive last: its pack + all-reduce + hand-back is the part of the
+        # exchange nothing can hide (the backward pass is over).  Split its tail off into a small final bucket (PRN_EXCHANGE_TAIL_BYTES, default 2 MB: the stem
+        # and the first blocks of stage 1), so that what runs after the last gradient is a 2 MB collective instead of a 25 MB one.
+        tail = int(_os.environ.get("PRN_EXCHANGE_TAIL_BYTES", str(2 << 20)))
+        if tail > 0 and self.buckets:
+            last, keep, size = self.buckets[-1], [], 0
+            while len(last) > 1 and size + last[-1].numel() * last[-1].element_size() <= tail:
+                size += last[-1].numel() * last[-1].element_size()
+                keep.insert(0, last.pop())
+            if keep:
+                self.buckets.append(keep)
         self.flat = [torch.empty(sum(p.numel() for p in b), device=dev, dtype=b[0].dtype) for b in self.buckets]
         # per-parameter windows of the flat buffers, built once: the pack / unpack are then ONE foreach copy each with no
         # per-step view construction (300 parameters: 3 ms of host time per step on the autograd thread otherwise)
@@ -75,6 +86,7 @@ class GradAllReduce:
         self.presence = torch.ones(len(self.params), device=dev, dtype=torch.float32)
         self._ones = torch.ones(len(self.params), device=dev, dtype=torch.float32)
         self._presence_work = None
+        self._zeros = {}
 
     # called by autograd on the backward thread, once per parameter per backward
     def _on_grad(self, p):
@@ -164,7 +176,14 @@ class GradAllReduce:
             if any(p.grad is not None for p in self.buckets[bi]) or self.world > 1:
                 for p in self.buckets[bi]:
                     if p.grad is None:
-                        p.grad = torch.zeros_like(p)
+                        # (one zero tensor per such parameter, made once: nothing writes through `.grad` here -- the reduced values live in the bucket
+                        # window `.grad` is pointed at below -- so it stays zero; a fresh torch.zeros_like per step was 43 fill launches on the compute stream)
+                        z = self._zeros.get(p) if ALIAS_GRADS else None      # (with the copy-back variant the tensor receives the reduced mean: a fresh one each step)
+                        if z is None or z.shape != p.shape or z.device != p.device:
+                            z = torch.zeros_like(p)
+                            if ALIAS_GRADS:
+                                self._zeros[p] = z
+                        p.grad = z
                         missing.append(self.index[p])
                 self._launch(bi)
         self.next = len(self.buckets)
