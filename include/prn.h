@@ -148,7 +148,7 @@ int prn_conv2d_fwd(const prn_conv_desc* d, const float* x, const float* w, const
  * concurrently must not share one).  Partial tiles are written with agent scope; the workgroup arriving last at a tile's
  * counter sums them in split order, so the result is bit-identical to prn_conv2d_fwd's.  counters == NULL, or a launch the
  * fold does not cover (strided / phase outputs, unaligned tensors), behaves exactly like prn_conv2d_fwd_phase.  The fold is
- * opt-in (environment PRN_CONV_FUSED_REDUCE=1, read per call): measured faster per layer, neutral on the training step.
+ * opt-in (environment PRN_CONV_FUSED_REDUCE=1, read once): measured faster per layer, neutral on the training step.
  * phase: 0 = whole operator, 1 = GEMM launch only, 2 = the separate sum only (a no-op when the fold was used).  */
 #define PRN_TILE_COUNTERS 4096
 /* w_images: NULL, or current split-kernel images of w (see prn_split_prepare) -- used when the descriptor's plan is the split kernel. */

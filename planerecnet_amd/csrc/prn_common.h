@@ -9,6 +9,20 @@
 
 void prn_set_error(const char* fmt, ...);
 
+// Tuning overrides from the environment (DESIGN.md lists them): read ONCE per switch, through a function-local `static const` -- C++11 makes that
+// initialisation thread-safe (the backward entry points are called from autograd's threads), and nothing ever writes them again.
+#include <stdlib.h>
+static inline int prn_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+struct prn_env4 { int v[4]; };
+static inline prn_env4 prn_env_ints(const char* name) {      // "a,b,c,d" (missing fields: 0)
+  prn_env4 r = {{0, 0, 0, 0}};
+  if (const char* e = getenv(name)) sscanf(e, "%d,%d,%d,%d", &r.v[0], &r.v[1], &r.v[2], &r.v[3]);
+  return r;
+}
+
 #define PRN_CHECK_LAUNCH(name)                                                        \
   do {                                                                                \
     hipError_t e_ = hipGetLastError();                                                \

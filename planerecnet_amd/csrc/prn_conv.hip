@@ -1241,8 +1241,7 @@ struct FwdPlan { int tm, tn, bk, splits, wm, wn; };   // block tile = (32*wm*tm)
 // into how many pieces.  Residency: 4 workgroups per CU for the 128-row / 128-column tiles, 8 for 64 x 64.  Returns the number
 // of tail tiles (0 = no tail split) and sets *pieces.  PRN_CONV_TAIL=0 switches it off (A/B).
 int plan_tail(const FwdPlan& p, int64_t tiles, int tilesM, int K, int64_t N, int HoWo, int* pieces) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("PRN_CONV_TAIL"); on = e ? atoi(e) : 1; }
+  static const int on = prn_env_int("PRN_CONV_TAIL", 1);
   *pieces = 0;
   if (!on || p.splits != 1 || p.wm != 2 || (HoWo & 3) != 0) return 0;
   const int64_t slots = 256 * ((p.tm * p.tn >= 2) ? 4 : 8);
@@ -1277,11 +1276,8 @@ int quantise_splits(int64_t tiles, int splits) {
 
 // Tile / slice / split choice.  PRN_CONV_FORCE="tm,tn,bk,splits" overrides it (tuning sweeps: tools/conv_bench.py).
 FwdPlan plan_fwd(int M, int64_t N, int K, bool narrow_ok = false, int phases = 1, bool nosplit = false, int ks = 0) {
-  static int forced[4] = {-1, 0, 0, 0};
-  if (forced[0] == -1) {
-    forced[0] = 0;
-    if (const char* e = getenv("PRN_CONV_FORCE")) sscanf(e, "%d,%d,%d,%d", &forced[0], &forced[1], &forced[2], &forced[3]);
-  }
+  static const prn_env4 forced_ = prn_env_ints("PRN_CONV_FORCE");
+  const int* forced = forced_.v;
   FwdPlan p;
   p.wm = 2; p.wn = 2;
   if (forced[0] > 0) {
@@ -1324,8 +1320,7 @@ constexpr bool narrow_available(int ks, int mode) {
 
 // epilogue through the LDS transpose (float4 stores)?
 bool wide_store_ok(const ConvArgs& a, const FwdPlan& p) {
-  static int wide = -1;                                    // PRN_CONV_WIDE_STORE=0: the per-element epilogue everywhere (A/B)
-  if (wide < 0) { const char* e = getenv("PRN_CONV_WIDE_STORE"); wide = e ? atoi(e) : 1; }
+  static const int wide = prn_env_int("PRN_CONV_WIDE_STORE", 1);                                    // PRN_CONV_WIDE_STORE=0: the per-element epilogue everywhere (A/B)
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   return wide && a.seg.nseg == 0 && p.wm == 2 && al16(a.y) && al16(a.addend) && al16(a.ws) && (a.zy & 3) == 0 && (a.HoWo & 3) == 0 &&
          (p.splits == 1 || (((int64_t)a.B * a.M * a.HoWo) & 3) == 0);
@@ -1338,15 +1333,13 @@ bool wide_store_ok(const ConvArgs& a, const FwdPlan& p) {
 // (54.8-54.9 ms either way, four alternating runs): inside a step the 7 us sum kernels already ran in the shadow of the
 // weight-gradient stream, and the fold lengthens conv_igemm_kernel itself (roofline.frac 0.54 -> 0.53).
 int conv_ilv() {
-  static int ilv = -1;                                     // PRN_CONV_ILV=0: the phase-separated K loops (A/B runs)
-  if (ilv < 0) { const char* e = getenv("PRN_CONV_ILV"); ilv = e ? atoi(e) : 3; }
+  static const int ilv = prn_env_int("PRN_CONV_ILV", 3);                                     // PRN_CONV_ILV=0: the phase-separated K loops (A/B runs)
   return ilv;
 }
 
 bool fused_reduce_ok(const ConvArgs& a, const FwdPlan& p, int phases, int tail_pieces, const unsigned* counters) {
   if (counters == nullptr) return false;
-  const char* e = getenv("PRN_CONV_FUSED_REDUCE");
-  const int on = e ? atoi(e) : 0;
+  static const int on = prn_env_int("PRN_CONV_FUSED_REDUCE", 0);
   const int pieces = p.splits > 1 ? p.splits : tail_pieces;
   const int64_t tiles = (int64_t)cdiv(a.M, 32 * p.wm * p.tm) * cdiv(a.N, 32 * p.wn * p.tn);
   return on && counters != nullptr && pieces > 1 && phases == 1 && a.ystride == 1 && a.zy == 0 && tiles <= PRN_TILE_COUNTERS && wide_store_ok(a, p) &&
@@ -1389,8 +1382,7 @@ int launch_fwd(const ConvArgs& a0, const FwdPlan& p, hipStream_t st, int phases 
   // (slower or equal on every shape), 64 x 128 tiles (never the best), and a two-wave 64 x 32 tile meant to replace the
   // K split on the 9600-pixel stages (64 -> 71 us on 1x1 1024->256, 144 -> 193 us on 3x3 256: the split is cheaper).
   if constexpr (KS == 3 && MODE == PRN_IN_ZERO) {
-    static int v3on = -1;                                  // PRN_CONV_V3=0 switches the float4 gather off (A/B)
-    if (v3on < 0) { const char* e = getenv("PRN_CONV_V3"); v3on = e ? atoi(e) : 1; }
+    static const int v3on = prn_env_int("PRN_CONV_V3", 1);                                  // PRN_CONV_V3=0 switches the float4 gather off (A/B)
     bool v3 = v3on && a.stride == 1 && a.pad == 1 && p.wm == 2 && p.wn == 2;
     if (a.seg.nseg > 0) { for (int sI = 0; sI < a.seg.nseg; ++sI) v3 = v3 && (a.seg.W[sI] & 3) == 0; }
     else v3 = v3 && (a.W & 3) == 0 && a.Wo == a.W && a.Ho == a.H;
@@ -1416,8 +1408,8 @@ WgPlan plan_wgrad(const prn_gemm_opts& o, int M, int K, int64_t N, int phases = 
   p.tm = (M > 64) ? 2 : 1;
   p.tj = (K > 64) ? 2 : 1;
   p.wm = 2;
-  static int ftm = -1, ftj = 0;            // PRN_WGRAD_TILE="tm,tj" overrides the tile (tuning sweeps)
-  if (ftm < 0) { ftm = 0; if (const char* e = getenv("PRN_WGRAD_TILE")) sscanf(e, "%d,%d", &ftm, &ftj); }
+  static const prn_env4 ft_ = prn_env_ints("PRN_WGRAD_TILE");            // PRN_WGRAD_TILE="tm,tj" overrides the tile (tuning sweeps)
+  const int ftm = ft_.v[0], ftj = ft_.v[1];
   if (ftm > 0) { p.tm = M > 32 ? ftm : 1; p.tj = K > 32 ? ftj : 1; }
   if (small) { p.tm = 1; p.tj = 1; }
   if (M <= 32 && K > 64) { p.wm = 1; p.tm = 1; p.tj = 1; }          // 32 x 128 tile
@@ -1436,8 +1428,7 @@ WgPlan plan_wgrad(const prn_gemm_opts& o, int M, int K, int64_t N, int phases = 
   // Bounds: the workspace round trip (2 * splits * M*K*4 bytes) stays a fraction of the MFMA time (splits <= 0.0035 *
   // pixels) and every split keeps at least 128 pixels.  Layers with more tiles than slots only split to ~2048 workgroups.
   const int target = o.wgrad_target > 0 ? o.wgrad_target : 2048;   // (opts: planerecnet_amd.ops lowers it while weight gradients are deferred, like wgrad_wgs)
-  static int forced = -1;          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
-  if (forced < 0) { const char* e = getenv("PRN_WGRAD_SPLITS"); forced = e ? atoi(e) : 0; }
+  static const int forced = prn_env_int("PRN_WGRAD_SPLITS", 0);          // PRN_WGRAD_SPLITS forces the split count (tuning sweeps)
   int R = (p.tm == 2 && p.tj == 2) ? 3 : ((p.tm + p.tj == 3 || p.wm == 1) ? 4 : 6);
   // opts.wgrad_wgs (planerecnet_amd.ops sets it while weight gradients are deferred to the side stream): plan a
   // launch whose tiles are fewer for THIS many workgroups instead of a full residency round.  A weight gradient that shares the GPU
@@ -1556,8 +1547,7 @@ int wgrad16_plan_of(const prn_conv_desc* d, int G) {
 // 4x4 / stride-2 zero-padded convolutions (the input gradient of the sub-pixel upsample-convolutions) on the 16-bit pipe by tap gather
 // (prn_split_conv_taps): K splits, 0 = keep the fp32 implicit GEMM
 int taps_plan_of(const prn_conv_desc* d) {
-  static int on = -1;                                      // PRN_SPLIT_TAPS=0: off (A/B)
-  if (on < 0) { const char* e = getenv("PRN_SPLIT_TAPS"); on = e ? atoi(e) : 1; }
+  static const int on = prn_env_int("PRN_SPLIT_TAPS", 1);                                      // PRN_SPLIT_TAPS=0: off (A/B)
   // (also the stride-2 1x1 downsample convolutions of the backbone's stage entries, models/backbone.py:45: one tap, every second pixel)
   const bool shape = (d->KH == 4 && d->stride == 2) || (d->KH == 1 && d->stride == 2 && d->pad == 0);
   if (!on || !(shape && d->in_mode == PRN_IN_ZERO && d->ystride <= 1 && (d->C & 31) == 0 && d->opts.split_kind == PRN_PIECES_F16)) return 0;
@@ -1565,8 +1555,7 @@ int taps_plan_of(const prn_conv_desc* d) {
 }
 // the sub-pixel phases themselves (forward of the upsample-convolutions): 1 = on the 16-bit pipe (four phases as the z axis of one launch), 0 = fp32
 int up2_plan_of(const prn_conv_desc* d) {
-  static int on = -1;                                      // PRN_SPLIT_UP2=0: off (A/B)
-  if (on < 0) { const char* e = getenv("PRN_SPLIT_UP2"); on = e ? atoi(e) : 1; }
+  static const int on = prn_env_int("PRN_SPLIT_UP2", 1);                                      // PRN_SPLIT_UP2=0: off (A/B)
   if (!on || !(d->KH == 2 && d->in_mode == PRN_IN_UP2_PHASE && (d->C & 31) == 0 && (d->W & 3) == 0 && d->opts.split_kind == PRN_PIECES_F16 && d->ystride <= 1)) return 0;
   return prn_split_gemm_plan(d->M, d->C * 4, d->B, d->H * d->W, 4, &d->opts) == 1 ? 1 : 0;
 }
@@ -2028,8 +2017,8 @@ int prn_gemm_batched_epi(int M, int C, int P, int nb, const float* U, const void
   a.ystride = 1; a.yW = P; a.yHW = P;
   a.zx = C * P; a.zw = M * C; a.zy = M * P;
   a.seg.nseg = 0;
-  static int forced[2] = {-1, 0};                       // PRN_WINO_TILE="tm,tn" (tuning)
-  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_WINO_TILE")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  static const prn_env4 forced_ = prn_env_ints("PRN_WINO_TILE");      // PRN_WINO_TILE="tm,tn" (tuning)
+  const int* forced = forced_.v;
   FwdPlan p;
   p.wm = 2; p.wn = 2; p.bk = 16; p.splits = 1;
   const int64_t t22 = (int64_t)cdiv(M, 128) * cdiv(P, 128) * nb;

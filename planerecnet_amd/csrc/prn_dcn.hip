@@ -366,8 +366,7 @@ __global__ __launch_bounds__(256) void dcn_dx_gather_kernel(const float* __restr
 }  // namespace
 
 static int channel_groups(int C, int64_t threads) {
-  static int forced = -1;                               // PRN_DCN_GROUPS forces the group count (tuning)
-  if (forced < 0) { const char* e = getenv("PRN_DCN_GROUPS"); forced = e ? atoi(e) : 0; }
+  static const int forced = prn_env_int("PRN_DCN_GROUPS", 0);                               // PRN_DCN_GROUPS forces the group count (tuning)
   int g = forced > 0 ? forced : (int)(1 + (256 * 8 * 256) / (threads > 0 ? threads : 1));     // aim for ~8 blocks of 256 threads per CU
   if (g > 16) g = 16;
   if (g > C) g = C;
@@ -437,8 +436,7 @@ int launch_dx(const OmView& v, const float* dcols, float* dx, char* wsb, const B
   int* starts = (int*)(wsb + l.starts);
   int* bsum = (int*)(wsb + l.bsum);
   CsrEntry* entries = (CsrEntry*)(wsb + l.entries);
-  static int one = -1;                                   // PRN_DCN_CSR1=0: the five-launch construction (A/B)
-  if (one < 0) { const char* e = getenv("PRN_DCN_CSR1"); one = e ? atoi(e) : 1; }
+  static const int one = prn_env_int("PRN_DCN_CSR1", 1);                                   // PRN_DCN_CSR1=0: the five-launch construction (A/B)
   if (one && H * W <= CSR1_MAX_BINS) {
     hipLaunchKernelGGL(dcn_csr_build_kernel, dim3(B * 9), dim3(CSR1_THREADS), (size_t)H * W * sizeof(int), st, v, starts, counts, entries, H, W, Ho, Wo, stride);
   } else {

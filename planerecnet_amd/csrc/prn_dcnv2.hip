@@ -932,8 +932,8 @@ inline int npad(const prn_dcn_desc* d) { return cdiv((int64_t)d->B * d->Ho * d->
 
 struct FPlan { int tm, splits; };
 FPlan plan_dcn_fwd(int M, int N, int K) {
-  static int forced[2] = {-1, 0};                        // PRN_DCN_FWD="tm,splits" (tuning sweeps)
-  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_FWD")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  static const prn_env4 forced_ = prn_env_ints("PRN_DCN_FWD");                        // PRN_DCN_FWD="tm,splits" (tuning sweeps)
+  const int* forced = forced_.v;
   FPlan p;
   const int kt = cdiv(K, 16);
   if (forced[0] > 0) { p.tm = forced[0]; p.splits = forced[1] > 0 ? forced[1] : 1; }
@@ -965,8 +965,7 @@ FPlan plan_dcn_fwd(int M, int N, int K) {
 // windowed forward: patch shape (fewest patches; the window of a patch must leave room for the offsets inside WROWS x WPITCH), tile height, K splits
 struct F2Plan { int on, tm, tilesM, splits, PH, PW, tilesY, tilesX, ptiles; };
 int dcn_v2_enabled() {
-  static int v = -1;                                     // PRN_DCN_V2=0: the gather kernels (A/B runs)
-  if (v < 0) { const char* e = getenv("PRN_DCN_V2"); v = e ? atoi(e) : 1; }
+  static const int v = prn_env_int("PRN_DCN_V2", 1);                                     // PRN_DCN_V2=0: the gather kernels (A/B runs)
   return v;
 }
 F2Plan plan_dcn_fwd2(const prn_dcn_desc* d) {
@@ -984,8 +983,8 @@ F2Plan plan_dcn_fwd2(const prn_dcn_desc* d) {
   p.tilesY = cdiv(d->Ho, p.PH); p.tilesX = cdiv(d->Wo, p.PW); p.ptiles = d->B * p.tilesY * p.tilesX;
   p.tm = d->M > 128 ? 4 : (d->M > 64 ? 2 : 1);
   p.tilesM = cdiv(d->M, 64 * p.tm);
-  static int forced[2] = {-1, 0};                        // PRN_DCN_FWD2="tm,splits" (tuning sweeps)
-  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_FWD2")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  static const prn_env4 forced_ = prn_env_ints("PRN_DCN_FWD2");                        // PRN_DCN_FWD2="tm,splits" (tuning sweeps)
+  const int* forced = forced_.v;
   if (forced[0] > 0) { p.tm = forced[0]; p.tilesM = cdiv(d->M, 64 * p.tm); }
   const int S = d->C / 2, res = p.tm == 4 ? 2 : 3;
   const int64_t tiles = (int64_t)p.ptiles * p.tilesM;
@@ -1009,8 +1008,8 @@ inline int64_t table1_bytes(const prn_dcn_desc* d) { return ((int64_t)npad(d) * 
 
 struct WPlan { int tm, tilesM, tilesJ, splits, chunks; };
 WPlan plan_dcn_wgrad(const prn_gemm_opts& o, int M, int K, int N) {
-  static int forced[2] = {-1, 0};                        // PRN_DCN_WGRAD="tm,splits"
-  if (forced[0] == -1) { forced[0] = 0; if (const char* e = getenv("PRN_DCN_WGRAD")) sscanf(e, "%d,%d", &forced[0], &forced[1]); }
+  static const prn_env4 forced_ = prn_env_ints("PRN_DCN_WGRAD");                        // PRN_DCN_WGRAD="tm,splits"
+  const int* forced = forced_.v;
   WPlan p;
   p.tm = (forced[0] > 0) ? forced[0] : (M > 128 ? 4 : (M > 64 ? 2 : 1));   // every output-channel tile re-gathers the columns: tallest tile
   p.tilesM = cdiv(M, 64 * p.tm);
@@ -1151,8 +1150,7 @@ extern "C" int prn_dcnv2_bwd_weight_phase(const prn_dcn_desc* d, const float* x,
   const WPlan p = plan_dcn_wgrad(d->opts, a.M, a.K, a.N);
   a.tilesM = p.tilesM; a.tilesJ = p.tilesJ; a.splits = p.splits; a.chunks = p.chunks;
   {
-    static int ilv = -1;                                   // PRN_DCN_WGRAD_ILV=0: the phase-separated loop (A/B)
-    if (ilv < 0) { const char* e = getenv("PRN_DCN_WGRAD_ILV"); ilv = e ? atoi(e) : 1; }
+    static const int ilv = prn_env_int("PRN_DCN_WGRAD_ILV", 1);                                   // PRN_DCN_WGRAD_ILV=0: the phase-separated loop (A/B)
     a.ilv = ilv;
   }
   PRN_REQUIRE(p.splits == 1 || ws != nullptr, "prn_dcnv2_bwd_weight: workspace required (%d splits)", p.splits);

@@ -637,8 +637,7 @@ int prn_split_gemm_plan(int M, int K, int B, int HW, int nz, const prn_gemm_opts
   if (tiles < 300) {
     splits = (int)(640 / (tiles > 0 ? tiles : 1));
     if (splits > kslices / 8) splits = kslices / 8;
-    static int smax = -1;                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 3.  Round 4: training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; since the partial sums of
-    if (smax < 0) { const char* e = getenv("PRN_SPLIT_KSPLIT_MAX"); smax = e ? atoi(e) : 3; }     // the stage-3 layers are summed by the BatchNorm kernel that reads them (round 5: one partial tensor less to read there) 43.51 / 43.52 (4) -> 43.35 / 43.30 (3), 43.40 / 43.50 (2).
+    static const int smax = prn_env_int("PRN_SPLIT_KSPLIT_MAX", 3);                                        // PRN_SPLIT_KSPLIT_MAX (tuning): 3.  Round 4: training step 45.4 (2) / 44.0 (3) / 44.1 (4) ms; since the partial sums of     // the stage-3 layers are summed by the BatchNorm kernel that reads them (round 5: one partial tensor less to read there) 43.51 / 43.52 (4) -> 43.35 / 43.30 (3), 43.40 / 43.50 (2).
                                                                  // A performance choice only (the fixture's ReLU-boundary channel that 3 splits once tipped is bounded separately by the parity test since round 5)
     // ... but a launch that reaches the tile floor only with four splits keeps four (the stage-4 reducing layers, 96 tiles: 288 < 300 with three)
     const int wide = splits > 4 ? 4 : splits;
@@ -716,8 +715,7 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
   const int kind = o->split_kind;
   PRN_REQUIRE(kind == PRN_PIECES_F16 || kind == PRN_PIECES_BF16, "prn_split_gemm: unknown piece format %d", kind);
   {
-    static int dbg = -1;                                           // PRN_SPLIT_DEBUG=1: one line per launch on stderr (which shapes a plan puts on the kernel)
-    if (dbg < 0) { const char* e = getenv("PRN_SPLIT_DEBUG"); dbg = e ? atoi(e) : 0; }
+    static const int dbg = prn_env_int("PRN_SPLIT_DEBUG", 0);                                           // PRN_SPLIT_DEBUG=1: one line per launch on stderr (which shapes a plan puts on the kernel)
     if (dbg) fprintf(stderr, "prn_split_gemm M=%d K=%d B=%d HW=%d nz=%d splits=%d epi=%d addend=%d\n", M, K, B, HW, nz, splits, epi, addend != nullptr);
   }
   if (phase != 2) {
@@ -737,11 +735,9 @@ int prn_split_gemm(const float* w, const void* w_images, const float* x, const f
       a.C = K; a.XH = 1; a.XW = HW; a.Wo = HW; a.KW = 1; a.stride = 1; a.pad = 0;
       {
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        static int wide_on = -1;                                 // PRN_SPLIT_WIDE_STORE=0: the per-element epilogue (A/B)
-        if (wide_on < 0) { const char* e = getenv("PRN_SPLIT_WIDE_STORE"); wide_on = e ? atoi(e) : 1; }
+        static const int wide_on = prn_env_int("PRN_SPLIT_WIDE_STORE", 1);                                 // PRN_SPLIT_WIDE_STORE=0: the per-element epilogue (A/B)
         a.wide = wide_on && (HW & 3) == 0 && ((int64_t)M * HW & 3) == 0 && (zy & 3) == 0 && al16(y) && al16(addend) && al16(partial);
-        static int policy = -1;
-        if (policy < 0) { const char* e = getenv("PRN_SPLIT_STORE_POLICY"); policy = e ? atoi(e) : 1; }
+        static const int policy = prn_env_int("PRN_SPLIT_STORE_POLICY", 1);
         a.store_policy = policy;
       }
       if (o->split_products >= 4) hipLaunchKernelGGL(split16_gemm_kernel<4>, dim3(a.total, splits), dim3(256), 0, st, a);

@@ -453,8 +453,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 }
 
 bool bn_small_ok(int B, int HW) {
-  static int on = -1;                                   // PRN_BN_SMALL=0 switches the one-pass kernels off (A/B)
-  if (on < 0) { const char* e = getenv("PRN_BN_SMALL"); on = e ? atoi(e) : 1; }
+  static const int on = prn_env_int("PRN_BN_SMALL", 1);                                   // PRN_BN_SMALL=0 switches the one-pass kernels off (A/B)
   return on && (HW & 3) == 0 && (int64_t)B * HW <= BN_SMALL_MAX;
 }
 }  // namespace
