@@ -157,7 +157,7 @@ def cpu_baseline(config_name, H, W, train, batch=1, budget_s=30.0):
     """The oracle (CPU restatement of the reference, oracle/) on the host cores of this box, on a BOUNDED sample of the workload (BASELINE.md 4 / SURVEY.md 8d):
     fwd + loss + bwd (train) or eval forward + post-process.  Two settings are timed and the faster one is the reported `value` (both are in `samples`):
     one image on min(16, physical cores) threads -- on the 256-core boxes a full-width OpenMP team is ~500x SLOWER on this model (fork / join on hundreds of
-    small ops) -- and, while the time budget lasts, the workload's own batch on min(64, physical cores) threads.  1 warm-up + 3 (batch: 2) timed iterations, median."""
+    small ops; 64 threads at batch 8 did not finish a warm-up iteration in ten minutes) -- and, while the time budget lasts, the workload's own batch on the same team.  1 warm-up + 3 (batch: 2) timed iterations, median."""
     from oracle import loss_ref, model_ref, synth
     phys = physical_cores()
     arch = model_ref.ARCH[config_name]
@@ -167,7 +167,7 @@ def cpu_baseline(config_name, H, W, train, batch=1, budget_s=30.0):
         leaves = [v for v in sd.values() if v.requires_grad]
     t_start = time.perf_counter()
     samples = []
-    for B, threads, n_timed in ((1, max(1, min(16, phys)), 3), (batch, max(1, min(64, phys)), 2)):
+    for B, threads, n_timed in ((1, max(1, min(16, phys)), 3), (batch, max(1, min(16, phys)), 2)):
         if B == 1 and samples and batch == 1:
             break
         if samples and time.perf_counter() - t_start > 0.4 * budget_s:

@@ -582,6 +582,10 @@ int prn_mask_loss_fwd(const float* logits, const unsigned char* labels, const fl
 int prn_mask_loss_bwd(const float* logits, const unsigned char* labels, const float* adj, const int64_t* img, const float* coef, const float* g_ins,
                       const float* g_lav, float* dlogits, int P, int HW, void* stream);
 
+/* Depth-gradient weights of the lava term from the GT depth alone (models/functions/losses.py:288-329): out[b][y][x] = w, w = min(S / max(gt, res)^2, 1e-2),
+ * set to 0 where w < 1e-4; S = gx^2 + gy^2 of the 3x3 Sobel / 8 on the reflect-padded map.  One launch for the ~20 elementwise launches of the tensor form. */
+int prn_lava_gt_weights(const float* gt, float* out, int B, int H, int W, float depth_resolution, void* stream);
+
 /* Virtual-normal loss, per-triplet part (models/functions/vnl.py:57-165 for all planes of all images at once):
  *   pred / gt [B*H*W] depths, gid [3][n] int32 cloud-point index of each triplet's points, seg [n] its segment (plane or
  *   non-planar region of one image), per segment: is_plane (uint8), plane normal (double[3]), image; fx / fy [B] (double).

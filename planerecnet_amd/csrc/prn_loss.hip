@@ -701,3 +701,42 @@ extern "C" int prn_vnl_trim_bwd(const double* loss, const int64_t* order, const 
   PRN_CHECK_LAUNCH("prn_vnl_trim_bwd");
   return 0;
 }
+
+// ---- depth-gradient weights of the lava term (models/functions/losses.py:288-329, GT only) -----------------------------------------------------
+// w = min(sobel^2(gt) / max(gt, res)^2, 1e-2), zeroed below 1e-4, with sobel^2 = gx^2 + gy^2 of the reflect-padded 3x3 Sobel / 8: one pass instead of
+// the ~20 elementwise launches of the tensor formulation (reflection pad, eight shifted views, two gradients, square, clamp, divide, clamp, compare, where).
+// Same operations in the same order and precision (no contraction: explicit round-to-nearest multiplies / adds).
+namespace {
+__global__ __launch_bounds__(256) void lava_gt_kernel(const float* __restrict__ gt, float* __restrict__ out, int64_t total, int H, int W, float res) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int x, y;
+  int64_t b;
+  prn_idx3(i, W, H, x, y, b);
+  const float* g = gt + b * H * W;
+  const int ym = y > 0 ? y - 1 : 1, yp = y < H - 1 ? y + 1 : H - 2;          // ReflectionPad2d(1)
+  const int xm = x > 0 ? x - 1 : 1, xp = x < W - 1 ? x + 1 : W - 2;
+  const float tl = g[ym * W + xm], tc = g[ym * W + x], tr = g[ym * W + xp];
+  const float ml = g[y * W + xm], mc = g[y * W + x], mr = g[y * W + xp];
+  const float bl = g[yp * W + xm], bc = g[yp * W + x], br = g[yp * W + xp];
+  float gx = __fsub_rn(tl, tr);
+  gx = __fadd_rn(gx, __fmul_rn(2.f, ml)); gx = __fsub_rn(gx, __fmul_rn(2.f, mr)); gx = __fadd_rn(gx, bl); gx = __fsub_rn(gx, br);
+  gx = __fdiv_rn(gx, 8.f);
+  float gy = __fadd_rn(tl, __fmul_rn(2.f, tc));
+  gy = __fadd_rn(gy, tr); gy = __fsub_rn(gy, bl); gy = __fsub_rn(gy, __fmul_rn(2.f, bc)); gy = __fsub_rn(gy, br);
+  gy = __fdiv_rn(gy, 8.f);
+  const float s = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
+  const float d = fmaxf(mc, res);
+  float w = __fdiv_rn(s, __fmul_rn(d, d));
+  w = fminf(w, 1e-2f);
+  out[i] = w < 1e-4f ? 0.f : w;
+}
+}  // namespace
+
+extern "C" int prn_lava_gt_weights(const float* gt, float* out, int B, int H, int W, float depth_resolution, void* stream) {
+  PRN_REQUIRE(gt && out && B > 0 && H >= 2 && W >= 2, "prn_lava_gt_weights: bad arguments");
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(lava_gt_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gt, out, total, H, W, depth_resolution);
+  PRN_CHECK_LAUNCH("prn_lava_gt_weights");
+  return 0;
+}

@@ -196,10 +196,18 @@ class PlaneRecNetLoss(nn.Module):
         if cfg.use_lava_loss:
             B, (H, W), (fh, fw) = h["B"], h["hw"], h["feat"]
             # Q3: dataset_name never equals 'ScanNet' / 'Stanford 2D3DS' (it is 'ScanNetDataset'), so valid_mask is None
-            grad = sobel_sq(gt_depths) / gt_depths.clamp(min=self.depth_resolution) ** 2
-            grad = grad.clamp(max=1e-2)
-            grad = torch.where(grad < 1e-4, torch.zeros_like(grad), grad)
-            t.lava_gsum = grad.flatten(1).sum(1)
+            if gt_depths.is_cuda and gt_depths.dtype == torch.float32 and LAVA_GT_KERNEL:
+                # sobel^2 / depth^2, both clamps and the threshold in one launch (include/prn.h: prn_lava_gt_weights), the per-image sums in the library's
+                # fixed-order channel sum (the map viewed as [1, B, H*W])
+                gd = gt_depths.contiguous()
+                grad = torch.empty_like(gd)
+                ops.check(ops.lib.prn_lava_gt_weights(ops._p(gd), ops._p(grad), B, H, W, float(self.depth_resolution), ops._stream()), "prn_lava_gt_weights")
+                t.lava_gsum = ops.channel_sum(grad.view(1, B, H, W))
+            else:
+                grad = sobel_sq(gt_depths) / gt_depths.clamp(min=self.depth_resolution) ** 2
+                grad = grad.clamp(max=1e-2)
+                grad = torch.where(grad < 1e-4, torch.zeros_like(grad), grad)
+                t.lava_gsum = grad.flatten(1).sum(1)
             adj = torch.empty(B, 1, fh, fw, device=device, dtype=torch.float32)
             ops.check(ops.lib.prn_resize_bilinear_bwd(ops._p(grad.contiguous()), ops._p(adj), B, fh, fw, H, W, ops._stream()), "prn_resize_bilinear_bwd")
             t.lava_adj = adj
@@ -351,6 +359,9 @@ def rmse_log(pred, gt, valid, clamp=1e-9):
     n = pred.shape[0]
     l1 = (torch.log(pred.reshape(n, -1).clamp(min=clamp)) - torch.log(gt.reshape(n, -1).clamp(min=clamp))).abs().mul(valid.reshape(n, -1))
     return torch.sqrt((l1 ** 2).sum(1) / valid.reshape(n, -1).sum(1)).mean()
+
+
+LAVA_GT_KERNEL = os.environ.get("PRN_LAVA_GT_KERNEL", "1") == "1"      # 0: the tensor formulation (cross-check)
 
 
 @torch.no_grad()

@@ -1358,3 +1358,28 @@ def test_wgrad16_grouped_and_batched_products():
             assert smax <= 4e-7 and srms <= 2.5e-8, (zi, smax, srms)
     finally:
         ops.set_split_gemm(**old)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 480, 640), (3, 7, 9), (1, 2, 2)])
+def test_lava_gt_weights_equal_the_tensor_formulation(B, H, W):
+    """prn_lava_gt_weights (one launch) against the tensor formulation of models/functions/losses.py:288-329 as planerecnet_amd.losses keeps it
+    (reflection pad, Sobel / 8, square, / clamp(depth)^2, clamp, threshold): the same operations in the same order -- bit for bit -- incl. depths below
+    the resolution clamp, flat regions (weight exactly 0) and steps (weight clamped to 1e-2)."""
+    import ctypes
+    from planerecnet_amd import losses, ops
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    gt = (0.5 + 4.0 * torch.rand(B, 1, H, W, generator=g))
+    gt[:, :, : H // 2, : W // 3] = 2.0                                  # a flat region
+    gt[:, :, H // 2:, W // 2:] *= 0.001                                # below the depth resolution
+    gt = gt.to(d)
+    res = 0.02
+    ref = losses.sobel_sq(gt) / gt.clamp(min=res) ** 2
+    ref = ref.clamp(max=1e-2)
+    ref = torch.where(ref < 1e-4, torch.zeros_like(ref), ref)
+    out = torch.empty_like(gt)
+    ops.check(ops.lib.prn_lava_gt_weights(ops._p(gt), ops._p(out), B, H, W, ctypes.c_float(res), ops._stream()), "prn_lava_gt_weights")
+    assert torch.equal(out, ref), (out - ref).abs().max().item()
+    assert (out == 0).any() and (out == 1e-2).any() if H > 2 else True
+    s = ops.channel_sum(out.view(1, B, H, W))
+    assert torch.allclose(s, ref.flatten(1).sum(1), rtol=1e-5)
