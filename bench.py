@@ -153,44 +153,64 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(config_name, H, W, train, batch=1, budget_s=30.0):
-    """The oracle (CPU restatement of the reference, oracle/) on the host cores of this box, on a BOUNDED sample of the workload (BASELINE.md 4 / SURVEY.md 8d):
-    fwd + loss + bwd (train) or eval forward + post-process.  Two settings are timed and the faster one is the reported `value` (both are in `samples`):
-    one image on min(16, physical cores) threads -- on the 256-core boxes a full-width OpenMP team is ~500x SLOWER on this model (fork / join on hundreds of
-    small ops; 64 threads at batch 8 did not finish a warm-up iteration in ten minutes) -- and, while the time budget lasts, the workload's own batch on the same team.  1 warm-up + 3 (batch: 2) timed iterations, median."""
+def _cpu_sample(config_name, H, W, train, B, threads, n_timed, budget_s):
+    """One setting of `cpu_baseline`: B images per iteration on `threads` threads, 1 warm-up + `n_timed` timed iterations (fewer when the
+    warm-up shows they would not fit `budget_s`)."""
     from oracle import loss_ref, model_ref, synth
-    phys = physical_cores()
     arch = model_ref.ARCH[config_name]
     sd = synth.make_state_dict(config_name, seed=0)
     if train:
         sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
         leaves = [v for v in sd.values() if v.requires_grad]
+    torch.set_num_threads(threads)
+    x, inst, gtd = synth.make_batch(B, H, W, seed=0)
+    times = []
     t_start = time.perf_counter()
+    for it in range(1 + n_timed):
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        if train:
+            out = model_ref.forward(sd, x, arch, training=True)
+            ls = loss_ref.joint_loss(*out, inst, gtd)
+            torch.autograd.grad(sum(ls.values()).sum(), leaves, allow_unused=True)
+        else:
+            with torch.no_grad():
+                model_ref.inference(sd, x, arch)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start + times[-1] > budget_s and it < n_timed:
+            break                                              # (the next iteration would not fit the budget)
+    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"images": B, "threads": threads, "img_per_s": B / med, "s_per_iteration": [round(t, 2) for t in times], "warm_up_only": len(times) == 1}
+
+
+def cpu_baseline(config_name, H, W, train, batch=1, budget_s=30.0):
+    """The oracle (CPU restatement of the reference, oracle/) on the host cores of this box, on a BOUNDED sample of the workload (BASELINE.md 4 / SURVEY.md 8d):
+    fwd + loss + bwd (train) or eval forward + post-process.  Two settings are timed and the faster one is the reported `value` (both are in `samples`):
+    one image on min(16, physical cores) threads -- on the 256-core boxes a full-width OpenMP team is ~500x SLOWER on this model (fork / join on hundreds of
+    small ops; 64 threads at batch 8 did not finish a warm-up iteration in ten minutes) -- and the workload's own batch on the same team.
+    Each setting runs in a CHILD process of this script (`--cpu-sample`, no GPU work) under a hard wall-clock limit, so that a host on which the
+    oracle crawls costs the bench a bounded time and is reported as `timed_out` instead of stalling the run; 1 warm-up + 3 (batch: 2) timed iterations, median."""
+    import subprocess
+    phys = physical_cores()
+    threads = max(1, min(16, phys))
+    settings = [(1, threads, 3, budget_s)] + ([(batch, threads, 2, budget_s)] if batch > 1 else [])
     samples = []
-    for B, threads, n_timed in ((1, max(1, min(16, phys)), 3), (batch, max(1, min(16, phys)), 2)):
-        if B == 1 and samples and batch == 1:
-            break
-        if samples and time.perf_counter() - t_start > 0.4 * budget_s:
-            break
-        torch.set_num_threads(threads)
-        x, inst, gtd = synth.make_batch(B, H, W, seed=0)
-        times = []
-        for it in range(1 + n_timed):
-            np.random.seed(0)
-            t0 = time.perf_counter()
-            if train:
-                out = model_ref.forward(sd, x, arch, training=True)
-                ls = loss_ref.joint_loss(*out, inst, gtd)
-                torch.autograd.grad(sum(ls.values()).sum(), leaves, allow_unused=True)
-            else:
-                with torch.no_grad():
-                    model_ref.inference(sd, x, arch)
-            times.append(time.perf_counter() - t0)
-            if it == 0 and samples and times[0] * (1 + n_timed) > budget_s - (time.perf_counter() - t_start) + times[0]:
-                break                                          # (the timed iterations of this setting would not fit the budget: its warm-up is reported as it is)
-        med = float(np.median(times[1:])) if len(times) > 1 else times[0]
-        samples.append({"images": B, "threads": threads, "img_per_s": B / med, "s_per_iteration": [round(t, 2) for t in times], "warm_up_only": len(times) == 1})
-    best = max(samples, key=lambda r: r["img_per_s"])
+    for B, th, n_timed, budget in settings:
+        spec = json.dumps({"config": config_name, "H": H, "W": W, "train": bool(train), "B": B, "threads": th, "n_timed": n_timed, "budget_s": budget})
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(th))
+        limit = 3.0 * budget + 60.0                            # (the child imports torch and builds the weights first: ~10 s here, 1-2 min on a cold image)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-sample", spec], env=env, capture_output=True, text=True, timeout=limit)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError("cpu sample failed (exit %d): %s" % (r.returncode, r.stderr[-400:]))
+            samples.append(json.loads(line[-1]))
+        except subprocess.TimeoutExpired:                      # (subprocess.run has killed the child it started)
+            samples.append({"images": B, "threads": th, "img_per_s": None, "timed_out_after_s": limit})
+    done = [r for r in samples if r["img_per_s"]]
+    if not done:
+        return {"value": None, "unit": "img/s", "cores": threads, "physical_cores": phys, "kind": "port", "sample": "no setting finished within its limit", "samples": samples}
+    best = max(done, key=lambda r: r["img_per_s"])
     return {"value": best["img_per_s"], "unit": "img/s", "cores": best["threads"], "physical_cores": phys, "kind": "port",
             "sample": "%d image(s) per iteration, %s %s at %dx%d, torch CPU fp32 oracle on %d threads, 1 warm-up + %d timed iterations (median; s per iteration: %s)"
                       % (best["images"], config_name, "fwd+loss+bwd" if train else "eval forward + post-process", H, W, best["threads"],
@@ -207,6 +227,10 @@ WORKLOADS = {   # name -> (config, per-GPU batch, H, W, train?, description)
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-sample":   # (the child of cpu_baseline: one setting, one JSON line, no GPU)
+        q = json.loads(sys.argv[2])
+        print(json.dumps(_cpu_sample(q["config"], q["H"], q["W"], q["train"], q["B"], q["threads"], q["n_timed"], q["budget_s"])), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
