@@ -442,6 +442,15 @@ int prn_gn_relu_bwd_ragged(const float* dy, const float* x, const float* beta, c
  * ([2][B][C] -> [2][C]; ragged: R = nseg * B). */
 int prn_sum_rows(const float* in, float* out, int nb, int R, int N, void* stream);
 
+/* ---- measurement aid -----------------------------------------------------------------------------------------------
+ * What do the helper launches that a fusion into a producer's epilogue would remove cost INSIDE the overlapped step (tools/ablation_bounds.py)?
+ * Bits 0-7 leave a family OUT (its consumers then read stale sums: RESULTS ARE WRONG, and the garbage changes the timing of data-dependent kernels, so
+ * only the weight-gradient family is measured this way); bits 8-15 issue the same families TWICE (idempotent launches: results unchanged; the step's
+ * increase is the family's cost on the critical path, second read partly from the Infinity Cache).  Never called by the package; returns the old mask.
+ * family bit 1: the forward BatchNorm statistics pass of the two-launch (large-map) form; 2: its backward counterpart; 4: the sums of weight-gradient
+ * split partials (reduce_splits); 8: prn_channel_sum; 16: the exact x0.5 resize and its adjoint (models/fpn.py:54). */
+int prn_debug_skip_launches(int mask);
+
 /* ---- resampling ---------------------------------------------------------------------------------------------------
  * bilinear, align_corners=False (F.interpolate / nn.Upsample): models/fpn.py:54 ; planerecnet.py:115,381,439,453,594 ;
  * losses.py:143,299.  bwd is the exact adjoint in gather form (overwrites dx, deterministic). */

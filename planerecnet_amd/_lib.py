@@ -196,6 +196,7 @@ SIGNATURES = {
     "prn_maxpool3s2_bwd": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "prn_sum_rows": (c_int, [P, P, c_int, c_int, c_int, P]),
     "prn_lava_gt_weights": (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
+    "prn_debug_skip_launches": (c_int, [c_int]),
     "prn_bottleneck_plan_bytes": (c_i64, []),
     "prn_bottleneck_params_bytes": (c_i64, []),
     "prn_bottleneck_plan": (c_int, [ctypes.POINTER(BottleneckDesc), P]),

@@ -23,6 +23,11 @@ static inline prn_env4 prn_env_ints(const char* name) {      // "a,b,c,d" (missi
   return r;
 }
 
+// Measurement aid (include/prn.h: prn_debug_skip_launches): launches the caller asked to leave out.  0 in every product run.
+extern int prn_skip_mask;
+#define PRN_SKIPPED(bit) (__builtin_expect(prn_skip_mask & (bit), 0))
+#define PRN_REPS(bit) (__builtin_expect(prn_skip_mask & ((bit) | ((bit) << 8)), 0) ? ((prn_skip_mask & (bit)) ? 0 : 2) : 1)   // launches of a family: 1; left out: 0; issued twice: 2
+
 #define PRN_CHECK_LAUNCH(name)                                                        \
   do {                                                                                \
     hipError_t e_ = hipGetLastError();                                                \

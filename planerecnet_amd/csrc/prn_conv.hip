@@ -1575,7 +1575,7 @@ int prn_launch_reduce_epilogue(const float* ws, const float* bias, const float* 
   return 0;
 }
 int prn_launch_reduce_splits(const float* ws, float* out, int64_t n, int splits, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, splits);
+  for (int r = PRN_REPS(4); r > 0; --r) hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, ws, out, n, splits);
   PRN_CHECK_LAUNCH("reduce_splits");
   return 0;
 }
@@ -1880,7 +1880,7 @@ extern "C" int prn_conv2d_wgrad_grouped(const prn_conv_desc* d, int G, const flo
   PRN_CHECK_LAUNCH("prn_conv2d_wgrad_grouped");
   if (p.splits > 1) {
     const int64_t n = (int64_t)G * a.M * a.K;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
+    for (int r = PRN_REPS(4); r > 0; --r) hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
     PRN_CHECK_LAUNCH("prn_conv2d_wgrad_grouped/reduce");
   }
   return 0;
@@ -1919,7 +1919,7 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
       PRN_CHECK_LAUNCH("prn_conv2d_wgrad/direct");
     }
     if (phase != 1) {
-      hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, sd, (const float*)ws, dw, n, S);
+      for (int r = PRN_REPS(4); r > 0; --r) hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, sd, (const float*)ws, dw, n, S);
       PRN_CHECK_LAUNCH("prn_conv2d_wgrad/direct reduce");
     }
     return 0;
@@ -1975,7 +1975,7 @@ int conv_wgrad_impl(const prn_conv_desc* d0, const prn_ragged* rg, const float* 
 reduce_only:
   if (p.splits > 1) {
     const int64_t n = (int64_t)g.phases * a.M * a.K;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
+    for (int r = PRN_REPS(4); r > 0; --r) hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, (const float*)ws, dw, n, p.splits);
     PRN_CHECK_LAUNCH("prn_conv2d_wgrad/reduce");
   }
   return 0;
@@ -2107,10 +2107,10 @@ extern "C" int prn_channel_sum(const float* x, float* out, double* ws, int B, in
   S = S > PRN_BN_SPLITS ? PRN_BN_SPLITS : (S < 1 ? 1 : S);
   hipStream_t st = (hipStream_t)stream;
   if (C >= 128 && (int64_t)B * HW <= 65536) S = 1;       // enough channels to fill the GPU on their own: no split, no second launch
-  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW, S == 1 ? out : nullptr);
-  PRN_CHECK_LAUNCH("prn_channel_sum/partial");
-  if (S == 1) return 0;
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, out, C, S);
-  PRN_CHECK_LAUNCH("prn_channel_sum/final");
+  for (int r = PRN_REPS(8); r > 0; --r) {
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW, S == 1 ? out : nullptr);
+    if (S > 1) hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, out, C, S);
+  }
+  PRN_CHECK_LAUNCH("prn_channel_sum");
   return 0;
 }

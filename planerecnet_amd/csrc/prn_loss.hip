@@ -705,9 +705,10 @@ extern "C" int prn_vnl_trim_bwd(const double* loss, const int64_t* order, const 
 // ---- depth-gradient weights of the lava term (models/functions/losses.py:288-329, GT only) -----------------------------------------------------
 // w = min(sobel^2(gt) / max(gt, res)^2, 1e-2), zeroed below 1e-4, with sobel^2 = gx^2 + gy^2 of the reflect-padded 3x3 Sobel / 8: one pass instead of
 // the ~20 elementwise launches of the tensor formulation (reflection pad, eight shifted views, two gradients, square, clamp, divide, clamp, compare, where).
-// Same operations in the same order and precision (no contraction: explicit round-to-nearest multiplies / adds).
+// Same operations in the same order and precision as the formulation evaluated in IEEE arithmetic (no a * b + c contraction: see the pragma).
 namespace {
 __global__ __launch_bounds__(256) void lava_gt_kernel(const float* __restrict__ gt, float* __restrict__ out, int64_t total, int H, int W, float res) {
+#pragma clang fp contract(off)   // (hipcc contracts a * b + c into one fma by default, and __fmul_rn / __fadd_rn are plain operators in this toolchain)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   int x, y;
@@ -719,15 +720,17 @@ __global__ __launch_bounds__(256) void lava_gt_kernel(const float* __restrict__ 
   const float tl = g[ym * W + xm], tc = g[ym * W + x], tr = g[ym * W + xp];
   const float ml = g[y * W + xm], mc = g[y * W + x], mr = g[y * W + xp];
   const float bl = g[yp * W + xm], bc = g[yp * W + x], br = g[yp * W + xp];
-  float gx = __fsub_rn(tl, tr);
-  gx = __fadd_rn(gx, __fmul_rn(2.f, ml)); gx = __fsub_rn(gx, __fmul_rn(2.f, mr)); gx = __fadd_rn(gx, bl); gx = __fsub_rn(gx, br);
-  gx = __fdiv_rn(gx, 8.f);
-  float gy = __fadd_rn(tl, __fmul_rn(2.f, tc));
-  gy = __fadd_rn(gy, tr); gy = __fsub_rn(gy, bl); gy = __fsub_rn(gy, __fmul_rn(2.f, bc)); gy = __fsub_rn(gy, br);
-  gy = __fdiv_rn(gy, 8.f);
-  const float s = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
+  float gx = tl - tr;                                                        // (plain operators: the __f*_rn wrappers are inline functions compiled with contraction allowed)
+  gx = gx + 2.f * ml; gx = gx - 2.f * mr; gx = gx + bl; gx = gx - br;        // (2 * v is exact, fused or not)
+  gx = gx / 8.f;
+  float gy = tl + 2.f * tc;
+  gy = gy + tr; gy = gy - bl; gy = gy - 2.f * bc; gy = gy - br;
+  gy = gy / 8.f;
+  const float gx2 = gx * gx, gy2 = gy * gy;
+  const float s = gx2 + gy2;
   const float d = fmaxf(mc, res);
-  float w = __fdiv_rn(s, __fmul_rn(d, d));
+  const float d2 = d * d;
+  float w = s / d2;
   w = fminf(w, 1e-2f);
   out[i] = w < 1e-4f ? 0.f : w;
 }

@@ -677,7 +677,7 @@ extern "C" int prn_bn_train_fwd_into(const float* x, float* stats, const float* 
     return 0;
   }
   const int S = bn_splits(B, HW);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
+  for (int r = PRN_REPS(1); r > 0; --r) hipLaunchKernelGGL(bn_partial_kernel, dim3(C, S), dim3(256), 0, st, x, ws, B, C, HW);
   PRN_CHECK_LAUNCH("prn_bn_train_fwd/partial");
   int gx = cdiv(HW, 256 * 8);
   if (gx < 1) gx = 1;
@@ -717,7 +717,7 @@ extern "C" int prn_bn_bwd_from(const float* dy, int64_t dy_batch_stride, const f
   const int S = bn_splits(B, HW);
   const int have = (!frozen || dgamma || dbeta) ? 1 : 0;
   if (have) {
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu, gamma, beta, dbs);
+    for (int r = PRN_REPS(2); r > 0; --r) hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, stats, ws, B, C, HW, relu, gamma, beta, dbs);
     PRN_CHECK_LAUNCH("prn_bn_bwd/partial");
   }
   int gx = cdiv(HW, 256 * 8);

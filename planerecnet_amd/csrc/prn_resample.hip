@@ -271,7 +271,7 @@ extern "C" int prn_resize_bilinear_add_fwd(const float* x, const float* addend, 
   PRN_REQUIRE(x && y && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_fwd: bad arguments");
   const int64_t n = (int64_t)BC * Ho * Wo;
   if (addend == nullptr && H == 2 * Ho && W == 2 * Wo && (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
-    hipLaunchKernelGGL(resize_down2_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, Ho, Wo);
+    for (int r = PRN_REPS(16); r > 0; --r) hipLaunchKernelGGL(resize_down2_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, Ho, Wo);
     PRN_CHECK_LAUNCH("prn_resize_bilinear_fwd/down2");
     return 0;
   }
@@ -291,7 +291,7 @@ extern "C" int prn_resize_bilinear_bwd_add(const float* dy, const float* addend,
   PRN_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "prn_resize_bilinear_bwd: bad arguments");
   const int64_t n = (int64_t)BC * H * W;
   if (H == 2 * Ho && W == 2 * Wo && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(addend)) & 7) == 0) {
-    hipLaunchKernelGGL(resize_down2_bwd_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n / 2, Ho, Wo);
+    for (int r = PRN_REPS(16); r > 0; --r) hipLaunchKernelGGL(resize_down2_bwd_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, dy, addend, dx, n / 2, Ho, Wo);
     PRN_CHECK_LAUNCH("prn_resize_bilinear_bwd/down2");
     return 0;
   }

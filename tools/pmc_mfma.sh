@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 rm -rf /tmp/pmc_mfma
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o t -- env PRN_BENCH_NO_FP32_RUN=1 python $R/bench.py --no-exchange-probe --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad --dcn-offsets 0 > /tmp/pmc_mfma.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o t -- env PRN_BENCH_NO_FP32_RUN=1 PRN_BENCH_NO_ENQUEUE_PROBE=1 PRN_BENCH_NO_CONDITIONING=1 python $R/bench.py --no-exchange-probe --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad --dcn-offsets 0 > /tmp/pmc_mfma.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json, os
 f = glob.glob('/tmp/pmc_mfma/*counter_collection.csv')

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o t -- env PRN_BENCH_NO_FP32_RUN=1 python $R/bench.py --no-exchange-probe --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad --dcn-offsets 0 > /tmp/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o t -- env PRN_BENCH_NO_FP32_RUN=1 PRN_BENCH_NO_ENQUEUE_PROBE=1 PRN_BENCH_NO_CONDITIONING=1 python $R/bench.py --no-exchange-probe --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --sync-wgrad --dcn-offsets 0 > /tmp/pmc_$c.log 2>&1
   ls /tmp/pmc_$c | head -5
 done
 python3 - <<'PY'
