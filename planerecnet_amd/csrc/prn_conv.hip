@@ -1557,6 +1557,7 @@ int taps_plan_of(const prn_conv_desc* d) {
 int up2_plan_of(const prn_conv_desc* d) {
   static const int on = prn_env_int("PRN_SPLIT_UP2", 1);                                      // PRN_SPLIT_UP2=0: off (A/B)
   if (!on || !(d->KH == 2 && d->in_mode == PRN_IN_UP2_PHASE && (d->C & 31) == 0 && (d->W & 3) == 0 && d->opts.split_kind == PRN_PIECES_F16 && d->ystride <= 1)) return 0;
+  if (!(d->epilogue == PRN_EPI_NONE || d->epilogue == PRN_EPI_RELU)) return 0;               // (the phase launch's epilogue has bias and ReLU only: a sigmoid stays on the fp32 kernel)
   return prn_split_gemm_plan(d->M, d->C * 4, d->B, d->H * d->W, 4, &d->opts) == 1 ? 1 : 0;
 }
 int64_t taps_ws_bytes(const prn_conv_desc* d, int splits) {

@@ -185,6 +185,44 @@ __global__ void dcn_dom_final_kernel(const float* __restrict__ part, float* __re
 // torchvision's atomicAdd backward); d_om stays deterministic.
 struct CsrEntry { int src; float w; };
 
+// Fixed order inside a bin (by source point, then weight bits).  The fills hand out a bin's slots with atomics, i.e. in arrival order; the gather sums
+// a bin front to back, so without this the input gradient differs in its last bit from run to run (advisor, round 5).  Bins hold a handful of entries
+// (a tap plane's points with a corner on this input pixel): an insertion sort by the one thread that owns the bin.
+__device__ __forceinline__ bool csr_before(const CsrEntry& a, const CsrEntry& b) {
+  return a.src < b.src || (a.src == b.src && __float_as_uint(a.w) < __float_as_uint(b.w));
+}
+__device__ __forceinline__ void csr_sort_bin(CsrEntry* __restrict__ e, int n) {
+  if (n <= 8) {                                         // the usual case: the whole bin in registers -- one round trip of loads, a 19-comparator network, one of stores
+    unsigned long long k[8];                            // (a chain of dependent global accesses, as in the loop below, costs ~2 us per step)
+    const unsigned long long* __restrict__ q = reinterpret_cast<const unsigned long long*>(e);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned long long v = i < n ? q[i] : ~0ull;                       // {src, w} as stored: src in the low word
+      k[i] = i < n ? ((v << 32) | (v >> 32)) : ~0ull;                          // key: src, then the weight's bits
+    }
+#define PRN_CSR_CX(I, J) { const unsigned long long lo = k[I] < k[J] ? k[I] : k[J], hi = k[I] < k[J] ? k[J] : k[I]; k[I] = lo; k[J] = hi; }
+    PRN_CSR_CX(0, 2) PRN_CSR_CX(1, 3) PRN_CSR_CX(4, 6) PRN_CSR_CX(5, 7) PRN_CSR_CX(0, 4) PRN_CSR_CX(1, 5) PRN_CSR_CX(2, 6) PRN_CSR_CX(3, 7)
+    PRN_CSR_CX(0, 1) PRN_CSR_CX(2, 3) PRN_CSR_CX(4, 5) PRN_CSR_CX(6, 7) PRN_CSR_CX(2, 4) PRN_CSR_CX(3, 5) PRN_CSR_CX(1, 4) PRN_CSR_CX(3, 6)
+    PRN_CSR_CX(1, 2) PRN_CSR_CX(3, 4) PRN_CSR_CX(5, 6)
+#undef PRN_CSR_CX
+    unsigned long long* __restrict__ o = reinterpret_cast<unsigned long long*>(e);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < n) o[i] = (k[i] << 32) | (k[i] >> 32);
+    return;
+  }
+  for (int i = 1; i < n; ++i) {
+    const CsrEntry v = e[i];
+    int j = i - 1;
+    while (j >= 0 && csr_before(v, e[j])) { e[j + 1] = e[j]; --j; }
+    e[j + 1] = v;
+  }
+}
+__global__ __launch_bounds__(256) void dcn_csr_sort_kernel(const int* __restrict__ starts, const int* __restrict__ counts, CsrEntry* __restrict__ entries, int nbins) {
+  const int bin = blockIdx.x * 256 + threadIdx.x;
+  if (bin < nbins && counts[bin] > 1) csr_sort_bin(entries + starts[bin], counts[bin]);
+}
+
 __global__ __launch_bounds__(256) void dcn_csr_count_kernel(OmView om, int* __restrict__ counts, int B, int H, int W,
                                                             int Ho, int Wo, int stride) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,6 +359,11 @@ __global__ __launch_bounds__(CSR1_THREADS) void dcn_csr_build_kernel(OmView om, 
     if (t.w10 != 0.f) entries[seg + atomicAdd(csr_bins + t.i10, 1)] = CsrEntry{src, t.w10 * t.mod};
     if (t.w11 != 0.f) entries[seg + atomicAdd(csr_bins + t.i11, 1)] = CsrEntry{src, t.w11 * t.mod};
   }
+  __syncthreads();                                      // (this workgroup wrote every entry of its segment; the cursors now hold the bins' ends)
+  for (int i = b0; i < b1; ++i) {
+    const int beg = i > 0 ? csr_bins[i - 1] : 0, n = csr_bins[i] - beg;
+    if (n > 1) csr_sort_bin(entries + seg + beg, n);
+  }
 }
 
 template <int CH>
@@ -445,6 +488,7 @@ int launch_dx(const OmView& v, const float* dcols, float* dx, char* wsb, const B
     hipLaunchKernelGGL(dcn_csr_block_sums_kernel, dim3(l.nblocks), dim3(256), 0, st, (const int*)counts, bsum, l.nbins);
     hipLaunchKernelGGL(dcn_csr_scan_kernel, dim3(l.nblocks), dim3(256), 0, st, counts, starts, (const int*)bsum, l.nbins);
     hipLaunchKernelGGL(dcn_csr_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, (const int*)starts, counts, entries, B, H, W, Ho, Wo, stride);
+    hipLaunchKernelGGL(dcn_csr_sort_kernel, dim3(cdiv(l.nbins, 256)), dim3(256), 0, st, (const int*)starts, (const int*)counts, entries, (int)l.nbins);
   }
   PRN_CHECK_LAUNCH("dcn d-input csr");
   const int HW = H * W;

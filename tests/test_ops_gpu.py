@@ -147,6 +147,34 @@ def test_up2_subpixel_phases_on_the_16bit_pipe(C, M, H, W):
         assert e2 <= max(2.0 * e0, 2e-6), (what, e0, e2)
 
 
+@pytest.mark.parametrize("epi", ["none", "relu", "sigmoid"])
+def test_up2_phase_descriptor_applies_its_epilogue_on_either_pipe(epi):
+    """A PRN_IN_UP2_PHASE descriptor with each of the three epilogues, fp32 kernels only (mode 0) and with the 16-bit pipe forced (mode 2): the
+    activation is applied in both (advisor, round 5: the phase launch of the split kernel has bias and ReLU only -- a sigmoid descriptor used to come
+    back without its activation there; it now stays on the fp32 kernel)."""
+    from planerecnet_amd import ops
+    from planerecnet_amd._lib import EPI_NONE, EPI_RELU, EPI_SIGMOID, IN_UP2_PHASE
+    d = dev()
+    C, M, H, W = 64, 128, 13, 16
+    x = rnd(2, C, H, W, seed=1).float().to(d)
+    w = rnd(M, C, 3, 3, seed=2, scale=(9 * C) ** -0.5).float().to(d)
+    b = rnd(M, seed=3).float().to(d)
+    wp = torch.empty(4, M, C, 2, 2, device=d, dtype=torch.float32)
+    ops.check(ops.lib.prn_up2_phase_weights(ops._p(w), ops._p(wp), M, C, ops._stream()), "prn_up2_phase_weights")
+    code = {"none": EPI_NONE, "relu": EPI_RELU, "sigmoid": EPI_SIGMOID}[epi]
+    act = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid}[epi]
+    old = ops.set_split_gemm(mode=0)
+    try:
+        for mode in (0, 2):
+            ops.set_split_gemm(mode=mode)
+            plain = ops.conv_fwd_raw(x, wp, b, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE, 1, EPI_NONE)
+            got = ops.conv_fwd_raw(x, wp, b, None, M, 2, 1, 0, 2 * H, 2 * W, IN_UP2_PHASE, 1, code)
+            assert (plain < 0).any()
+            close(got, act(plain.double()).cpu(), "up2 phase epilogue %s, mode %d" % (epi, mode), rtol=3e-6 if epi != "sigmoid" or mode == 0 else 2e-5)
+    finally:
+        ops.set_split_gemm(**old)
+
+
 @pytest.mark.parametrize("C,M,H,W,pad,K", [(64, 160, 22, 30, 3, 4), (32, 96, 17, 12, 1, 4), (96, 130, 10, 16, 2, 4), (64, 160, 21, 30, 0, 1), (32, 72, 16, 16, 0, 1)])
 def test_conv4x4_stride2_on_the_16bit_pipe_is_the_fp32_conv(C, M, H, W, pad, K):
     """The 4x4 / stride-2 zero-padded convolution (input gradient of the sub-pixel upsample-convolutions, ops._ConvUp2.backward) with the split kernel's
@@ -369,6 +397,33 @@ def test_deform_conv2d_torchvision_signature_fwd_bwd(B, C, H, W, M, stride, pad,
     gd = torch.autograd.grad(yd, xs, go.float().to(d))
     for n, g1, g0 in zip(["dx", "d_offset", "dw", "db", "d_mask"], gd, gr):
         close(g1, g0, "dcn " + n, rtol=5e-4)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 30, 40), (1, 16, 120, 160)])
+def test_deform_conv2d_input_gradient_is_bit_stable_run_to_run(B, C, H, W):
+    """The input gradient of the deformable convolution is a gather over CSR bins whose slots the fill hands out with atomics (arrival order); the bins are
+    sorted (source point, weight) before the gather, so ten repetitions give ONE result -- on the one-launch construction (30x40: the bins of a tap plane in
+    LDS) and on the five-launch one (120x160 > 15360 bins per plane).  Offsets of ~2 pixels r.m.s.: ~4-10 entries per bin, orders that did differ between
+    runs before the sort (advisor, round 5)."""
+    from planerecnet_amd import ops
+    d = dev()
+    M = C
+    x = rnd(B, C, H, W, seed=1).float().to(d).requires_grad_(True)
+    off = (rnd(B, 18, H, W, seed=2, scale=2.0) + 0.137).float().to(d).requires_grad_(True)
+    msk = (2 * torch.sigmoid(rnd(B, 9, H, W, seed=6))).float().to(d).requires_grad_(True)
+    w = rnd(M, C, 3, 3, seed=3, scale=(9 * C) ** -0.5).float().to(d).requires_grad_(True)
+    go = rnd(B, M, H, W, seed=5).float().to(d)
+    first = None
+    for rep in range(10):
+        y = ops.deform_conv2d(x, off, w, None, stride=(1, 1), padding=(1, 1), mask=msk)
+        gx, goff, gm = torch.autograd.grad(y, [x, off, msk], go)
+        ops.wgrad_join()
+        if first is None:
+            first = (gx.clone(), goff.clone(), gm.clone())
+            assert float(gx.abs().max()) > 0
+        else:
+            assert torch.equal(gx, first[0]), "dx differs in repetition %d: %g" % (rep, (gx - first[0]).abs().max().item())
+            assert torch.equal(goff, first[1]) and torch.equal(gm, first[2])
 
 
 @pytest.mark.parametrize("stride", [1, 2])
