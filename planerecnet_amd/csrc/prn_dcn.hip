@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void dcn_csr_fill_kernel(OmView om, const int*
 // block sums + scan + fill (five launches of ~5 us, i.e. five launch boundaries on the input-gradient chain per DCN layer).  H*W <= CSR1_MAX_BINS.
 constexpr int CSR1_THREADS = 1024;
 constexpr int CSR1_MAX_BINS = 15360;                    // 60 KB of LDS words (+ the scan scratch): 30x40 .. 96x160 input maps
+static_assert(CSR1_MAX_BINS * 4 + (CSR1_THREADS / 64) * 4 <= 64 * 1024, "the bins and the scan scratch of one tap plane must fit gfx950's 64 KB of LDS per workgroup");
 
 __global__ __launch_bounds__(CSR1_THREADS) void dcn_csr_build_kernel(OmView om, int* __restrict__ starts, int* __restrict__ counts,
                                                                       CsrEntry* __restrict__ entries, int H, int W, int Ho, int Wo, int stride) {
