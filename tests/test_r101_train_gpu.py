@@ -337,6 +337,58 @@ def test_r101_b8_losses_equal_oracle(net101):
     assert not missing, missing[:5]
 
 
+@pytest.mark.parametrize("B", [2, 8])
+def test_r101_train_step_is_bit_stable_run_to_run(net101, B):
+    """The same weights, batch and loss targets through forward + loss + backward three times (B = 8: the benchmark's launch plan -- K-split hand-overs, ragged
+    heads, deferred grouped weight gradients on the side stream): all five loss terms and all 477 parameter gradients are bit-identical between repetitions.  The
+    deformable layers' offset / modulator convolutions are moved off their zero initialisation so that every bilinear corner of the sampler is in play: the CSR bins
+    of its input gradient are sorted before the gather (csrc/prn_dcn.hip), every split sum in the library is taken in a fixed order, the loss kernels' partial sums
+    are reduced in index order."""
+    from oracle import synth
+    from planerecnet_amd import ops
+    from planerecnet_amd.losses import PlaneRecNetLoss
+    net, sd = net101
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(77)
+        for n, p in net.named_parameters():
+            if "offset_conv" in n or "modulator_conv" in n:
+                p.copy_((0.02 * torch.randn(p.shape, generator=g)).to(p.device))
+    net.train()
+    start = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x, inst, gtd = synth.make_batch(B, 480, 640, seed=31)
+    x, gtd = x.cuda(), gtd.cuda()
+    inst = [{k: v.cuda() for k, v in g_.items()} for g_ in inst]
+    crit = PlaneRecNetLoss().cuda()
+    params = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    first = None
+    ops.set_wgrad_async(True)
+    try:
+        for rep in range(3):
+            with torch.no_grad():
+                for k, v in net.state_dict().items():          # (BatchNorm running statistics back to the same start)
+                    v.copy_(start[k])
+            net.zero_grad(set_to_none=True)
+            np.random.seed(5)                                  # (the VNL triplets are drawn from numpy's stream on this path)
+            out = net(x)
+            losses = crit(net, *out, inst, gtd)
+            sum(losses.values()).sum().backward()
+            ops.wgrad_join()
+            torch.cuda.synchronize()
+            snap = {"loss " + k: v.detach().clone() for k, v in losses.items()}
+            snap.update({n: p.grad.detach().clone() for n, p in params if p.grad is not None})
+            if first is None:
+                first = snap
+                assert len(snap) >= 470 and all(torch.isfinite(v).all() for v in snap.values())
+                continue
+            assert set(snap) == set(first)
+            differ = [k for k, v in snap.items() if not torch.equal(v, first[k])]
+            assert not differ, "repetition %d: %d tensors differ from the first run, e.g. %s" % (rep, len(differ), differ[:6])
+    finally:
+        ops.set_wgrad_async(False)
+        net.load_state_dict(sd)
+
+
 def _b8_sample_index(numel, ns, seed):
     """The sample positions of tests/golden/make_golden_r101_b8.py (all of a tensor of <= ns elements)."""
     if numel <= ns:
