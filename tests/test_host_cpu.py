@@ -198,3 +198,23 @@ def test_simple_inference_cli_surface():
     assert a.image == "a.png:b.png" and a.nms_mode == "mask" and a.score_threshold == 0.2 and a.top_k == 7 and a.depth_mode == "gray"
     for flag in ("trained_model", "config", "images", "max_img", "ibims1", "ibims1_pd", "no_mask", "no_box", "no_text", "depth_shift"):
         assert hasattr(a, flag), flag
+
+
+def test_block_ownership_calibration_survives_an_import_under_no_grad():
+    """planerecnet_amd.blocks measures once, at import, what a solely owned incoming gradient looks like (TensorImpl use count, Python reference count) with a
+    two-element autograd graph; an application that first imports the package inside a torch.no_grad() / inference_mode() region must get the same numbers (the
+    probe re-enables grad mode for itself) instead of an exception at import."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "ctx = {'plain': None, 'no_grad': torch.no_grad(), 'inference': torch.inference_mode()}[sys.argv[1]]\n"
+            "if ctx is not None: ctx.__enter__()\n"
+            "from planerecnet_amd import blocks\n"
+            "print('OWNED', blocks._OWNED)\n") % root
+    seen = []
+    for mode in ("plain", "no_grad", "inference"):
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen.append([ln for ln in r.stdout.splitlines() if ln.startswith("OWNED")][-1])
+    assert seen[0] == seen[1] == seen[2] and seen[0] != "OWNED (0, 0)", seen
