@@ -77,6 +77,11 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        from . import ops
+        if ops.WGRAD_ASYNC:
+            # deferred weight gradients (ops.set_wgrad_async) are written to `.grad` by the side stream's launches: a loop that forgot ops.wgrad_join() would
+            # step without them.  Idempotent -- nothing queued, nothing launched; the stream wait is two runtime calls.
+            ops.wgrad_join()
         # one pass over the parameters: (parameter, group, gradient) of those that have a gradient
         plist, grads = [], []
         for g in self.param_groups:

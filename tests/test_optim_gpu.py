@@ -136,3 +136,38 @@ def test_fused_adam_skips_tensors_no_rank_had_a_gradient_for():
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert torch.allclose(a, b, rtol=5e-6, atol=1e-7), i
         assert torch.allclose(ref.state[a]["exp_avg_sq"], mine.state[b]["exp_avg_sq"], rtol=5e-6, atol=1e-9), i
+
+
+def test_fused_adam_joins_the_deferred_weight_gradients_itself():
+    """With ops.set_wgrad_async(True) the convolution weight gradients are launched on the side stream and written to `.grad` there; the contract is
+    ops.wgrad_join() after backward().  A loop that forgets it must still step with every gradient: FusedAdam.step joins (idempotent).  Two steps of a small
+    conv stack with and without the explicit join end in bit-identical parameters."""
+    from planerecnet_amd import ops
+    from planerecnet_amd.optim import FusedAdam
+    d = torch.device("cuda:0")
+
+    def run(explicit_join):
+        torch.manual_seed(3)
+        ws = [torch.nn.Parameter(torch.randn(32, 32, 3, 3, device=d) * 0.05) for _ in range(3)]
+        opt = FusedAdam(ws, lr=1e-2)
+        x = torch.randn(2, 32, 20, 24, generator=torch.Generator().manual_seed(4)).to(d)
+        ops.set_wgrad_async(True)
+        try:
+            for _ in range(2):
+                opt.zero_grad()
+                h = x
+                for w in ws:
+                    h = ops.conv2d(h, w, None, 1, 1)
+                h.square().mean().backward()
+                if explicit_join:
+                    ops.wgrad_join()
+                opt.step()
+        finally:
+            ops.wgrad_join()
+            ops.set_wgrad_async(False)
+        torch.cuda.synchronize()
+        return [w.detach().clone() for w in ws]
+
+    a, b = run(True), run(False)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert all(torch.isfinite(u).all() for u in a)
