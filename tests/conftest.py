@@ -26,6 +26,60 @@ if os.environ.get("PRN_TEST_POISON"):
     _torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
 
 
+# PRN_TEST_GUARD=1: every 4-byte device tensor the python side allocates uninitialised (torch.empty / empty_like: the library's outputs, workspaces, saved
+# buffers) sits between two 4 KB guard bands filled with a pattern; after every test the bands of all tensors allocated during it are compared with the
+# pattern.  A kernel that writes past the end (or before the start) of its buffer -- harmless or not depending on what the caching allocator placed next to it,
+# i.e. on the history of the session -- damages its OWN band and is reported with the allocation's shape and call site, in every run.  (A debugging mode for the
+# GPU tier: tensors stay alive until the end of their test, so memory use is the sum of a test's allocations.)
+if os.environ.get("PRN_TEST_GUARD"):
+    import traceback as _tb
+    import torch as _torch
+    _g_empty, _g_empty_like = _torch.empty, _torch.empty_like
+    _G = 1024                                                  # elements per band (4 KB: a multiple of every alignment the library asks for)
+    _PAT = 0x7FA5C3D1                                          # (as a float: a NaN with a payload nothing computes)
+    _GUARDED = []                                              # (base tensor, numel, shape, site)
+
+    def _site():
+        for fr in reversed(_tb.extract_stack(limit=12)[:-2]):
+            if "planerecnet_amd" in fr.filename or "/tests/" in fr.filename:
+                return "%s:%d" % (os.path.basename(fr.filename), fr.lineno)
+        return "?"
+
+    def _guard(t):
+        if not (t.is_cuda and t.dtype.itemsize == 4 and t.numel() and t.is_contiguous()):
+            return t
+        n = t.numel()
+        pad = (-n) % 64                                        # the tail band starts 256-byte aligned
+        base = _g_empty(n + pad + 2 * _G, device=t.device, dtype=_torch.int32)
+        base[:_G].fill_(_PAT)
+        base[_G + n:].fill_(_PAT)
+        _GUARDED.append((base, n, tuple(t.shape), _site()))
+        return base[_G:_G + n].view(t.dtype).view(t.shape)
+
+    _torch.empty = lambda *a, **k: _guard(_g_empty(*a, **k))
+    _torch.empty_like = lambda *a, **k: _guard(_g_empty_like(*a, **k))
+
+    @pytest.fixture(autouse=True)
+    def _check_guard_bands():
+        del _GUARDED[:]
+        yield
+        if not _GUARDED or not _torch.cuda.is_available():
+            return
+        _torch.cuda.synchronize()
+        damaged = []
+        flags = _torch.stack([((b[:_G] != _PAT).any() | (b[_G + n:] != _PAT).any()) for b, n, _, _ in _GUARDED]).cpu()
+        for (b, n, shape, site), f in zip(_GUARDED, flags.tolist()):
+            if f:
+                head = int((b[:_G] != _PAT).sum())
+                tail = b[_G + n:]
+                bad = (tail != _PAT).nonzero().flatten()
+                damaged.append("%s allocated at %s: %d words before the start, %d words past the end (first at +%d, last at +%d)" %
+                               (shape, site, head, bad.numel(), int(bad[0]) if bad.numel() else -1, int(bad[-1]) if bad.numel() else -1))
+        n_all = len(_GUARDED)
+        del _GUARDED[:]
+        assert not damaged, "%d of %d guarded allocations were written outside their bounds:\n  %s" % (len(damaged), n_all, "\n  ".join(damaged[:20]))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
