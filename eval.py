@@ -99,6 +99,7 @@ def evaluate(net, dataset, during_training=False, eval_nums=-1):
 
 def main():
     parse_args()
+    torch.set_num_threads(4)                                   # host-side tensor ops are small: a wide OpenMP team only adds fork / join latency (as train.py)
     if args.autopsy:
         raise SystemExit("eval.py: --autopsy writes tensorboard images (tensorboardX + cv2 colour maps); not part of this build")
     if args.trained_model == "interrupt":

@@ -121,6 +121,7 @@ def inference_images(net, in_folder, out_folder, max_img=0, depth_mode="colored"
 
 def main(argv=None):
     parse_args(argv)
+    torch.set_num_threads(4)                                   # host-side tensor ops are small: a wide OpenMP team only adds fork / join latency (as train.py)
     from planerecnet_amd import timer
     from planerecnet_amd.planerecnet import PlaneRecNet
     timer.disable_all()
