@@ -253,7 +253,9 @@ def main():
                     "steps under-estimate the penalty of the broad setting (50.4 vs 50.2 ms in-process where separate runs give 51.4 vs 50.1)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the extra steps that time the gradient-exchange path on a one-rank group")
     ap.add_argument("--graph", action="store_true", help="replay the network's forward / backward as two hipGraphs (measured SLOWER "
-                    "than eager launches on ROCm 7.2: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay; kept as an option)")
+                    "than eager launches on ROCm 7.2 in round 1: 144.7 vs 134.3 ms/step -- ~2000 kernel nodes per replay.  Since the per-step operand refresh of the 16-bit-pipe launches "
+                    "(ops.split_refresh_all) uploads its item table from pageable memory whenever the set of derived buffers changes -- which a capture's private pool makes happen -- "
+                    "the capture is refused by the runtime and the run falls back to eager launches with a message; `hip_graph` in the line says which ran)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     args.config = args.config or wl[0]
